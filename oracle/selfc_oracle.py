@@ -1,0 +1,336 @@
+"""CPU oracle for the SelfC invertible-rescaling hot path.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it.  The product path (``selfc_amd``) never routes through this file and
+fails loudly when its HIP extension is missing.
+
+It is a functional restatement (plain fp32 torch ops on CPU, parameters passed
+as flat ``{state_dict-key: tensor}`` dicts) of the reference algorithm; every
+function cites the reference file:line it follows (paths relative to
+``/root/reference/codes``).  Parity is PINNED: ``tools/make_golden.py`` imports
+the real reference modules in the build container and stores their
+inputs/outputs under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks
+this restatement against those vectors (bit-exact for the index shuffles,
+<=1e-6 for the float paths).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+
+def _sub(params: Params, prefix: str) -> Params:
+    """View of ``params`` restricted to keys under ``prefix.`` (prefix stripped)."""
+    if not prefix:
+        return params
+    p = prefix + "."
+    return {k[len(p):]: v for k, v in params.items() if k.startswith(p)}
+
+
+def lrelu(x: torch.Tensor) -> torch.Tensor:
+    # nn.LeakyReLU(negative_slope=0.2): Subnet_constructor.py:16,107
+    return torch.where(x >= 0, x, x * 0.2)
+
+
+# ----------------------------------------------------------------------------
+# a1  HaarDownsampling  (models/modules/Inv_arch.py:44-84)
+# ----------------------------------------------------------------------------
+
+def haar_fwd(x: torch.Tensor) -> torch.Tensor:
+    """(N,C,H,W) -> (N,4C,H/2,W/2); out[:, k*C+c] = band k of channel c.
+
+    Inv_arch.py:49-58 builds the four +-1 2x2 kernels, :69 applies them as a
+    stride-2 depthwise conv and divides by 4, :70-72 transposes (C,4)->(4,C).
+    The summation order a+b+c+d (row-major over the 2x2 window) reproduces the
+    reference's fp32 bits (checked against the golden vectors with torch.equal).
+    """
+    a = x[:, :, 0::2, 0::2]
+    b = x[:, :, 0::2, 1::2]
+    c = x[:, :, 1::2, 0::2]
+    d = x[:, :, 1::2, 1::2]
+    ll = (((a + b) + c) + d) / 4.0
+    hl = (((a - b) + c) - d) / 4.0
+    lh = (((a + b) - c) - d) / 4.0
+    hh = (((a - b) - c) + d) / 4.0
+    return torch.cat((ll, hl, lh, hh), dim=1)
+
+
+def haar_inv(y: torch.Tensor) -> torch.Tensor:
+    """(N,4C,h,w) -> (N,C,2h,2w): Inv_arch.py:78-81 (conv_transpose2d, no /4)."""
+    n, c4, h, w = y.shape
+    c = c4 // 4
+    ll, hl, lh, hh = y[:, 0:c], y[:, c:2 * c], y[:, 2 * c:3 * c], y[:, 3 * c:4 * c]
+    out = y.new_empty((n, c, 2 * h, 2 * w))
+    out[:, :, 0::2, 0::2] = ((ll + hl) + lh) + hh
+    out[:, :, 0::2, 1::2] = ((ll - hl) + lh) - hh
+    out[:, :, 1::2, 0::2] = ((ll + hl) - lh) - hh
+    out[:, :, 1::2, 1::2] = ((ll - hl) - lh) + hh
+    return out
+
+
+def haar_jacobian(shape: Sequence[int], rev: bool) -> float:
+    """Inv_arch.py:66-67,75-76: elements/4*log(1/16) (fwd) or *log(16) (rev);
+    ``shape`` is the shape of the tensor handed to that call."""
+    elements = shape[1] * shape[2] * shape[3]
+    return elements / 4 * (math.log(16.0) if rev else math.log(1 / 16.0))
+
+
+# ----------------------------------------------------------------------------
+# a6  PixelUnshuffle / FrequencyAnalyzer (models/modules/SelfC_GMM_arch_inv.py:46-82)
+# ----------------------------------------------------------------------------
+
+def pixel_unshuffle_ref(x: torch.Tensor, s: int) -> torch.Tensor:
+    """SelfC_GMM_arch_inv.py:51-60: out channel = (sy*S+sx)*C + c."""
+    n, c, h, w = x.shape
+    x = x.reshape(n, c, h // s, s, w // s, s).permute(0, 3, 5, 1, 2, 4)
+    return x.reshape(n, c * s * s, h // s, w // s)
+
+
+def freq_fwd(x: torch.Tensor, k: int = 4) -> torch.Tensor:
+    """(N,3,H,W) -> (N,3+3k^2,H/k,W/k): SelfC_GMM_arch_inv.py:75-78.
+
+    ``nn.Upsample(1/k, mode='area')`` == k x k block mean; ``nn.Upsample(k,
+    mode='area')`` == nearest replicate."""
+    lo = F.avg_pool2d(x, k)
+    up = lo.repeat_interleave(k, dim=2).repeat_interleave(k, dim=3)
+    hi = pixel_unshuffle_ref(x - up, k)
+    return torch.cat((lo, hi), dim=1)
+
+
+def freq_inv(y: torch.Tensor, k: int = 4) -> torch.Tensor:
+    """(N,3+3k^2,h,w) -> (N,3,kh,kw): SelfC_GMM_arch_inv.py:80-82.
+
+    Uses nn.PixelShuffle channel order c*k^2+sy*k+sx, which is NOT the inverse
+    of the forward's order (SURVEY trap 3) - reproduced as is."""
+    lo = y[:, 0:3]
+    hi = y[:, 3:]
+    up = lo.repeat_interleave(k, dim=2).repeat_interleave(k, dim=3)
+    return up + F.pixel_shuffle(hi, k)
+
+
+# ----------------------------------------------------------------------------
+# a12 Quantization (models/modules/Quantization.py:4-26)
+# ----------------------------------------------------------------------------
+
+def quantize(x: torch.Tensor, quant_v: float = 255.0, is_clip: bool = True) -> torch.Tensor:
+    if is_clip:
+        x = torch.clamp(x, 0, 1)
+    return (x * quant_v).round() / quant_v
+
+
+# ----------------------------------------------------------------------------
+# a3  DenseBlock (2-D)  (models/modules/Subnet_constructor.py:8-34)
+# ----------------------------------------------------------------------------
+
+def dense_block(p: Params, x: torch.Tensor, is_res: bool = False) -> torch.Tensor:
+    feats = [x]
+    for i in range(1, 5):
+        inp = feats[0] if i == 1 else torch.cat(feats, dim=1)
+        feats.append(lrelu(F.conv2d(inp, p[f"conv{i}.weight"], p.get(f"conv{i}.bias"), 1, 1)))
+    out = F.conv2d(torch.cat(feats, dim=1), p["conv5.weight"], p.get("conv5.bias"), 1, 1)
+    return out + x if is_res else out
+
+
+# ----------------------------------------------------------------------------
+# a4  D2DTInput  (models/modules/Subnet_constructor.py:98-133)
+# ----------------------------------------------------------------------------
+
+def d2dt(p: Params, x: torch.Tensor, t: int) -> torch.Tensor:
+    """(B*T,Cin,H,W) -> (B*T,Cout,H,W).
+
+    conv1-4 are Conv3d (1,3,3) pad (0,1,1) == per-frame 3x3 convs
+    (Subnet_constructor.py:102-105,126-129); conv5 is Conv3d (3,1,1) pad (1,0,0)
+    == 3-tap temporal conv inside each clip with zero padding at the clip ends
+    (:106,130).  Frames are laid out clip-major (b*T + t), :119-124."""
+    bt, cin, h, w = x.shape
+    assert bt % t == 0, "frame count must be a multiple of the temporal length"
+    feats = [x]
+    for i in range(1, 5):
+        wgt = p[f"conv{i}.weight"]           # (gc, cin_i, 1, 3, 3)
+        inp = feats[0] if i == 1 else torch.cat(feats, dim=1)
+        feats.append(lrelu(F.conv2d(inp, wgt[:, :, 0], p.get(f"conv{i}.bias"), 1, 1)))
+    d = torch.cat(feats, dim=1)              # (B*T, cin+128, H, W)
+    w5 = p["conv5.weight"]                   # (cout, cin+128, 3, 1, 1)
+    cout = w5.shape[0]
+    d5 = d.reshape(bt // t, t, d.shape[1], h, w)
+    out = torch.zeros((bt // t, t, cout, h, w), dtype=x.dtype)
+    for dt in (-1, 0, 1):
+        wk = w5[:, :, dt + 1, 0, 0]          # (cout, C)
+        lo, hi = max(0, -dt), min(t, t - dt)  # output frames whose tap t+dt is inside the clip
+        if hi <= lo:
+            continue
+        contrib = torch.einsum("oc,btchw->btohw", wk, d5[:, lo + dt:hi + dt])
+        out[:, lo:hi] += contrib
+    if p.get("conv5.bias") is not None:
+        out = out + p["conv5.bias"].view(1, 1, -1, 1, 1)
+    return out.reshape(bt, cout, h, w)
+
+
+def subnet_apply(kind: str, p: Params, x: torch.Tensor, t: int) -> torch.Tensor:
+    """Dispatch on the ``subnet()`` factory name (Subnet_constructor.py:719-788)."""
+    if kind == "DBNet":
+        return dense_block(p, x)
+    if kind == "D2DTNet":
+        return d2dt(p, x, t)
+    raise ValueError(f"oracle covers DBNet and D2DTNet only, got {kind!r}")
+
+
+# ----------------------------------------------------------------------------
+# a2  InvBlockExp  (models/modules/Inv_arch.py:8-41)
+# ----------------------------------------------------------------------------
+
+def invblock(kind: str, p: Params, x: torch.Tensor, split1: int, t: int,
+             rev: bool = False, clamp: float = 1.0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Returns (cat(y1,y2), s).  Inv_arch.py:21-33."""
+    x1, x2 = x[:, :split1], x[:, split1:]
+    pf, pg, ph = _sub(p, "F"), _sub(p, "G"), _sub(p, "H")
+    if not rev:
+        y1 = x1 + subnet_apply(kind, pf, x2, t)
+        s = clamp * (torch.sigmoid(subnet_apply(kind, ph, y1, t)) * 2 - 1)
+        y2 = x2 * torch.exp(s) + subnet_apply(kind, pg, y1, t)
+    else:
+        s = clamp * (torch.sigmoid(subnet_apply(kind, ph, x1, t)) * 2 - 1)
+        y2 = (x2 - subnet_apply(kind, pg, x1, t)) / torch.exp(s)
+        y1 = x1 - subnet_apply(kind, pf, y2, t)
+    return torch.cat((y1, y2), dim=1), s
+
+
+def invblock_jacobian(s: torch.Tensor, n: int, rev: bool) -> torch.Tensor:
+    """Inv_arch.py:35-41."""
+    return (-torch.sum(s) if rev else torch.sum(s)) / n
+
+
+# ----------------------------------------------------------------------------
+# a10 SelfC-large InvBlock stack (models/modules/SelfC_GMM_arch_inv.py:432-490)
+# ----------------------------------------------------------------------------
+
+def large_block_indices(params: Params) -> List[int]:
+    idx = sorted({int(k.split(".")[1]) for k in params if k.startswith("operations.")})
+    return idx
+
+
+def large_fwd(params: Params, x: torch.Tensor, t: int = 7, kind: str = "D2DTNet",
+              split1: int = 3) -> torch.Tensor:
+    """FrequencyAnalyzer then every InvBlockExp in order: SelfC_GMM_arch_inv.py:454-469.
+    Returns the (N,51,h,w) latent (``loss_c`` is identically 0 there, :466)."""
+    out = freq_fwd(x)
+    for i in large_block_indices(params):
+        out, _ = invblock(kind, _sub(params, f"operations.{i}"), out, split1, t, rev=False)
+    return out
+
+
+def large_inv_from_latent(params: Params, z: torch.Tensor, t: int = 7, kind: str = "D2DTNet",
+                          split1: int = 3) -> torch.Tensor:
+    """Reversed InvBlockExp stack then FrequencyAnalyzer reverse on a full
+    51-channel latent (the op loop of SelfC_GMM_arch_inv.py:486-489)."""
+    out = z
+    for i in reversed(large_block_indices(params)):
+        out, _ = invblock(kind, _sub(params, f"operations.{i}"), out, split1, t, rev=True)
+    return freq_inv(out)
+
+
+def large_roundtrip(params: Params, x: torch.Tensor, t: int = 7) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The BASELINE metric's unit of work: FA.fwd -> 8x fwd -> Quantization of
+    the LR channels -> 8x inv -> FA.inv, with the forward's own HF channels fed
+    back.  Returns (latent, reconstruction)."""
+    z = large_fwd(params, x, t)
+    zq = torch.cat((quantize(z[:, :3]), z[:, 3:]), dim=1)
+    return z, large_inv_from_latent(params, zq, t)
+
+
+# ----------------------------------------------------------------------------
+# a11 Haar nets (Inv_arch.py:87-127, SelfC_arch_inv.py:276-338)
+# ----------------------------------------------------------------------------
+
+def haar_net_fwd(params: Params, x: torch.Tensor, block_num: Sequence[int], t: int = 7,
+                 kind: str = "DBNet", split1: int = 3) -> torch.Tensor:
+    """[Haar, block_num[i] x InvBlockExp] per level: Inv_arch.py:93-102,108-111.
+    Returns the full latent; IRN's forward then slices it (:112-114)."""
+    out = x
+    op = 0
+    for nb in block_num:
+        out = haar_fwd(out)
+        op += 1
+        for _ in range(nb):
+            out, _ = invblock(kind, _sub(params, f"operations.{op}"), out, split1, t, rev=False)
+            op += 1
+    return out
+
+
+def haar_net_inv(params: Params, z: torch.Tensor, block_num: Sequence[int], t: int = 7,
+                 kind: str = "DBNet", split1: int = 3) -> torch.Tensor:
+    ops: List[Tuple[str, int]] = []
+    op = 0
+    for nb in block_num:
+        ops.append(("haar", op))
+        op += 1
+        for _ in range(nb):
+            ops.append(("blk", op))
+            op += 1
+    out = z
+    for typ, i in reversed(ops):
+        if typ == "haar":
+            out = haar_inv(out)
+        else:
+            out, _ = invblock(kind, _sub(params, f"operations.{i}"), out, split1, t, rev=True)
+    return out
+
+
+# ----------------------------------------------------------------------------
+# a7  GlobalAgg  (models/modules/SelfC_GMM_arch_inv.py:257-285)
+# ----------------------------------------------------------------------------
+
+def global_agg(p: Params, x: torch.Tensor, t: int) -> torch.Tensor:
+    bt, c, h, w = x.shape
+    b = bt // t
+    proj1 = F.conv2d(x, p["proj1.weight"], p["proj1.bias"])                       # :266
+    pooled = F.adaptive_avg_pool2d(x, (32, 32)).reshape(bt, c, 32 * 32)           # :269-270
+    g = (pooled @ p["fc.weight"].t() + p["fc.bias"]).squeeze(-1).reshape(b, t, c)  # :271-272
+    q = g @ p["proj2.weight"].t() + p["proj2.bias"]                               # :273
+    k = g @ p["proj3.weight"].t() + p["proj3.bias"]                               # :274
+    a = torch.softmax((q @ k.transpose(1, 2)) / c, dim=-1)                        # :275-277
+    v = proj1.reshape(b, t, c, h, w).permute(0, 2, 3, 4, 1).reshape(b, c * h * w, t)  # :279-280
+    mixed = (v @ a).reshape(b, c, h, w, t).permute(0, 4, 1, 2, 3).reshape(bt, c, h, w)  # :281-284
+    return x + mixed
+
+
+# ----------------------------------------------------------------------------
+# a8  STPNet v2  (models/modules/SelfC_GMM_arch_inv.py:289-430)
+# ----------------------------------------------------------------------------
+
+def stp_v2_parameters(params: Params, lr: torch.Tensor, t: int, stp_blk_num: int = 6) -> torch.Tensor:
+    """lr (B*T,3,h,w) -> raw head output (B*T, Cp, h, w) (``self.parameters`` of
+    the reference, frame-major here instead of (b,Cp,t,h,w)); :358-376."""
+    x = d2dt(_sub(params, "local_m1"), lr, t)
+    x = global_agg(_sub(params, "global_m1"), x, t)
+    x = d2dt(_sub(params, "local_m2"), x, t)
+    x = global_agg(_sub(params, "global_m2"), x, t)
+    for i in range(stp_blk_num - 2):
+        x = d2dt(_sub(params, f"other_stp_modules.{2 * i}"), x, t)
+        x = global_agg(_sub(params, f"other_stp_modules.{2 * i + 1}"), x, t)
+    tail = sorted({int(k.split(".")[1]) for k in params if k.startswith("tail_gmm.")})
+    for j in tail:                                   # tail_gmm = [lrelu, conv1x1x1]* : :327-344
+        x = lrelu(x)
+        wgt = params[f"tail_gmm.{j}.weight"]
+        x = F.conv2d(x, wgt.reshape(wgt.shape[0], wgt.shape[1], 1, 1), params[f"tail_gmm.{j}.bias"])
+    return x
+
+
+def stp_v2_gmm_sample(raw: torch.Tensor, eps: torch.Tensor, hf_dim: int = 48, k: int = 5) -> torch.Tensor:
+    """raw (N, hf_dim*K*3, h, w), eps (N, hf_dim, K, h, w) -> (N, hf_dim, h, w).
+
+    :382-394: reshape (hf_dim,K,3); pi = softmax over the hf_dim axis (trap 6),
+    log-scale = clamp(idx1,-7,7), mean = idx2; v = sum_k pi*(eps*exp(ls)+mean).
+    The reference draws eps on the device (:412-417); here it is injected."""
+    n, _, h, w = raw.shape
+    r = raw.reshape(n, hf_dim, k, 3, h, w)
+    pi = torch.softmax(r[:, :, :, 0], dim=1)
+    ls = torch.clamp(r[:, :, :, 1], -7, 7)
+    mu = r[:, :, :, 2]
+    return (pi * (eps * torch.exp(ls) + mu)).sum(2)

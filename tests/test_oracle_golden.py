@@ -1,0 +1,124 @@
+"""Pin the CPU oracle (oracle/selfc_oracle.py) against vectors produced by the
+real reference modules (tools/make_golden.py).  Bit-exact for the index
+shuffles (Haar, FrequencyAnalyzer, Quantization), <=2e-6 relative for float
+paths (different but equivalent summation orders of the same fp32 convs)."""
+import torch
+
+from conftest import load_golden, rel_err, subdict
+from oracle import selfc_oracle as O
+
+T = 7
+FTOL = 2e-6
+
+
+def test_haar_bit_exact():
+    g = load_golden("g1_haar")
+    assert torch.equal(O.haar_fwd(g["x"]), g["y"])
+    assert torch.equal(O.haar_fwd(g["y"]), g["y2"])           # second level, C=12
+    assert torch.equal(O.haar_inv(g["y"]), g["xr"])
+    assert torch.equal(O.haar_inv(g["zrand"]), g["zrand_inv"])  # odd sizes (5x7)
+    assert abs(O.haar_jacobian(g["x"].shape, False) - float(g["jac_fwd"])) < 1e-9
+    assert abs(O.haar_jacobian(g["y"].shape, True) - float(g["jac_rev"])) < 1e-9
+    # rev(fwd(x)) == x to fp32 rounding
+    assert (O.haar_inv(O.haar_fwd(g["x"])) - g["x"]).abs().max() < 5e-7
+
+
+def test_freq_bit_exact_and_not_inverse():
+    g = load_golden("g2_freq")
+    assert torch.equal(O.freq_fwd(g["x"]), g["y"])
+    assert torch.equal(O.freq_inv(g["z"]), g["z_rev"])
+    assert torch.equal(O.freq_inv(g["y"]), g["y_rev"])
+    # trap 3: rev is not the inverse of fwd
+    assert (O.freq_inv(O.freq_fwd(g["x"])) - g["x"]).abs().max() > 0.1
+
+
+def test_quant_bit_exact():
+    g = load_golden("g9_quant")
+    assert torch.equal(O.quantize(g["x"]), g["y"])
+
+
+def test_denseblock():
+    g = load_golden("g3_denseblock")
+    for tag in ("f", "g"):
+        y = O.dense_block(subdict(g, tag), g[f"{tag}_x"])
+        assert rel_err(y, g[f"{tag}_y"]) < FTOL
+
+
+def test_d2dt_clip_boundaries():
+    g = load_golden("g4_d2dt")
+    for tag in ("f", "g"):
+        y = O.d2dt(subdict(g, tag), g[f"{tag}_x"], T)
+        assert rel_err(y, g[f"{tag}_y"]) < FTOL
+    # zero padding at clip ends: frames of clip 0 do not see clip 1
+    x = g["f_x"].clone()
+    y0 = O.d2dt(subdict(g, "f"), x, T)
+    x[T:] += 1.0
+    y1 = O.d2dt(subdict(g, "f"), x, T)
+    assert torch.equal(y0[:T], y1[:T])
+
+
+def _check_invblock(name, kind, t):
+    g = load_golden(name)
+    y, s = O.invblock(kind, g, g["x"], 3, t, rev=False)
+    assert rel_err(y, g["y_fwd"]) < FTOL and rel_err(s, g["s_fwd"]) < 5e-6
+    assert abs(O.invblock_jacobian(s, g["x"].shape[0], False).item() - g["jac_fwd"].item()) < 1e-3 * abs(g["jac_fwd"].item()) + 1e-4
+    y, s = O.invblock(kind, g, g["x"], 3, t, rev=True)
+    assert rel_err(y, g["y_rev"]) < FTOL and rel_err(s, g["s_rev"]) < 5e-6
+    assert abs(O.invblock_jacobian(s, g["x"].shape[0], True).item() - g["jac_rev"].item()) < 1e-3 * abs(g["jac_rev"].item()) + 1e-4
+    # invertibility
+    z, _ = O.invblock(kind, g, g["x"], 3, t, rev=False)
+    xr, _ = O.invblock(kind, g, z, 3, t, rev=True)
+    assert rel_err(xr, g["x"]) < 1e-5
+
+
+def test_invblock_dbnet():
+    _check_invblock("g5_invblock_dbnet", "DBNet", T)
+
+
+def test_invblock_d2dt():
+    _check_invblock("g5_invblock_d2dt", "D2DTNet", T)
+
+
+def test_large_stack():
+    g = load_golden("g8_large_stack")
+    z = O.large_fwd(g, g["x"], T)
+    assert rel_err(z, g["z"]) < 1e-5
+    assert float(g["loss_c"]) == 0.0
+    xr = O.large_inv_from_latent(g, g["z"], T)
+    assert rel_err(xr, g["x_rev"]) < 1e-5
+
+
+def test_haar_net():
+    g = load_golden("g8_haar_net")
+    z = O.haar_net_fwd(g, g["x"], [1], T, "DBNet")
+    assert rel_err(z, g["z"]) < FTOL
+    assert rel_err(z[:, :3], g["lr"]) < FTOL
+    assert abs((z[:, 3:] ** 2).mean().item() - g["hf_meansq"].item()) < 1e-6
+    xr = O.haar_net_inv(g, g["z"], [1], T, "DBNet")
+    assert rel_err(xr, g["x_rev"]) < FTOL
+    assert rel_err(xr, g["x"]) < 1e-5
+
+
+def test_globalagg():
+    g = load_golden("g6_globalagg")
+    for tag in ("a", "b"):
+        y = O.global_agg(g, g[f"{tag}_x"], T)
+        assert rel_err(y, g[f"{tag}_y"]) < FTOL
+
+
+def test_stp_gmm_head_and_sample():
+    g = load_golden("g7_stp_gmm")
+    raw = O.stp_v2_parameters(g, g["lr"], T)
+    assert rel_err(raw, g["raw"]) < 2e-5
+    v = O.stp_v2_gmm_sample(g["raw"], g["eps"])
+    assert rel_err(v, g["v"]) < 2e-6
+
+
+def test_stp_l2_full_reverse():
+    g = load_golden("g7_stp_l2_full_rev")
+    ops = load_golden("g8_large_stack")
+    stp = subdict(g, "stp_net")
+    hf = O.stp_v2_parameters(stp, g["lr"], T)
+    assert rel_err(hf, g["hf"]) < 2e-5
+    xr = O.large_inv_from_latent(ops, torch.cat((g["lr"], hf), 1), T)
+    assert rel_err(xr, g["x_rev"]) < 5e-5

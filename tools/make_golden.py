@@ -1,0 +1,210 @@
+"""Generate tests/golden/*.npz by running the REAL reference modules on CPU.
+
+Runs only in the build container (needs /root/reference, which never travels to
+the GPU box).  The reference is imported read-only (no bytecode written); only
+its inputs / seeded weights / outputs are stored - no reference source text.
+
+    python tools/make_golden.py            # (re)writes tests/golden/*.npz
+
+Vectors:
+  g1_haar          HaarDownsampling fwd/rev, (7,3,32,32) and 2nd level C=12
+  g2_freq          FrequencyAnalyzer fwd and rev (not inverses - trap 3)
+  g3_denseblock    DenseBlock(9,3), DenseBlock(3,9) with non-zero conv5
+  g4_d2dt          D2DTInput(48,3), (3,48) at T=7, b=2 (clip boundaries)
+  g5_invblock_*    InvBlockExp fwd / rev / s / jacobian (DBNet 12ch, D2DT 51ch)
+  g8_large_stack   SelfC-large FrequencyAnalyzer + 8 InvBlockExp fwd, and the op
+                   loop reversed on the forward's own latent
+  g8_haar_nets     InvRescaleNet / Haar SelfC op stack (DBNet,[1],1)
+  g9_quant         Quantization on edge values
+  g6_globalagg     GlobalAgg(64) at 16x16 (replicating bins) and 20x36
+  g7_stp           STPNet v2 raw head output + GMM sample with injected eps (7,3,8,12); l2 full reverse
+"""
+import os
+import sys
+import types
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+REF = "/root/reference/codes"
+sys.path.insert(0, REF)
+_tv = types.ModuleType("torchvision")
+_tvo = types.ModuleType("torchvision.ops")
+_tv.ops = _tvo
+sys.modules["torchvision"] = _tv
+sys.modules["torchvision.ops"] = _tvo
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from global_var import GlobalVar  # noqa: E402
+import models.modules.Inv_arch as IA  # noqa: E402
+import models.modules.Subnet_constructor as SC  # noqa: E402
+import models.modules.SelfC_GMM_arch_inv as GA  # noqa: E402
+from models.modules.Quantization import Quantization  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+T = 7
+
+
+def sd_np(mod, prefix=""):
+    return {prefix + k: v.detach().numpy().copy() for k, v in mod.state_dict().items()}
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+def rerandomise_conv5(mod, gen, std=0.02):
+    """DenseBlock zero-inits conv5 (Subnet_constructor.py:22): make it non-zero so
+    the golden exercises the layer."""
+    with torch.no_grad():
+        mod.conv5.weight.copy_(torch.randn(mod.conv5.weight.shape, generator=gen) * std)
+        mod.conv5.bias.copy_(torch.randn(mod.conv5.bias.shape, generator=gen) * std)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    GlobalVar.set_Temporal_LEN(T)
+    g = torch.Generator().manual_seed(1234)
+
+    with torch.no_grad():
+        # ---- G1 Haar
+        x = torch.rand(7, 3, 32, 32, generator=g)
+        h1 = IA.HaarDownsampling(3)
+        y = h1(x)
+        jac_f = h1.jacobian(x)
+        h2 = IA.HaarDownsampling(12)
+        y2 = h2(y)
+        xr = h1(y, rev=True)
+        jac_r = h1.jacobian(y, rev=True)
+        zrand = torch.randn(2, 12, 5, 7, generator=g)
+        save("g1_haar", x=x.numpy(), y=y.numpy(), y2=y2.numpy(), xr=xr.numpy(),
+             zrand=zrand.numpy(), zrand_inv=h1(zrand, rev=True).numpy(),
+             jac_fwd=np.float64(jac_f), jac_rev=np.float64(jac_r),
+             haar_weights=h1.haar_weights.numpy())
+
+        # ---- G2 FrequencyAnalyzer
+        fa = GA.FrequencyAnalyzer(3)
+        x = torch.rand(7, 3, 32, 48, generator=g)
+        yf = fa(x)
+        zr = torch.randn(7, 51, 8, 12, generator=g)
+        save("g2_freq", x=x.numpy(), y=yf.numpy(), z=zr.numpy(), z_rev=fa(zr, rev=True).numpy(),
+             y_rev=fa(yf, rev=True).numpy())
+
+        # ---- G3 DenseBlock
+        torch.manual_seed(3)
+        arrs = {}
+        for tag, (ci, co) in {"f": (9, 3), "g": (3, 9)}.items():
+            m = SC.DenseBlock(ci, co, "xavier")
+            rerandomise_conv5(m, g)
+            x = torch.randn(2, ci, 16, 20, generator=g)
+            arrs.update(sd_np(m, f"{tag}."))
+            arrs[f"{tag}_x"] = x.numpy()
+            arrs[f"{tag}_y"] = m(x).numpy()
+        save("g3_denseblock", **arrs)
+
+        # ---- G4 D2DTInput
+        torch.manual_seed(4)
+        arrs = {}
+        for tag, (ci, co) in {"f": (48, 3), "g": (3, 48)}.items():
+            m = SC.D2DTInput(ci, co, "xavier")
+            x = torch.randn(2 * T, ci, 12, 20, generator=g)
+            arrs.update(sd_np(m, f"{tag}."))
+            arrs[f"{tag}_x"] = x.numpy()
+            arrs[f"{tag}_y"] = m(x).numpy()
+        save("g4_d2dt", **arrs)
+
+        # ---- G5 InvBlockExp
+        torch.manual_seed(5)
+        blk = IA.InvBlockExp(SC.subnet("DBNet", "xavier"), 12, 3)
+        for sub in (blk.F, blk.G, blk.H):
+            rerandomise_conv5(sub, g)
+        x = torch.randn(T, 12, 16, 16, generator=g) * 0.5
+        yf = blk(x)
+        s_f = blk.s.clone()
+        jf = blk.jacobian(x)
+        yr = blk(x, rev=True)
+        s_r = blk.s.clone()
+        jr = blk.jacobian(x, rev=True)
+        save("g5_invblock_dbnet", x=x.numpy(), y_fwd=yf.numpy(), s_fwd=s_f.numpy(), jac_fwd=jf.numpy(),
+             y_rev=yr.numpy(), s_rev=s_r.numpy(), jac_rev=jr.numpy(), **sd_np(blk))
+
+        blk = GA.InvBlockExp(SC.subnet("D2DTNet", "xavier"), 51, 3)
+        x = torch.randn(2 * T, 51, 12, 16, generator=g) * 0.5
+        yf = blk(x)
+        s_f = blk.s.clone()
+        jf = blk.jacobian(x)
+        yr = blk(x, rev=True)
+        s_r = blk.s.clone()
+        jr = blk.jacobian(x, rev=True)
+        save("g5_invblock_d2dt", x=x.numpy(), y_fwd=yf.numpy(), s_fwd=s_f.numpy(), jac_fwd=jf.numpy(),
+             y_rev=yr.numpy(), s_rev=s_r.numpy(), jac_rev=jr.numpy(), **sd_np(blk))
+
+        # ---- G8 SelfC-large stack (seed 10 = yml manual_seed)
+        torch.manual_seed(10)
+        opt = {"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": "l2", "scale": 4, "gmm_k": 5}
+        net = GA.SelfCInvNet(opt, 3, 3, "D2DTNet", [4, 4], 2).eval()
+        x = torch.rand(T, 3, 32, 48, generator=g)
+        z, loss_c = net(x=x, rev=False)
+        out = z
+        for op in reversed(net.operations):
+            out = op.forward(out, True)
+        ops_sd = {k: v for k, v in sd_np(net).items() if k.startswith("operations.")}
+        save("g8_large_stack", x=x.numpy(), z=z.numpy(), loss_c=loss_c.numpy(), x_rev=out.numpy(), **ops_sd)
+        # full reverse through STP(l2): pins the caller-visible reverse call
+        lrq = Quantization()(z[:, :3])
+        xs, hf = net(x=lrq, rev=True)
+        stp_sd = {k: v for k, v in sd_np(net).items() if k.startswith("stp_net.")}
+        save("g7_stp_l2_full_rev", lr=lrq.numpy(), x_rev=xs.numpy(), hf=hf.numpy(), **stp_sd)
+
+        # ---- G8 Haar nets (config C1)
+        torch.manual_seed(8)
+        irn = IA.InvRescaleNet(3, 3, SC.subnet("DBNet", "xavier"), [1], 1)
+        for sub in (irn.operations[1].F, irn.operations[1].G, irn.operations[1].H):
+            rerandomise_conv5(sub, g)
+        x = torch.rand(T, 3, 64, 64, generator=g)
+        lr, hfm = irn(x)
+        zfull = irn.operations[1](irn.operations[0](x))
+        xinv = irn.operations[0](irn.operations[1](zfull, rev=True), rev=True)
+        save("g8_haar_net", x=x.numpy(), lr=lr.numpy(), hf_meansq=hfm.numpy(), z=zfull.numpy(),
+             x_rev=xinv.numpy(), **sd_np(irn))
+
+        # ---- G9 Quantization
+        q = Quantization()
+        v = torch.tensor([-0.3, 0.0, 0.001, 0.00196, 0.00197, 0.5, 0.50196, 0.998, 1.0, 1.7,
+                          1.5 / 255, 2.5 / 255, 0.4999 / 255, 254.5 / 255], dtype=torch.float32)
+        v = torch.cat([v, torch.rand(200, generator=g) * 1.2 - 0.1])
+        save("g9_quant", x=v.numpy(), y=q(v).numpy())
+
+        # ---- G6 GlobalAgg
+        torch.manual_seed(6)
+        ga = GA.GlobalAgg(64)
+        arrs = sd_np(ga)
+        for tag, (hh, ww) in {"a": (16, 16), "b": (20, 36)}.items():
+            x = torch.randn(T, 64, hh, ww, generator=g)
+            arrs[f"{tag}_x"] = x.numpy()
+            arrs[f"{tag}_y"] = ga(x).numpy()
+        save("g6_globalagg", **arrs)
+
+        # ---- G7 STP v2 raw head (gmm): sampling needs the device RNG in the
+        # reference (trap 5), so pin the pre-sampling tensor and the formula with
+        # an injected eps (computed here with the reference's own expression).
+        torch.manual_seed(7)
+        opt = {"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": "gmm", "scale": 4, "gmm_k": 5}
+        stp = GA.STPNet(opt).eval()
+        stp.reparametrize = lambda mu, logvar: eps_holder["eps"].mul(torch.exp(logvar)).add_(mu)
+        lr = torch.rand(T, 3, 8, 12, generator=g)
+        eps = torch.randn(1, 48, 5, T, 8, 12, generator=g)
+        eps_holder = {"eps": eps}
+        stp(lr.reshape(1, T, 3, 8, 12).transpose(1, 2))
+        raw = stp.parameters                          # (1,720,T,8,12)
+        v = stp.gmm_v                                 # (1,48,T,8,12)
+        save("g7_stp_gmm", lr=lr.numpy(), raw=raw[0].transpose(0, 1).numpy(),
+             eps=eps[0].permute(2, 0, 1, 3, 4).numpy(), v=v[0].transpose(0, 1).numpy(), **sd_np(stp))
+
+
+if __name__ == "__main__":
+    main()
