@@ -1,0 +1,130 @@
+/* selfc_hip.h - C ABI of libselfc_hip.so, the MI355X (gfx950) implementation of
+ * SelfC's invertible-rescaling hot path.
+ *
+ * The reference (tianyuan168326/SelfC) has NO native code and no FFI: every op
+ * below replaces a composition of stock torch ops inside a Python nn.Module.
+ * Each entry point cites the reference expression it replaces (paths relative
+ * to codes/).  The binding a reference maintainer would add is a ctypes stub;
+ * it is shown in INTEGRATION.md and implemented in selfc_amd/_lib.py.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by
+ *     the caller; no allocation, no host synchronisation inside any call;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     work is enqueued on it, calls are re-entrant and hipGraph-capturable;
+ *   - return value: 0 on success, SELFC_EINVAL (-1) for a shape/argument the
+ *     kernels do not cover (nothing is launched), or -(hipError_t) - 1000 when
+ *     the HIP runtime refused a launch;
+ *   - "NCHW" tensors are the reference's own layout (fp32, contiguous).
+ *
+ * Internal ("latent") layout used between kernels, for an InvBlockExp with
+ * channel split (c1, c2), c1 <= 3:
+ *   x1    fp32 [N][H][W][4]        first c1 channels real
+ *   x2    fp32 [N][H][W][c2p]      c2p = roundup(c2, 4)
+ *   fd    f16  [N][H][W][FC]       F subnet dense buffer, FC = roundup(c2,32)+128:
+ *                                  [x2 as f16 | zero pad | f1 f2 f3 f4]
+ *   gd,hd f16  [N][H][W][128]      G / H subnet dense feature buffers
+ * N = B*T frames, clip-major (frame n = b*T + t), as in Subnet_constructor.py:119-124.
+ */
+#ifndef SELFC_HIP_H
+#define SELFC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SELFC_OK 0
+#define SELFC_EINVAL (-1)
+
+#define SELFC_SUBNET_D2DT 0   /* Subnet_constructor.py:98-133  (temporal conv5) */
+#define SELFC_SUBNET_DB2D 1   /* Subnet_constructor.py:8-34    (3x3 conv5)      */
+
+/* library / build identification: returns a static string "selfc_hip gfx950 <abi>" */
+const char* selfc_version(void);
+/* number of bytes the packed weights of one conv occupy; mirrors selfc_amd/packing.py */
+int selfc_abi_version(void);
+
+/* ---- split / merge transforms (HBM-bound) --------------------------------- */
+
+/* HaarDownsampling.forward(x, rev=False): Inv_arch.py:64-73.
+ * x NCHW (N,C,H,W) -> y NCHW (N,4C,H/2,W/2), y[:,k*C+c] = band k. H, W even. */
+int selfc_haar_fwd_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream);
+/* HaarDownsampling.forward(x, rev=True): Inv_arch.py:74-81. y (N,4C,h,w) -> x (N,C,2h,2w). */
+int selfc_haar_inv_nchw(const float* y, float* x, int N, int C, int h, int w, void* stream);
+
+/* FrequencyAnalyzer.forward(x, rev=False): SelfC_GMM_arch_inv.py:73-78 (k = 4 or 2).
+ * x NCHW (N,3,H,W) -> latent x1 (lo, 3 ch), x2 (3k^2 ch, channel (sy*k+sx)*3+c),
+ * and, when fd != NULL, the f16 copy of x2 in channels [0,3k^2) of the F dense
+ * buffer with channel stride FC. */
+int selfc_freq_fwd(const float* x, float* x1, float* x2, void* fd, int FC,
+                   int N, int H, int W, int k, void* stream);
+/* FrequencyAnalyzer.forward(x, rev=True): SelfC_GMM_arch_inv.py:79-82 (nn.PixelShuffle
+ * channel order c*k^2+sy*k+sx - deliberately not the inverse of the forward). */
+int selfc_freq_inv(const float* x1, const float* x2, float* x, int N, int h, int w, int k, void* stream);
+
+/* NCHW (N,c1+c2,H,W) <-> latent (x1,x2[,fd]); the narrow/cat of Inv_arch.py:22,33. */
+int selfc_nchw_to_latent(const float* x, float* x1, float* x2, void* fd, int FC,
+                         int N, int c1, int c2, int H, int W, void* stream);
+int selfc_latent_to_nchw(const float* x1, const float* x2, float* y,
+                         int N, int c1, int c2, int H, int W, void* stream);
+
+/* Quantization.forward on the LR channels, in place on x1: Quantization.py:7-17
+ * (clamp to [0,1], round-half-even(x*255)/255). n = number of floats. */
+int selfc_quantize_inplace(float* x, size_t n, void* stream);
+
+/* ---- dense-block subnets --------------------------------------------------- */
+
+typedef struct {
+  const void* w3[4];     /* packed f16 MFMA A-fragments of conv1..conv4 (packing.py) */
+  const float* b3[4];    /* 32 fp32 biases each                                       */
+  const void* w5;        /* packed conv5 fragments                                    */
+  const float* b5;       /* conv5 bias, zero-padded to a multiple of 32 floats        */
+} selfc_subnet_w;
+
+typedef struct {
+  selfc_subnet_w F;      /* F: c2 -> c1 */
+  selfc_subnet_w G;      /* G: c1 -> c2 ; G.w5 holds the G+H conv5 fragments interleaved */
+  selfc_subnet_w H;      /* H: c1 -> c2 ; H.w5 unused (NULL)                             */
+  float clamp;           /* InvBlockExp.clamp, Inv_arch.py:15 */
+} selfc_invblock_w;
+
+typedef struct {
+  int kind;              /* SELFC_SUBNET_D2DT / SELFC_SUBNET_DB2D */
+  int N, T, H, W;        /* frames (B*T), temporal length, latent height/width */
+  int c1, c2;            /* channel split (c1 <= 3, c2 <= 96 for D2DT, c2 <= 32 for DB2D) */
+  float* x1;             /* latent state, updated in place */
+  float* x2;
+  void* fd;              /* workspaces (see layout above) */
+  void* gd;
+  void* hd;
+  float* s_out;          /* optional: InvBlockExp.s as fp32 [N][H][W][c2p], or NULL */
+} selfc_latent;
+
+/* InvBlockExp.forward(x, rev): Inv_arch.py:21-33 on the latent layout.
+ * Precondition: channels [0,c2) of `fd` hold x2 as f16 when rev == 0 (every
+ * producer in this library maintains that).  Postcondition: the same holds for
+ * the updated x2, so blocks chain without touching NCHW. */
+int selfc_invblock_run(const selfc_invblock_w* blk, const selfc_latent* lat, int rev, void* stream);
+/* nblk consecutive InvBlockExp (the op loops of SelfC_GMM_arch_inv.py:455-456 and
+ * :486-487): blocks 0..nblk-1 when rev == 0, nblk-1..0 when rev != 0. */
+int selfc_invstack_run(const selfc_invblock_w* blks, int nblk, const selfc_latent* lat, int rev, void* stream);
+
+/* One stand-alone subnet (DenseBlock.forward / D2DTInput.forward,
+ * Subnet_constructor.py:26-34,115-133): input NHWC fp32 `xin` with channel
+ * stride cinp = roundup(cin,4), output NHWC fp32 `yout` with stride
+ * coutp = roundup(cout,4); `dense` is a [N][H][W][DC] f16 workspace with
+ * DC = (cin <= 3 ? 128 : roundup(cin,32)+128). */
+int selfc_subnet_run(const selfc_subnet_w* w, int kind, const float* xin, float* yout, void* dense,
+                     int N, int T, int H, int W, int cin, int cout, void* stream);
+
+/* NHWC(4-padded) fp32 <-> NCHW fp32 helpers for the stand-alone subnet entry. */
+int selfc_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, void* stream);
+int selfc_nhwc4_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SELFC_HIP_H */

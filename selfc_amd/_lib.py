@@ -1,0 +1,96 @@
+"""ctypes binding of libselfc_hip.so (C ABI: include/selfc_hip.h).
+
+This is the binding a reference maintainer would add: plain
+pointers (``tensor.data_ptr()``), sizes and the current HIP stream.  Loading
+fails loudly - there is no fallback implementation behind it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libselfc_hip.so")
+
+SUBNET_D2DT = 0
+SUBNET_DB2D = 1
+
+#: every symbol include/selfc_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "selfc_version", "selfc_abi_version",
+    "selfc_haar_fwd_nchw", "selfc_haar_inv_nchw", "selfc_freq_fwd", "selfc_freq_inv",
+    "selfc_nchw_to_latent", "selfc_latent_to_nchw", "selfc_quantize_inplace",
+    "selfc_invblock_run", "selfc_invstack_run", "selfc_subnet_run",
+    "selfc_nchw_to_nhwc4", "selfc_nhwc4_to_nchw",
+]
+
+
+class SubnetW(C.Structure):
+    _fields_ = [("w3", C.c_void_p * 4), ("b3", C.c_void_p * 4), ("w5", C.c_void_p), ("b5", C.c_void_p)]
+
+
+class InvBlockW(C.Structure):
+    _fields_ = [("F", SubnetW), ("G", SubnetW), ("H", SubnetW), ("clamp", C.c_float)]
+
+
+class Latent(C.Structure):
+    _fields_ = [("kind", C.c_int), ("N", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("c1", C.c_int), ("c2", C.c_int),
+                ("x1", C.c_void_p), ("x2", C.c_void_p), ("fd", C.c_void_p), ("gd", C.c_void_p),
+                ("hd", C.c_void_p), ("s_out", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C selfc_amd/csrc`). selfc_amd has no CPU / eager fallback.")
+        L = C.CDLL(LIB_PATH)
+        vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+        L.selfc_version.restype = C.c_char_p
+        L.selfc_version.argtypes = []
+        L.selfc_abi_version.restype = i
+        L.selfc_abi_version.argtypes = []
+        sigs = {
+            "selfc_haar_fwd_nchw": [vp, vp, i, i, i, i, vp],
+            "selfc_haar_inv_nchw": [vp, vp, i, i, i, i, vp],
+            "selfc_freq_fwd": [vp, vp, vp, vp, i, i, i, i, i, vp],
+            "selfc_freq_inv": [vp, vp, vp, i, i, i, i, vp],
+            "selfc_nchw_to_latent": [vp, vp, vp, vp, i, i, i, i, i, i, vp],
+            "selfc_latent_to_nchw": [vp, vp, vp, i, i, i, i, i, vp],
+            "selfc_quantize_inplace": [vp, sz, vp],
+            "selfc_invblock_run": [C.POINTER(InvBlockW), C.POINTER(Latent), i, vp],
+            "selfc_invstack_run": [C.POINTER(InvBlockW), i, C.POINTER(Latent), i, vp],
+            "selfc_subnet_run": [C.POINTER(SubnetW), i, vp, vp, vp, i, i, i, i, i, i, vp],
+            "selfc_nchw_to_nhwc4": [vp, vp, i, i, i, i, vp],
+            "selfc_nhwc4_to_nchw": [vp, vp, i, i, i, i, vp],
+        }
+        for name, args in sigs.items():
+            fn = getattr(L, name)
+            fn.restype = i
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc == -1:
+        raise RuntimeError(f"{what}: SELFC_EINVAL - shape/argument not covered by the HIP kernels")
+    raise RuntimeError(f"{what}: HIP runtime error {-(rc + 1000)}")
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream (kernels are enqueued there)."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("selfc_amd runs on MI355X only: tensor is on %s (no CPU fallback)" % t.device)

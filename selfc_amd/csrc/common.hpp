@@ -1,0 +1,41 @@
+// Shared device helpers for the gfx950 kernels of libselfc_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace selfc {
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// native 16-byte vector: unlike HIP's uint4 struct, a load of it is a first-class value (no
+// aggregate memcpy into a private array, which hipcc fails to promote out of scratch)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// LDS pixel stride of a staged activation tile: 32 f16 channels (64 B) + 16 B
+// pad = 5 sixteen-byte slots; 5 is coprime with the 16 slots of a 256-B bank
+// row, so 16 consecutive pixels read by one ds_read_b128 lane group hit 16
+// different slots.
+constexpr int PS = 80;
+
+__device__ __forceinline__ float lrelu02(float v) { return v >= 0.f ? v : 0.2f * v; }
+
+// MI355X deals consecutive workgroup ids round-robin over its 8 XCDs (private
+// L2 each).  Remap so that each XCD receives a CONTIGUOUS range of logical tile
+// ids: neighbouring tiles (which share halo pixels and the same weights) then
+// hit the same L2.  Bijective for any grid size.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  f16x2 h = {(f16)a, (f16)b};
+  return __builtin_bit_cast(uint32_t, h);
+}
+
+}  // namespace selfc

@@ -1,0 +1,738 @@
+// Dense-block convolutions + fused affine coupling for gfx950 (MI355X).
+//
+//   conv3x3_kernel   conv1..4 of DenseBlock / D2DTInput (Subnet_constructor.py:27-30,
+//                    126-129) as a direct (im2col-free) convolution on a concat-free
+//                    NHWC f16 dense buffer: reads channel ranges ("stages") of the
+//                    buffer, appends 32 channels.  With EPI != LRELU it is the 3x3
+//                    conv5 of the 2-D DenseBlock (:31) with the coupling of
+//                    Inv_arch.py:25-31 fused into the epilogue.
+//   tconv5_kernel    conv5 of D2DTInput (:106,130): 3-tap temporal conv, frames of a
+//                    clip walked sequentially so every dense feature is read once;
+//                    coupling fused into the epilogue.
+//
+// MFMA orientation: D[outch][pixel] = sum_k W[outch][k] * act[k][pixel], i.e. the
+// packed weights are the A operand and the activations the B operand.  A lane
+// then owns one pixel and 4-channel groups of it, so epilogue loads/stores are
+// 8/16-byte vectors on NHWC rows.  Operands are f16 (weights and activations
+// rounded once), accumulation and all coupling arithmetic are fp32.
+#include "common.hpp"
+#include "../../include/selfc_hip.h"
+
+using namespace selfc;
+
+namespace {
+
+inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 1000; }
+
+enum { EPI_LRELU = 0, EPI_PLAIN = 1, EPI_F = 2, EPI_GH = 3 };
+
+struct C3Stage {
+  int coff;   // first channel of the stage in the dense buffer
+  int width;  // 16 or 32 channels
+  int kind;   // 0: 9-tap stage of the dense buffer; 1: im2col stage built from x1 (K = 9*c1 <= 32)
+};
+
+// The stage list of a conv is regular, so it is described by four integers and
+// decoded with scalar arithmetic (a by-value array indexed by the stage loop
+// would be spilled to scratch):
+//   has_im2col : stage 0 is the im2col stage, stages s >= 1 are features s-1
+//   otherwise  : stages 0..n_in-1 cover the cin16 input channels in 32-wide
+//                pieces (last one 16 wide when cin16 % 32 == 16), followed by
+//                features at channel fbase + 32*i.
+struct C3Args {
+  const f16* dense[2];   // per net (blockIdx.z, or the G/H loop of EPI_GH)
+  const f16* w[2];       // packed A fragments
+  const float* bias[2];  // 32 floats
+  const float* x1;       // NHWC4 fp32 source of the im2col stage
+  f16* out[2];           // EPI_LRELU: dense buffer to append to
+  int N, H, W, C;        // frames, latent size, channel stride of dense / out
+  int c1;                // channels of the im2col source
+  int nstages;
+  int out_coff;
+  int tiles_x, tiles_y;
+  int has_im2col, cin16, n_in, fbase;
+  // coupling / plain epilogue (EPI != LRELU)
+  float* x1io;           // EPI_F: y1 = x1 +- F, in place          [N][H][W][4]
+  float* x2io;           // EPI_GH: y2, in place                   [N][H][W][c2p]
+  f16* fd;               // EPI_GH: f16 copy of y2 into the F dense buffer (stride fC) or null
+  float* s_out;          // EPI_GH: optional s                      [N][H][W][c2p]
+  float* plain;          // EPI_PLAIN: fp32 NHWC output, stride coutp
+  int c2p, fC, coutp, rev;
+  float clamp;
+};
+
+// ---------------------------------------------------------------------------------
+// conv3x3: workgroup = TH x TW output pixels of one frame, NW waves, MT 32-pixel
+// M-tiles (2 rows x 16 cols) per wave.  Per stage: the (TH+2)x(TW+2) halo tile of
+// <=32 channels and the stage's weight fragments are staged in LDS (register
+// prefetch of stage s+1 is issued before the MFMAs of stage s).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ C3Stage stage_of(const C3Args& a, const int s) {
+  if (a.has_im2col) return s == 0 ? C3Stage{0, 32, 1} : C3Stage{a.fbase + 32 * (s - 1), 32, 0};
+  if (s < a.n_in) return C3Stage{32 * s, (a.cin16 - 32 * s >= 32) ? 32 : 16, 0};
+  return C3Stage{a.fbase + 32 * (s - a.n_in), 32, 0};
+}
+
+template <int TH, int TW, int NW, int MT, int EPI>
+__global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
+  static_assert(TH * TW == NW * MT * 32, "tile must be covered by the waves' M-tiles");
+  static_assert(TW % 16 == 0 && TH % 2 == 0, "M-tiles are 2 rows x 16 cols");
+  constexpr int HWD = TW + 2, NPIX = (TH + 2) * HWD;
+  constexpr int NT = NW * 64;
+  constexpr int ACT_BYTES = ((NPIX * PS + 1023) / 1024) * 1024;
+  constexpr int AITER = (NPIX * 4 + NT - 1) / NT;
+  constexpr int WITER = (18 * 64 + NT - 1) / NT;
+  constexpr int NNETS = (EPI == EPI_GH) ? 2 : 1;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const lact = smem;
+  unsigned char* const lw = smem + ACT_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wg = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tx = wg % a.tiles_x;
+  const int ty = (wg / a.tiles_x) % a.tiles_y;
+  const int n = wg / (a.tiles_x * a.tiles_y);
+  const int tx0 = tx * TW, ty0 = ty * TH;
+  const int H = a.H, W = a.W, C = a.C;
+
+  // this lane's pixel in each of the wave's M-tiles
+  int pbase[MT];      // byte offset of the pixel's tap (0,0) in the LDS halo tile (+ k-half)
+  int py[MT], px[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int mt = wave * MT + m;
+    const int by = mt / (TW / 16), bx = mt % (TW / 16);
+    py[m] = 2 * by + ((lane & 31) >> 4);
+    px[m] = 16 * bx + (lane & 15);
+    pbase[m] = (py[m] * HWD + px[m]) * PS + (lane >> 5) * 16;
+  }
+
+  f32x16 acc[NNETS][MT];
+#pragma unroll
+  for (int q = 0; q < NNETS; ++q)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][m][r] = 0.f;
+
+#pragma unroll
+  for (int net_i = 0; net_i < NNETS; ++net_i) {
+    const int net = (EPI == EPI_GH) ? net_i : (int)blockIdx.z;
+    // ternaries, not a.dense[net]: a dynamically indexed by-value array goes to scratch
+    const f16* __restrict__ dense = net ? a.dense[1] : a.dense[0];
+    const u32x4* __restrict__ wsrc = reinterpret_cast<const u32x4*>(net ? a.w[1] : a.w[0]);
+
+    u32x4 areg[AITER];
+    u32x4 wreg[WITER];
+    int fragbase = 0;  // fragments consumed by earlier stages
+
+    // -- staging helpers -------------------------------------------------------
+    auto load_stage = [&](const C3Stage st, const int fb) __attribute__((always_inline)) {
+      const int cshift = st.width == 32 ? 2 : 1;  // 16-byte chunks per pixel: 4 or 2
+      const int nitems = NPIX << cshift;
+#pragma unroll
+      for (int it = 0; it < AITER; ++it) {
+        // branch-free: masked items load from a clamped (valid) address and are zeroed by a select
+        const int i = tid + it * NT;
+        const int p = i >> cshift, q = i & ((1 << cshift) - 1);
+        const int hy = p / HWD, hx = p - hy * HWD;
+        const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+        const bool ok = (i < nitems) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
+        const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(dense + ((size_t)(n * H + yc) * W + xc) * C + st.coff + q * 8);
+        areg[it] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+      }
+      const int nfr = 9 * (st.width >> 4);
+#pragma unroll
+      for (int it = 0; it < WITER; ++it) {
+        const int i = min(tid + it * NT, nfr * 64 - 1);  // unconditional (clamped): keeps wreg in registers
+        wreg[it] = wsrc[(size_t)fb * 64 + i];
+      }
+    };
+    auto store_stage = [&](const C3Stage st) __attribute__((always_inline)) {
+      const int cshift = st.width == 32 ? 2 : 1;
+      const int nitems = NPIX << cshift;
+#pragma unroll
+      for (int it = 0; it < AITER; ++it) {
+        const int i = tid + it * NT;
+        if (i < nitems) {
+          const int p = i >> cshift, q = i & ((1 << cshift) - 1);
+          *reinterpret_cast<u32x4*>(lact + p * PS + q * 16) = areg[it];
+        }
+      }
+      const int nfr = 9 * (st.width >> 4);
+#pragma unroll
+      for (int it = 0; it < WITER; ++it) {
+        const int i = tid + it * NT;
+        if (i < nfr * 64) *reinterpret_cast<u32x4*>(lw + i * 16) = wreg[it];
+      }
+    };
+    // im2col stage: row of pixel p holds x1[p + tap][c] at k = tap*c1 + c, zero above 9*c1
+    auto fill_im2col = [&]() __attribute__((always_inline)) {
+      const int c1 = a.c1;
+      for (int i = tid; i < TH * TW * 10; i += NT) {
+        const int p = i / 10, tap = i - p * 10;
+        const int ly = p / TW, lx = p - ly * TW;
+        unsigned char* row = lact + ((ly + 1) * HWD + (lx + 1)) * PS;
+        if (tap == 9) {
+          for (int k = 9 * c1; k < 32; ++k) reinterpret_cast<f16*>(row)[k] = (f16)0.f;
+        } else {
+          const int y = ty0 + ly + tap / 3 - 1, x = tx0 + lx + tap % 3 - 1;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (y >= 0 && y < H && x >= 0 && x < W)
+            v = *reinterpret_cast<const float4*>(a.x1 + ((size_t)(n * H + y) * W + x) * 4);
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int c = 0; c < c1; ++c) reinterpret_cast<f16*>(row)[tap * c1 + c] = (f16)vv[c];
+        }
+      }
+      for (int i = tid; i < 2 * 64; i += NT) *reinterpret_cast<u32x4*>(lw + i * 16) = wsrc[i];
+    };
+
+    // -- prologue: stage 0 --------------------------------------------------------
+    if (net_i > 0) __syncthreads();  // previous net's last MFMAs are done with LDS
+    if (a.has_im2col) {
+      fill_im2col();
+    } else {
+      const C3Stage st0 = stage_of(a, 0);
+      load_stage(st0, 0);
+      store_stage(st0);
+    }
+    __syncthreads();
+
+    for (int s = 0; s < a.nstages; ++s) {
+      const C3Stage st = stage_of(a, s);
+      const C3Stage stn = stage_of(a, s + 1);
+      const int nfr = st.kind == 1 ? 2 : 9 * (st.width >> 4);
+      const bool more = s + 1 < a.nstages;
+      if (more) load_stage(stn, fragbase + nfr);
+
+      if (st.kind == 1) {
+        constexpr int CTR = (HWD + 1) * PS;  // centre tap
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const f16x8 af = *reinterpret_cast<const f16x8*>(lw + ks * 1024 + lane * 16);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const f16x8 bf = *reinterpret_cast<const f16x8*>(lact + pbase[m] + CTR + ks * 32);
+            acc[net_i][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[net_i][m], 0, 0, 0);
+          }
+        }
+      } else if (st.width == 32) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const f16x8 af = *reinterpret_cast<const f16x8*>(lw + (tap * 2 + ks) * 1024 + lane * 16);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              const f16x8 bf = *reinterpret_cast<const f16x8*>(lact + pbase[m] + ((tap / 3) * HWD + tap % 3) * PS + ks * 32);
+              acc[net_i][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[net_i][m], 0, 0, 0);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const f16x8 af = *reinterpret_cast<const f16x8*>(lw + tap * 1024 + lane * 16);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const f16x8 bf = *reinterpret_cast<const f16x8*>(lact + pbase[m] + ((tap / 3) * HWD + tap % 3) * PS);
+            acc[net_i][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[net_i][m], 0, 0, 0);
+          }
+        }
+      }
+      fragbase += nfr;
+      if (more) {
+        __syncthreads();
+        store_stage(stn);
+        __syncthreads();
+      }
+    }
+  }
+
+  // -- epilogue -------------------------------------------------------------------
+  // acc[..][m][r]: pixel = lane&31 of M-tile m, outch = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int half = lane >> 5;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int y = ty0 + py[m], x = tx0 + px[m];
+    if (y >= H || x >= W) continue;
+    const size_t pix = (size_t)(n * H + y) * W + x;
+    if (EPI == EPI_LRELU) {
+      const float* __restrict__ bias = blockIdx.z ? a.bias[1] : a.bias[0];
+      f16* dst = (blockIdx.z ? a.out[1] : a.out[0]) + pix * C + a.out_coff + 4 * half;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + 8 * g + 4 * half);
+        uint2 u;
+        u.x = pack2(lrelu02(acc[0][m][4 * g + 0] + b.x), lrelu02(acc[0][m][4 * g + 1] + b.y));
+        u.y = pack2(lrelu02(acc[0][m][4 * g + 2] + b.z), lrelu02(acc[0][m][4 * g + 3] + b.w));
+        *reinterpret_cast<uint2*>(dst + 8 * g) = u;
+      }
+    } else if (EPI == EPI_PLAIN) {
+      const float* __restrict__ bias = a.bias[0];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int oc = 8 * g + 4 * half;
+        if (oc < a.coutp) {
+          const float4 b = *reinterpret_cast<const float4*>(bias + oc);
+          *reinterpret_cast<float4*>(a.plain + pix * a.coutp + oc) =
+              make_float4(acc[0][m][4 * g] + b.x, acc[0][m][4 * g + 1] + b.y, acc[0][m][4 * g + 2] + b.z, acc[0][m][4 * g + 3] + b.w);
+        }
+      }
+    } else if (EPI == EPI_F) {
+      // y1 = x1 + F(x2)  (Inv_arch.py:25)  /  y1 = x1 - F(y2)  (:31); outch 0..3 live in g == 0, half == 0
+      if (half == 0) {
+        const float4 b = *reinterpret_cast<const float4*>(a.bias[0]);
+        float4 v = *reinterpret_cast<float4*>(a.x1io + pix * 4);
+        const float sgn = a.rev ? -1.f : 1.f;
+        v.x += sgn * (acc[0][m][0] + b.x);
+        v.y += sgn * (acc[0][m][1] + b.y);
+        v.z += sgn * (acc[0][m][2] + b.z);
+        v.w += sgn * (acc[0][m][3] + b.w);
+        *reinterpret_cast<float4*>(a.x1io + pix * 4) = v;
+      }
+    } else {  // EPI_GH: s = clamp*(2*sigmoid(H)-1); y2 = x2*exp(s)+G  /  (x2-G)/exp(s)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int oc = 8 * g + 4 * half;
+        if (oc < a.c2p) {
+          const float4 bg = *reinterpret_cast<const float4*>(a.bias[0] + oc);
+          const float4 bh = *reinterpret_cast<const float4*>(a.bias[1] + oc);
+          const float4 xv = *reinterpret_cast<const float4*>(a.x2io + pix * a.c2p + oc);
+          const float xin[4] = {xv.x, xv.y, xv.z, xv.w};
+          const float gb[4] = {bg.x, bg.y, bg.z, bg.w}, hb[4] = {bh.x, bh.y, bh.z, bh.w};
+          float yo[4], so[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float gv = acc[0][m][4 * g + j] + gb[j];
+            const float hv = acc[1][m][4 * g + j] + hb[j];
+            const float s = a.clamp * (2.f / (1.f + expf(-hv)) - 1.f);
+            so[j] = s;
+            yo[j] = a.rev ? (xin[j] - gv) / expf(s) : xin[j] * expf(s) + gv;
+          }
+          *reinterpret_cast<float4*>(a.x2io + pix * a.c2p + oc) = make_float4(yo[0], yo[1], yo[2], yo[3]);
+          if (a.s_out) *reinterpret_cast<float4*>(a.s_out + pix * a.c2p + oc) = make_float4(so[0], so[1], so[2], so[3]);
+          if (a.fd) {
+            uint2 u;
+            u.x = pack2(yo[0], yo[1]);
+            u.y = pack2(yo[2], yo[3]);
+            *reinterpret_cast<uint2*>(a.fd + pix * a.fC + oc) = u;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// tconv5: out[t] = W0 d[t-1] + W1 d[t] + W2 d[t+1] (+bias), zero outside the clip.
+// Workgroup = 8 waves x 16 pixels of one clip; all weight fragments live in LDS for
+// the lifetime of the workgroup; each wave walks t = 0..T-1, loads d[t] once as MFMA
+// B fragments straight from global memory (no cross-wave reuse -> no LDS), and adds
+// its three contributions to rotating accumulators for out[t+1], out[t], out[t-1].
+// MFMA 16x16x32: A = W[16 outch][32 k] (LDS), B = d[32 k][16 px].
+// ---------------------------------------------------------------------------------
+struct T5Args {
+  const f16* dense[2];
+  const f16* w;           // fragments [3 taps][NETS][KS][OT][64 lanes][8]
+  const float* bias[2];   // OT*16 floats (zero padded)
+  const float* x1;        // HASX: NHWC4 fp32, channels 0..2 are the first three K entries
+  int B, T, HW, C;        // clips, frames per clip, pixels per frame, channel stride of dense
+  float* x1io;
+  float* x2io;
+  f16* fd;
+  float* s_out;
+  float* plain;
+  int c2p, fC, coutp, rev;
+  float clamp;
+};
+
+template <int NETS, int OT, int KD, int HASX, int EPI>
+__global__ __launch_bounds__(512) void tconv5_kernel(const T5Args a) {
+  constexpr int KS = KD + HASX;
+  constexpr int NFRAG = 3 * NETS * KS * OT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    const uint4* __restrict__ wsrc = reinterpret_cast<const uint4*>(a.w);
+    for (int i = tid; i < NFRAG * 64; i += 512) *reinterpret_cast<uint4*>(smem + (size_t)i * 16) = wsrc[i];
+  }
+  __syncthreads();
+
+  const int tiles = (a.HW + 127) / 128;
+  const int wg = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int b = wg / tiles;
+  const int p0 = (wg % tiles) * 128 + wave * 16;
+  const int pl = p0 + (lane & 15);
+  const bool pvalid = pl < a.HW;
+  const int pc = pvalid ? pl : a.HW - 1;   // clamp loads of masked lanes to a valid pixel
+  const int kq = lane >> 4;                // this lane's 8-channel group of a 32-wide k-step
+  if (p0 >= a.HW) return;                  // whole wave outside (no barriers below)
+
+  f32x4 accp[NETS][OT], accc[NETS][OT], accn[NETS][OT];
+#pragma unroll
+  for (int q = 0; q < NETS; ++q)
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+      accp[q][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+      accc[q][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+      accn[q][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+  u32x4 bcur[NETS][KD], bnxt[NETS][KD];
+  float4 xcur = make_float4(0.f, 0.f, 0.f, 0.f), xnxt = xcur;
+
+  auto load_frame = [&](u32x4 (&dst)[NETS][KD], float4& xd, const int t) __attribute__((always_inline)) {
+    const size_t pix = (size_t)(b * a.T + t) * a.HW + pc;
+#pragma unroll
+    for (int q = 0; q < NETS; ++q)
+#pragma unroll
+      for (int ks = 0; ks < KD; ++ks)
+        dst[q][ks] = *reinterpret_cast<const u32x4*>((q ? a.dense[1] : a.dense[0]) + pix * a.C + ks * 32 + kq * 8);
+    if (HASX) xd = *reinterpret_cast<const float4*>(a.x1 + pix * 4);
+  };
+
+  auto epilogue = [&](const int t, f32x4 (&acc)[NETS][OT]) __attribute__((always_inline)) {
+    if (!pvalid) return;
+    const size_t pix = (size_t)(b * a.T + t) * a.HW + pl;
+    if (EPI == EPI_PLAIN) {
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+        const int oc = o * 16 + kq * 4;
+        if (oc < a.coutp) {
+          const float4 bb = *reinterpret_cast<const float4*>(a.bias[0] + oc);
+          *reinterpret_cast<float4*>(a.plain + pix * a.coutp + oc) =
+              make_float4(acc[0][o][0] + bb.x, acc[0][o][1] + bb.y, acc[0][o][2] + bb.z, acc[0][o][3] + bb.w);
+        }
+      }
+    } else if (EPI == EPI_F) {
+      if (kq == 0) {
+        const float4 bb = *reinterpret_cast<const float4*>(a.bias[0]);
+        float4 v = *reinterpret_cast<float4*>(a.x1io + pix * 4);
+        const float sgn = a.rev ? -1.f : 1.f;
+        v.x += sgn * (acc[0][0][0] + bb.x);
+        v.y += sgn * (acc[0][0][1] + bb.y);
+        v.z += sgn * (acc[0][0][2] + bb.z);
+        v.w += sgn * (acc[0][0][3] + bb.w);
+        *reinterpret_cast<float4*>(a.x1io + pix * 4) = v;
+      }
+    } else {
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+        const int oc = o * 16 + kq * 4;
+        if (oc < a.c2p) {
+          const float4 bg = *reinterpret_cast<const float4*>(a.bias[0] + oc);
+          const float4 bh = *reinterpret_cast<const float4*>(a.bias[NETS - 1] + oc);
+          const float4 xv = *reinterpret_cast<const float4*>(a.x2io + pix * a.c2p + oc);
+          const float xin[4] = {xv.x, xv.y, xv.z, xv.w};
+          const float gb[4] = {bg.x, bg.y, bg.z, bg.w}, hb[4] = {bh.x, bh.y, bh.z, bh.w};
+          float yo[4], so[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float gv = acc[0][o][j] + gb[j];
+            const float hv = acc[NETS - 1][o][j] + hb[j];
+            const float s = a.clamp * (2.f / (1.f + expf(-hv)) - 1.f);
+            so[j] = s;
+            yo[j] = a.rev ? (xin[j] - gv) / expf(s) : xin[j] * expf(s) + gv;
+          }
+          *reinterpret_cast<float4*>(a.x2io + pix * a.c2p + oc) = make_float4(yo[0], yo[1], yo[2], yo[3]);
+          if (a.s_out) *reinterpret_cast<float4*>(a.s_out + pix * a.c2p + oc) = make_float4(so[0], so[1], so[2], so[3]);
+          if (a.fd) {
+            uint2 u;
+            u.x = pack2(yo[0], yo[1]);
+            u.y = pack2(yo[2], yo[3]);
+            *reinterpret_cast<uint2*>(a.fd + pix * a.fC + oc) = u;
+          }
+        }
+      }
+    }
+  };
+
+  load_frame(bcur, xcur, 0);
+  for (int t = 0; t < a.T; ++t) {
+    if (t + 1 < a.T) load_frame(bnxt, xnxt, t + 1);
+#pragma unroll
+    for (int q = 0; q < NETS; ++q) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        f16x8 bf;
+        if (HASX && ks == 0) {
+          // K entries 0..2 = the three input channels of this frame; lanes of k-groups 1..3 carry zeros
+          u32x4 u = {0u, 0u, 0u, 0u};
+          if (kq == 0) {
+            u.x = pack2(xcur.x, xcur.y);
+            u.y = pack2(xcur.z, 0.f);
+          }
+          bf = __builtin_bit_cast(f16x8, u);
+        } else {
+          bf = __builtin_bit_cast(f16x8, bcur[q][ks - HASX]);
+        }
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+          const unsigned char* wb = smem + ((size_t)((q * KS + ks) * OT + o) * 64 + lane) * 16;
+          constexpr size_t TAPSTRIDE = (size_t)NETS * KS * OT * 1024;
+          const f16x8 a0 = *reinterpret_cast<const f16x8*>(wb);
+          const f16x8 a1 = *reinterpret_cast<const f16x8*>(wb + TAPSTRIDE);
+          const f16x8 a2 = *reinterpret_cast<const f16x8*>(wb + 2 * TAPSTRIDE);
+          accn[q][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bf, accn[q][o], 0, 0, 0);  // -> out[t+1]
+          accc[q][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf, accc[q][o], 0, 0, 0);  // -> out[t]
+          accp[q][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bf, accp[q][o], 0, 0, 0);  // -> out[t-1]
+        }
+        // keep the scheduler from hoisting every k-step's weight reads (it spills at 90 fragments)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (t >= 1) epilogue(t - 1, accp);
+#pragma unroll
+    for (int q = 0; q < NETS; ++q)
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+        accp[q][o] = accc[q][o];
+        accc[q][o] = accn[q][o];
+        accn[q][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int q = 0; q < NETS; ++q)
+#pragma unroll
+      for (int ks = 0; ks < KD; ++ks) bcur[q][ks] = bnxt[q][ks];
+    xcur = xnxt;
+  }
+  epilogue(a.T - 1, accp);
+}
+
+// fp32 NHWC (stride cinp) -> f16 channels [0, cin32) of the dense buffer (zero padded)
+__global__ void nhwc_to_dense_kernel(const float* __restrict__ x, f16* __restrict__ d, size_t npix, int cin, int cinp, int cin32, int DC) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix) return;
+  for (int c0 = 0; c0 < cin32; c0 += 4) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < cinp) {
+      const float4 r = *reinterpret_cast<const float4*>(x + i * cinp + c0);
+      v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c0 + j >= cin) v[j] = 0.f;
+    uint2 u;
+    u.x = pack2(v[0], v[1]);
+    u.y = pack2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(d + i * DC + c0) = u;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// host-side launch helpers
+// ---------------------------------------------------------------------------------
+constexpr int C3_TH = 16, C3_TW = 16, C3_NW = 4, C3_MT = 2;
+constexpr int C3_LDS = (((C3_TH + 2) * (C3_TW + 2) * PS + 1023) / 1024) * 1024 + 18 * 1024;
+
+template <int EPI>
+int launch_conv3x3(C3Args& a, int nets_z, hipStream_t s) {
+  a.tiles_x = (a.W + C3_TW - 1) / C3_TW;
+  a.tiles_y = (a.H + C3_TH - 1) / C3_TH;
+  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), 1, (unsigned)nets_z);
+  hipLaunchKernelGGL((conv3x3_kernel<C3_TH, C3_TW, C3_NW, C3_MT, EPI>), grid, dim3(C3_NW * 64), C3_LDS, s, a);
+  return hip_rc(hipGetLastError());
+}
+
+// stage description of conv `layer` (1..5) of a dense block with `cin` inputs.
+// Dense layout: cin <= 3 : [f1 f2 f3 f4] (input comes from x1 through the im2col stage)
+//               cin  > 3 : [x (cin, zero padded to cin32) | f1 f2 f3 f4]
+void build_stages(C3Args& a, int cin, int layer) {
+  if (cin <= 3) {
+    a.has_im2col = 1; a.cin16 = 0; a.n_in = 0; a.fbase = 0;
+    a.nstages = 1 + (layer - 1);
+  } else {
+    a.has_im2col = 0;
+    a.cin16 = (cin + 15) & ~15;
+    a.n_in = (a.cin16 + 31) / 32;
+    a.fbase = (cin + 31) & ~31;
+    a.nstages = a.n_in + (layer - 1);
+  }
+}
+
+inline int dense_channels(int cin) { return cin <= 3 ? 128 : ((cin + 31) & ~31) + 128; }
+
+template <int NETS, int OT, int KD, int HASX, int EPI>
+int launch_t5(const T5Args& a, hipStream_t s) {
+  constexpr int lds = 3 * NETS * (KD + HASX) * OT * 1024;
+  static bool attr_done = false;
+  if (lds > 64 * 1024 && !attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv5_kernel<NETS, OT, KD, HASX, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return hip_rc(e);
+    attr_done = true;
+  }
+  const int tiles = (a.HW + 127) / 128;
+  hipLaunchKernelGGL((tconv5_kernel<NETS, OT, KD, HASX, EPI>), dim3((unsigned)(tiles * a.B)), dim3(512), lds, s, a);
+  return hip_rc(hipGetLastError());
+}
+
+// dispatch over the compiled (outch tiles, dense k-steps) combinations
+template <int NETS, int HASX, int EPI>
+int dispatch_t5(const T5Args& a, int ot, int kd, hipStream_t s) {
+#define SELFC_T5_CASE(OT_, KD_) \
+  if (ot == OT_ && kd == KD_) return launch_t5<NETS, OT_, KD_, HASX, EPI>(a, s);
+  SELFC_T5_CASE(1, 4) SELFC_T5_CASE(1, 5) SELFC_T5_CASE(1, 6) SELFC_T5_CASE(1, 7)
+  SELFC_T5_CASE(2, 4) SELFC_T5_CASE(2, 5) SELFC_T5_CASE(2, 6)
+  SELFC_T5_CASE(3, 4) SELFC_T5_CASE(3, 5) SELFC_T5_CASE(3, 6)
+  SELFC_T5_CASE(4, 4) SELFC_T5_CASE(4, 5) SELFC_T5_CASE(4, 6)
+#undef SELFC_T5_CASE
+  return SELFC_EINVAL;
+}
+
+bool latent_ok(const selfc_latent* l) {
+  if (!l || !l->x1 || !l->x2 || !l->fd || !l->gd || !l->hd) return false;
+  if (l->N <= 0 || l->T <= 0 || l->N % l->T || l->H <= 0 || l->W <= 0) return false;
+  if (l->c1 < 1 || l->c1 > 3 || l->c2 < 4) return false;
+  if (l->kind == SELFC_SUBNET_D2DT) return l->c2 <= 96;
+  if (l->kind == SELFC_SUBNET_DB2D) return l->c2 <= 32;
+  return false;
+}
+
+// conv1..4 of one subnet (or of the G/H pair when wb != null) on its dense buffer(s)
+int run_conv1to4(const selfc_subnet_w* wa, const selfc_subnet_w* wb, void* da, void* db, const float* x1,
+                 int cin, int N, int H, int W, hipStream_t s) {
+  for (int layer = 1; layer <= 4; ++layer) {
+    C3Args a{};
+    a.dense[0] = (const f16*)da; a.out[0] = (f16*)da;
+    a.w[0] = (const f16*)wa->w3[layer - 1]; a.bias[0] = wa->b3[layer - 1];
+    if (wb) {
+      a.dense[1] = (const f16*)db; a.out[1] = (f16*)db;
+      a.w[1] = (const f16*)wb->w3[layer - 1]; a.bias[1] = wb->b3[layer - 1];
+    }
+    a.x1 = x1;
+    a.N = N; a.H = H; a.W = W; a.C = dense_channels(cin); a.c1 = cin <= 3 ? cin : 0;
+    build_stages(a, cin, layer);
+    a.out_coff = (cin <= 3 ? 0 : ((cin + 31) & ~31)) + 32 * (layer - 1);
+    const int rc = launch_conv3x3<EPI_LRELU>(a, wb ? 2 : 1, s);
+    if (rc) return rc;
+  }
+  return SELFC_OK;
+}
+
+int check_subnet(const selfc_subnet_w* w, bool need5) {
+  for (int i = 0; i < 4; ++i)
+    if (!w->w3[i] || !w->b3[i]) return SELFC_EINVAL;
+  if (need5 && (!w->w5 || !w->b5)) return SELFC_EINVAL;
+  return SELFC_OK;
+}
+
+int run_F(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStream_t s) {
+  int rc = run_conv1to4(&blk->F, nullptr, l->fd, nullptr, nullptr, l->c2, l->N, l->H, l->W, s);
+  if (rc) return rc;
+  const int FC = dense_channels(l->c2);
+  if (l->kind == SELFC_SUBNET_D2DT) {
+    T5Args a{};
+    a.dense[0] = (const f16*)l->fd; a.w = (const f16*)blk->F.w5; a.bias[0] = blk->F.b5;
+    a.B = l->N / l->T; a.T = l->T; a.HW = l->H * l->W; a.C = FC;
+    a.x1io = l->x1; a.rev = rev;
+    return dispatch_t5<1, 0, EPI_F>(a, 1, FC / 32, s);
+  }
+  C3Args a{};
+  a.dense[0] = (const f16*)l->fd; a.w[0] = (const f16*)blk->F.w5; a.bias[0] = blk->F.b5;
+  a.N = l->N; a.H = l->H; a.W = l->W; a.C = FC;
+  build_stages(a, l->c2, 5);
+  a.x1io = l->x1; a.rev = rev;
+  return launch_conv3x3<EPI_F>(a, 1, s);
+}
+
+int run_GH(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStream_t s) {
+  int rc = run_conv1to4(&blk->G, &blk->H, l->gd, l->hd, l->x1, l->c1, l->N, l->H, l->W, s);
+  if (rc) return rc;
+  const int c2p = (l->c2 + 3) & ~3;
+  const int FC = dense_channels(l->c2);
+  if (l->kind == SELFC_SUBNET_D2DT) {
+    T5Args a{};
+    a.dense[0] = (const f16*)l->gd; a.dense[1] = (const f16*)l->hd;
+    a.w = (const f16*)blk->G.w5; a.bias[0] = blk->G.b5; a.bias[1] = blk->H.b5;
+    a.x1 = l->x1;
+    a.B = l->N / l->T; a.T = l->T; a.HW = l->H * l->W; a.C = 128;
+    a.x2io = l->x2; a.fd = (f16*)l->fd; a.fC = FC; a.s_out = l->s_out; a.c2p = c2p;
+    a.rev = rev; a.clamp = blk->clamp;
+    return dispatch_t5<2, 1, EPI_GH>(a, (l->c2 + 15) / 16, 4, s);
+  }
+  C3Args a{};
+  a.dense[0] = (const f16*)l->gd; a.dense[1] = (const f16*)l->hd;
+  a.w[0] = (const f16*)blk->G.w5; a.w[1] = (const f16*)blk->H.w5;
+  a.bias[0] = blk->G.b5; a.bias[1] = blk->H.b5;
+  a.x1 = l->x1; a.c1 = l->c1;
+  a.N = l->N; a.H = l->H; a.W = l->W; a.C = 128;
+  build_stages(a, l->c1, 5);
+  a.x2io = l->x2; a.fd = (f16*)l->fd; a.fC = FC; a.s_out = l->s_out; a.c2p = c2p;
+  a.rev = rev; a.clamp = blk->clamp;
+  return launch_conv3x3<EPI_GH>(a, 1, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* selfc_version(void) { return "selfc_hip gfx950 abi1"; }
+int selfc_abi_version(void) { return 1; }
+
+int selfc_invblock_run(const selfc_invblock_w* blk, const selfc_latent* lat, int rev, void* stream) {
+  if (!blk || !latent_ok(lat)) return SELFC_EINVAL;
+  const bool db2d = lat->kind == SELFC_SUBNET_DB2D;
+  if (check_subnet(&blk->F, true) || check_subnet(&blk->G, true) || check_subnet(&blk->H, db2d)) return SELFC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (!rev) {
+    if ((rc = run_F(blk, lat, 0, s))) return rc;   // y1 = x1 + F(x2)
+    return run_GH(blk, lat, 0, s);                 // y2 = x2*exp(s(y1)) + G(y1)
+  }
+  if ((rc = run_GH(blk, lat, 1, s))) return rc;    // y2 = (x2 - G(x1)) / exp(s(x1))
+  return run_F(blk, lat, 1, s);                    // y1 = x1 - F(y2)
+}
+
+int selfc_invstack_run(const selfc_invblock_w* blks, int nblk, const selfc_latent* lat, int rev, void* stream) {
+  if (!blks || nblk < 0) return SELFC_EINVAL;
+  for (int i = 0; i < nblk; ++i) {
+    const int rc = selfc_invblock_run(&blks[rev ? nblk - 1 - i : i], lat, rev, stream);
+    if (rc) return rc;
+  }
+  return SELFC_OK;
+}
+
+int selfc_subnet_run(const selfc_subnet_w* w, int kind, const float* xin, float* yout, void* dense,
+                     int N, int T, int H, int W, int cin, int cout, void* stream) {
+  if (!w || !xin || !yout || !dense || N <= 0 || T <= 0 || N % T || H <= 0 || W <= 0 || cin < 1 || cout < 1) return SELFC_EINVAL;
+  if (check_subnet(w, true)) return SELFC_EINVAL;
+  if (cin > 96) return SELFC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int DC = dense_channels(cin);
+  const int coutp = (cout + 3) & ~3;
+  if (cin > 3) {
+    const size_t npix = (size_t)N * H * W;
+    hipLaunchKernelGGL(nhwc_to_dense_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s,
+                       xin, (f16*)dense, npix, cin, (cin + 3) & ~3, (cin + 31) & ~31, DC);
+    int rc = hip_rc(hipGetLastError());
+    if (rc) return rc;
+  }
+  int rc = run_conv1to4(w, nullptr, dense, nullptr, cin <= 3 ? xin : nullptr, cin, N, H, W, s);
+  if (rc) return rc;
+  if (kind == SELFC_SUBNET_D2DT) {
+    if (cout > 64) return SELFC_EINVAL;
+    T5Args a{};
+    a.dense[0] = (const f16*)dense; a.w = (const f16*)w->w5; a.bias[0] = w->b5;
+    a.x1 = cin <= 3 ? xin : nullptr;
+    a.B = N / T; a.T = T; a.HW = H * W; a.C = DC;
+    a.plain = yout; a.coutp = coutp;
+    const int ot = (cout + 15) / 16;
+    if (cin <= 3) return dispatch_t5<1, 1, EPI_PLAIN>(a, ot, 4, s);
+    return dispatch_t5<1, 0, EPI_PLAIN>(a, ot, DC / 32, s);
+  }
+  if (kind != SELFC_SUBNET_DB2D || cout > 32) return SELFC_EINVAL;
+  C3Args a{};
+  a.dense[0] = (const f16*)dense; a.w[0] = (const f16*)w->w5; a.bias[0] = w->b5;
+  a.x1 = cin <= 3 ? xin : nullptr; a.c1 = cin <= 3 ? cin : 0;
+  a.N = N; a.H = H; a.W = W; a.C = DC;
+  build_stages(a, cin, 5);
+  a.plain = yout; a.coutp = coutp;
+  return launch_conv3x3<EPI_PLAIN>(a, 1, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,334 @@
+// HBM-bound split/merge transforms and layout kernels (gfx950).
+//   Haar butterfly + band shuffle      <- Inv_arch.py:64-81
+//   FrequencyAnalyzer fwd / rev        <- SelfC_GMM_arch_inv.py:62-82
+//   NCHW <-> latent (narrow / cat)     <- Inv_arch.py:22,33
+//   Quantization                       <- Quantization.py:7-17
+// One thread per low-resolution pixel; reads of NCHW planes and writes of NHWC
+// rows are 16-B vectors, consecutive lanes touch consecutive addresses.
+#include "common.hpp"
+#include "../../include/selfc_hip.h"
+
+using namespace selfc;
+
+namespace {
+
+constexpr int TPB = 256;
+
+inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 1000; }
+inline unsigned nblocks(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+
+// ---------------------------------------------------------------- Haar
+// y[:, k*C + c] = band k of channel c; sums in the order ((a+b)+c)+d so the
+// fp32 bits equal the reference's depthwise conv2d (pinned by tests/golden/g1).
+__global__ void haar_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                int N, int C, int h, int w) {
+  const size_t total = (size_t)N * C * h * w;
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= total) return;
+  const int xx = (int)(i % w);
+  const int yy = (int)((i / w) % h);
+  const int c = (int)((i / ((size_t)w * h)) % C);
+  const int n = (int)(i / ((size_t)w * h * C));
+  const int W = 2 * w;
+  const float* p = x + (((size_t)n * C + c) * (2 * h) + 2 * yy) * W + 2 * xx;
+  const float2 r0 = *reinterpret_cast<const float2*>(p);
+  const float2 r1 = *reinterpret_cast<const float2*>(p + W);
+  const float a = r0.x, b = r0.y, cc = r1.x, d = r1.y;
+  const size_t plane = (size_t)h * w;
+  float* o = y + ((size_t)n * 4 * C + c) * plane + (size_t)yy * w + xx;
+  o[0] = (((a + b) + cc) + d) / 4.0f;
+  o[(size_t)C * plane] = (((a - b) + cc) - d) / 4.0f;
+  o[(size_t)2 * C * plane] = (((a + b) - cc) - d) / 4.0f;
+  o[(size_t)3 * C * plane] = (((a - b) - cc) + d) / 4.0f;
+}
+
+__global__ void haar_inv_kernel(const float* __restrict__ y, float* __restrict__ x,
+                                int N, int C, int h, int w) {
+  const size_t total = (size_t)N * C * h * w;
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= total) return;
+  const int xx = (int)(i % w);
+  const int yy = (int)((i / w) % h);
+  const int c = (int)((i / ((size_t)w * h)) % C);
+  const int n = (int)(i / ((size_t)w * h * C));
+  const size_t plane = (size_t)h * w;
+  const float* p = y + ((size_t)n * 4 * C + c) * plane + (size_t)yy * w + xx;
+  const float ll = p[0], hl = p[(size_t)C * plane], lh = p[(size_t)2 * C * plane], hh = p[(size_t)3 * C * plane];
+  const int W = 2 * w;
+  float* o = x + (((size_t)n * C + c) * (2 * h) + 2 * yy) * W + 2 * xx;
+  float2 r0, r1;
+  r0.x = ((ll + hl) + lh) + hh;
+  r0.y = ((ll - hl) + lh) - hh;
+  r1.x = ((ll + hl) - lh) - hh;
+  r1.y = ((ll - hl) - lh) + hh;
+  *reinterpret_cast<float2*>(o) = r0;
+  *reinterpret_cast<float2*>(o + W) = r1;
+}
+
+// ---------------------------------------------------------------- FrequencyAnalyzer
+// forward: lo = KxK block mean (row-major sequential sum / K^2, the order of
+// torch's CPU avg_pool2d), hi[(sy*K+sx)*3+c] = x - lo.
+template <int K>
+__global__ void freq_fwd_kernel(const float* __restrict__ x, float* __restrict__ x1, float* __restrict__ x2,
+                                f16* __restrict__ fd, int FC, int N, int h, int w) {
+  constexpr int C2 = 3 * K * K;
+  const size_t total = (size_t)N * h * w;
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= total) return;
+  const int xx = (int)(i % w);
+  const int yy = (int)((i / w) % h);
+  const int n = (int)(i / ((size_t)w * h));
+  const int H = K * h, W = K * w;
+  float lo[4] = {0.f, 0.f, 0.f, 0.f};
+  float hi[C2];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float* p = x + (((size_t)n * 3 + c) * H + (size_t)K * yy) * W + (size_t)K * xx;
+    float v[K][K];
+#pragma unroll
+    for (int sy = 0; sy < K; ++sy) {
+      if (K == 4) {
+        const float4 r = *reinterpret_cast<const float4*>(p + (size_t)sy * W);
+        v[sy][0] = r.x; v[sy][1] = r.y; v[sy][2] = r.z; v[sy][3] = r.w;
+      } else {
+        const float2 r = *reinterpret_cast<const float2*>(p + (size_t)sy * W);
+        v[sy][0] = r.x; v[sy][1] = r.y;
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int sy = 0; sy < K; ++sy)
+#pragma unroll
+      for (int sx = 0; sx < K; ++sx) s += v[sy][sx];
+    const float m = s / (float)(K * K);
+    lo[c] = m;
+#pragma unroll
+    for (int sy = 0; sy < K; ++sy)
+#pragma unroll
+      for (int sx = 0; sx < K; ++sx) hi[(sy * K + sx) * 3 + c] = v[sy][sx] - m;
+  }
+  *reinterpret_cast<float4*>(x1 + i * 4) = make_float4(lo[0], lo[1], lo[2], 0.f);
+  float4* o2 = reinterpret_cast<float4*>(x2 + i * C2);
+#pragma unroll
+  for (int j = 0; j < C2 / 4; ++j) o2[j] = make_float4(hi[4 * j], hi[4 * j + 1], hi[4 * j + 2], hi[4 * j + 3]);
+  if (fd != nullptr) {
+    uint2* of = reinterpret_cast<uint2*>(fd + i * (size_t)FC);
+#pragma unroll
+    for (int j = 0; j < C2 / 4; ++j) {
+      uint2 u;
+      u.x = pack2(hi[4 * j], hi[4 * j + 1]);
+      u.y = pack2(hi[4 * j + 2], hi[4 * j + 3]);
+      of[j] = u;
+    }
+  }
+}
+
+// reverse: out[c][K*y+sy][K*x+sx] = lo[c] + hf[c*K^2 + sy*K + sx]  (nn.PixelShuffle order)
+template <int K>
+__global__ void freq_inv_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                float* __restrict__ x, int N, int h, int w) {
+  constexpr int C2 = 3 * K * K;
+  const size_t total = (size_t)N * h * w;
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= total) return;
+  const int xx = (int)(i % w);
+  const int yy = (int)((i / w) % h);
+  const int n = (int)(i / ((size_t)w * h));
+  const int H = K * h, W = K * w;
+  const float4 l4 = *reinterpret_cast<const float4*>(x1 + i * 4);
+  const float lo[3] = {l4.x, l4.y, l4.z};
+  float hf[C2];
+  const float4* p2 = reinterpret_cast<const float4*>(x2 + i * C2);
+#pragma unroll
+  for (int j = 0; j < C2 / 4; ++j) {
+    const float4 r = p2[j];
+    hf[4 * j] = r.x; hf[4 * j + 1] = r.y; hf[4 * j + 2] = r.z; hf[4 * j + 3] = r.w;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float* o = x + (((size_t)n * 3 + c) * H + (size_t)K * yy) * W + (size_t)K * xx;
+#pragma unroll
+    for (int sy = 0; sy < K; ++sy) {
+      if (K == 4) {
+        float4 r;
+        r.x = lo[c] + hf[c * 16 + sy * 4 + 0];
+        r.y = lo[c] + hf[c * 16 + sy * 4 + 1];
+        r.z = lo[c] + hf[c * 16 + sy * 4 + 2];
+        r.w = lo[c] + hf[c * 16 + sy * 4 + 3];
+        *reinterpret_cast<float4*>(o + (size_t)sy * W) = r;
+      } else {
+        float2 r;
+        r.x = lo[c] + hf[c * 4 + sy * 2 + 0];
+        r.y = lo[c] + hf[c * 4 + sy * 2 + 1];
+        *reinterpret_cast<float2*>(o + (size_t)sy * W) = r;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- NCHW <-> latent
+__global__ void nchw_to_latent_kernel(const float* __restrict__ x, float* __restrict__ x1, float* __restrict__ x2,
+                                      f16* __restrict__ fd, int FC, int N, int c1, int c2, int c2p, size_t HW) {
+  const size_t total = (size_t)N * HW;
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= total) return;
+  const size_t n = i / HW, p = i - n * HW;
+  const float* src = x + n * (size_t)(c1 + c2) * HW + p;
+  float v1[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < c1; ++c) v1[c] = src[(size_t)c * HW];
+  *reinterpret_cast<float4*>(x1 + i * 4) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+  for (int c0 = 0; c0 < c2p; c0 += 4) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (c0 + j < c2) ? src[(size_t)(c1 + c0 + j) * HW] : 0.f;
+    *reinterpret_cast<float4*>(x2 + i * c2p + c0) = make_float4(v[0], v[1], v[2], v[3]);
+    if (fd != nullptr) {
+      uint2 u;
+      u.x = pack2(v[0], v[1]);
+      u.y = pack2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(fd + i * (size_t)FC + c0) = u;
+    }
+  }
+}
+
+__global__ void latent_to_nchw_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                      float* __restrict__ y, int N, int c1, int c2, int c2p, size_t HW) {
+  const size_t total = (size_t)N * HW;
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= total) return;
+  const size_t n = i / HW, p = i - n * HW;
+  float* dst = y + n * (size_t)(c1 + c2) * HW + p;
+  const float4 a = *reinterpret_cast<const float4*>(x1 + i * 4);
+  const float v1[4] = {a.x, a.y, a.z, a.w};
+  for (int c = 0; c < c1; ++c) dst[(size_t)c * HW] = v1[c];
+  for (int c0 = 0; c0 < c2p; c0 += 4) {
+    const float4 r = *reinterpret_cast<const float4*>(x2 + i * c2p + c0);
+    const float v[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c0 + j < c2) dst[(size_t)(c1 + c0 + j) * HW] = v[j];
+  }
+}
+
+__global__ void nchw_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int Cp, size_t HW) {
+  const size_t total = (size_t)N * HW;
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= total) return;
+  const size_t n = i / HW, p = i - n * HW;
+  const float* src = x + n * (size_t)C * HW + p;
+  for (int c0 = 0; c0 < Cp; c0 += 4) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (c0 + j < C) ? src[(size_t)(c0 + j) * HW] : 0.f;
+    *reinterpret_cast<float4*>(y + i * Cp + c0) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+__global__ void nhwc4_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int Cp, size_t HW) {
+  const size_t total = (size_t)N * HW;
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= total) return;
+  const size_t n = i / HW, p = i - n * HW;
+  float* dst = y + n * (size_t)C * HW + p;
+  for (int c0 = 0; c0 < Cp; c0 += 4) {
+    const float4 r = *reinterpret_cast<const float4*>(x + i * Cp + c0);
+    const float v[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c0 + j < C) dst[(size_t)(c0 + j) * HW] = v[j];
+  }
+}
+
+// Quantization.py:7-17: clamp(x,0,1); round(x*255)/255 with round-half-to-even (torch.round).
+__global__ void quantize_kernel(float* __restrict__ x, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n4) return;
+  float4 v = reinterpret_cast<float4*>(x)[i];
+  float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float t = fminf(fmaxf(f[j], 0.f), 1.f);
+    f[j] = rintf(t * 255.0f) / 255.0f;
+  }
+  reinterpret_cast<float4*>(x)[i] = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int selfc_haar_fwd_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return SELFC_EINVAL;
+  const size_t total = (size_t)N * C * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(haar_fwd_kernel, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x, y, N, C, H / 2, W / 2);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_haar_inv_nchw(const float* y, float* x, int N, int C, int h, int w, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || h <= 0 || w <= 0) return SELFC_EINVAL;
+  const size_t total = (size_t)N * C * h * w;
+  hipLaunchKernelGGL(haar_inv_kernel, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, y, x, N, C, h, w);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_freq_fwd(const float* x, float* x1, float* x2, void* fd, int FC, int N, int H, int W, int k, void* stream) {
+  if (!x || !x1 || !x2 || N <= 0 || H <= 0 || W <= 0 || (k != 4 && k != 2) || H % k || W % k) return SELFC_EINVAL;
+  if (fd && (FC < 3 * k * k || (FC & 3))) return SELFC_EINVAL;
+  const int h = H / k, w = W / k;
+  const size_t total = (size_t)N * h * w;
+  if (k == 4)
+    hipLaunchKernelGGL(freq_fwd_kernel<4>, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x, x1, x2, (f16*)fd, FC, N, h, w);
+  else
+    hipLaunchKernelGGL(freq_fwd_kernel<2>, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x, x1, x2, (f16*)fd, FC, N, h, w);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_freq_inv(const float* x1, const float* x2, float* x, int N, int h, int w, int k, void* stream) {
+  if (!x || !x1 || !x2 || N <= 0 || h <= 0 || w <= 0 || (k != 4 && k != 2)) return SELFC_EINVAL;
+  const size_t total = (size_t)N * h * w;
+  if (k == 4)
+    hipLaunchKernelGGL(freq_inv_kernel<4>, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x1, x2, x, N, h, w);
+  else
+    hipLaunchKernelGGL(freq_inv_kernel<2>, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x1, x2, x, N, h, w);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_nchw_to_latent(const float* x, float* x1, float* x2, void* fd, int FC, int N, int c1, int c2, int H, int W, void* stream) {
+  if (!x || !x1 || !x2 || N <= 0 || c1 < 1 || c1 > 4 || c2 < 1 || H <= 0 || W <= 0) return SELFC_EINVAL;
+  const int c2p = (c2 + 3) & ~3;
+  if (fd && (FC < c2p || (FC & 3))) return SELFC_EINVAL;
+  const size_t HW = (size_t)H * W;
+  hipLaunchKernelGGL(nchw_to_latent_kernel, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x, x1, x2, (f16*)fd, FC, N, c1, c2, c2p, HW);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_latent_to_nchw(const float* x1, const float* x2, float* y, int N, int c1, int c2, int H, int W, void* stream) {
+  if (!y || !x1 || !x2 || N <= 0 || c1 < 1 || c1 > 4 || c2 < 1 || H <= 0 || W <= 0) return SELFC_EINVAL;
+  const int c2p = (c2 + 3) & ~3;
+  const size_t HW = (size_t)H * W;
+  hipLaunchKernelGGL(latent_to_nchw_kernel, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x1, x2, y, N, c1, c2, c2p, HW);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0) return SELFC_EINVAL;
+  const size_t HW = (size_t)H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x, y, N, C, (C + 3) & ~3, HW);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_nhwc4_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0) return SELFC_EINVAL;
+  const size_t HW = (size_t)H * W;
+  hipLaunchKernelGGL(nhwc4_to_nchw_kernel, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x, y, N, C, (C + 3) & ~3, HW);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_quantize_inplace(float* x, size_t n, void* stream) {
+  if (!x || (n & 3)) return SELFC_EINVAL;
+  if (n == 0) return SELFC_OK;
+  hipLaunchKernelGGL(quantize_kernel, dim3(nblocks(n / 4)), dim3(TPB), 0, (hipStream_t)stream, x, n / 4);
+  return hip_rc(hipGetLastError());
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+"""Invertible rescaling blocks on MI355X: InvBlockExp, HaarDownsampling, InvRescaleNet.
+
+Mirrors codes/models/modules/Inv_arch.py (:8-41, :44-84, :87-127); the same
+InvBlockExp is what SelfC_arch_inv.py:8-41 and SelfC_GMM_arch_inv.py:8-41 define.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib, runtime as rt
+from ..global_var import GlobalVar
+
+
+class InvBlockExp(nn.Module):
+    """Affine coupling layer (Inv_arch.py:8-41).
+
+    forward : y1 = x1 + F(x2); s = clamp*(2*sigmoid(H(y1))-1); y2 = x2*exp(s) + G(y1)
+    reverse : s = clamp*(2*sigmoid(H(x1))-1); y2 = (x2-G(x1))/exp(s); y1 = x1 - F(y2)
+    One call = selfc_invblock_run: 8 dense 3x3 conv launches + 2 conv5 launches with
+    the coupling fused into their epilogues."""
+
+    def __init__(self, subnet_constructor, channel_num, channel_split_num, clamp=1.):
+        super().__init__()
+        self.split_len1 = channel_split_num
+        self.split_len2 = channel_num - channel_split_num
+        self.clamp = clamp
+        self.F = subnet_constructor(self.split_len2, self.split_len1)
+        self.G = subnet_constructor(self.split_len1, self.split_len2)
+        self.H = subnet_constructor(self.split_len1, self.split_len2)
+
+    def _temporal_len(self):
+        if self.F.kind == rt.SUBNET_D2DT:
+            t = GlobalVar.get_Temporal_LEN()
+            if not t:
+                raise RuntimeError("GlobalVar.set_Temporal_LEN(T) must be called before an InvBlockExp(D2DTNet) forward")
+            return t
+        return 1
+
+    def forward(self, x, rev=False):
+        x = rt.as_input(x)
+        rt.no_autograd_guard(x, *self.parameters())
+        n, c, h, w = x.shape
+        if c != self.split_len1 + self.split_len2:
+            raise RuntimeError(f"InvBlockExp expects {self.split_len1 + self.split_len2} channels, got {c}")
+        t = self._temporal_len()
+        if n % t:
+            raise RuntimeError(f"{n} frames are not a multiple of the temporal length {t}")
+        ws = rt.workspace(x.device, self.F.kind, n, t, h, w, self.split_len1, self.split_len2)
+        pb = rt.packed_block(self)
+        rt.nchw_to_latent(x, ws)
+        bw, lat = pb.struct(), ws.latent(want_s=True)
+        rt.call("selfc_invblock_run", bw, lat, 1 if rev else 0, _lib.stream_ptr())
+        self.s = rt.s_to_nchw(ws)
+        return rt.latent_to_nchw(ws)
+
+    def jacobian(self, x, rev=False):
+        jac = torch.sum(self.s)
+        return (-jac if rev else jac) / x.shape[0]
+
+
+class HaarDownsampling(nn.Module):
+    """2x2 Haar butterfly + band shuffle (Inv_arch.py:44-84).  ``haar_weights`` is
+    kept as a frozen parameter only because it is part of the checkpoint layout;
+    the kernel hard-codes the +-1 pattern it encodes."""
+
+    def __init__(self, channel_in):
+        super().__init__()
+        self.channel_in = channel_in
+        w = torch.ones(4, 1, 2, 2)
+        w[1, 0, 0, 1] = w[1, 0, 1, 1] = -1
+        w[2, 0, 1, 0] = w[2, 0, 1, 1] = -1
+        w[3, 0, 1, 0] = w[3, 0, 0, 1] = -1
+        self.haar_weights = nn.Parameter(torch.cat([w] * channel_in, 0), requires_grad=False)
+
+    def forward(self, x, rev=False):
+        x = rt.as_input(x)
+        n, c, h, w = x.shape
+        self.elements = c * h * w
+        sp = _lib.stream_ptr()
+        if not rev:
+            if c != self.channel_in:
+                raise RuntimeError(f"HaarDownsampling({self.channel_in}) got {c} channels")
+            self.last_jac = self.elements / 4 * np.log(1 / 16.)
+            y = torch.empty((n, 4 * c, h // 2, w // 2), dtype=x.dtype, device=x.device)
+            rt.call("selfc_haar_fwd_nchw", x.data_ptr(), y.data_ptr(), n, c, h, w, sp)
+            return y
+        if c != 4 * self.channel_in:
+            raise RuntimeError(f"HaarDownsampling({self.channel_in}) reverse got {c} channels")
+        self.last_jac = self.elements / 4 * np.log(16.)
+        y = torch.empty((n, c // 4, 2 * h, 2 * w), dtype=x.dtype, device=x.device)
+        rt.call("selfc_haar_inv_nchw", x.data_ptr(), y.data_ptr(), n, c // 4, h, w, sp)
+        return y
+
+    def jacobian(self, x, rev=False):
+        return self.last_jac
+
+
+class InvRescaleNet(nn.Module):
+    """IRN-style [Haar, block_num[i] x InvBlockExp] x down_num (Inv_arch.py:87-127)."""
+
+    def __init__(self, channel_in=3, channel_out=3, subnet_constructor=None, block_num=[], down_num=2):
+        super().__init__()
+        operations = []
+        current_channel = channel_in
+        for i in range(down_num):
+            operations.append(HaarDownsampling(current_channel))
+            current_channel *= 4
+            for _ in range(block_num[i]):
+                operations.append(InvBlockExp(subnet_constructor, current_channel, channel_out))
+        self.operations = nn.ModuleList(operations)
+
+    def forward(self, x, rev=False, cal_jacobian=False):
+        out = x
+        jacobian = 0
+        if not rev:
+            for op in self.operations:
+                out = op.forward(out, rev)
+                if cal_jacobian:
+                    jacobian += op.jacobian(out, rev)
+            return out[:, 0:3], (out[:, 3:] ** 2).mean()
+        b, c, h, w = out.size()
+        # the reference concatenates 45 uniform-random HF channels whatever the net needs (:116-118)
+        out = torch.cat([out, torch.rand((b, 45, h, w), device=out.device)], dim=1)
+        last = self.operations[-1]
+        need = last.split_len1 + last.split_len2 if isinstance(last, InvBlockExp) else 4 * last.channel_in
+        out = out[:, :need]   # the reference's narrow() silently ignores the excess channels
+        for op in reversed(self.operations):
+            out = op.forward(out, rev)
+            if cal_jacobian:
+                jacobian += op.jacobian(out, rev)
+        return out, None

@@ -1,0 +1,133 @@
+"""Dense-block subnets and the ``subnet()`` plugin factory on MI355X.
+
+Mirrors codes/models/modules/Subnet_constructor.py: ``DenseBlock`` (:8-34),
+``D2DTInput`` (:98-133) and ``subnet`` (:719-788) keep their constructor
+signatures, attribute names (conv1..conv5, lrelu) and therefore their
+state_dict keys / tensor shapes, so reference checkpoints load strict=True.
+The nn.Conv layers only own the parameters; forward repacks them once into MFMA
+fragments (selfc_amd/packing.py) and runs csrc/dense_conv.hip through the C ABI.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib, runtime as rt
+from ..global_var import GlobalVar
+from ..packing import dense_channels, roundup
+from . import module_util as mutil
+
+
+class _DenseSubnet(nn.Module):
+    kind = None  # SUBNET_DB2D / SUBNET_D2DT
+
+    def _check(self):
+        if self.gc != 32:
+            raise NotImplementedError("selfc_amd dense-block kernels are built for growth channels gc=32")
+        if self.channel_in > 96 or self.channel_out > (32 if self.kind == rt.SUBNET_DB2D else 64):
+            raise NotImplementedError(f"subnet {self.channel_in}->{self.channel_out} is outside the compiled kernel set")
+
+    def packed(self) -> rt.PackedSubnet:
+        key = rt.params_key(self)
+        if getattr(self, "_pk_key", None) != key:
+            self._check()
+            self._pk = rt.PackedSubnet(self)
+            self._pk_key = key
+        return self._pk
+
+    def _run(self, x: torch.Tensor, T: int) -> torch.Tensor:
+        """x NCHW (N,cin,H,W) -> NCHW (N,cout,H,W) through selfc_subnet_run."""
+        x = rt.as_input(x)
+        rt.no_autograd_guard(x, *self.parameters())
+        n, cin, h, w = x.shape
+        if cin != self.channel_in:
+            raise RuntimeError(f"expected {self.channel_in} input channels, got {cin}")
+        if n % T:
+            raise RuntimeError(f"{n} frames are not a multiple of the temporal length {T}")
+        pk = self.packed()
+        dev, sp = x.device, _lib.stream_ptr()
+        cinp, coutp = roundup(cin, 4), roundup(self.channel_out, 4)
+        xin = torch.empty((n, h, w, cinp), dtype=torch.float32, device=dev)
+        rt.call("selfc_nchw_to_nhwc4", x.data_ptr(), xin.data_ptr(), n, cin, h, w, sp)
+        dense = torch.zeros((n, h, w, dense_channels(cin)), dtype=torch.float16, device=dev)
+        yout = torch.empty((n, h, w, coutp), dtype=torch.float32, device=dev)
+        sw = pk.struct()
+        rt.call("selfc_subnet_run", sw, self.kind, xin.data_ptr(), yout.data_ptr(), dense.data_ptr(),
+                n, T, h, w, cin, self.channel_out, sp)
+        y = torch.empty((n, self.channel_out, h, w), dtype=torch.float32, device=dev)
+        rt.call("selfc_nhwc4_to_nchw", yout.data_ptr(), y.data_ptr(), n, self.channel_out, h, w, sp)
+        return y
+
+
+class DenseBlock(_DenseSubnet):
+    """2-D dense block, 5x Conv2d 3x3 (Subnet_constructor.py:8-34)."""
+    kind = rt.SUBNET_DB2D
+
+    def __init__(self, channel_in, channel_out, init='xavier', gc=32, bias=True, INN_init=True, is_res=False):
+        super().__init__()
+        self.channel_in, self.channel_out, self.gc = channel_in, channel_out, gc
+        self.conv1 = nn.Conv2d(channel_in, gc, 3, 1, 1, bias=bias)
+        self.conv2 = nn.Conv2d(channel_in + gc, gc, 3, 1, 1, bias=bias)
+        self.conv3 = nn.Conv2d(channel_in + 2 * gc, gc, 3, 1, 1, bias=bias)
+        self.conv4 = nn.Conv2d(channel_in + 3 * gc, gc, 3, 1, 1, bias=bias)
+        self.conv5 = nn.Conv2d(channel_in + 4 * gc, channel_out, 3, 1, 1, bias=bias)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.2, inplace=True)
+        first4 = [self.conv1, self.conv2, self.conv3, self.conv4]
+        if INN_init:
+            # xavier*0.1 (or kaiming*0.1) on conv1-4, conv5 = 0: identity coupling at init (:17-22)
+            (mutil.initialize_weights_xavier if init == 'xavier' else mutil.initialize_weights)(first4, 0.1)
+            mutil.initialize_weights(self.conv5, 0)
+        else:
+            mutil.initialize_weights_xavier(first4 + [self.conv5], 1)
+        self.is_res = is_res
+
+    def forward(self, x):
+        y = self._run(x, 1)
+        return y + x if self.is_res else y
+
+
+class D2DTInput(_DenseSubnet):
+    """Per-frame 3x3 dense convs + 3-tap temporal conv5 (Subnet_constructor.py:98-133).
+
+    The INN_init branch only matches nn.Conv2d in the reference's helpers, so for
+    these Conv3d layers it is a no-op and PyTorch's default init stays (trap 4);
+    ``is_res`` is accepted and ignored, as in the reference."""
+    kind = rt.SUBNET_D2DT
+
+    def __init__(self, channel_in, channel_out, init='xavier', gc=32, bias=True, INN_init=True, is_res=False):
+        super().__init__()
+        self.channel_in, self.channel_out, self.gc = channel_in, channel_out, gc
+        self.conv1 = nn.Conv3d(channel_in, gc, (1, 3, 3), 1, (0, 1, 1), bias=bias)
+        self.conv2 = nn.Conv3d(channel_in + gc, gc, (1, 3, 3), 1, (0, 1, 1), bias=bias)
+        self.conv3 = nn.Conv3d(channel_in + 2 * gc, gc, (1, 3, 3), 1, (0, 1, 1), bias=bias)
+        self.conv4 = nn.Conv3d(channel_in + 3 * gc, gc, (1, 3, 3), 1, (0, 1, 1), bias=bias)
+        self.conv5 = nn.Conv3d(channel_in + 4 * gc, channel_out, (3, 1, 1), 1, (1, 0, 0), bias=bias)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.2, inplace=True)
+        if INN_init:
+            first4 = [self.conv1, self.conv2, self.conv3, self.conv4]
+            (mutil.initialize_weights_xavier if init == 'xavier' else mutil.initialize_weights)(first4, 0.1)
+            mutil.initialize_weights(self.conv5, 0)
+
+    def forward(self, x, io_type="2d"):
+        if io_type == '3d':                       # (b,c,t,h,w) in and out (:117-118,131)
+            b, c, t, h, w = x.shape
+            y = self._run(x.transpose(1, 2).reshape(b * t, c, h, w), t)
+            return y.reshape(b, t, -1, h, w).transpose(1, 2)
+        t = GlobalVar.get_Temporal_LEN()
+        if not t:
+            raise RuntimeError("GlobalVar.set_Temporal_LEN(T) must be called before a D2DTInput forward")
+        return self._run(x, t)
+
+
+def subnet(net_structure, init='xavier'):
+    """String-keyed factory, Subnet_constructor.py:719-788.  Live names of the
+    shipped configs: 'DBNet' and 'D2DTNet'; any other name returns None exactly
+    like the reference (it then fails at first use)."""
+    def constructor(channel_in, channel_out, gc=32):
+        if net_structure == 'DBNet':
+            return DenseBlock(channel_in, channel_out, init) if init == 'xavier' else DenseBlock(channel_in, channel_out)
+        if net_structure == 'D2DTNet':
+            if init == 'xavier':
+                return D2DTInput(channel_in, channel_out, init, gc=gc)
+            return D2DTInput(channel_in, channel_out)
+        return None
+
+    return constructor

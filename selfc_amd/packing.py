@@ -1,0 +1,108 @@
+"""Repack reference-layout conv weights into the MFMA A-fragment layout the
+kernels of selfc_amd/csrc/dense_conv.hip read.
+
+Reference layouts (state_dict contract):
+  conv1..4   (32, cin + 32*(i-1), 3, 3)  [DenseBlock]  or (.., 1, 3, 3) [D2DTInput]
+  conv5      (cout, cin + 128, 3, 3)     [DenseBlock]  or (cout, cin+128, 3, 1, 1) [D2DTInput]
+Input-channel order of every conv is the reference's ``torch.cat((x, x1, x2, x3, x4), 1)``
+(Subnet_constructor.py:28-31): first the cin inputs, then the 32-channel features.
+
+Kernel K order of a 3x3 conv ("stages", see build_stages() in dense_conv.hip):
+  cin <= 3 : [im2col stage: k = tap*cin + c, zero padded to 32] + features
+  cin  > 3 : [input channels in 32-wide pieces (last one 16 wide if roundup(cin,16)%32==16)] + features
+  every non-im2col stage is tap-major: for tap in 0..8: for k in 0..width-1.
+A 32x32x16 A fragment f holds W[outch = lane&31][k = 16 f + 8 (lane>>5) + j], j = 0..7.
+
+Temporal conv5 (tconv5_kernel): fragments [tap][net][kstep][otile][lane][8] of the
+16x16x32 MFMA, W[outch = 16 otile + (lane&15)][k = 32 kstep + 8 (lane>>4) + j]; k-step 0
+is the 3 input channels when cin <= 3, then the dense buffer's channels in order.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+
+F16 = torch.float16
+
+
+def roundup(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def dense_channels(cin: int) -> int:
+    """Channel stride of a subnet's f16 dense buffer (dense_conv.hip: dense_channels)."""
+    return 128 if cin <= 3 else roundup(cin, 32) + 128
+
+
+def _k_expand_3x3(w: torch.Tensor, cin: int, nfeat: int) -> torch.Tensor:
+    """w (O, cin + 32*nfeat, 3, 3) fp32 -> (O, K) in kernel K order."""
+    o = w.shape[0]
+    w9 = w.reshape(o, w.shape[1], 9)                       # tap = ky*3 + kx
+    cols: List[torch.Tensor] = []
+    if cin <= 3:
+        st = torch.zeros(o, 32, dtype=w.dtype, device=w.device)
+        st[:, : 9 * cin] = w9[:, :cin, :].permute(0, 2, 1).reshape(o, 9 * cin)   # k = tap*cin + c
+        cols.append(st)
+    else:
+        cin16 = roundup(cin, 16)
+        for c0 in range(0, cin16, 32):
+            width = 32 if cin16 - c0 >= 32 else 16
+            st = torch.zeros(o, 9, width, dtype=w.dtype, device=w.device)
+            real = max(0, min(width, cin - c0))
+            st[:, :, :real] = w9[:, c0:c0 + real, :].permute(0, 2, 1)
+            cols.append(st.reshape(o, 9 * width))
+    for i in range(nfeat):
+        st = w9[:, cin + 32 * i: cin + 32 * (i + 1), :].permute(0, 2, 1)            # (O, 9, 32)
+        cols.append(st.reshape(o, 9 * 32))
+    return torch.cat(cols, dim=1)
+
+
+def pack_conv3x3(weight: torch.Tensor, cin: int, layer: int) -> torch.Tensor:
+    """conv `layer` (1..5) of a dense block -> f16 [nfrag, 64, 8] (32 output rows,
+    zero padded when the conv has fewer, i.e. the 2-D conv5)."""
+    w = weight.detach().float()
+    if w.dim() == 5:                                       # Conv3d (1,3,3)
+        assert w.shape[2] == 1
+        w = w[:, :, 0]
+    assert w.shape[2:] == (3, 3) and w.shape[1] == cin + 32 * (layer - 1), (tuple(w.shape), cin, layer)
+    assert w.shape[0] <= 32
+    if w.shape[0] < 32:
+        w = torch.cat((w, w.new_zeros(32 - w.shape[0], *w.shape[1:])), 0)
+    wk = _k_expand_3x3(w, cin, layer - 1)                  # (32, K)
+    nfrag = wk.shape[1] // 16
+    frag = wk.reshape(32, nfrag, 2, 8).permute(1, 2, 0, 3).reshape(nfrag, 64, 8)
+    return frag.to(F16).contiguous()
+
+
+def pack_tconv5(weights: Sequence[torch.Tensor], cin: int) -> torch.Tensor:
+    """1 or 2 (G, H) temporal conv5 weights (cout, cin+128, 3, 1, 1) -> f16
+    [3, nets, KS, OT, 64, 8]."""
+    nets = len(weights)
+    cout = weights[0].shape[0]
+    ot = roundup(cout, 16) // 16
+    hasx = cin <= 3
+    kd = dense_channels(cin) // 32
+    ks = kd + (1 if hasx else 0)
+    dev = weights[0].device
+    wk = torch.zeros(nets, 3, ot * 16, ks * 32, dtype=torch.float32, device=dev)
+    for n, w in enumerate(weights):
+        w = w.detach().float()
+        assert w.shape[1:] == (cin + 128, 3, 1, 1) and w.shape[0] == cout, tuple(w.shape)
+        w3 = w[:, :, :, 0, 0].permute(2, 0, 1)             # (tap, cout, C)
+        if hasx:
+            wk[n, :, :cout, :cin] = w3[:, :, :cin]
+            wk[n, :, :cout, 32:32 + 128] = w3[:, :, cin:]
+        else:
+            cin32 = roundup(cin, 32)
+            wk[n, :, :cout, :cin] = w3[:, :, :cin]
+            wk[n, :, :cout, cin32:cin32 + 128] = w3[:, :, cin:]
+    frag = wk.reshape(nets, 3, ot, 16, ks, 4, 8).permute(1, 0, 4, 2, 5, 3, 6).reshape(3, nets, ks, ot, 64, 8)
+    return frag.to(F16).contiguous()
+
+
+def pad_bias(bias, n: int = 64, device=None) -> torch.Tensor:
+    out = torch.zeros(n, dtype=torch.float32, device=device if bias is None else bias.device)
+    if bias is not None:
+        out[: bias.numel()] = bias.detach().float()
+    return out

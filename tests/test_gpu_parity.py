@@ -1,0 +1,257 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors captured
+from the reference and against the CPU oracle.  Tolerances: bit-exact for the
+index shuffles; "1e-3 relative fp32" (BASELINE.json) for float paths, measured as
+max|a-b| / max|b| (conftest.rel_err).  Run with `-m gpu` on the MI355X box."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_err, subdict
+from oracle import selfc_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+T = 7
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from selfc_amd import _lib
+    _lib.lib()           # fails loudly if libselfc_hip.so is missing
+    from selfc_amd import GlobalVar
+    GlobalVar.set_Temporal_LEN(T)
+    return torch.device("cuda:0")
+
+
+def test_library_loaded():
+    from selfc_amd import _lib
+    assert b"gfx950" in _lib.lib().selfc_version()
+
+
+def test_haar_bit_exact(dev):
+    from selfc_amd.modules.Inv_arch import HaarDownsampling
+    g = load_golden("g1_haar")
+    h1, h2 = HaarDownsampling(3).to(dev), HaarDownsampling(12).to(dev)
+    assert torch.equal(h1.haar_weights.cpu(), g["haar_weights"])
+    y = h1(g["x"].to(dev))
+    assert torch.equal(y.cpu(), g["y"])
+    assert abs(h1.jacobian(None) - float(g["jac_fwd"])) < 1e-9
+    assert torch.equal(h2(y).cpu(), g["y2"])
+    assert torch.equal(h1(g["y"].to(dev), rev=True).cpu(), g["xr"])
+    assert abs(h1.jacobian(None, rev=True) - float(g["jac_rev"])) < 1e-9
+    assert torch.equal(h1(g["zrand"].to(dev), rev=True).cpu(), g["zrand_inv"])
+
+
+def test_freq_bit_exact(dev):
+    from selfc_amd.modules.SelfC_GMM_arch_inv import FrequencyAnalyzer
+    g = load_golden("g2_freq")
+    fa = FrequencyAnalyzer(3)
+    assert torch.equal(fa(g["x"].to(dev)).cpu(), g["y"])
+    assert torch.equal(fa(g["z"].to(dev), rev=True).cpu(), g["z_rev"])
+    assert torch.equal(fa(g["y"].to(dev), rev=True).cpu(), g["y_rev"])
+    # integer-valued input: every sum is exact, so this pins the pure index shuffle
+    xi = torch.randint(0, 64, (2, 3, 8, 12)).float() * 16
+    assert torch.equal(fa(xi.to(dev)).cpu(), O.freq_fwd(xi))
+
+
+def test_quant_bit_exact(dev):
+    from selfc_amd.modules.Quantization import Quantization
+    g = load_golden("g9_quant")
+    assert torch.equal(Quantization()(g["x"].to(dev)).cpu(), g["y"])
+
+
+def test_denseblock(dev):
+    from selfc_amd.modules.Subnet_constructor import DenseBlock
+    g = load_golden("g3_denseblock")
+    for tag, (ci, co) in {"f": (9, 3), "g": (3, 9)}.items():
+        m = DenseBlock(ci, co, "xavier")
+        m.load_state_dict(subdict(g, tag), strict=True)
+        with torch.no_grad():
+            y = m.to(dev)(g[f"{tag}_x"].to(dev))
+        assert rel_err(y.cpu(), g[f"{tag}_y"]) < TOL
+
+
+def test_d2dt(dev):
+    from selfc_amd.modules.Subnet_constructor import D2DTInput
+    g = load_golden("g4_d2dt")
+    for tag, (ci, co) in {"f": (48, 3), "g": (3, 48)}.items():
+        m = D2DTInput(ci, co, "xavier")
+        m.load_state_dict(subdict(g, tag), strict=True)
+        with torch.no_grad():
+            y = m.to(dev)(g[f"{tag}_x"].to(dev))
+        assert rel_err(y.cpu(), g[f"{tag}_y"]) < TOL
+        with torch.no_grad():   # io_type='3d' path
+            x3 = g[f"{tag}_x"].reshape(2, T, ci, 12, 20).transpose(1, 2).to(dev)
+            y3 = m(x3, io_type="3d").transpose(1, 2).reshape(2 * T, co, 12, 20)
+        assert rel_err(y3.cpu(), g[f"{tag}_y"]) < TOL
+
+
+def _invblock(dev, name, kind, cnum):
+    from selfc_amd.modules.Inv_arch import InvBlockExp
+    from selfc_amd.modules.Subnet_constructor import subnet
+    g = load_golden(name)
+    blk = InvBlockExp(subnet(kind, "xavier"), cnum, 3)
+    blk.load_state_dict({k: v for k, v in g.items() if k[:2] in ("F.", "G.", "H.")}, strict=True)
+    blk.to(dev)
+    x = g["x"].to(dev)
+    with torch.no_grad():
+        y = blk(x)
+        assert rel_err(y.cpu(), g["y_fwd"]) < TOL
+        assert rel_err(blk.s.cpu(), g["s_fwd"]) < TOL
+        assert abs(blk.jacobian(x).item() - g["jac_fwd"].item()) < 2e-3 * abs(g["jac_fwd"].item()) + 1e-2
+        xr = blk(y, rev=True)                       # invertibility through the kernels
+        assert rel_err(xr.cpu(), g["x"]) < TOL
+        yr = blk(x, rev=True)
+        assert rel_err(yr.cpu(), g["y_rev"]) < TOL
+        assert rel_err(blk.s.cpu(), g["s_rev"]) < TOL
+        assert abs(blk.jacobian(x, rev=True).item() - g["jac_rev"].item()) < 2e-3 * abs(g["jac_rev"].item()) + 1e-2
+
+
+def test_invblock_dbnet(dev):
+    _invblock(dev, "g5_invblock_dbnet", "DBNet", 12)
+
+
+def test_invblock_d2dt(dev):
+    _invblock(dev, "g5_invblock_d2dt", "D2DTNet", 51)
+
+
+OPT = {"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": "l2", "scale": 4, "gmm_k": 5}
+
+
+def _large_net(dev, g, fh_loss="l2", stp=None):
+    from selfc_amd.modules.SelfC_GMM_arch_inv import SelfCInvNet
+    net = SelfCInvNet(dict(OPT, fh_loss=fh_loss), 3, 3, "D2DTNet", [4, 4], 2)
+    sd = {k: v for k, v in g.items() if k.startswith("operations.")}
+    if stp is not None:
+        sd.update({k: v for k, v in stp.items() if k.startswith("stp_net.")})
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("stp_net.") for k in missing)
+    return net.to(dev).eval()
+
+
+def test_large_stack_golden(dev):
+    g = load_golden("g8_large_stack")
+    net = _large_net(dev, g)
+    with torch.no_grad():
+        z, loss_c = net(x=g["x"].to(dev), rev=False)
+        assert float(loss_c) == 0.0
+        assert rel_err(z.cpu(), g["z"]) < TOL
+        assert rel_err(z[:, :3].cpu(), g["z"][:, :3]) < TOL          # the LR video itself
+        xr = net.inverse_from_latent(g["z"].to(dev))
+        assert rel_err(xr.cpu(), g["x_rev"]) < TOL
+
+
+def test_large_full_reverse_with_stp_l2(dev):
+    g = load_golden("g8_large_stack")
+    s = load_golden("g7_stp_l2_full_rev")
+    net = _large_net(dev, g, "l2", s)
+    with torch.no_grad():
+        xr, hf = net(x=s["lr"].to(dev), rev=True)
+    assert rel_err(hf.cpu(), s["hf"]) < 2e-3
+    assert rel_err(xr.cpu(), s["x_rev"]) < 2e-3
+
+
+def test_stp_gmm_injected_eps(dev):
+    from selfc_amd.modules.SelfC_GMM_arch_inv import STPNet
+    g = load_golden("g7_stp_gmm")
+    stp = STPNet(dict(OPT, fh_loss="gmm"))
+    stp.load_state_dict({k: v for k, v in g.items() if k.split(".")[0] in
+                         ("local_m1", "local_m2", "global_m1", "global_m2", "other_stp_modules", "tail_gmm")}, strict=True)
+    stp.to(dev).eval()
+    eps = g["eps"].permute(1, 2, 0, 3, 4).unsqueeze(0).to(dev)        # (1,48,5,T,h,w)
+    stp.eps = eps
+    with torch.no_grad():
+        stp(g["lr"].to(dev).reshape(1, T, 3, 8, 12).transpose(1, 2))
+    raw = stp.stp_parameters[0].transpose(0, 1)
+    assert rel_err(raw.cpu(), g["raw"]) < 2e-3
+    v = stp.sample()[0].transpose(0, 1)
+    assert rel_err(v.cpu(), g["v"]) < 2e-3
+
+
+def test_haar_net(dev):
+    from selfc_amd.modules.Inv_arch import InvRescaleNet
+    from selfc_amd.modules.Subnet_constructor import subnet
+    g = load_golden("g8_haar_net")
+    irn = InvRescaleNet(3, 3, subnet("DBNet", "xavier"), [1], 1)
+    irn.load_state_dict({k: v for k, v in g.items() if k.startswith("operations.")}, strict=True)
+    irn.to(dev)
+    with torch.no_grad():
+        lr, hfm = irn(g["x"].to(dev))
+        assert rel_err(lr.cpu(), g["lr"]) < TOL
+        assert abs(hfm.item() - g["hf_meansq"].item()) < 1e-3 * g["hf_meansq"].item()
+        out = g["z"].to(dev)
+        for op in reversed(irn.operations):
+            out = op(out, rev=True)
+        assert rel_err(out.cpu(), g["x_rev"]) < TOL
+
+
+@pytest.mark.parametrize("b,h,w", [(1, 36, 52), (2, 20, 44), (3, 64, 64)])
+def test_large_vs_oracle_ragged_sizes(dev, b, h, w):
+    """latent sizes that are not multiples of the 16x16 tile / 128-pixel strip; several clips."""
+    g = load_golden("g8_large_stack")
+    net = _large_net(dev, g)
+    gen = torch.Generator().manual_seed(b * 1000 + h)
+    x = torch.rand(b * T, 3, h, w, generator=gen)
+    z_ref = O.large_fwd(g, x, T)
+    with torch.no_grad():
+        z, _ = net(x=x.to(dev), rev=False)
+        assert rel_err(z.cpu(), z_ref) < TOL
+        xr = net.inverse_from_latent(z_ref.to(dev))
+    assert rel_err(xr.cpu(), O.large_inv_from_latent(g, z_ref, T)) < TOL
+
+
+def test_temporal_len_one_and_clip_isolation(dev):
+    """T=1 (every frame its own clip: temporal taps see only zero padding) and clip isolation."""
+    from selfc_amd import GlobalVar
+    g = load_golden("g8_large_stack")
+    net = _large_net(dev, g)
+    x = torch.rand(3, 3, 32, 32, generator=torch.Generator().manual_seed(5))
+    try:
+        GlobalVar.set_Temporal_LEN(1)
+        with torch.no_grad():
+            z, _ = net(x=x.to(dev), rev=False)
+        assert rel_err(z.cpu(), O.large_fwd(g, x, 1)) < TOL
+    finally:
+        GlobalVar.set_Temporal_LEN(T)
+    xa = torch.rand(2 * T, 3, 32, 32, generator=torch.Generator().manual_seed(6))
+    xb = xa.clone()
+    xb[T:] = torch.rand(T, 3, 32, 32, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        za, _ = net(x=xa.to(dev), rev=False)
+        zb, _ = net(x=xb.to(dev), rev=False)
+    assert torch.equal(za[:T], zb[:T])          # clip 0 never sees clip 1
+
+
+def test_full_size_properties(dev):
+    """BASELINE config 2 shape (4 x 7x3x256x448): stack invertibility on the device
+    (latent -> inverse blocks -> same latent) and one septuplet against the oracle."""
+    from selfc_amd import runtime as rt, _lib
+    g = load_golden("g8_large_stack")
+    net = _large_net(dev, g)
+    x = torch.rand(4 * T, 3, 256, 448, generator=torch.Generator().manual_seed(1234))
+    xd = x.to(dev)
+    with torch.no_grad():
+        z, _ = net(x=xd, rev=False)
+        ws = net._workspace(xd, 4 * T, 64, 112)
+        arr, nblk = net._stack()
+        rt.call("selfc_invstack_run", arr, nblk, ws.latent(), 1, _lib.stream_ptr())
+        z0 = rt.latent_to_nchw(ws)
+        fa = net.operations[0](xd)
+    assert rel_err(z0.cpu(), fa.cpu()) < TOL
+    z_ref = O.large_fwd(g, x[:T], T)
+    assert rel_err(z[:T].cpu(), z_ref) < TOL
+
+
+def test_rejects_bad_arguments(dev):
+    from selfc_amd import _lib
+    L = _lib.lib()
+    assert L.selfc_haar_fwd_nchw(None, None, 1, 3, 8, 8, None) == -1
+    x = torch.zeros(1, 3, 7, 8, device=dev)
+    assert L.selfc_haar_fwd_nchw(x.data_ptr(), x.data_ptr(), 1, 3, 7, 8, None) == -1   # odd height
+    assert L.selfc_invstack_run(None, 1, None, 0, None) == -1
+    from selfc_amd.modules.Subnet_constructor import D2DTInput
+    with pytest.raises(RuntimeError):
+        D2DTInput(48, 3).to(dev)(torch.zeros(7, 3, 8, 8, device=dev))   # wrong channel count
+    with pytest.raises(RuntimeError):
+        D2DTInput(48, 3)(torch.zeros(7, 48, 8, 8))                      # CPU tensor: no fallback

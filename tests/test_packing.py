@@ -1,0 +1,134 @@
+"""Host logic: the MFMA fragment packers (selfc_amd/packing.py).  The kernels'
+K order and lane maps are re-stated here in plain torch ("what the kernel
+contracts"), fed with the packed fragments, and compared with F.conv2d / the
+oracle on the reference-layout weights."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import selfc_oracle as O
+from selfc_amd import packing as P
+
+
+def stages(cin, layer):
+    """mirror of build_stages()/stage_of() in csrc/dense_conv.hip"""
+    st = []
+    if cin <= 3:
+        st.append(("im2col", 0, 32))
+        fbase = 0
+    else:
+        cin16 = P.roundup(cin, 16)
+        for c0 in range(0, cin16, 32):
+            st.append(("dense", c0, 32 if cin16 - c0 >= 32 else 16))
+        fbase = P.roundup(cin, 32)
+    for i in range(layer - 1):
+        st.append(("dense", fbase + 32 * i, 32))
+    return st
+
+
+def unpack_a32(frag):
+    """[nfrag,64,8] -> W[32][K] with W[lane&31][16 f + 8 (lane>>5) + j]"""
+    nfrag = frag.shape[0]
+    return frag.float().reshape(nfrag, 2, 32, 8).permute(2, 0, 1, 3).reshape(32, nfrag * 16)
+
+
+def act_k(dense, x1, cin, layer):
+    """dense (N,H,W,C), x1 (N,H,W,4) -> (N,H,W,K) in kernel K order (zero padded halo)"""
+    n, h, w, _ = dense.shape
+    dp = F.pad(dense, (0, 0, 1, 1, 1, 1))
+    xp = F.pad(x1, (0, 0, 1, 1, 1, 1)) if x1 is not None else None
+    cols = []
+    for kind, coff, width in stages(cin, layer):
+        if kind == "im2col":
+            v = torch.zeros(n, h, w, 32)
+            for tap in range(9):
+                ky, kx = divmod(tap, 3)
+                v[..., tap * cin:(tap + 1) * cin] = xp[:, ky:ky + h, kx:kx + w, :cin]
+            cols.append(v)
+        else:
+            for tap in range(9):
+                ky, kx = divmod(tap, 3)
+                cols.append(dp[:, ky:ky + h, kx:kx + w, coff:coff + width])
+    return torch.cat(cols, dim=-1)
+
+
+def make_dense(x, feats, cin):
+    """NCHW x and list of NCHW 32-ch features -> NHWC dense buffer in the kernel layout"""
+    n, _, h, w = x.shape
+    d = torch.zeros(n, h, w, P.dense_channels(cin))
+    fbase = 0
+    if cin > 3:
+        d[..., :cin] = x.permute(0, 2, 3, 1)
+        fbase = P.roundup(cin, 32)
+    for i, f in enumerate(feats):
+        d[..., fbase + 32 * i: fbase + 32 * (i + 1)] = f.permute(0, 2, 3, 1)
+    return d
+
+
+@pytest.mark.parametrize("cin,layer,cout,conv3d", [(48, 1, 32, True), (48, 4, 32, True), (3, 1, 32, True),
+                                                   (3, 3, 32, True), (9, 2, 32, False), (9, 5, 3, False),
+                                                   (3, 5, 9, False), (64, 3, 32, True), (12, 4, 32, False), (2, 2, 32, False)])
+def test_pack_conv3x3(cin, layer, cout, conv3d):
+    g = torch.Generator().manual_seed(cin * 10 + layer)
+    ctot = cin + 32 * (layer - 1)
+    w = torch.randn(cout, ctot, 3, 3, generator=g) * 0.1
+    x = torch.randn(2, cin, 6, 7, generator=g)
+    feats = [torch.randn(2, 32, 6, 7, generator=g) for _ in range(layer - 1)]
+    ref = F.conv2d(torch.cat([x] + feats, 1), w.half().float(), None, 1, 1)          # f16-rounded weights
+    frag = P.pack_conv3x3(w.unsqueeze(2) if conv3d else w, cin, layer)
+    assert frag.dtype == torch.float16 and frag.shape[1:] == (64, 8)
+    wk = unpack_a32(frag)
+    x1 = None
+    if cin <= 3:
+        x1 = torch.zeros(2, 6, 7, 4)
+        x1[..., :cin] = x.permute(0, 2, 3, 1)
+    ak = act_k(make_dense(x, feats, cin), x1, cin, layer)
+    assert ak.shape[-1] == wk.shape[1]
+    out = torch.einsum("ok,nhwk->nohw", wk, ak)
+    assert torch.allclose(out[:, :cout], ref, atol=1e-4, rtol=1e-4)
+    assert out[:, cout:].abs().max() == 0 if cout < 32 else True
+
+
+@pytest.mark.parametrize("cin,cout,nets", [(48, 3, 1), (3, 48, 2), (3, 64, 1), (64, 64, 1), (12, 3, 1), (3, 12, 2)])
+def test_pack_tconv5(cin, cout, nets):
+    g = torch.Generator().manual_seed(cin + cout)
+    T, B, h, w = 5, 2, 3, 4
+    ws = [torch.randn(cout, cin + 128, 3, 1, 1, generator=g) * 0.1 for _ in range(nets)]
+    frag = P.pack_tconv5(ws, cin)
+    hasx = cin <= 3
+    kd = P.dense_channels(cin) // 32
+    ks = kd + (1 if hasx else 0)
+    ot = P.roundup(cout, 16) // 16
+    assert frag.shape == (3, nets, ks, ot, 64, 8)
+    # W[tap][net][16 o + (lane&15)][32 ks + 8 (lane>>4) + j]
+    wk = frag.float().reshape(3, nets, ks, ot, 4, 16, 8).permute(1, 0, 3, 5, 2, 4, 6).reshape(nets, 3, ot * 16, ks * 32)
+    for n in range(nets):
+        x = torch.randn(B * T, cin, h, w, generator=g)
+        feats = [torch.randn(B * T, 32, h, w, generator=g) for _ in range(4)]
+        d = torch.cat([x] + feats, 1)                                            # reference cat order
+        p = {"conv5.weight": ws[n].half().float()}
+        # oracle's temporal conv on the concatenated features (bypass conv1-4): restate with einsum
+        d5 = d.reshape(B, T, -1, h, w)
+        ref = torch.zeros(B, T, cout, h, w)
+        for dt in (-1, 0, 1):
+            lo, hi = max(0, -dt), min(T, T - dt)
+            ref[:, lo:hi] += torch.einsum("oc,btchw->btohw", p["conv5.weight"][:, :, dt + 1, 0, 0], d5[:, lo + dt:hi + dt])
+        # kernel-side K vector: [x padded to 32 if cin<=3] + dense buffer channels
+        dense = make_dense(x, feats, cin)
+        kv = dense
+        if hasx:
+            xk = torch.zeros(B * T, h, w, 32)
+            xk[..., :cin] = x.permute(0, 2, 3, 1)
+            kv = torch.cat((xk, dense), -1)
+        kv = kv.reshape(B, T, h, w, -1)
+        out = torch.zeros(B, T, ot * 16, h, w)
+        for tap in range(3):
+            dt = tap - 1
+            lo, hi = max(0, -dt), min(T, T - dt)
+            out[:, lo:hi] += torch.einsum("ok,bthwk->btohw", wk[n, tap], kv[:, lo + dt:hi + dt])
+        assert torch.allclose(out[:, :, :cout], ref, atol=1e-4, rtol=1e-4)
+
+
+def test_pad_bias():
+    b = P.pad_bias(torch.arange(3.0))
+    assert b.shape == (64,) and b[:3].tolist() == [0.0, 1.0, 2.0] and b[3:].abs().sum() == 0
