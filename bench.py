@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: septuplets/s (7x3x256x448), forward + inverse InvBlock stack.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+
+One step = the hot path over one batch of 4 synthetic septuplets per GPU, already
+resident in HBM: FrequencyAnalyzer.fwd -> 8 x InvBlockExp.fwd -> Quantization ->
+8 x InvBlockExp.rev -> FrequencyAnalyzer.rev (BASELINE.json configs[1]).
+Septuplets are independent: ranks shard them with no data-path collective (weak
+scaling); the only collectives are the timing barrier and the MAX over ranks.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
+(dense 3x3 conv kernel, MFMA-bound, timed live with HIP events on its launch
+stream) and `cpu_baseline` (the CPU oracle = a port of the reference path, timed
+on this box's host cores at N=1).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+T, H, W, B_PER_GPU = 7, 256, 448, 4
+OPT = {"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": "gmm", "scale": 4, "gmm_k": 5}
+PEAK_F16_TFLOPS = 2500.0     # dense f16/bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+# algorithmic MACs of conv1..4 of F, G and H per LR pixel-frame per block and direction
+MAC_CONV3_PX = 9 * 32 * (48 + 80 + 112 + 144) + 2 * 9 * 32 * (3 + 35 + 67 + 99)
+MAC_BLOCK_PX = 267408        # whole InvBlockExp, SURVEY 8d
+
+
+def build_net(device):
+    from selfc_amd import GlobalVar
+    from selfc_amd.modules.SelfC_GMM_arch_inv import SelfCInvNet
+    GlobalVar.set_Temporal_LEN(T)
+    torch.manual_seed(10)                      # manual_seed of train_rescaling_selfc_large.yml
+    net = SelfCInvNet(OPT, 3, 3, "D2DTNet", [4, 4], 2).eval()
+    return net.to(device)
+
+
+def cpu_baseline(net, x_cpu, budget_s=20.0):
+    """Oracle (port of the reference's torch path) on one septuplet of the same workload."""
+    from oracle import selfc_oracle as O      # checker / baseline only
+    params = {k: v.detach().cpu() for k, v in net.state_dict().items() if k.startswith("operations.")}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        z, xr = O.large_roundtrip(params, x_cpu, T)          # warm-up + parity reference
+        first = time.perf_counter() - t0
+        times = []
+        while sum(times) + first < budget_s and len(times) < 5:
+            t0 = time.perf_counter()
+            O.large_roundtrip(params, x_cpu, T)
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2] if times else first
+    return {"value": 1.0 / med, "unit": "septuplets/s", "cores": cores, "kind": "port",
+            "sample": f"1 septuplet 7x3x{H}x{W}, fwd+quant+inv through the CPU oracle, {len(times)} timed runs (median), "
+                      f"torch fp32 {torch.get_num_threads()} threads"}, z, xr
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from selfc_amd import _lib
+    from selfc_amd.pipeline import RescaleRoundTrip
+    L = _lib.lib()
+    net = build_net(dev)
+    n_frames = B_PER_GPU * T
+    g = torch.Generator().manual_seed(1234 + rank)
+    x_cpu = torch.rand(n_frames, 3, H, W, generator=g)
+    x = x_cpu.to(dev)
+    rt = RescaleRoundTrip(net, n_frames, H, W, dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.no_grad():
+        use_graph = not args.no_graph
+        if use_graph:
+            rt.capture(x)
+            step = rt.replay
+        else:
+            step = lambda: rt.run(x)          # noqa: E731
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+        # ---- roofline leg: same K steps, eager, HIP events around every launch on its stream
+        L.selfc_profile_reset()
+        L.selfc_profile_enable(1)
+        for _ in range(args.steps):
+            rt.run(x)
+        torch.cuda.synchronize()
+        L.selfc_profile_enable(0)
+        cls_ms, cls_n = {}, {}
+        for cls, name in enumerate(["conv3x3", "conv5_F", "conv5_GH", "transforms"]):
+            ms, n = C.c_double(), C.c_longlong()
+            L.selfc_profile_read(cls, C.byref(ms), C.byref(n))
+            cls_ms[name], cls_n[name] = ms.value, n.value
+        L.selfc_profile_reset()
+
+    npx = n_frames * (H // 4) * (W // 4)
+    flops_conv3_per_launch = 2.0 * MAC_CONV3_PX * npx * 16 / 128          # 128 launches per step (8 per block-direction)
+    avg_ms = cls_ms["conv3x3"] / max(cls_n["conv3x3"], 1)
+    achieved = flops_conv3_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    roofline = {"bound": "mfma", "kernel": "conv3x3_kernel (conv1-4 of F,G,H)", "achieved": round(achieved, 1),
+                "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4),
+                "traffic": None, "avg_launch_us": round(avg_ms * 1e3, 2), "launches": cls_n["conv3x3"],
+                "flops_per_launch": flops_conv3_per_launch}
+    sept = B_PER_GPU * world * args.steps
+    value = sept / dt
+    whole_flops = 2.0 * MAC_BLOCK_PX * npx * 16
+    out = {
+        "metric": "septuplets/sec (7x3x256x448) fwd+inv InvBlock stack", "value": round(value, 2), "unit": "septuplets/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "SelfC-large FrequencyAnalyzer + 8 InvBlockExp(D2DTNet) fwd, Quantization, 8 InvBlockExp rev, "
+                               "FrequencyAnalyzer rev; 4 septuplets 7x3x256x448 per GPU, inputs resident in HBM, seeded default-init weights",
+                   "septuplets_per_gpu": B_PER_GPU, "launch": "hipGraph replay" if use_graph else "eager",
+                   "sharding": f"{world} rank(s) x {B_PER_GPU} independent septuplets, no data-path collective"},
+        "roofline": roofline,
+        "stack_tflops": round(whole_flops * world * args.steps / dt / 1e12, 1),
+        "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in cls_ms.items()},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb, z_ref, xr_ref = cpu_baseline(net, x_cpu[:T])
+        out["cpu_baseline"] = cb
+        with torch.no_grad():
+            z = rt.forward_latent(x)[:T].cpu()
+            xr = rt.run(x)[:T].cpu()
+        out["parity"] = {"latent_rel_err": float((z - z_ref).abs().max() / z_ref.abs().max()),
+                         "roundtrip_rel_err": float((xr - xr_ref).abs().max() / xr_ref.abs().max()),
+                         "tolerance": 1e-3, "against": "CPU oracle, septuplet 0"}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

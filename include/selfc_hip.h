@@ -124,6 +124,16 @@ int selfc_subnet_run(const selfc_subnet_w* w, int kind, const float* xin, float*
 int selfc_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, void* stream);
 int selfc_nhwc4_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream);
 
+/* ---- live kernel timing (bench.py roofline leg) ------------------------------
+ * HIP events are recorded on the launch stream around every kernel launch while
+ * enabled.  Classes: 0 dense 3x3 conv (conv1..4), 1 conv5+coupling of F,
+ * 2 conv5+coupling of G/H, 3 split/merge/layout transforms, 4 stand-alone conv5.
+ * Not thread-safe; keep disabled while capturing a hipGraph.  The reference has
+ * no counterpart (its only timing is commented-out time.time(), SelfC_model.py:194). */
+int selfc_profile_enable(int on);
+int selfc_profile_read(int cls, double* total_ms, long long* launches);   /* waits for the recorded events */
+int selfc_profile_reset(void);
+
 #ifdef __cplusplus
 }
 #endif

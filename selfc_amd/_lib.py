@@ -20,6 +20,7 @@ SYMBOLS = [
     "selfc_nchw_to_latent", "selfc_latent_to_nchw", "selfc_quantize_inplace",
     "selfc_invblock_run", "selfc_invstack_run", "selfc_subnet_run",
     "selfc_nchw_to_nhwc4", "selfc_nhwc4_to_nchw",
+    "selfc_profile_enable", "selfc_profile_read", "selfc_profile_reset",
 ]
 
 
@@ -68,6 +69,9 @@ def lib():
             "selfc_subnet_run": [C.POINTER(SubnetW), i, vp, vp, vp, i, i, i, i, i, i, vp],
             "selfc_nchw_to_nhwc4": [vp, vp, i, i, i, i, vp],
             "selfc_nhwc4_to_nchw": [vp, vp, i, i, i, i, vp],
+            "selfc_profile_enable": [i],
+            "selfc_profile_read": [i, C.POINTER(C.c_double), C.POINTER(C.c_longlong)],
+            "selfc_profile_reset": [],
         }
         for name, args in sigs.items():
             fn = getattr(L, name)

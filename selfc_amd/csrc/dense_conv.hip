@@ -16,6 +16,7 @@
 // 8/16-byte vectors on NHWC rows.  Operands are f16 (weights and activations
 // rounded once), accumulation and all coupling arithmetic are fp32.
 #include "common.hpp"
+#include "prof.hpp"
 #include "../../include/selfc_hip.h"
 
 using namespace selfc;
@@ -534,6 +535,7 @@ int launch_conv3x3(C3Args& a, int nets_z, hipStream_t s) {
   a.tiles_x = (a.W + C3_TW - 1) / C3_TW;
   a.tiles_y = (a.H + C3_TH - 1) / C3_TH;
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), 1, (unsigned)nets_z);
+  ProfScope prof(EPI == EPI_LRELU ? PROF_CONV3X3 : EPI == EPI_F ? PROF_CONV5_F : EPI == EPI_GH ? PROF_CONV5_GH : PROF_CONV5_PLAIN, s);
   hipLaunchKernelGGL((conv3x3_kernel<C3_TH, C3_TW, C3_NW, C3_MT, EPI>), grid, dim3(C3_NW * 64), C3_LDS, s, a);
   return hip_rc(hipGetLastError());
 }
@@ -567,6 +569,7 @@ int launch_t5(const T5Args& a, hipStream_t s) {
     attr_done = true;
   }
   const int tiles = (a.HW + 127) / 128;
+  ProfScope prof(EPI == EPI_F ? PROF_CONV5_F : EPI == EPI_GH ? PROF_CONV5_GH : PROF_CONV5_PLAIN, s);
   hipLaunchKernelGGL((tconv5_kernel<NETS, OT, KD, HASX, EPI>), dim3((unsigned)(tiles * a.B)), dim3(512), lds, s, a);
   return hip_rc(hipGetLastError());
 }

@@ -6,6 +6,7 @@
 // One thread per low-resolution pixel; reads of NCHW planes and writes of NHWC
 // rows are 16-B vectors, consecutive lanes touch consecutive addresses.
 #include "common.hpp"
+#include "prof.hpp"
 #include "../../include/selfc_hip.h"
 
 using namespace selfc;
@@ -260,6 +261,7 @@ extern "C" {
 int selfc_haar_fwd_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return SELFC_EINVAL;
   const size_t total = (size_t)N * C * (H / 2) * (W / 2);
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
   hipLaunchKernelGGL(haar_fwd_kernel, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x, y, N, C, H / 2, W / 2);
   return hip_rc(hipGetLastError());
 }
@@ -267,6 +269,7 @@ int selfc_haar_fwd_nchw(const float* x, float* y, int N, int C, int H, int W, vo
 int selfc_haar_inv_nchw(const float* y, float* x, int N, int C, int h, int w, void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || h <= 0 || w <= 0) return SELFC_EINVAL;
   const size_t total = (size_t)N * C * h * w;
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
   hipLaunchKernelGGL(haar_inv_kernel, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, y, x, N, C, h, w);
   return hip_rc(hipGetLastError());
 }
@@ -276,6 +279,7 @@ int selfc_freq_fwd(const float* x, float* x1, float* x2, void* fd, int FC, int N
   if (fd && (FC < 3 * k * k || (FC & 3))) return SELFC_EINVAL;
   const int h = H / k, w = W / k;
   const size_t total = (size_t)N * h * w;
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
   if (k == 4)
     hipLaunchKernelGGL(freq_fwd_kernel<4>, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x, x1, x2, (f16*)fd, FC, N, h, w);
   else
@@ -286,6 +290,7 @@ int selfc_freq_fwd(const float* x, float* x1, float* x2, void* fd, int FC, int N
 int selfc_freq_inv(const float* x1, const float* x2, float* x, int N, int h, int w, int k, void* stream) {
   if (!x || !x1 || !x2 || N <= 0 || h <= 0 || w <= 0 || (k != 4 && k != 2)) return SELFC_EINVAL;
   const size_t total = (size_t)N * h * w;
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
   if (k == 4)
     hipLaunchKernelGGL(freq_inv_kernel<4>, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x1, x2, x, N, h, w);
   else
@@ -298,6 +303,7 @@ int selfc_nchw_to_latent(const float* x, float* x1, float* x2, void* fd, int FC,
   const int c2p = (c2 + 3) & ~3;
   if (fd && (FC < c2p || (FC & 3))) return SELFC_EINVAL;
   const size_t HW = (size_t)H * W;
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
   hipLaunchKernelGGL(nchw_to_latent_kernel, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x, x1, x2, (f16*)fd, FC, N, c1, c2, c2p, HW);
   return hip_rc(hipGetLastError());
 }
@@ -306,6 +312,7 @@ int selfc_latent_to_nchw(const float* x1, const float* x2, float* y, int N, int 
   if (!y || !x1 || !x2 || N <= 0 || c1 < 1 || c1 > 4 || c2 < 1 || H <= 0 || W <= 0) return SELFC_EINVAL;
   const int c2p = (c2 + 3) & ~3;
   const size_t HW = (size_t)H * W;
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
   hipLaunchKernelGGL(latent_to_nchw_kernel, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x1, x2, y, N, c1, c2, c2p, HW);
   return hip_rc(hipGetLastError());
 }
@@ -313,6 +320,7 @@ int selfc_latent_to_nchw(const float* x1, const float* x2, float* y, int N, int 
 int selfc_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0) return SELFC_EINVAL;
   const size_t HW = (size_t)H * W;
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
   hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x, y, N, C, (C + 3) & ~3, HW);
   return hip_rc(hipGetLastError());
 }
@@ -320,6 +328,7 @@ int selfc_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, vo
 int selfc_nhwc4_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0) return SELFC_EINVAL;
   const size_t HW = (size_t)H * W;
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
   hipLaunchKernelGGL(nhwc4_to_nchw_kernel, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x, y, N, C, (C + 3) & ~3, HW);
   return hip_rc(hipGetLastError());
 }
@@ -327,6 +336,7 @@ int selfc_nhwc4_to_nchw(const float* x, float* y, int N, int C, int H, int W, vo
 int selfc_quantize_inplace(float* x, size_t n, void* stream) {
   if (!x || (n & 3)) return SELFC_EINVAL;
   if (n == 0) return SELFC_OK;
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
   hipLaunchKernelGGL(quantize_kernel, dim3(nblocks(n / 4)), dim3(TPB), 0, (hipStream_t)stream, x, n / 4);
   return hip_rc(hipGetLastError());
 }

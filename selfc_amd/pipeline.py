@@ -1,0 +1,75 @@
+"""The metric's unit of work as one pre-bound launch sequence.
+
+``RescaleRoundTrip`` runs, for a batch of septuplets already resident in HBM,
+FrequencyAnalyzer.fwd -> N x InvBlockExp.fwd -> Quantization (LR channels) ->
+N x InvBlockExp.rev -> FrequencyAnalyzer.rev, i.e. SelfCModel.test()'s two netG
+calls (SelfC_model.py:213-230) with the forward's own HF channels fed back
+(the STP sampler is a separate, later stage).  Everything stays
+in the kernels' latent layout; no allocation happens inside ``run`` so it can be
+captured into a hipGraph (``capture()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib, runtime as rt
+from .global_var import GlobalVar
+
+
+class RescaleRoundTrip:
+    def __init__(self, net, n_frames: int, H: int, W: int, device):
+        t = GlobalVar.get_Temporal_LEN()
+        if not t or n_frames % t:
+            raise RuntimeError("set GlobalVar temporal length to a divisor of the frame count first")
+        self.net = net
+        self.k = net.operations[0].k
+        self.N, self.H, self.W = n_frames, H, W
+        self.h, self.w = H // self.k, W // self.k
+        blk = net._blocks()[0]
+        self.ws = rt.Workspace(device, blk.F.kind, n_frames, t, self.h, self.w, blk.split_len1, blk.split_len2)
+        self.arr, self.keep = rt.block_array(net._blocks())
+        self.nblk = len(self.keep)
+        self.lat = self.ws.latent()
+        self.out = torch.empty((n_frames, 3, H, W), dtype=torch.float32, device=device)
+        self.graph = None
+        self.static_x = None
+
+    def run(self, x: torch.Tensor) -> torch.Tensor:
+        ws, L, sp = self.ws, _lib.lib(), _lib.stream_ptr()
+        chk = _lib.check
+        chk(L.selfc_freq_fwd(x.data_ptr(), ws.x1.data_ptr(), ws.x2.data_ptr(), ws.fd.data_ptr(), ws.FC,
+                             self.N, self.H, self.W, self.k, sp), "selfc_freq_fwd")
+        chk(L.selfc_invstack_run(self.arr, self.nblk, C.byref(self.lat), 0, sp), "selfc_invstack_run fwd")
+        chk(L.selfc_quantize_inplace(ws.x1.data_ptr(), ws.x1.numel(), sp), "selfc_quantize_inplace")
+        chk(L.selfc_invstack_run(self.arr, self.nblk, C.byref(self.lat), 1, sp), "selfc_invstack_run rev")
+        chk(L.selfc_freq_inv(ws.x1.data_ptr(), ws.x2.data_ptr(), self.out.data_ptr(), self.N, self.h, self.w, self.k, sp),
+            "selfc_freq_inv")
+        return self.out
+
+    def forward_latent(self, x: torch.Tensor) -> torch.Tensor:
+        """fwd half only; returns the (N,51,h,w) NCHW latent (for parity checks)."""
+        ws, L, sp = self.ws, _lib.lib(), _lib.stream_ptr()
+        _lib.check(L.selfc_freq_fwd(x.data_ptr(), ws.x1.data_ptr(), ws.x2.data_ptr(), ws.fd.data_ptr(), ws.FC,
+                                    self.N, self.H, self.W, self.k, sp), "selfc_freq_fwd")
+        _lib.check(L.selfc_invstack_run(self.arr, self.nblk, C.byref(self.lat), 0, sp), "selfc_invstack_run fwd")
+        return rt.latent_to_nchw(ws)
+
+    def capture(self, x: torch.Tensor):
+        """Record one run into a hipGraph (replay with ``replay()``); x must stay at this address."""
+        self.static_x = x
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.run(x)                    # warm-up outside capture (lazy function attributes etc.)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.run(x)
+        self.graph = g
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
