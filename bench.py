@@ -44,24 +44,40 @@ def build_net(device):
 
 
 def cpu_baseline(net, x_cpu, budget_s=20.0):
-    """Oracle (port of the reference's torch path) on one septuplet of the same workload."""
+    """Oracle (port of the reference's torch path) on one septuplet of the same workload.
+
+    torch's CPU convs scale badly past a few dozen threads on a many-core host, so
+    the thread count is calibrated on a 64x64 septuplet first and the one used is
+    reported as `cores`."""
     from oracle import selfc_oracle as O      # checker / baseline only
     params = {k: v.detach().cpu() for k, v in net.state_dict().items() if k.startswith("operations.")}
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
+    small = x_cpu[:, :, :64, :64].contiguous()
+    best_t, best_n = None, 1
     with torch.no_grad():
+        for nthr in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+            torch.set_num_threads(nthr)
+            O.large_fwd(params, small, T)
+            t0 = time.perf_counter()
+            O.large_fwd(params, small, T)
+            dt = time.perf_counter() - t0
+            if best_t is None or dt < best_t:
+                best_t, best_n = dt, nthr
+        torch.set_num_threads(best_n)
         t0 = time.perf_counter()
-        z, xr = O.large_roundtrip(params, x_cpu, T)          # warm-up + parity reference
-        first = time.perf_counter() - t0
-        times = []
-        while sum(times) + first < budget_s and len(times) < 5:
+        z = O.large_fwd(params, x_cpu, T)                     # also the parity reference
+        zq = torch.cat((O.quantize(z[:, :3]), z[:, 3:]), 1)
+        xr = O.large_inv_from_latent(params, zq, T)
+        times = [time.perf_counter() - t0]
+        while sum(times) < budget_s and len(times) < 6:
             t0 = time.perf_counter()
             O.large_roundtrip(params, x_cpu, T)
             times.append(time.perf_counter() - t0)
-    med = sorted(times)[len(times) // 2] if times else first
-    return {"value": 1.0 / med, "unit": "septuplets/s", "cores": cores, "kind": "port",
-            "sample": f"1 septuplet 7x3x{H}x{W}, fwd+quant+inv through the CPU oracle, {len(times)} timed runs (median), "
-                      f"torch fp32 {torch.get_num_threads()} threads"}, z, xr
+    timed = times[1:] if len(times) > 1 else times
+    med = sorted(timed)[len(timed) // 2]
+    return {"value": 1.0 / med, "unit": "septuplets/s", "cores": best_n, "kind": "port",
+            "sample": f"1 septuplet 7x3x{H}x{W}, fwd+quant+inv through the CPU oracle (torch fp32), {len(timed)} timed run(s), median; "
+                      f"{best_n} threads (calibrated) of {ncpu} host CPUs"}, z, zq, xr
 
 
 def main():
@@ -159,14 +175,18 @@ def main():
         "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in cls_ms.items()},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb, z_ref, xr_ref = cpu_baseline(net, x_cpu[:T])
+        cb, z_ref, zq_ref, xr_ref = cpu_baseline(net, x_cpu[:T])
         out["cpu_baseline"] = cb
         with torch.no_grad():
             z = rt.forward_latent(x)[:T].cpu()
-            xr = rt.run(x)[:T].cpu()
-        out["parity"] = {"latent_rel_err": float((z - z_ref).abs().max() / z_ref.abs().max()),
-                         "roundtrip_rel_err": float((xr - xr_ref).abs().max() / xr_ref.abs().max()),
-                         "tolerance": 1e-3, "against": "CPU oracle, septuplet 0"}
+            # inverse half on the SAME quantised latent as the oracle (a comparison through the
+            # quantiser would turn a 1e-4 LR difference into a full 1/255 step)
+            zin = torch.zeros(n_frames, 51, H // 4, W // 4)
+            zin[:T] = zq_ref
+            xr = rt.inverse_latent(zin.to(dev))[:T].cpu()
+        out["parity"] = {"fwd_latent_rel_err": float((z - z_ref).abs().max() / z_ref.abs().max()),
+                         "inv_rel_err": float((xr - xr_ref).abs().max() / xr_ref.abs().max()),
+                         "tolerance": 1e-3, "metric": "max|a-b|/max|b|", "against": "CPU oracle, septuplet 0"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

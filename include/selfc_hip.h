@@ -21,9 +21,11 @@
  * channel split (c1, c2), c1 <= 3:
  *   x1    fp32 [N][H][W][4]        first c1 channels real
  *   x2    fp32 [N][H][W][c2p]      c2p = roundup(c2, 4)
- *   fd    f16  [N][H][W][FC]       F subnet dense buffer, FC = roundup(c2,32)+128:
- *                                  [x2 as f16 | zero pad | f1 f2 f3 f4]
- *   gd,hd f16  [N][H][W][128]      G / H subnet dense feature buffers
+ *   fd    f16  [FC/32][N][H][W][32]  F subnet dense buffer, FC = roundup(c2,32)+128 channels
+ *                                  [x2 as f16 | zero pad | f1 f2 f3 f4], stored as 32-channel
+ *                                  planes so that each group of a pixel is one contiguous 64 B
+ *   gd,hd f16  [4][N][H][W][32]    G / H subnet dense feature buffers (f1..f4)
+ * All workspaces must be zero-initialised once by the caller (pad channels are never written).
  * N = B*T frames, clip-major (frame n = b*T + t), as in Subnet_constructor.py:119-124.
  */
 #ifndef SELFC_HIP_H
@@ -58,7 +60,7 @@ int selfc_haar_inv_nchw(const float* y, float* x, int N, int C, int h, int w, vo
 /* FrequencyAnalyzer.forward(x, rev=False): SelfC_GMM_arch_inv.py:73-78 (k = 4 or 2).
  * x NCHW (N,3,H,W) -> latent x1 (lo, 3 ch), x2 (3k^2 ch, channel (sy*k+sx)*3+c),
  * and, when fd != NULL, the f16 copy of x2 in channels [0,3k^2) of the F dense
- * buffer with channel stride FC. */
+ * buffer (FC = its channel count, used for validation only). */
 int selfc_freq_fwd(const float* x, float* x1, float* x2, void* fd, int FC,
                    int N, int H, int W, int k, void* stream);
 /* FrequencyAnalyzer.forward(x, rev=True): SelfC_GMM_arch_inv.py:79-82 (nn.PixelShuffle
@@ -115,8 +117,8 @@ int selfc_invstack_run(const selfc_invblock_w* blks, int nblk, const selfc_laten
 /* One stand-alone subnet (DenseBlock.forward / D2DTInput.forward,
  * Subnet_constructor.py:26-34,115-133): input NHWC fp32 `xin` with channel
  * stride cinp = roundup(cin,4), output NHWC fp32 `yout` with stride
- * coutp = roundup(cout,4); `dense` is a [N][H][W][DC] f16 workspace with
- * DC = (cin <= 3 ? 128 : roundup(cin,32)+128). */
+ * coutp = roundup(cout,4); `dense` is a zero-initialised [DC/32][N][H][W][32] f16
+ * workspace with DC = (cin <= 3 ? 128 : roundup(cin,32)+128). */
 int selfc_subnet_run(const selfc_subnet_w* w, int kind, const float* xin, float* yout, void* dense,
                      int N, int T, int H, int W, int cin, int cout, void* stream);
 

@@ -15,6 +15,7 @@
 // then owns one pixel and 4-channel groups of it, so epilogue loads/stores are
 // 8/16-byte vectors on NHWC rows.  Operands are f16 (weights and activations
 // rounded once), accumulation and all coupling arithmetic are fp32.
+#include <stdlib.h>
 #include "common.hpp"
 #include "prof.hpp"
 #include "../../include/selfc_hip.h"
@@ -46,7 +47,8 @@ struct C3Args {
   const float* bias[2];  // 32 floats
   const float* x1;       // NHWC4 fp32 source of the im2col stage
   f16* out[2];           // EPI_LRELU: dense buffer to append to
-  int N, H, W, C;        // frames, latent size, channel stride of dense / out
+  int N, H, W;           // frames, latent size
+  size_t plane;          // halfs per 32-channel plane of a dense buffer = N*H*W*32
   int c1;                // channels of the im2col source
   int nstages;
   int out_coff;
@@ -55,11 +57,12 @@ struct C3Args {
   // coupling / plain epilogue (EPI != LRELU)
   float* x1io;           // EPI_F: y1 = x1 +- F, in place          [N][H][W][4]
   float* x2io;           // EPI_GH: y2, in place                   [N][H][W][c2p]
-  f16* fd;               // EPI_GH: f16 copy of y2 into the F dense buffer (stride fC) or null
+  f16* fd;               // EPI_GH: f16 copy of y2 into planes 0.. of the F dense buffer, or null
   float* s_out;          // EPI_GH: optional s                      [N][H][W][c2p]
   float* plain;          // EPI_PLAIN: fp32 NHWC output, stride coutp
-  int c2p, fC, coutp, rev;
+  int c2p, coutp, rev;
   float clamp;
+  int ablate;            // developer timing aid (env SELFC_ABLATE): 1 skip MFMA loop, 2 skip global loads, 4 skip LDS staging
 };
 
 // ---------------------------------------------------------------------------------
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
   const int ty = (wg / a.tiles_x) % a.tiles_y;
   const int n = wg / (a.tiles_x * a.tiles_y);
   const int tx0 = tx * TW, ty0 = ty * TH;
-  const int H = a.H, W = a.W, C = a.C;
+  const int H = a.H, W = a.W;
 
   // this lane's pixel in each of the wave's M-tiles
   int pbase[MT];      // byte offset of the pixel's tap (0,0) in the LDS halo tile (+ k-half)
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
 
     // -- staging helpers -------------------------------------------------------
     auto load_stage = [&](const C3Stage st, const int fb) __attribute__((always_inline)) {
+      if (a.ablate & 2) return;
       const int cshift = st.width == 32 ? 2 : 1;  // 16-byte chunks per pixel: 4 or 2
       const int nitems = NPIX << cshift;
 #pragma unroll
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
         const int y = ty0 + hy - 1, x = tx0 + hx - 1;
         const bool ok = (i < nitems) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
         const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
-        const u32x4 v = *reinterpret_cast<const u32x4*>(dense + ((size_t)(n * H + yc) * W + xc) * C + st.coff + q * 8);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(dense + (size_t)(st.coff >> 5) * a.plane + ((size_t)(n * H + yc) * W + xc) * 32 + q * 8);
         areg[it] = ok ? v : u32x4{0u, 0u, 0u, 0u};
       }
       const int nfr = 9 * (st.width >> 4);
@@ -152,6 +156,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
       }
     };
     auto store_stage = [&](const C3Stage st) __attribute__((always_inline)) {
+      if (a.ablate & 4) return;
       const int cshift = st.width == 32 ? 2 : 1;
       const int nitems = NPIX << cshift;
 #pragma unroll
@@ -169,25 +174,49 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
         if (i < nfr * 64) *reinterpret_cast<u32x4*>(lw + i * 16) = wreg[it];
       }
     };
-    // im2col stage: row of pixel p holds x1[p + tap][c] at k = tap*c1 + c, zero above 9*c1
+    // im2col stage: row of pixel p holds x1[p + tap][c] at k = tap*c1 + c, zero above 9*c1.
+    // Two phases so that no global-load latency is serialised: (1) the (TH+2)x(TW+2) halo of
+    // x1 goes to LDS as 4 x f16 per pixel (parked in the weight area, which is filled last),
+    // (2) rows are assembled LDS -> LDS.
     auto fill_im2col = [&]() __attribute__((always_inline)) {
+      if (a.ablate & 16) return;
       const int c1 = a.c1;
-      for (int i = tid; i < TH * TW * 10; i += NT) {
-        const int p = i / 10, tap = i - p * 10;
-        const int ly = p / TW, lx = p - ly * TW;
-        unsigned char* row = lact + ((ly + 1) * HWD + (lx + 1)) * PS;
-        if (tap == 9) {
-          for (int k = 9 * c1; k < 32; ++k) reinterpret_cast<f16*>(row)[k] = (f16)0.f;
-        } else {
-          const int y = ty0 + ly + tap / 3 - 1, x = tx0 + lx + tap % 3 - 1;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (y >= 0 && y < H && x >= 0 && x < W)
-            v = *reinterpret_cast<const float4*>(a.x1 + ((size_t)(n * H + y) * W + x) * 4);
-          const float vv[4] = {v.x, v.y, v.z, v.w};
-          for (int c = 0; c < c1; ++c) reinterpret_cast<f16*>(row)[tap * c1 + c] = (f16)vv[c];
-        }
+      constexpr int XITER = (NPIX + NT - 1) / NT;
+      unsigned char* const lx = lw + 4096;          // 8 B per halo pixel, after the 2 im2col weight fragments
+      float4 xv[XITER];
+#pragma unroll
+      for (int it = 0; it < XITER; ++it) {
+        const int p = tid + it * NT;
+        const int hy = p / HWD, hx = p - hy * HWD;
+        const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+        const bool ok = (p < NPIX) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
+        const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+        const float4 v = *reinterpret_cast<const float4*>(a.x1 + ((size_t)(n * H + yc) * W + xc) * 4);
+        xv[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       for (int i = tid; i < 2 * 64; i += NT) *reinterpret_cast<u32x4*>(lw + i * 16) = wsrc[i];
+#pragma unroll
+      for (int it = 0; it < XITER; ++it) {
+        const int p = tid + it * NT;
+        if (p < NPIX) {
+          uint2 u;
+          u.x = pack2(xv[it].x, xv[it].y);
+          u.y = pack2(xv[it].z, xv[it].w);
+          *reinterpret_cast<uint2*>(lx + p * 8) = u;
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < TH * TW * 10; i += NT) {
+        const int p = i / 10, tap = i - p * 10;
+        const int ly = p / TW, lxx = p - ly * TW;
+        f16* row = reinterpret_cast<f16*>(lact + ((ly + 1) * HWD + (lxx + 1)) * PS);
+        if (tap == 9) {
+          for (int k = 9 * c1; k < 32; ++k) row[k] = (f16)0.f;
+        } else {
+          const f16* src = reinterpret_cast<const f16*>(lx + ((ly + tap / 3) * HWD + (lxx + tap % 3)) * 8);
+          for (int c = 0; c < c1; ++c) row[tap * c1 + c] = src[c];
+        }
+      }
     };
 
     // -- prologue: stage 0 --------------------------------------------------------
@@ -208,7 +237,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
       const bool more = s + 1 < a.nstages;
       if (more) load_stage(stn, fragbase + nfr);
 
-      if (st.kind == 1) {
+      if (a.ablate & 1) {
+      } else if (st.kind == 1) {
         constexpr int CTR = (HWD + 1) * PS;  // centre tap
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -255,21 +285,42 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
   // -- epilogue -------------------------------------------------------------------
   // acc[..][m][r]: pixel = lane&31 of M-tile m, outch = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int half = lane >> 5;
+  if (a.ablate & 8) {   // keep the accumulators alive without the stores
+    float keep = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) keep += acc[0][m][0] + acc[NNETS - 1][m][5];
+    if (keep == 123.456f) a.out[0][0] = (f16)keep;
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int y = ty0 + py[m], x = tx0 + px[m];
     if (y >= H || x >= W) continue;
     const size_t pix = (size_t)(n * H + y) * W + x;
     if (EPI == EPI_LRELU) {
+      // lanes l and l+32 own the same pixel and interleaved 4-channel groups; one half-swap per
+      // dword hands each lane 8 contiguous channels -> two 16-byte stores per M-tile
       const float* __restrict__ bias = blockIdx.z ? a.bias[1] : a.bias[0];
-      f16* dst = (blockIdx.z ? a.out[1] : a.out[0]) + pix * C + a.out_coff + 4 * half;
+      f16* dst = (blockIdx.z ? a.out[1] : a.out[0]) + (size_t)(a.out_coff >> 5) * a.plane + pix * 32 + 8 * half;
+      uint32_t r[4][2];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 b = *reinterpret_cast<const float4*>(bias + 8 * g + 4 * half);
-        uint2 u;
-        u.x = pack2(lrelu02(acc[0][m][4 * g + 0] + b.x), lrelu02(acc[0][m][4 * g + 1] + b.y));
-        u.y = pack2(lrelu02(acc[0][m][4 * g + 2] + b.z), lrelu02(acc[0][m][4 * g + 3] + b.w));
-        *reinterpret_cast<uint2*>(dst + 8 * g) = u;
+        r[g][0] = pack2(lrelu02(acc[0][m][4 * g + 0] + b.x), lrelu02(acc[0][m][4 * g + 1] + b.y));
+        r[g][1] = pack2(lrelu02(acc[0][m][4 * g + 2] + b.z), lrelu02(acc[0][m][4 * g + 3] + b.w));
+      }
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        // before: r[2gp] = {lower: ch 16gp+0..3, upper: 16gp+4..7}, r[2gp+1] = {lower: 16gp+8..11, upper: 16gp+12..15}
+        // swap(r[2gp].upper <-> r[2gp+1].lower): lower lane holds ch 16gp+0..7, upper lane ch 16gp+8..15
+        u32x4 v;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(r[2 * gp][d], r[2 * gp + 1][d], false, false);
+          v[d] = sw[0];
+          v[2 + d] = sw[1];
+        }
+        *reinterpret_cast<u32x4*>(dst + 16 * gp) = v;
       }
     } else if (EPI == EPI_PLAIN) {
       const float* __restrict__ bias = a.bias[0];
@@ -319,7 +370,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
             uint2 u;
             u.x = pack2(yo[0], yo[1]);
             u.y = pack2(yo[2], yo[3]);
-            *reinterpret_cast<uint2*>(a.fd + pix * a.fC + oc) = u;
+            *reinterpret_cast<uint2*>(a.fd + (size_t)(oc >> 5) * a.plane + pix * 32 + (oc & 31)) = u;
           }
         }
       }
@@ -340,13 +391,14 @@ struct T5Args {
   const f16* w;           // fragments [3 taps][NETS][KS][OT][64 lanes][8]
   const float* bias[2];   // OT*16 floats (zero padded)
   const float* x1;        // HASX: NHWC4 fp32, channels 0..2 are the first three K entries
-  int B, T, HW, C;        // clips, frames per clip, pixels per frame, channel stride of dense
+  int B, T, HW;           // clips, frames per clip, pixels per frame
+  size_t plane;           // halfs per 32-channel plane = B*T*HW*32
   float* x1io;
   float* x2io;
   f16* fd;
   float* s_out;
   float* plain;
-  int c2p, fC, coutp, rev;
+  int c2p, coutp, rev;
   float clamp;
 };
 
@@ -392,7 +444,7 @@ __global__ __launch_bounds__(512) void tconv5_kernel(const T5Args a) {
     for (int q = 0; q < NETS; ++q)
 #pragma unroll
       for (int ks = 0; ks < KD; ++ks)
-        dst[q][ks] = *reinterpret_cast<const u32x4*>((q ? a.dense[1] : a.dense[0]) + pix * a.C + ks * 32 + kq * 8);
+        dst[q][ks] = *reinterpret_cast<const u32x4*>((q ? a.dense[1] : a.dense[0]) + (size_t)ks * a.plane + pix * 32 + kq * 8);
     if (HASX) xd = *reinterpret_cast<const float4*>(a.x1 + pix * 4);
   };
 
@@ -445,7 +497,7 @@ __global__ __launch_bounds__(512) void tconv5_kernel(const T5Args a) {
             uint2 u;
             u.x = pack2(yo[0], yo[1]);
             u.y = pack2(yo[2], yo[3]);
-            *reinterpret_cast<uint2*>(a.fd + pix * a.fC + oc) = u;
+            *reinterpret_cast<uint2*>(a.fd + (size_t)(oc >> 5) * a.plane + pix * 32 + (oc & 31)) = u;
           }
         }
       }
@@ -504,8 +556,8 @@ __global__ __launch_bounds__(512) void tconv5_kernel(const T5Args a) {
   epilogue(a.T - 1, accp);
 }
 
-// fp32 NHWC (stride cinp) -> f16 channels [0, cin32) of the dense buffer (zero padded)
-__global__ void nhwc_to_dense_kernel(const float* __restrict__ x, f16* __restrict__ d, size_t npix, int cin, int cinp, int cin32, int DC) {
+// fp32 NHWC (stride cinp) -> f16 channels [0, cin32) of the plane-blocked dense buffer (zero padded)
+__global__ void nhwc_to_dense_kernel(const float* __restrict__ x, f16* __restrict__ d, size_t npix, int cin, int cinp, int cin32) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= npix) return;
   for (int c0 = 0; c0 < cin32; c0 += 4) {
@@ -520,7 +572,7 @@ __global__ void nhwc_to_dense_kernel(const float* __restrict__ x, f16* __restric
     uint2 u;
     u.x = pack2(v[0], v[1]);
     u.y = pack2(v[2], v[3]);
-    *reinterpret_cast<uint2*>(d + i * DC + c0) = u;
+    *reinterpret_cast<uint2*>(d + (size_t)(c0 >> 5) * npix * 32 + i * 32 + (c0 & 31)) = u;
   }
 }
 
@@ -534,6 +586,8 @@ template <int EPI>
 int launch_conv3x3(C3Args& a, int nets_z, hipStream_t s) {
   a.tiles_x = (a.W + C3_TW - 1) / C3_TW;
   a.tiles_y = (a.H + C3_TH - 1) / C3_TH;
+  static const int ablate = getenv("SELFC_ABLATE") ? atoi(getenv("SELFC_ABLATE")) : 0;
+  a.ablate = ablate;
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), 1, (unsigned)nets_z);
   ProfScope prof(EPI == EPI_LRELU ? PROF_CONV3X3 : EPI == EPI_F ? PROF_CONV5_F : EPI == EPI_GH ? PROF_CONV5_GH : PROF_CONV5_PLAIN, s);
   hipLaunchKernelGGL((conv3x3_kernel<C3_TH, C3_TW, C3_NW, C3_MT, EPI>), grid, dim3(C3_NW * 64), C3_LDS, s, a);
@@ -608,7 +662,7 @@ int run_conv1to4(const selfc_subnet_w* wa, const selfc_subnet_w* wb, void* da, v
       a.w[1] = (const f16*)wb->w3[layer - 1]; a.bias[1] = wb->b3[layer - 1];
     }
     a.x1 = x1;
-    a.N = N; a.H = H; a.W = W; a.C = dense_channels(cin); a.c1 = cin <= 3 ? cin : 0;
+    a.N = N; a.H = H; a.W = W; a.plane = (size_t)N * H * W * 32; a.c1 = cin <= 3 ? cin : 0;
     build_stages(a, cin, layer);
     a.out_coff = (cin <= 3 ? 0 : ((cin + 31) & ~31)) + 32 * (layer - 1);
     const int rc = launch_conv3x3<EPI_LRELU>(a, wb ? 2 : 1, s);
@@ -631,13 +685,13 @@ int run_F(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStream
   if (l->kind == SELFC_SUBNET_D2DT) {
     T5Args a{};
     a.dense[0] = (const f16*)l->fd; a.w = (const f16*)blk->F.w5; a.bias[0] = blk->F.b5;
-    a.B = l->N / l->T; a.T = l->T; a.HW = l->H * l->W; a.C = FC;
+    a.B = l->N / l->T; a.T = l->T; a.HW = l->H * l->W; a.plane = (size_t)l->N * l->H * l->W * 32;
     a.x1io = l->x1; a.rev = rev;
     return dispatch_t5<1, 0, EPI_F>(a, 1, FC / 32, s);
   }
   C3Args a{};
   a.dense[0] = (const f16*)l->fd; a.w[0] = (const f16*)blk->F.w5; a.bias[0] = blk->F.b5;
-  a.N = l->N; a.H = l->H; a.W = l->W; a.C = FC;
+  a.N = l->N; a.H = l->H; a.W = l->W; a.plane = (size_t)l->N * l->H * l->W * 32;
   build_stages(a, l->c2, 5);
   a.x1io = l->x1; a.rev = rev;
   return launch_conv3x3<EPI_F>(a, 1, s);
@@ -647,14 +701,13 @@ int run_GH(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStrea
   int rc = run_conv1to4(&blk->G, &blk->H, l->gd, l->hd, l->x1, l->c1, l->N, l->H, l->W, s);
   if (rc) return rc;
   const int c2p = (l->c2 + 3) & ~3;
-  const int FC = dense_channels(l->c2);
   if (l->kind == SELFC_SUBNET_D2DT) {
     T5Args a{};
     a.dense[0] = (const f16*)l->gd; a.dense[1] = (const f16*)l->hd;
     a.w = (const f16*)blk->G.w5; a.bias[0] = blk->G.b5; a.bias[1] = blk->H.b5;
     a.x1 = l->x1;
-    a.B = l->N / l->T; a.T = l->T; a.HW = l->H * l->W; a.C = 128;
-    a.x2io = l->x2; a.fd = (f16*)l->fd; a.fC = FC; a.s_out = l->s_out; a.c2p = c2p;
+    a.B = l->N / l->T; a.T = l->T; a.HW = l->H * l->W; a.plane = (size_t)l->N * l->H * l->W * 32;
+    a.x2io = l->x2; a.fd = (f16*)l->fd; a.s_out = l->s_out; a.c2p = c2p;
     a.rev = rev; a.clamp = blk->clamp;
     return dispatch_t5<2, 1, EPI_GH>(a, (l->c2 + 15) / 16, 4, s);
   }
@@ -663,9 +716,9 @@ int run_GH(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStrea
   a.w[0] = (const f16*)blk->G.w5; a.w[1] = (const f16*)blk->H.w5;
   a.bias[0] = blk->G.b5; a.bias[1] = blk->H.b5;
   a.x1 = l->x1; a.c1 = l->c1;
-  a.N = l->N; a.H = l->H; a.W = l->W; a.C = 128;
+  a.N = l->N; a.H = l->H; a.W = l->W; a.plane = (size_t)l->N * l->H * l->W * 32;
   build_stages(a, l->c1, 5);
-  a.x2io = l->x2; a.fd = (f16*)l->fd; a.fC = FC; a.s_out = l->s_out; a.c2p = c2p;
+  a.x2io = l->x2; a.fd = (f16*)l->fd; a.s_out = l->s_out; a.c2p = c2p;
   a.rev = rev; a.clamp = blk->clamp;
   return launch_conv3x3<EPI_GH>(a, 1, s);
 }
@@ -711,7 +764,7 @@ int selfc_subnet_run(const selfc_subnet_w* w, int kind, const float* xin, float*
   if (cin > 3) {
     const size_t npix = (size_t)N * H * W;
     hipLaunchKernelGGL(nhwc_to_dense_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s,
-                       xin, (f16*)dense, npix, cin, (cin + 3) & ~3, (cin + 31) & ~31, DC);
+                       xin, (f16*)dense, npix, cin, (cin + 3) & ~3, (cin + 31) & ~31);
     int rc = hip_rc(hipGetLastError());
     if (rc) return rc;
   }
@@ -722,7 +775,7 @@ int selfc_subnet_run(const selfc_subnet_w* w, int kind, const float* xin, float*
     T5Args a{};
     a.dense[0] = (const f16*)dense; a.w = (const f16*)w->w5; a.bias[0] = w->b5;
     a.x1 = cin <= 3 ? xin : nullptr;
-    a.B = N / T; a.T = T; a.HW = H * W; a.C = DC;
+    a.B = N / T; a.T = T; a.HW = H * W; a.plane = (size_t)N * H * W * 32;
     a.plain = yout; a.coutp = coutp;
     const int ot = (cout + 15) / 16;
     if (cin <= 3) return dispatch_t5<1, 1, EPI_PLAIN>(a, ot, 4, s);
@@ -732,7 +785,7 @@ int selfc_subnet_run(const selfc_subnet_w* w, int kind, const float* xin, float*
   C3Args a{};
   a.dense[0] = (const f16*)dense; a.w[0] = (const f16*)w->w5; a.bias[0] = w->b5;
   a.x1 = cin <= 3 ? xin : nullptr; a.c1 = cin <= 3 ? cin : 0;
-  a.N = N; a.H = H; a.W = W; a.C = DC;
+  a.N = N; a.H = H; a.W = W; a.plane = (size_t)N * H * W * 32;
   build_stages(a, cin, 5);
   a.plain = yout; a.coutp = coutp;
   return launch_conv3x3<EPI_PLAIN>(a, 1, s);

@@ -112,14 +112,13 @@ __global__ void freq_fwd_kernel(const float* __restrict__ x, float* __restrict__
   float4* o2 = reinterpret_cast<float4*>(x2 + i * C2);
 #pragma unroll
   for (int j = 0; j < C2 / 4; ++j) o2[j] = make_float4(hi[4 * j], hi[4 * j + 1], hi[4 * j + 2], hi[4 * j + 3]);
-  if (fd != nullptr) {
-    uint2* of = reinterpret_cast<uint2*>(fd + i * (size_t)FC);
+  if (fd != nullptr) {   // plane-blocked dense buffer: [C/32][N*h*w][32]
 #pragma unroll
     for (int j = 0; j < C2 / 4; ++j) {
       uint2 u;
       u.x = pack2(hi[4 * j], hi[4 * j + 1]);
       u.y = pack2(hi[4 * j + 2], hi[4 * j + 3]);
-      of[j] = u;
+      *reinterpret_cast<uint2*>(fd + (size_t)((4 * j) >> 5) * total * 32 + i * 32 + ((4 * j) & 31)) = u;
     }
   }
 }
@@ -187,7 +186,7 @@ __global__ void nchw_to_latent_kernel(const float* __restrict__ x, float* __rest
       uint2 u;
       u.x = pack2(v[0], v[1]);
       u.y = pack2(v[2], v[3]);
-      *reinterpret_cast<uint2*>(fd + i * (size_t)FC + c0) = u;
+      *reinterpret_cast<uint2*>(fd + (size_t)(c0 >> 5) * total * 32 + i * 32 + (c0 & 31)) = u;
     }
   }
 }

@@ -47,7 +47,7 @@ class _DenseSubnet(nn.Module):
         cinp, coutp = roundup(cin, 4), roundup(self.channel_out, 4)
         xin = torch.empty((n, h, w, cinp), dtype=torch.float32, device=dev)
         rt.call("selfc_nchw_to_nhwc4", x.data_ptr(), xin.data_ptr(), n, cin, h, w, sp)
-        dense = torch.zeros((n, h, w, dense_channels(cin)), dtype=torch.float16, device=dev)
+        dense = torch.zeros((dense_channels(cin) // 32, n, h, w, 32), dtype=torch.float16, device=dev)
         yout = torch.empty((n, h, w, coutp), dtype=torch.float32, device=dev)
         sw = pk.struct()
         rt.call("selfc_subnet_run", sw, self.kind, xin.data_ptr(), yout.data_ptr(), dense.data_ptr(),

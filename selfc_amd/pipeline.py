@@ -56,6 +56,15 @@ class RescaleRoundTrip:
         _lib.check(L.selfc_invstack_run(self.arr, self.nblk, C.byref(self.lat), 0, sp), "selfc_invstack_run fwd")
         return rt.latent_to_nchw(ws)
 
+    def inverse_latent(self, z: torch.Tensor) -> torch.Tensor:
+        """rev half only on a given (N,51,h,w) NCHW latent; returns the (N,3,H,W) reconstruction."""
+        ws, L, sp = self.ws, _lib.lib(), _lib.stream_ptr()
+        rt.nchw_to_latent(z.contiguous(), ws, with_fd=False)
+        _lib.check(L.selfc_invstack_run(self.arr, self.nblk, C.byref(self.lat), 1, sp), "selfc_invstack_run rev")
+        _lib.check(L.selfc_freq_inv(ws.x1.data_ptr(), ws.x2.data_ptr(), self.out.data_ptr(), self.N, self.h, self.w, self.k, sp),
+                   "selfc_freq_inv")
+        return self.out
+
     def capture(self, x: torch.Tensor):
         """Record one run into a hipGraph (replay with ``replay()``); x must stay at this address."""
         self.static_x = x

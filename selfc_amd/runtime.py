@@ -40,9 +40,10 @@ class Workspace:
         f32, f16 = torch.float32, torch.float16
         self.x1 = torch.zeros((N, H, W, 4), dtype=f32, device=device)
         self.x2 = torch.zeros((N, H, W, self.c2p), dtype=f32, device=device)
-        self.fd = torch.zeros((N, H, W, self.FC), dtype=f16, device=device)
-        self.gd = torch.zeros((N, H, W, 128), dtype=f16, device=device)
-        self.hd = torch.zeros((N, H, W, 128), dtype=f16, device=device)
+        # dense buffers are plane-blocked: [C/32][N][H][W][32] (every 32-channel group contiguous per pixel)
+        self.fd = torch.zeros((self.FC // 32, N, H, W, 32), dtype=f16, device=device)
+        self.gd = torch.zeros((4, N, H, W, 32), dtype=f16, device=device)
+        self.hd = torch.zeros((4, N, H, W, 32), dtype=f16, device=device)
         self.s: Optional[torch.Tensor] = None
         self.device = device
 
