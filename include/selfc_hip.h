@@ -126,10 +126,34 @@ int selfc_subnet_run(const selfc_subnet_w* w, int kind, const float* xin, float*
 int selfc_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, void* stream);
 int selfc_nhwc4_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream);
 
+/* ---- STP (self-conditioned latent predictor), activations fp32 NHWC [N][H*W][64] -------------
+ *
+ * GlobalAgg.forward: SelfC_GMM_arch_inv.py:265-285.  y = x + (proj1(x) viewed (b,C*h*w,T)) @ A,
+ * A = softmax(proj2(g) proj3(g)^T / C, dim=-1), g = fc(adaptive_avg_pool2d(x, 32x32)).
+ * `wmap` [H*W] is fc folded through the adaptive pooling (host, selfc_amd/packing.py:pool_weight_map),
+ * `w1` proj1 as pointwise fragments (pack_pointwise), w2/b2/w3/b3 the fp32 Linear(64,64) params,
+ * `partial` selfc_globalagg_partial_floats(N,HW) floats, `attn` (N/T)*T*T floats. C = 64, T <= 8, x != y. */
+int selfc_globalagg_run(const float* x, float* y, const float* wmap, float fc_bias, const void* w1, const float* b1,
+                        const float* w2, const float* b2, const float* w3, const float* b3,
+                        float* partial, float* attn, int N, int T, int HW, void* stream);
+size_t selfc_globalagg_partial_floats(int N, int HW);
+
+/* Pointwise conv = the Conv3d(.,.,1) layers of STPNet.tail_gmm (SelfC_GMM_arch_inv.py:327-344):
+ * out[px][o] = act_out(sum_k W[o][k] act_in(in[px][k]) + b[o]); act = LeakyReLU(0.2) when the flag is set.
+ * in: fp32 or f16 rows of cin (32 | cin <= 256) channels; out: fp32 or f16 rows of stride cout_stride;
+ * cout a multiple of 16; `w` from pack_pointwise, bias zero-padded to cout. */
+int selfc_pwconv_run(const void* in, int in_is_f32, void* out, int out_is_f32, const void* w, const float* bias,
+                     size_t npix, int cin, int cout, int cout_stride, int lrelu_in, int lrelu_out, void* stream);
+
+/* GMM sample of STPNet.forward (SelfC_GMM_arch_inv.py:382-394): raw fp32 [npix][hf_dim*K*3] in the
+ * reference's (hf_dim, K, 3) order, eps fp32 [npix][hf_dim*K]; v fp32 [npix][hf_dim] (= the x2 latent
+ * layout).  pi = softmax over the hf_dim axis, log-sigma clamped to [-7,7].  hf_dim = 48, K in {1,3,5}. */
+int selfc_gmm_sample(const float* raw, const float* eps, float* v, size_t npix, int hf_dim, int K, void* stream);
+
 /* ---- live kernel timing (bench.py roofline leg) ------------------------------
  * HIP events are recorded on the launch stream around every kernel launch while
  * enabled.  Classes: 0 dense 3x3 conv (conv1..4), 1 conv5+coupling of F,
- * 2 conv5+coupling of G/H, 3 split/merge/layout transforms, 4 stand-alone conv5.
+ * 2 conv5+coupling of G/H, 3 split/merge/layout transforms, 4 stand-alone conv5, 5 STP kernels.
  * Not thread-safe; keep disabled while capturing a hipGraph.  The reference has
  * no counterpart (its only timing is commented-out time.time(), SelfC_model.py:194). */
 int selfc_profile_enable(int on);

@@ -21,6 +21,7 @@ SYMBOLS = [
     "selfc_invblock_run", "selfc_invstack_run", "selfc_subnet_run",
     "selfc_nchw_to_nhwc4", "selfc_nhwc4_to_nchw",
     "selfc_profile_enable", "selfc_profile_read", "selfc_profile_reset",
+    "selfc_globalagg_run", "selfc_globalagg_partial_floats", "selfc_pwconv_run", "selfc_gmm_sample",
 ]
 
 
@@ -72,11 +73,16 @@ def lib():
             "selfc_profile_enable": [i],
             "selfc_profile_read": [i, C.POINTER(C.c_double), C.POINTER(C.c_longlong)],
             "selfc_profile_reset": [],
+            "selfc_globalagg_run": [vp, vp, vp, f, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
+            "selfc_pwconv_run": [vp, i, vp, i, vp, vp, sz, i, i, i, i, i, vp],
+            "selfc_gmm_sample": [vp, vp, vp, sz, i, i, vp],
         }
         for name, args in sigs.items():
             fn = getattr(L, name)
             fn.restype = i
             fn.argtypes = args
+        L.selfc_globalagg_partial_floats.restype = sz
+        L.selfc_globalagg_partial_floats.argtypes = [i, i]
         _lib = L
     return _lib
 

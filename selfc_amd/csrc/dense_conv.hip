@@ -83,7 +83,11 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
   static_assert(TW % 16 == 0 && TH % 2 == 0, "M-tiles are 2 rows x 16 cols");
   constexpr int HWD = TW + 2, NPIX = (TH + 2) * HWD;
   constexpr int NT = NW * 64;
-  constexpr int ACT_BYTES = ((NPIX * PS + 1023) / 1024) * 1024;
+  // Row pitch of the LDS halo image, rounded to a whole 256-B bank row: a ds_read_b128 lane group
+  // mixes pixels {0-3,12-15} of one tile row with {4-11} of the next; with the pitch a multiple of
+  // 16 slots both rows see the same pixel->slot map (5*px mod 16) and the two sets are disjoint.
+  constexpr int ROWB = ((HWD * PS + 255) / 256) * 256;
+  constexpr int ACT_BYTES = (TH + 2) * ROWB;
   constexpr int AITER = (NPIX * 4 + NT - 1) / NT;
   constexpr int WITER = (18 * 64 + NT - 1) / NT;
   constexpr int NNETS = (EPI == EPI_GH) ? 2 : 1;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
     const int by = mt / (TW / 16), bx = mt % (TW / 16);
     py[m] = 2 * by + ((lane & 31) >> 4);
     px[m] = 16 * bx + (lane & 15);
-    pbase[m] = (py[m] * HWD + px[m]) * PS + (lane >> 5) * 16;
+    pbase[m] = py[m] * ROWB + px[m] * PS + (lane >> 5) * 16;
   }
 
   f32x16 acc[NNETS][MT];
@@ -164,7 +168,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
         const int i = tid + it * NT;
         if (i < nitems) {
           const int p = i >> cshift, q = i & ((1 << cshift) - 1);
-          *reinterpret_cast<u32x4*>(lact + p * PS + q * 16) = areg[it];
+          const int hy = p / HWD, hx = p - hy * HWD;
+          *reinterpret_cast<u32x4*>(lact + hy * ROWB + hx * PS + q * 16) = areg[it];
         }
       }
       const int nfr = 9 * (st.width >> 4);
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
       for (int i = tid; i < TH * TW * 10; i += NT) {
         const int p = i / 10, tap = i - p * 10;
         const int ly = p / TW, lxx = p - ly * TW;
-        f16* row = reinterpret_cast<f16*>(lact + ((ly + 1) * HWD + (lxx + 1)) * PS);
+        f16* row = reinterpret_cast<f16*>(lact + (ly + 1) * ROWB + (lxx + 1) * PS);
         if (tap == 9) {
           for (int k = 9 * c1; k < 32; ++k) row[k] = (f16)0.f;
         } else {
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
 
       if (a.ablate & 1) {
       } else if (st.kind == 1) {
-        constexpr int CTR = (HWD + 1) * PS;  // centre tap
+        constexpr int CTR = ROWB + PS;  // centre tap
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const f16x8 af = *reinterpret_cast<const f16x8*>(lw + ks * 1024 + lane * 16);
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
             const f16x8 af = *reinterpret_cast<const f16x8*>(lw + (tap * 2 + ks) * 1024 + lane * 16);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-              const f16x8 bf = *reinterpret_cast<const f16x8*>(lact + pbase[m] + ((tap / 3) * HWD + tap % 3) * PS + ks * 32);
+              const f16x8 bf = *reinterpret_cast<const f16x8*>(lact + pbase[m] + (tap / 3) * ROWB + (tap % 3) * PS + ks * 32);
               acc[net_i][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[net_i][m], 0, 0, 0);
             }
           }
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
           const f16x8 af = *reinterpret_cast<const f16x8*>(lw + tap * 1024 + lane * 16);
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            const f16x8 bf = *reinterpret_cast<const f16x8*>(lact + pbase[m] + ((tap / 3) * HWD + tap % 3) * PS);
+            const f16x8 bf = *reinterpret_cast<const f16x8*>(lact + pbase[m] + (tap / 3) * ROWB + (tap % 3) * PS);
             acc[net_i][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[net_i][m], 0, 0, 0);
           }
         }
@@ -580,7 +585,7 @@ __global__ void nhwc_to_dense_kernel(const float* __restrict__ x, f16* __restric
 // host-side launch helpers
 // ---------------------------------------------------------------------------------
 constexpr int C3_TH = 16, C3_TW = 16, C3_NW = 4, C3_MT = 2;
-constexpr int C3_LDS = (((C3_TH + 2) * (C3_TW + 2) * PS + 1023) / 1024) * 1024 + 18 * 1024;
+constexpr int C3_LDS = (C3_TH + 2) * ((((C3_TW + 2) * PS + 255) / 256) * 256) + 18 * 1024;
 
 template <int EPI>
 int launch_conv3x3(C3Args& a, int nets_z, hipStream_t s) {

@@ -60,34 +60,67 @@ class FrequencyAnalyzer(nn.Module):
 
 
 class GlobalAgg(nn.Module):
-    """Temporal 7x7 attention over globally pooled descriptors (:257-285).
-    NOTE (round 1): parameters/state_dict match the reference; the arithmetic still
-    runs as stock torch ops on the GPU - native kernels are the next STP milestone."""
+    """Temporal TxT attention over globally pooled descriptors (:257-285) on the kernels of
+    csrc/stp.hip: weighted pooling (fc folded through adaptive_avg_pool2d into one HxW map),
+    a tiny per-clip attention kernel, and a fused temporal-mix + 1x1 projection + residual."""
 
     def __init__(self, c):
         super().__init__()
+        if c != 64:
+            raise NotImplementedError("selfc_amd GlobalAgg kernels are built for c = 64 (the only value the reference uses)")
         self.fc = nn.Linear(32 * 32, 1)
         self.proj1 = nn.Conv2d(c, c, 1, 1, 0)
         self.proj2 = nn.Linear(c, c)
         self.proj3 = nn.Linear(c, c)
 
+    def _packed(self, h, w):
+        key = rt.params_key(self) + (h, w)
+        if getattr(self, "_pk_key", None) != key:
+            from ..packing import pack_pointwise, pad_bias, pool_weight_map
+            f32 = lambda t: t.detach().float().contiguous()  # noqa: E731
+            self._pk = dict(wmap=pool_weight_map(self.fc.weight, h, w), fcb=float(self.fc.bias.detach().item()),
+                            w1=pack_pointwise(self.proj1.weight), b1=pad_bias(self.proj1.bias, 64),
+                            w2=f32(self.proj2.weight), b2=f32(self.proj2.bias),
+                            w3=f32(self.proj3.weight), b3=f32(self.proj3.bias))
+            self._pk_key = key
+        return self._pk
+
+    def run_nhwc(self, x, y, n, t, h, w, scratch):
+        """x, y: fp32 NHWC [n][h*w][64] (distinct buffers); scratch: dict cache for partial/attn buffers."""
+        pk = self._packed(h, w)
+        L = _lib.lib()
+        nfl = L.selfc_globalagg_partial_floats(n, h * w)
+        if "gagg_partial" not in scratch or scratch["gagg_partial"].numel() < nfl:
+            scratch["gagg_partial"] = torch.empty(nfl, dtype=torch.float32, device=x.device)
+            scratch["gagg_attn"] = torch.empty((n // t) * t * t, dtype=torch.float32, device=x.device)
+        rt.call("selfc_globalagg_run", x.data_ptr(), y.data_ptr(), pk["wmap"].data_ptr(), pk["fcb"],
+                pk["w1"].data_ptr(), pk["b1"].data_ptr(), pk["w2"].data_ptr(), pk["b2"].data_ptr(),
+                pk["w3"].data_ptr(), pk["b3"].data_ptr(), scratch["gagg_partial"].data_ptr(),
+                scratch["gagg_attn"].data_ptr(), n, t, h * w, _lib.stream_ptr())
+
     def forward(self, x):
+        x = rt.as_input(x)
+        rt.no_autograd_guard(x, *self.parameters())
         t = GlobalVar.get_Temporal_LEN()
-        bt, c, h, w = x.size()
-        b = bt // t
-        p1 = self.proj1(x)
-        g = self.fc(F.adaptive_avg_pool2d(x, (32, 32)).reshape(bt, c, 32 * 32)).squeeze(-1).reshape(b, t, c)
-        a = F.softmax(torch.matmul(self.proj2(g), self.proj3(g).transpose(1, 2)) / c, dim=-1)
-        v = p1.reshape(b, t, c, h, w).permute(0, 2, 3, 4, 1).reshape(b, c * h * w, t)
-        mixed = torch.matmul(v, a).reshape(b, c, h, w, t).permute(0, 4, 1, 2, 3).reshape(bt, c, h, w)
-        return x + mixed
+        n, c, h, w = x.shape
+        if not t or n % t or c != 64:
+            raise RuntimeError(f"GlobalAgg expects (b*T,64,h,w) with T={t!r}, got {tuple(x.shape)}")
+        sp = _lib.stream_ptr()
+        xin = torch.empty((n, h, w, 64), dtype=torch.float32, device=x.device)
+        rt.call("selfc_nchw_to_nhwc4", x.data_ptr(), xin.data_ptr(), n, 64, h, w, sp)
+        yout = torch.empty_like(xin)
+        self.run_nhwc(xin, yout, n, t, h, w, self.__dict__.setdefault("_scratch", {}))
+        y = torch.empty_like(x)
+        rt.call("selfc_nhwc4_to_nchw", yout.data_ptr(), y.data_ptr(), n, 64, h, w, sp)
+        return y
 
 
 class STPNet(nn.Module):
     """Self-conditioned latent predictor v2 (:289-430): 6 x [D2DTInput + GlobalAgg] + 1x1x1 MLP
     head; GMM sample v = sum_k pi*(eps*exp(clamp(logsigma,-7,7)) + mu) with pi = softmax over the
-    hf_dim axis (trap 6).  The D2DTInput subnets run on the HIP kernels; GlobalAgg / head are
-    torch ops this round.  ``eps`` can be injected (``self.eps``) for reproducible parity."""
+    hf_dim axis (trap 6).  Runs end to end on HIP kernels in fp32 NHWC (``run_nhwc``): the dense
+    blocks through selfc_subnet_run, GlobalAgg / head / sampler through csrc/stp.hip.  Noise is
+    torch's device Philox stream unless ``self.eps`` (b, hf_dim, K, t, h, w) is injected."""
 
     def __init__(self, opt):
         super().__init__()
@@ -125,35 +158,97 @@ class STPNet(nn.Module):
                                           nn.ReLU(inplace=True), nn.Conv3d(c, self.hf_dim * self.K * 3, 1, 1, 0, bias=True))
         self.eps = None   # optional injected noise (b, hf_dim, K, t, h, w)
 
-    def forward(self, x):
-        b, c, t, h, w = x.size()
-        temp = x.transpose(1, 2).reshape(b * t, c, h, w)
-        temp = self.local_m1(temp)
+    # -- native pipeline ------------------------------------------------------------------
+    def _chain(self):
+        mods = [self.local_m1]
         if self.global_module:
-            temp = self.global_m1(temp)
-        temp = self.local_m2(temp)
+            mods.append(self.global_m1)
+        mods.append(self.local_m2)
         if self.global_module:
-            temp = self.global_m2(temp)
-        temp = self.other_stp_modules(temp)
-        bt, c, hh, ww = temp.size()
-        t = GlobalVar.get_Temporal_LEN()
-        b = bt // t
-        temp = temp.reshape(b, t, c, hh, ww).transpose(1, 2)
-        # the reference stores this as `self.parameters` (shadowing nn.Module.parameters, :377);
-        # kept under a non-clashing name here
-        self.stp_parameters = self.tail_gmm(temp)
-        if self.fh_loss == "l2":
-            return
-        p = self.stp_parameters.reshape(b, self.hf_dim, self.K, 3, t, hh, ww)
-        pi = F.softmax(p[:, :, :, 0], dim=1)
-        log_scale = torch.clamp(p[:, :, :, 1], -7, 7)
-        mean = p[:, :, :, 2]
-        self.gmm_v = (pi * self.reparametrize(mean, log_scale)).sum(2)
+            mods.append(self.global_m2)
+        return mods + list(self.other_stp_modules)
 
-    def reparametrize(self, mu, logvar):
-        std = torch.exp(logvar)
-        eps = self.eps if self.eps is not None else torch.randn_like(std)
-        return eps.mul(std).add_(mu)
+    def _tail_packed(self):
+        convs = [m for m in self.tail_gmm if isinstance(m, nn.Conv3d)]
+        key = rt.params_key(*convs)
+        if getattr(self, "_tail_key", None) != key:
+            from ..packing import pack_pointwise, pad_bias, roundup
+            self._tail = [(pack_pointwise(m.weight), pad_bias(m.bias, roundup(m.out_channels, 16)), m.in_channels, m.out_channels)
+                          for m in convs]
+            self._tail_key = key
+        return self._tail
+
+    def run_nhwc(self, x1, hf_out, n, t, h, w, keep_raw=False):
+        """x1: fp32 NHWC4 [n][h*w][4] (LR frames); hf_out: fp32 [n][h*w][hf_dim] (e.g. the latent x2
+        buffer).  Returns the raw head output [n][h*w][Cp] when keep_raw (else None)."""
+        if self.fh_loss == "gmm_thin":
+            raise NotImplementedError("fh_loss 'gmm_thin' (ReLU head) has no kernel; the shipped configs use 'gmm' / 'l2'")
+        if self.hf_dim != 48:
+            raise NotImplementedError("STP head kernels are built for hf_dim = 48 (scale 4)")
+        dev, sp = x1.device, _lib.stream_ptr()
+        sc = self.__dict__.setdefault("_scratch", {})
+        shape_key = (n, h, w, str(dev))
+        if sc.get("key") != shape_key:
+            sc.clear()
+            sc["key"] = shape_key
+            sc["feat"] = [torch.empty((n, h * w, 64), dtype=torch.float32, device=dev) for _ in range(2)]
+            sc["dense4"] = torch.zeros((4, n, h, w, 32), dtype=torch.float16, device=dev)
+            sc["dense6"] = torch.zeros((6, n, h, w, 32), dtype=torch.float16, device=dev)
+        cur, nxt = None, 0
+        for m in self._chain():
+            dst = sc["feat"][nxt]
+            if isinstance(m, D2DTInput):
+                src = x1 if cur is None else sc["feat"][cur]
+                dense = sc["dense4"] if m.channel_in <= 3 else sc["dense6"]
+                sw = m.packed().struct()
+                rt.call("selfc_subnet_run", sw, m.kind, src.data_ptr(), dst.data_ptr(), dense.data_ptr(),
+                        n, t, h, w, m.channel_in, m.channel_out, sp)
+            else:
+                m.run_nhwc(sc["feat"][cur], dst, n, t, h, w, sc)
+            cur, nxt = nxt, 1 - nxt
+        feat = sc["feat"][cur]
+        npix = n * h * w
+        tail = self._tail_packed()
+        if self.fh_loss == "l2":
+            wp, bp, cin, cout = tail[0]
+            rt.call("selfc_pwconv_run", feat.data_ptr(), 1, hf_out.data_ptr(), 1, wp.data_ptr(), bp.data_ptr(),
+                    npix, cin, cout, cout, 1, 0, sp)
+            return hf_out if keep_raw else None
+        if "h1" not in sc:
+            sc["h1"] = torch.empty((npix, tail[0][3]), dtype=torch.float16, device=dev)
+            sc["h2"] = torch.empty((npix, tail[1][3]), dtype=torch.float16, device=dev)
+            sc["raw"] = torch.empty((npix, tail[2][3]), dtype=torch.float32, device=dev)
+        (w0, b0, ci0, co0), (w1_, b1_, ci1, co1), (w2_, b2_, ci2, co2) = tail
+        # tail_gmm = [lrelu, conv, lrelu, conv, lrelu, conv]: each LeakyReLU is fused into the producer's epilogue
+        rt.call("selfc_pwconv_run", feat.data_ptr(), 1, sc["h1"].data_ptr(), 0, w0.data_ptr(), b0.data_ptr(), npix, ci0, co0, co0, 1, 1, sp)
+        rt.call("selfc_pwconv_run", sc["h1"].data_ptr(), 0, sc["h2"].data_ptr(), 0, w1_.data_ptr(), b1_.data_ptr(), npix, ci1, co1, co1, 0, 1, sp)
+        rt.call("selfc_pwconv_run", sc["h2"].data_ptr(), 0, sc["raw"].data_ptr(), 1, w2_.data_ptr(), b2_.data_ptr(), npix, ci2, co2, co2, 0, 0, sp)
+        if self.eps is not None:
+            b = n // t
+            eps = self.eps.reshape(b, self.hf_dim, self.K, t, h, w).permute(0, 3, 4, 5, 1, 2).reshape(npix, self.hf_dim * self.K)
+            eps = eps.to(device=dev, dtype=torch.float32).contiguous()
+        else:
+            eps = torch.randn((npix, self.hf_dim * self.K), dtype=torch.float32, device=dev)
+        rt.call("selfc_gmm_sample", sc["raw"].data_ptr(), eps.data_ptr(), hf_out.data_ptr(), npix, self.hf_dim, self.K, sp)
+        return sc["raw"] if keep_raw else None
+
+    # -- reference-shaped API ---------------------------------------------------------------
+    def forward(self, x):
+        """x (b,3,t,h,w); side effects as in the reference: ``stp_parameters`` (the reference's
+        ``self.parameters``, (b,Cp,t,h,w)) and, for GMM heads, ``gmm_v`` (b,hf_dim,t,h,w)."""
+        b, c, t, h, w = x.size()
+        xf = rt.as_input(x.transpose(1, 2).reshape(b * t, c, h, w))
+        rt.no_autograd_guard(xf, *self.parameters())
+        n, sp = b * t, _lib.stream_ptr()
+        x1 = torch.empty((n, h, w, 4), dtype=torch.float32, device=xf.device)
+        rt.call("selfc_nchw_to_nhwc4", xf.data_ptr(), x1.data_ptr(), n, 3, h, w, sp)
+        hf = torch.empty((n, h * w, self.hf_dim), dtype=torch.float32, device=xf.device)
+        raw = self.run_nhwc(x1, hf, n, t, h, w, keep_raw=True)
+        to5d = lambda a: a.reshape(b, t, h, w, -1).permute(0, 4, 1, 2, 3)  # noqa: E731
+        # the reference stores this as `self.parameters` (shadowing nn.Module.parameters, :377)
+        self.stp_parameters = to5d(raw)
+        if self.fh_loss != "l2":
+            self.gmm_v = to5d(hf)
 
     def neg_llh(self, hf):
         if self.fh_loss == "l2":
@@ -219,13 +314,15 @@ class SelfCInvNet(nn.Module):
             out = rt.latent_to_nchw(ws)
             return out, out.new_zeros(())          # loss_c = out.mean()*0 (:466)
         n, c, h, w = x.shape
-        t = GlobalVar.get_Temporal_LEN()
-        b = n // t
-        lr_input = x[:, 0:3].reshape(b, t, 3, h, w).transpose(1, 2)
-        self.stp_net(lr_input)
-        recon_hf = self.stp_net.sample().transpose(1, 2).reshape(b * t, -1, h, w)
+        if c < 3:
+            raise RuntimeError(f"SelfCInvNet reverse expects the 3 LR channels, got {tuple(x.shape)}")
+        lr = x[:, 0:3].contiguous()
         ws = self._workspace(x, n, h, w)
-        rt.nchw_to_latent(torch.cat((x[:, 0:3], recon_hf), dim=1).contiguous(), ws, with_fd=False)
+        # LR frames -> latent x1; STP predicts the HF channels straight into the latent x2 buffer (:475-485)
+        rt.call("selfc_nchw_to_nhwc4", lr.data_ptr(), ws.x1.data_ptr(), n, 3, h, w, sp)
+        self.stp_net.run_nhwc(ws.x1, ws.x2, n, ws.T, h, w)
+        recon_hf = torch.empty((n, ws.c2, h, w), dtype=torch.float32, device=x.device)
+        rt.call("selfc_nhwc4_to_nchw", ws.x2.data_ptr(), recon_hf.data_ptr(), n, ws.c2, h, w, sp)
         lat = ws.latent()
         rt.call("selfc_invstack_run", arr, nblk, lat, 1, sp)
         out = torch.empty((n, 3, h * k, w * k), dtype=torch.float32, device=x.device)

@@ -106,3 +106,33 @@ def pad_bias(bias, n: int = 64, device=None) -> torch.Tensor:
     if bias is not None:
         out[: bias.numel()] = bias.detach().float()
     return out
+
+
+def pack_pointwise(weight: torch.Tensor) -> torch.Tensor:
+    """1x1(x1) conv / Linear weight (cout, cin[,1,1[,1]]) -> f16 [OT, KS, 64, 8] fragments of the
+    16x16x32 MFMA: W[16 o + (lane&15)][32 ks + 8 (lane>>4) + j] (stp.hip: pwconv_kernel, gagg_mix_kernel)."""
+    w = weight.detach().float().reshape(weight.shape[0], -1)
+    cout, cin = w.shape
+    assert cin % 32 == 0, cin
+    ot, ks = roundup(cout, 16) // 16, cin // 32
+    wp = torch.zeros(ot * 16, cin, dtype=torch.float32, device=w.device)
+    wp[:cout] = w
+    frag = wp.reshape(ot, 16, ks, 4, 8).permute(0, 2, 3, 1, 4).reshape(ot, ks, 64, 8)
+    return frag.to(F16).contiguous()
+
+
+def pool_weight_map(fc_weight: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """Fold ``fc(adaptive_avg_pool2d(x, (32,32)).flatten())`` (SelfC_GMM_arch_inv.py:269-271) into one
+    (h*w,) map: g = sum_px x[px] * wmap[px] + fc.bias.  adaptive_avg_pool2d bin i covers
+    [floor(i*L/32), ceil((i+1)*L/32)) - bins overlap when 32 does not divide L and replicate when L < 32."""
+    dev = fc_weight.device
+
+    def bins(length):
+        m = torch.zeros(32, length, dtype=torch.float64, device=dev)
+        for i in range(32):
+            s, e = (i * length) // 32, -((-(i + 1) * length) // 32)
+            m[i, s:e] = 1.0 / (e - s)
+        return m
+
+    fcw = fc_weight.detach().double().reshape(32, 32)
+    return (bins(h).t() @ fcw @ bins(w)).reshape(h * w).float().contiguous()

@@ -82,3 +82,47 @@ class RescaleRoundTrip:
     def replay(self):
         self.graph.replay()
         return self.out
+
+
+class MultiStreamRoundTrip:
+    """The same unit of work, with the batch of septuplets split over `nstreams` HIP
+    streams (whole clips per stream - they are independent).  Each conv launch is
+    short (one to three waves of workgroups), so its prologue / epilogue latency is
+    exposed; kernels of different streams overlap and fill those gaps.  Fork/join is
+    expressed with stream events so the whole step still captures into one hipGraph."""
+
+    def __init__(self, net, n_frames: int, H: int, W: int, device, nstreams: int = 2):
+        t = GlobalVar.get_Temporal_LEN()
+        clips = n_frames // t
+        if clips % nstreams:
+            raise RuntimeError(f"{clips} clips do not split evenly over {nstreams} streams")
+        self.nstreams = nstreams
+        self.per = n_frames // nstreams
+        self.parts = [RescaleRoundTrip(net, self.per, H, W, device) for _ in range(nstreams)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(nstreams)]
+        self.out = torch.empty((n_frames, 3, H, W), dtype=torch.float32, device=device)
+        for i, p in enumerate(self.parts):           # parts write straight into slices of one output
+            p.out = self.out[i * self.per:(i + 1) * self.per]
+        self.graph = None
+
+    def run(self, x: torch.Tensor) -> torch.Tensor:
+        cur = torch.cuda.current_stream()
+        for i, (p, st) in enumerate(zip(self.parts, self.streams)):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                p.run(x[i * self.per:(i + 1) * self.per])
+        for st in self.streams:
+            cur.wait_stream(st)
+        return self.out
+
+    def capture(self, x: torch.Tensor):
+        self.run(x)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.run(x)
+        self.graph = g
+
+    def replay(self):
+        self.graph.replay()
+        return self.out

@@ -169,6 +169,18 @@ def test_stp_gmm_injected_eps(dev):
     assert rel_err(v.cpu(), g["v"]) < 2e-3
 
 
+def test_globalagg(dev):
+    from selfc_amd.modules.SelfC_GMM_arch_inv import GlobalAgg
+    g = load_golden("g6_globalagg")
+    ga = GlobalAgg(64)
+    ga.load_state_dict({k: v for k, v in g.items() if k.split(".")[0] in ("fc", "proj1", "proj2", "proj3")}, strict=True)
+    ga.to(dev)
+    for tag in ("a", "b"):          # 16x16: replicating pooling bins; 20x36: overlapping bins
+        with torch.no_grad():
+            y = ga(g[f"{tag}_x"].to(dev))
+        assert rel_err(y.cpu(), g[f"{tag}_y"]) < TOL
+
+
 def test_haar_net(dev):
     from selfc_amd.modules.Inv_arch import InvRescaleNet
     from selfc_amd.modules.Subnet_constructor import subnet

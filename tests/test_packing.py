@@ -132,3 +132,26 @@ def test_pack_tconv5(cin, cout, nets):
 def test_pad_bias():
     b = P.pad_bias(torch.arange(3.0))
     assert b.shape == (64,) and b[:3].tolist() == [0.0, 1.0, 2.0] and b[3:].abs().sum() == 0
+
+
+@pytest.mark.parametrize("h,w", [(16, 16), (64, 112), (20, 36), (8, 12), (33, 65)])
+def test_pool_weight_map_equals_fc_of_adaptive_pool(h, w):
+    """GlobalAgg's fc(adaptive_avg_pool2d(x,32x32)) folded into one HxW map (overlapping and replicating bins)."""
+    g = torch.Generator().manual_seed(h * 100 + w)
+    fcw = torch.randn(1, 1024, generator=g)
+    x = torch.randn(3, 5, h, w, generator=g)
+    ref = (F.adaptive_avg_pool2d(x, (32, 32)).reshape(3, 5, 1024) @ fcw.t()).squeeze(-1)
+    got = (x.reshape(3, 5, h * w) * P.pool_weight_map(fcw, h, w)).sum(-1)
+    assert torch.allclose(got, ref, atol=2e-5, rtol=1e-5)
+
+
+def test_pack_pointwise_lane_map():
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(720, 256, 1, 1, 1, generator=g)
+    fr = P.pack_pointwise(w)
+    assert fr.shape == (45, 8, 64, 8) and fr.dtype == torch.float16
+    # W[16 o + (lane&15)][32 ks + 8 (lane>>4) + j]
+    wk = fr.float().reshape(45, 8, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(720, 256)
+    assert torch.equal(wk, w.reshape(720, 256).half().float())
+    fr = P.pack_pointwise(torch.randn(48, 64, generator=g))        # cout padded to whole tiles
+    assert fr.shape == (3, 2, 64, 8)
