@@ -124,6 +124,22 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][m][r] = 0.f;
 
+  unsigned gofs[AITER];   // halfs, inside one plane
+  int lofs[AITER];        // bytes, inside the LDS halo image
+  unsigned okmask = 0;    // bit it: item it is an in-image pixel
+#pragma unroll
+  for (int it = 0; it < AITER; ++it) {
+    const int i = tid + it * NT;
+    const int p = min(i >> 2, NPIX - 1), q = i & 3;
+    const int hy = p / HWD, hx = p - hy * HWD;
+    const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+    const bool ok = (y >= 0) & (y < H) & (x >= 0) & (x < W);
+    const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+    gofs[it] = (unsigned)(((n * H + yc) * W + xc) * 32 + q * 8);
+    lofs[it] = hy * ROWB + hx * PS + q * 16;
+    okmask |= (ok ? 1u : 0u) << it;
+  }
+
 #pragma unroll
   for (int net_i = 0; net_i < NNETS; ++net_i) {
     const int net = (EPI == EPI_GH) ? net_i : (int)blockIdx.z;
@@ -133,26 +149,21 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
 
     u32x4 areg[AITER];
     u32x4 wreg[WITER];
-    int fragbase = 0;  // fragments consumed by earlier stages
+    int fragbase = 0;      // fragments consumed by earlier stages
 
     // -- staging helpers -------------------------------------------------------
+    // Item i = tid + it*NT covers 16-byte chunk q = i&3 of halo pixel p = i>>2.  Its global offset
+    // inside a 32-channel plane, its LDS offset and its validity do not depend on the stage, so they
+    // are computed once (the per-stage address math was as expensive to issue as the stage's MFMAs).
+    // A 16-wide stage simply stages the (zero) pad half of its plane as well.
     auto load_stage = [&](const C3Stage st, const int fb) __attribute__((always_inline)) {
       if (a.ablate & 2) return;
-      const int cshift = st.width == 32 ? 2 : 1;  // 16-byte chunks per pixel: 4 or 2
-      const int nitems = NPIX << cshift;
+      const f16* __restrict__ src = dense + (size_t)(st.coff >> 5) * a.plane;
+      if (!(a.ablate & 64))
 #pragma unroll
-      for (int it = 0; it < AITER; ++it) {
-        // branch-free: masked items load from a clamped (valid) address and are zeroed by a select
-        const int i = tid + it * NT;
-        const int p = i >> cshift, q = i & ((1 << cshift) - 1);
-        const int hy = p / HWD, hx = p - hy * HWD;
-        const int y = ty0 + hy - 1, x = tx0 + hx - 1;
-        const bool ok = (i < nitems) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
-        const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
-        const u32x4 v = *reinterpret_cast<const u32x4*>(dense + (size_t)(st.coff >> 5) * a.plane + ((size_t)(n * H + yc) * W + xc) * 32 + q * 8);
-        areg[it] = ok ? v : u32x4{0u, 0u, 0u, 0u};
-      }
+      for (int it = 0; it < AITER; ++it) areg[it] = *reinterpret_cast<const u32x4*>(src + gofs[it]);
       const int nfr = 9 * (st.width >> 4);
+      if (!(a.ablate & 32))
 #pragma unroll
       for (int it = 0; it < WITER; ++it) {
         const int i = min(tid + it * NT, nfr * 64 - 1);  // unconditional (clamped): keeps wreg in registers
@@ -161,16 +172,12 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
     };
     auto store_stage = [&](const C3Stage st) __attribute__((always_inline)) {
       if (a.ablate & 4) return;
-      const int cshift = st.width == 32 ? 2 : 1;
-      const int nitems = NPIX << cshift;
 #pragma unroll
       for (int it = 0; it < AITER; ++it) {
-        const int i = tid + it * NT;
-        if (i < nitems) {
-          const int p = i >> cshift, q = i & ((1 << cshift) - 1);
-          const int hy = p / HWD, hx = p - hy * HWD;
-          *reinterpret_cast<u32x4*>(lact + hy * ROWB + hx * PS + q * 16) = areg[it];
-        }
+        // out-of-image pixels become the conv's zero padding here (a select right after the load
+        // would make the compiler drain the prefetch before the MFMA phase)
+        if (tid + it * NT < NPIX * 4)
+          *reinterpret_cast<u32x4*>(lact + lofs[it]) = ((okmask >> it) & 1u) ? areg[it] : u32x4{0u, 0u, 0u, 0u};
       }
       const int nfr = 9 * (st.width >> 4);
 #pragma unroll
@@ -211,15 +218,40 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
         }
       }
       __syncthreads();
-      for (int i = tid; i < TH * TW * 10; i += NT) {
-        const int p = i / 10, tap = i - p * 10;
-        const int ly = p / TW, lxx = p - ly * TW;
-        f16* row = reinterpret_cast<f16*>(lact + (ly + 1) * ROWB + (lxx + 1) * PS);
-        if (tap == 9) {
-          for (int k = 9 * c1; k < 32; ++k) row[k] = (f16)0.f;
-        } else {
-          const f16* src = reinterpret_cast<const f16*>(lx + ((ly + tap / 3) * HWD + (lxx + tap % 3)) * 8);
-          for (int c = 0; c < c1; ++c) row[tap * c1 + c] = src[c];
+      if (c1 == 3) {
+        // one output pixel per item: 9 x 8-byte reads of the halo, one 64-byte row (k = tap*3 + c) out
+        for (int p = tid; p < TH * TW; p += NT) {
+          const int ly = p / TW, lxx = p - ly * TW;
+          f16 rowv[32];
+#pragma unroll
+          for (int k = 27; k < 32; ++k) rowv[k] = (f16)0.f;
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) {
+            const f16x4 sv = *reinterpret_cast<const f16x4*>(lx + ((ly + tap / 3) * HWD + (lxx + tap % 3)) * 8);
+            rowv[tap * 3 + 0] = sv[0];
+            rowv[tap * 3 + 1] = sv[1];
+            rowv[tap * 3 + 2] = sv[2];
+          }
+          unsigned char* row = lact + (ly + 1) * ROWB + (lxx + 1) * PS;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rowv[8 * j + e];
+            *reinterpret_cast<f16x8*>(row + 16 * j) = o;
+          }
+        }
+      } else {
+        for (int i = tid; i < TH * TW * 10; i += NT) {
+          const int p = i / 10, tap = i - p * 10;
+          const int ly = p / TW, lxx = p - ly * TW;
+          f16* row = reinterpret_cast<f16*>(lact + (ly + 1) * ROWB + (lxx + 1) * PS);
+          if (tap == 9) {
+            for (int k = 9 * c1; k < 32; ++k) row[k] = (f16)0.f;
+          } else {
+            const f16* src = reinterpret_cast<const f16*>(lx + ((ly + tap / 3) * HWD + (lxx + tap % 3)) * 8);
+            for (int c = 0; c < c1; ++c) row[tap * c1 + c] = src[c];
+          }
         }
       }
     };
