@@ -147,7 +147,7 @@ def main():
         torch.cuda.synchronize()
         L.selfc_profile_enable(0)
         cls_ms, cls_n = {}, {}
-        for cls, name in enumerate(["conv3x3", "conv5_F", "conv5_GH", "transforms"]):
+        for cls, name in [(0, "conv3x3"), (1, "conv5_F"), (2, "conv5_GH"), (3, "transforms"), (6, "fused_gh")]:
             ms, n = C.c_double(), C.c_longlong()
             L.selfc_profile_read(cls, C.byref(ms), C.byref(n))
             cls_ms[name], cls_n[name] = ms.value, n.value

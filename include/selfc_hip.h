@@ -84,6 +84,9 @@ typedef struct {
   const float* b3[4];    /* 32 fp32 biases each                                       */
   const void* w5;        /* packed conv5 fragments                                    */
   const float* b5;       /* conv5 bias, zero-padded to a multiple of 32 floats        */
+  const void* wfused;    /* optional (cin == 3 subnets): fused conv1..4 fragment stream of
+                            packing.py:pack_fused_gh; when G and H both carry one, their
+                            conv1..4 run as ONE persistent fused launch (csrc/fused_gh.hip) */
 } selfc_subnet_w;
 
 typedef struct {
@@ -153,7 +156,8 @@ int selfc_gmm_sample(const float* raw, const float* eps, float* v, size_t npix, 
 /* ---- live kernel timing (bench.py roofline leg) ------------------------------
  * HIP events are recorded on the launch stream around every kernel launch while
  * enabled.  Classes: 0 dense 3x3 conv (conv1..4), 1 conv5+coupling of F,
- * 2 conv5+coupling of G/H, 3 split/merge/layout transforms, 4 stand-alone conv5, 5 STP kernels.
+ * 2 conv5+coupling of G/H, 3 split/merge/layout transforms, 4 stand-alone conv5, 5 STP kernels,
+ * 6 fused G/H conv1..4.
  * Not thread-safe; keep disabled while capturing a hipGraph.  The reference has
  * no counterpart (its only timing is commented-out time.time(), SelfC_model.py:194). */
 int selfc_profile_enable(int on);

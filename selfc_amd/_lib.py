@@ -26,7 +26,8 @@ SYMBOLS = [
 
 
 class SubnetW(C.Structure):
-    _fields_ = [("w3", C.c_void_p * 4), ("b3", C.c_void_p * 4), ("w5", C.c_void_p), ("b5", C.c_void_p)]
+    _fields_ = [("w3", C.c_void_p * 4), ("b3", C.c_void_p * 4), ("w5", C.c_void_p), ("b5", C.c_void_p),
+                ("wfused", C.c_void_p)]
 
 
 class InvBlockW(C.Structure):

@@ -22,6 +22,21 @@
 
 using namespace selfc;
 
+namespace selfc {
+// csrc/fused_gh.hip
+struct FGArgs {
+  const float* x1;
+  const f16* w[2];
+  const float* bias[2][4];
+  f16* dense[2];
+  int N, H, W;
+  int tiles_x, tiles_y, ntiles;
+  size_t plane;
+  int ablate;
+};
+int launch_fused_gh(FGArgs& a, hipStream_t s);
+}  // namespace selfc
+
 namespace {
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 1000; }
@@ -124,6 +139,13 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][m][r] = 0.f;
 
+  // conv1-4 epilogue biases: fetched now so their latency hides behind the whole K loop
+  float4 ebias[4];
+  if (EPI == EPI_LRELU) {
+    const float* __restrict__ bias = blockIdx.z ? a.bias[1] : a.bias[0];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ebias[g] = *reinterpret_cast<const float4*>(bias + 8 * g + 4 * (lane >> 5));
+  }
   unsigned gofs[AITER];   // halfs, inside one plane
   int lofs[AITER];        // bytes, inside the LDS halo image
   unsigned okmask = 0;    // bit it: item it is an in-image pixel
@@ -337,12 +359,11 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
     if (EPI == EPI_LRELU) {
       // lanes l and l+32 own the same pixel and interleaved 4-channel groups; one half-swap per
       // dword hands each lane 8 contiguous channels -> two 16-byte stores per M-tile
-      const float* __restrict__ bias = blockIdx.z ? a.bias[1] : a.bias[0];
       f16* dst = (blockIdx.z ? a.out[1] : a.out[0]) + (size_t)(a.out_coff >> 5) * a.plane + pix * 32 + 8 * half;
       uint32_t r[4][2];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 b = *reinterpret_cast<const float4*>(bias + 8 * g + 4 * half);
+        const float4 b = ebias[g];
         r[g][0] = pack2(lrelu02(acc[0][m][4 * g + 0] + b.x), lrelu02(acc[0][m][4 * g + 1] + b.y));
         r[g][1] = pack2(lrelu02(acc[0][m][4 * g + 2] + b.z), lrelu02(acc[0][m][4 * g + 3] + b.w));
       }
@@ -735,7 +756,19 @@ int run_F(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStream
 }
 
 int run_GH(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStream_t s) {
-  int rc = run_conv1to4(&blk->G, &blk->H, l->gd, l->hd, l->x1, l->c1, l->N, l->H, l->W, s);
+  int rc;
+  static const bool no_fuse = getenv("SELFC_NO_FUSE") != nullptr;     // developer A/B switch
+  if (blk->G.wfused && blk->H.wfused && l->c1 == 3 && !no_fuse) {
+    FGArgs fa{};
+    fa.x1 = l->x1;
+    fa.w[0] = (const f16*)blk->G.wfused; fa.w[1] = (const f16*)blk->H.wfused;
+    for (int i = 0; i < 4; ++i) { fa.bias[0][i] = blk->G.b3[i]; fa.bias[1][i] = blk->H.b3[i]; }
+    fa.dense[0] = (f16*)l->gd; fa.dense[1] = (f16*)l->hd;
+    fa.N = l->N; fa.H = l->H; fa.W = l->W;
+    rc = launch_fused_gh(fa, s);
+  } else {
+    rc = run_conv1to4(&blk->G, &blk->H, l->gd, l->hd, l->x1, l->c1, l->N, l->H, l->W, s);
+  }
   if (rc) return rc;
   const int c2p = (l->c2 + 3) & ~3;
   if (l->kind == SELFC_SUBNET_D2DT) {
@@ -764,8 +797,8 @@ int run_GH(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStrea
 
 extern "C" {
 
-const char* selfc_version(void) { return "selfc_hip gfx950 abi1"; }
-int selfc_abi_version(void) { return 1; }
+const char* selfc_version(void) { return "selfc_hip gfx950 abi2"; }
+int selfc_abi_version(void) { return 2; }
 
 int selfc_invblock_run(const selfc_invblock_w* blk, const selfc_latent* lat, int rev, void* stream) {
   if (!blk || !latent_ok(lat)) return SELFC_EINVAL;

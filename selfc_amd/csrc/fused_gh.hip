@@ -1,0 +1,352 @@
+// Fused conv1..conv4 of the G / H dense blocks (Subnet_constructor.py:126-129, cin = 3) for gfx950.
+//
+// One persistent workgroup owns a 16x16 output tile at a time and computes all four 3x3 convs of
+// one net with every intermediate feature kept in LDS (halo recompute: conv k is evaluated on the
+// tile grown by 4-k pixels), instead of four launches that each round-trip the features through
+// HBM with 1-3 waves of short-lived workgroups.  Per tile and net:
+//
+//   X  : y1 halo (24x24 px, 4 x f16 per pixel: c0 c1 c2 0)          <- x1 buffer (fp32 NHWC4)
+//   F1 : lrelu(conv1) on 22x22      F2 : conv2 on 20x20      F3 : conv3 on 18x18     (f16, LDS)
+//   conv4 on 16x16 -> HBM only.  The centre 16x16 crops of F1..F3 also go to HBM (planes 0..2 of
+//   the net's dense buffer) because the temporal conv5 reads all four features.
+//   Features outside the image are stored as ZERO (they are the next conv's zero padding).
+//
+// MFMA 32x32x16 f16, D[outch][pixel]; M-tiles are 32 consecutive pixels of the conv's region in
+// row-major order (region widths 22/20/18 need not be multiples of 16; with the LDS row pitch a
+// multiple of 256 B the 16-lane groups of ds_read_b128 still hit 16 distinct slots).
+// The 3-channel input enters as an "im2col48" stage: K = 12 taps x 4 (c0 c1 c2 0), so a lane's 8
+// K-entries are two whole pixels of X = two ds_read_b64, no repacking (3 MFMAs instead of 2).
+// Weights: the packed fragment stream of the four convs (120 KiB per net) is read in chunks of
+// <= 21 fragments through an LDS double buffer; the stream wraps around from conv4 to the next
+// tile's conv1, so the prefetch never stalls at a tile boundary.  One barrier per chunk.
+#include <stdlib.h>
+#include <type_traits>
+#include "common.hpp"
+#include "prof.hpp"
+#include "../../include/selfc_hip.h"
+
+using namespace selfc;
+
+namespace selfc {
+
+struct FGArgs {
+  const float* x1;          // [N][H][W][4] fp32 (y1)
+  const f16* w[2];          // fused fragment stream per net (packing.py: pack_fused_gh), 120 fragments
+  const float* bias[2][4];  // 32 floats per conv
+  f16* dense[2];            // plane-blocked [4][N][H][W][32]
+  int N, H, W;
+  int tiles_x, tiles_y, ntiles;
+  size_t plane;
+  int ablate;               // developer timing aid (env SELFC_ABLATE_F): 1 no MFMA, 2 no epilogue, 4 no weight stream, 8 no operand reads
+};
+
+namespace {
+
+constexpr int TS = 16;
+constexpr int XS = TS + 8;                 // X halo side (24)
+constexpr int XPITCH = XS * 8;             // bytes
+constexpr int X_BYTES = XS * XPITCH;       // 4608
+constexpr int P1 = 1792, P2 = 1792, P3 = 1536;                       // LDS row pitch of F1..F3 (bytes, multiples of 256)
+constexpr int F1_BYTES = 22 * P1, F2_BYTES = 20 * P2, F3_BYTES = 18 * P3;
+constexpr int WCH = 21;                    // fragments per weight chunk buffer
+constexpr int W_BYTES = WCH * 1024;
+constexpr int OFF_F1 = 0, OFF_F2 = OFF_F1 + F1_BYTES, OFF_F3 = OFF_F2 + F2_BYTES;
+constexpr int OFF_X = OFF_F3 + F3_BYTES;   // 2 buffers
+constexpr int OFF_W = OFF_X + 2 * X_BYTES; // 2 buffers
+constexpr int OFF_B = OFF_W + 2 * W_BYTES; // biases of the four convs: 4 x 32 floats
+constexpr int FG_LDS = OFF_B + 512;
+static_assert(FG_LDS <= 160 * 1024, "LDS budget");
+constexpr int NWAVE = 8, NTHR = NWAVE * 64;   // 2 waves per SIMD: one wave's epilogue / LDS latency hides under the other's MFMAs
+constexpr int WITER = (WCH * 64 + NTHR - 1) / NTHR;   // 3
+
+template <int J> struct FeatGeom;
+template <> struct FeatGeom<1> { static constexpr int off = OFF_F1, pitch = P1; };
+template <> struct FeatGeom<2> { static constexpr int off = OFF_F2, pitch = P2; };
+template <> struct FeatGeom<3> { static constexpr int off = OFF_F3, pitch = P3; };
+
+// fragment offsets of the fused stream: per conv [im2col48: 3][feature j: 18 each]
+constexpr int LAYER_OFF[5] = {0, 0, 3, 24, 63};
+constexpr int STREAM_FRAGS = 120;
+
+struct Ctx {
+  unsigned char* smem;
+  const u32x4* wsrc;
+  int tid, lane, wave, half;
+  int par;            // weight buffer that holds the CURRENT chunk
+  u32x4 wreg[WITER];
+};
+
+template <int OFF, int NFR>
+__device__ __forceinline__ void w_prefetch(Ctx& c) {
+#pragma unroll
+  for (int it = 0; it < WITER; ++it) {
+    const int i = min(c.tid + it * NTHR, NFR * 64 - 1);
+    c.wreg[it] = c.wsrc[OFF * 64 + i];
+  }
+}
+template <int NFR>
+__device__ __forceinline__ void w_commit(Ctx& c) {
+  unsigned char* dst = c.smem + OFF_W + (c.par ^ 1) * W_BYTES;
+#pragma unroll
+  for (int it = 0; it < WITER; ++it) {
+    const int i = c.tid + it * NTHR;
+    if (i < NFR * 64) *reinterpret_cast<u32x4*>(dst + i * 16) = c.wreg[it];
+  }
+}
+
+// One 3x3 conv K (1..4) of the current tile.  NEXT_OFF/NEXT_N: the chunk that follows this conv's
+// last chunk in the stream (prefetched during that chunk).
+template <int K>
+__device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int net, const int xbuf,
+                                           const int n, const int ty0, const int tx0) {
+  constexpr int R = TS + 2 * (4 - K);
+  constexpr int NPX = R * R;
+  constexpr int NTL = (NPX + 31) / 32;
+  constexpr int MT = (NTL + NWAVE - 1) / NWAVE;
+  constexpr int NCH = K == 1 ? 1 : K - 1;          // weight chunks of this conv: [im2col(+f1)], [f2], [f3]
+  unsigned char* const smem = c.smem;
+
+  int r[MT], cc[MT];
+  bool valid[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int mt = c.wave + NWAVE * m;
+    const int q = mt * 32 + (c.lane & 31);
+    valid[m] = (mt < NTL) & (q < NPX);
+    const int qc = min(q, NPX - 1);
+    r[m] = qc / R;
+    cc[m] = qc - r[m] * R;
+  }
+  f32x16 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+
+  // per-lane X offsets of the two pixels (taps) each im2col48 k-step needs: tap = 2*(2ks+half)+{0,1}
+  int xo[3][2];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int t0 = 4 * ks + e, t1 = 4 * ks + 2 + e;          // half 0 / half 1
+      const int o0 = t0 < 9 ? ((t0 / 3) * XS + t0 % 3) * 8 : -1;
+      const int o1 = t1 < 9 ? ((t1 / 3) * XS + t1 % 3) * 8 : -1;
+      xo[ks][e] = c.half ? o1 : o0;
+    }
+
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    // ---- prefetch the chunk that follows (compile-time position in the stream)
+    if (ch + 1 < NCH) {
+      if (ch == 0) w_prefetch<LAYER_OFF[K] + 21, 18>(c);
+      else w_prefetch<LAYER_OFF[K] + 39, 18>(c);
+    } else {
+      if (K == 1) w_prefetch<LAYER_OFF[2], 21>(c);
+      else if (K == 2) w_prefetch<LAYER_OFF[3], 21>(c);
+      else if (K == 3) w_prefetch<LAYER_OFF[4], 21>(c);
+      else w_prefetch<LAYER_OFF[1], 3>(c);                      // wraps to the next tile's conv1
+    }
+    const unsigned char* wb = smem + OFF_W + c.par * W_BYTES + c.lane * 16;
+    const unsigned char* xb = smem + OFF_X + xbuf * X_BYTES;
+    // The chunk is a flat list of MFMA steps: [3 im2col48 k-steps (chunk 0 only)] + [18 (tap, k-step)
+    // steps of feature J = ch + 1 (K >= 2)].  One wave per SIMD has no other wave to hide LDS latency
+    // behind, so operand fragments are fetched two steps ahead into a 3-deep register ring; the
+    // sched_barriers pin "reads of step s+2, then MFMAs of step s".
+    const int NIM = ch == 0 ? 3 : 0;
+    const int NS = NIM + (K >= 2 ? 18 : 0);
+    const int J = ch + 1;
+    const int pitch = J == 1 ? P1 : J == 2 ? P2 : P3;
+    const unsigned char* fb = smem + (J == 1 ? OFF_F1 : J == 2 ? OFF_F2 : OFF_F3);
+    int pb[MT], xbase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      pb[m] = (r[m] + K - J - 1) * pitch + (cc[m] + K - J - 1) * PS + c.half * 16;
+      xbase[m] = ((r[m] + K - 1) * XS + (cc[m] + K - 1)) * 8;
+    }
+    f16x8 ringA[3];
+    f16x8 ringB[3][MT];
+    auto load_step = [&](const int st, f16x8& A, f16x8 (&B)[MT]) __attribute__((always_inline)) {
+      A = *reinterpret_cast<const f16x8*>(wb + st * 1024);
+      if (st < NIM) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          uint2 p0 = make_uint2(0u, 0u), p1 = make_uint2(0u, 0u);
+          if (xo[st][0] >= 0) p0 = *reinterpret_cast<const uint2*>(xb + xbase[m] + xo[st][0]);
+          if (xo[st][1] >= 0) p1 = *reinterpret_cast<const uint2*>(xb + xbase[m] + xo[st][1]);
+          const u32x4 u = {p0.x, p0.y, p1.x, p1.y};
+          B[m] = __builtin_bit_cast(f16x8, u);
+        }
+      } else {
+        const int fs = st - NIM, tap = fs >> 1, ks = fs & 1;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          B[m] = *reinterpret_cast<const f16x8*>(fb + pb[m] + (tap / 3) * pitch + (tap % 3) * PS + ks * 32);
+      }
+    };
+    load_step(0, ringA[0], ringB[0]);
+    if (NS > 1) load_step(1, ringA[1], ringB[1]);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      if (st + 2 < NS) load_step(st + 2, ringA[(st + 2) % 3], ringB[(st + 2) % 3]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ringA[st % 3], ringB[st % 3][m], acc[m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if (ch == NCH - 1) {
+      // ---- epilogue: bias + LeakyReLU, zero outside the image, f16 -> LDS feature image (+ HBM crop)
+      const float* bias = reinterpret_cast<const float*>(smem + OFF_B) + 32 * (K - 1);   // LDS copy (no global latency here)
+      f16* __restrict__ dplane = a.dense[net] + (size_t)(K - 1) * a.plane;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int ar = r[m] - (4 - K), ac = cc[m] - (4 - K);
+        const int y = ty0 + ar, x = tx0 + ac;
+        const bool inimg = (y >= 0) & (y < a.H) & (x >= 0) & (x < a.W);
+        uint32_t rr[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b = *reinterpret_cast<const float4*>(bias + 8 * g + 4 * c.half);
+          const float v0 = inimg ? lrelu02(acc[m][4 * g + 0] + b.x) : 0.f;
+          const float v1 = inimg ? lrelu02(acc[m][4 * g + 1] + b.y) : 0.f;
+          const float v2 = inimg ? lrelu02(acc[m][4 * g + 2] + b.z) : 0.f;
+          const float v3 = inimg ? lrelu02(acc[m][4 * g + 3] + b.w) : 0.f;
+          rr[g][0] = pack2(v0, v1);
+          rr[g][1] = pack2(v2, v3);
+        }
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          u32x4 v;
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(rr[2 * gp][d], rr[2 * gp + 1][d], false, false);
+            v[d] = sw[0];
+            v[2 + d] = sw[1];
+          }
+          if (valid[m]) {
+            if (K < 4) {
+              constexpr int pitch = FeatGeom<(K < 4 ? K : 1)>::pitch;
+              *reinterpret_cast<u32x4*>(smem + FeatGeom<(K < 4 ? K : 1)>::off + r[m] * pitch + cc[m] * PS + (16 * gp + 8 * c.half) * 2) = v;
+            }
+            const bool centre = (ar >= 0) & (ar < TS) & (ac >= 0) & (ac < TS);
+            if (centre && inimg)
+              *reinterpret_cast<u32x4*>(dplane + ((size_t)(n * a.H + y) * a.W + x) * 32 + 16 * gp + 8 * c.half) = v;
+          }
+        }
+      }
+    }
+    // ---- hand the weight buffers over: next chunk -> the other buffer, one barrier per chunk
+    if (ch + 1 < NCH) w_commit<18>(c);
+    else if (K == 4) w_commit<3>(c);
+    else w_commit<21>(c);
+    if (K == 4 && ch == NCH - 1) return;   // the tile loop stores the next X halo before its barrier
+    __syncthreads();
+    c.par ^= 1;
+  }
+}
+
+__global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Ctx c;
+  c.smem = smem;
+  c.tid = threadIdx.x;
+  c.lane = c.tid & 63;
+  c.wave = c.tid >> 6;
+  c.half = c.lane >> 5;
+  c.par = 0;
+  const int net = blockIdx.y;
+  c.wsrc = reinterpret_cast<const u32x4*>(net ? a.w[1] : a.w[0]);
+  const int total = a.ntiles * a.N;
+  int t = blockIdx.x;
+  if (t >= total) return;
+
+  constexpr int XITER = (XS * XS + NTHR - 1) / NTHR;   // 2
+  float4 xv[XITER];
+  unsigned xok = 0;   // bit it: halo pixel it is inside the image (mask applied at store time, not after the load)
+  auto x_load = [&](const int tile) __attribute__((always_inline)) {
+    xok = 0;
+    const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, n = tile / a.ntiles;
+#pragma unroll
+    for (int it = 0; it < XITER; ++it) {
+      const int p = min(c.tid + it * NTHR, XS * XS - 1);
+      const int hy = p / XS, hx = p - hy * XS;
+      const int y = ty * TS + hy - 4, x = tx * TS + hx - 4;
+      const bool ok = (y >= 0) & (y < a.H) & (x >= 0) & (x < a.W);
+      const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
+      xv[it] = *reinterpret_cast<const float4*>(a.x1 + ((size_t)(n * a.H + yc) * a.W + xc) * 4);
+      xok |= (ok ? 1u : 0u) << it;
+    }
+  };
+  auto x_store = [&](const int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < XITER; ++it) {
+      const int p = c.tid + it * NTHR;
+      if (p < XS * XS) {
+        uint2 u;
+        u.x = pack2(xv[it].x, xv[it].y);
+        u.y = pack2(xv[it].z, 0.f);
+        if (!((xok >> it) & 1u)) u = make_uint2(0u, 0u);
+        *reinterpret_cast<uint2*>(smem + OFF_X + buf * X_BYTES + p * 8) = u;
+      }
+    }
+  };
+
+  // prologue: biases -> LDS, first tile's X halo and the first weight chunk
+  if (c.tid < 128) {
+    const float* bsrc = net ? a.bias[1][c.tid >> 5] : a.bias[0][c.tid >> 5];
+    reinterpret_cast<float*>(smem + OFF_B)[c.tid] = bsrc[c.tid & 31];
+  }
+  x_load(t);
+  w_prefetch<LAYER_OFF[1], 3>(c);
+  x_store(0);
+  c.par = 1;            // w_commit writes buffer par^1 = 0
+  w_commit<3>(c);
+  __syncthreads();
+  c.par = 0;
+
+  int xbuf = 0;
+  for (; t < total; t += gridDim.x) {
+    const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, n = t / a.ntiles;
+    const int tnext = t + gridDim.x;
+    const bool more = tnext < total;
+    if (more) x_load(tnext);                      // lands while this tile computes
+    conv_fused<1>(c, a, net, xbuf, n, ty * TS, tx * TS);
+    conv_fused<2>(c, a, net, xbuf, n, ty * TS, tx * TS);
+    conv_fused<3>(c, a, net, xbuf, n, ty * TS, tx * TS);
+    conv_fused<4>(c, a, net, xbuf, n, ty * TS, tx * TS);
+    if (more) x_store(xbuf ^ 1);
+    __syncthreads();
+    c.par ^= 1;
+    xbuf ^= 1;
+  }
+}
+
+inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 1000; }
+
+}  // namespace
+
+// Called from dense_conv.hip (run_GH) when the block carries fused fragment streams.
+int launch_fused_gh(FGArgs& a, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_gh_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS);
+    if (e != hipSuccess) return hip_rc(e);
+    attr_done = true;
+  }
+  a.tiles_x = (a.W + TS - 1) / TS;
+  a.tiles_y = (a.H + TS - 1) / TS;
+  a.ntiles = a.tiles_x * a.tiles_y;
+  a.plane = (size_t)a.N * a.H * a.W * 32;
+  const int total = a.ntiles * a.N;
+  const int gx = total < 128 ? total : 128;       // 128 persistent workgroups per net: one per CU overall
+  static const int ablate = getenv("SELFC_ABLATE_F") ? atoi(getenv("SELFC_ABLATE_F")) : 0;
+  a.ablate = ablate;
+  ProfScope prof(PROF_FUSED_GH, s);
+  hipLaunchKernelGGL(fused_gh_kernel, dim3((unsigned)gx, 2), dim3(NTHR), FG_LDS, s, a);
+  return hip_rc(hipGetLastError());
+}
+
+}  // namespace selfc

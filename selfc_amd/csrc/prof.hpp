@@ -6,7 +6,7 @@
 
 namespace selfc {
 
-enum ProfClass { PROF_CONV3X3 = 0, PROF_CONV5_F = 1, PROF_CONV5_GH = 2, PROF_TRANSFORM = 3, PROF_CONV5_PLAIN = 4, PROF_STP = 5, PROF_NCLASS = 6 };
+enum ProfClass { PROF_CONV3X3 = 0, PROF_CONV5_F = 1, PROF_CONV5_GH = 2, PROF_TRANSFORM = 3, PROF_CONV5_PLAIN = 4, PROF_STP = 5, PROF_FUSED_GH = 6, PROF_NCLASS = 7 };
 
 bool prof_enabled();
 // returns an event already recorded on `s` (start marker) or nullptr when profiling is off

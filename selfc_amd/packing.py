@@ -136,3 +136,28 @@ def pool_weight_map(fc_weight: torch.Tensor, h: int, w: int) -> torch.Tensor:
 
     fcw = fc_weight.detach().double().reshape(32, 32)
     return (bins(h).t() @ fcw @ bins(w)).reshape(h * w).float().contiguous()
+
+
+def pack_fused_gh(weights: Sequence[torch.Tensor], cin: int = 3) -> torch.Tensor:
+    """conv1..conv4 weights of a cin == 3 dense block -> the fragment stream of csrc/fused_gh.hip:
+    per conv [im2col48: K = 12 taps x 4 (c0 c1 c2 0), 3 fragments][feature j = 1..: tap-major, 18
+    fragments each]  -> f16 [120, 64, 8]."""
+    assert cin == 3 and len(weights) == 4
+    frags = []
+    for layer, wt in enumerate(weights, start=1):
+        w = wt.detach().float()
+        if w.dim() == 5:
+            w = w[:, :, 0]
+        assert w.shape == (32, cin + 32 * (layer - 1), 3, 3), tuple(w.shape)
+        w9 = w.reshape(32, w.shape[1], 9)
+        im = torch.zeros(32, 12, 4, dtype=torch.float32, device=w.device)
+        im[:, :9, :3] = w9[:, :3, :].permute(0, 2, 1)                    # k = tap*4 + c
+        cols = [im.reshape(32, 48)]
+        for i in range(layer - 1):
+            cols.append(w9[:, cin + 32 * i: cin + 32 * (i + 1), :].permute(0, 2, 1).reshape(32, 288))
+        wk = torch.cat(cols, dim=1)
+        nfrag = wk.shape[1] // 16
+        frags.append(wk.reshape(32, nfrag, 2, 8).permute(1, 2, 0, 3).reshape(nfrag, 64, 8))
+    out = torch.cat(frags, dim=0)
+    assert out.shape[0] == 120
+    return out.to(F16).contiguous()

@@ -8,7 +8,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import _lib
-from .packing import dense_channels, pack_conv3x3, pack_tconv5, pad_bias, roundup
+from .packing import dense_channels, pack_conv3x3, pack_fused_gh, pack_tconv5, pad_bias, roundup
 
 SUBNET_D2DT = _lib.SUBNET_D2DT
 SUBNET_DB2D = _lib.SUBNET_DB2D
@@ -86,6 +86,10 @@ class PackedSubnet:
         else:
             self.w5 = pack_conv3x3(mod.conv5.weight, self.cin, 5)
         self.b5 = pad_bias(mod.conv5.bias, 64, dev)
+        # cin == 3 temporal subnets (G / H of the coupling): fused conv1..4 stream
+        self.wfused = None
+        if self.cin == 3 and self.kind == SUBNET_D2DT:
+            self.wfused = pack_fused_gh([getattr(mod, f"conv{i}").weight for i in range(1, 5)], 3)
 
     def struct(self) -> _lib.SubnetW:
         s = _lib.SubnetW()
@@ -94,6 +98,7 @@ class PackedSubnet:
             s.b3[i] = _ptr(self.b3[i])
         s.w5 = _ptr(self.w5)
         s.b5 = _ptr(self.b5)
+        s.wfused = _ptr(self.wfused)
         return s
 
 

@@ -17,15 +17,15 @@ def test_exports_match_header():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _lib.lib().selfc_abi_version() == 1
+    assert _lib.lib().selfc_abi_version() == 2
     assert b"gfx950" in _lib.lib().selfc_version()
 
 
 def test_struct_layout_matches_header():
     from selfc_amd import _lib
     p = ctypes.sizeof(ctypes.c_void_p)
-    assert ctypes.sizeof(_lib.SubnetW) == 10 * p
-    assert ctypes.sizeof(_lib.InvBlockW) == 30 * p + 8        # float + tail padding
+    assert ctypes.sizeof(_lib.SubnetW) == 11 * p
+    assert ctypes.sizeof(_lib.InvBlockW) == 33 * p + 8        # float + tail padding
     assert ctypes.sizeof(_lib.Latent) == 8 * 4 + 6 * p        # 7 ints padded to 8, 6 pointers
 
 

@@ -155,3 +155,31 @@ def test_pack_pointwise_lane_map():
     assert torch.equal(wk, w.reshape(720, 256).half().float())
     fr = P.pack_pointwise(torch.randn(48, 64, generator=g))        # cout padded to whole tiles
     assert fr.shape == (3, 2, 64, 8)
+
+
+@pytest.mark.parametrize("layer", [1, 2, 4])
+def test_pack_fused_gh_stream(layer):
+    """fused conv1..4 stream of csrc/fused_gh.hip: per conv [im2col48: k = tap*4 + c][features tap-major]."""
+    g = torch.Generator().manual_seed(40 + layer)
+    ws = [torch.randn(32, 3 + 32 * i, 1, 3, 3, generator=g) * 0.1 for i in range(4)]
+    stream = P.pack_fused_gh(ws, 3)
+    assert stream.shape == (120, 64, 8)
+    layer_off = [0, 3, 24, 63, 120]
+    wk = unpack_a32(stream[layer_off[layer - 1]:layer_off[layer]])          # (32, 48 + 288*(layer-1))
+    x = torch.randn(2, 3, 6, 7, generator=g)
+    feats = [torch.randn(2, 32, 6, 7, generator=g) for _ in range(layer - 1)]
+    ref = F.conv2d(torch.cat([x] + feats, 1), ws[layer - 1][:, :, 0].half().float(), None, 1, 1)
+    xp = F.pad(x.permute(0, 2, 3, 1), (0, 0, 1, 1, 1, 1))
+    cols = [torch.zeros(2, 6, 7, 48)]
+    for tap in range(9):
+        ky, kx = divmod(tap, 3)
+        cols[0][..., tap * 4: tap * 4 + 3] = xp[:, ky:ky + 6, kx:kx + 7, :]
+    for f in feats:
+        fp = F.pad(f.permute(0, 2, 3, 1), (0, 0, 1, 1, 1, 1))
+        for tap in range(9):
+            ky, kx = divmod(tap, 3)
+            cols.append(fp[:, ky:ky + 6, kx:kx + 7, :])
+    ak = torch.cat(cols, -1)
+    assert ak.shape[-1] == wk.shape[1]
+    out = torch.einsum("ok,nhwk->nohw", wk, ak)
+    assert torch.allclose(out, ref, atol=1e-4, rtol=1e-4)
