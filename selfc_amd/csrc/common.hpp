@@ -21,7 +21,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // different slots.
 constexpr int PS = 80;
 
-__device__ __forceinline__ float lrelu02(float v) { return v >= 0.f ? v : 0.2f * v; }
+// LeakyReLU(0.2) = max(v, 0.2 v): two VALU ops (0.2f*v rounds exactly as in v >= 0 ? v : 0.2f*v)
+__device__ __forceinline__ float lrelu02(float v) { return fmaxf(v, 0.2f * v); }
 
 // MI355X deals consecutive workgroup ids round-robin over its 8 XCDs (private
 // L2 each).  Remap so that each XCD receives a CONTIGUOUS range of logical tile

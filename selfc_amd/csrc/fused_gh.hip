@@ -117,11 +117,19 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
     r[m] = qc / R;
     cc[m] = qc - r[m] * R;
   }
+  // accumulators start at the bias (row = outch (e&3) + 8*(e>>2) + 4*half), read from the LDS copy
   f32x16 acc[MT];
+  {
+    const float* bl = reinterpret_cast<const float*>(smem + OFF_B) + 32 * (K - 1) + 4 * c.half;
+    f32x16 binit;
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+    for (int g = 0; g < 4; ++g) {
+      const float4 b = *reinterpret_cast<const float4*>(bl + 8 * g);
+      binit[4 * g + 0] = b.x; binit[4 * g + 1] = b.y; binit[4 * g + 2] = b.z; binit[4 * g + 3] = b.w;
+    }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    for (int m = 0; m < MT; ++m) acc[m] = binit;
+  }
 
   // per-lane X offsets of the two pixels (taps) each im2col48 k-step needs: tap = 2*(2ks+half)+{0,1}
   int xo[3][2];
@@ -198,8 +206,9 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
 
     if (ch == NCH - 1) {
       // ---- epilogue: bias + LeakyReLU, zero outside the image, f16 -> LDS feature image (+ HBM crop)
-      const float* bias = reinterpret_cast<const float*>(smem + OFF_B) + 32 * (K - 1);   // LDS copy (no global latency here)
       f16* __restrict__ dplane = a.dense[net] + (size_t)(K - 1) * a.plane;
+      // the region leaves the image only for tiles on the frame border (wave-uniform test)
+      const bool border = (ty0 - (4 - K) < 0) | (tx0 - (4 - K) < 0) | (ty0 + TS + (4 - K) > a.H) | (tx0 + TS + (4 - K) > a.W);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int ar = r[m] - (4 - K), ac = cc[m] - (4 - K);
@@ -208,13 +217,13 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
         uint32_t rr[4][2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const float4 b = *reinterpret_cast<const float4*>(bias + 8 * g + 4 * c.half);
-          const float v0 = inimg ? lrelu02(acc[m][4 * g + 0] + b.x) : 0.f;
-          const float v1 = inimg ? lrelu02(acc[m][4 * g + 1] + b.y) : 0.f;
-          const float v2 = inimg ? lrelu02(acc[m][4 * g + 2] + b.z) : 0.f;
-          const float v3 = inimg ? lrelu02(acc[m][4 * g + 3] + b.w) : 0.f;
-          rr[g][0] = pack2(v0, v1);
-          rr[g][1] = pack2(v2, v3);
+          rr[g][0] = pack2(lrelu02(acc[m][4 * g + 0]), lrelu02(acc[m][4 * g + 1]));
+          rr[g][1] = pack2(lrelu02(acc[m][4 * g + 2]), lrelu02(acc[m][4 * g + 3]));
+        }
+        if (border) {   // features outside the image are the next conv's zero padding
+          const uint32_t keep = inimg ? 0xffffffffu : 0u;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) { rr[g][0] &= keep; rr[g][1] &= keep; }
         }
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) {
@@ -341,7 +350,11 @@ int launch_fused_gh(FGArgs& a, hipStream_t s) {
   a.ntiles = a.tiles_x * a.tiles_y;
   a.plane = (size_t)a.N * a.H * a.W * 32;
   const int total = a.ntiles * a.N;
-  const int gx = total < 128 ? total : 128;       // 128 persistent workgroups per net: one per CU overall
+  // persistent workgroups, at most 128 per net (one per CU overall); sized so that every
+  // workgroup walks the same number of tiles (no straggler round) and unused CUs stay free for
+  // kernels of other streams
+  const int rounds = (total + 127) / 128;
+  const int gx = (total + rounds - 1) / rounds;
   static const int ablate = getenv("SELFC_ABLATE_F") ? atoi(getenv("SELFC_ABLATE_F")) : 0;
   a.ablate = ablate;
   ProfScope prof(PROF_FUSED_GH, s);
