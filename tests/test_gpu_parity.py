@@ -255,6 +255,45 @@ def test_full_size_properties(dev):
     assert rel_err(z[:T].cpu(), z_ref) < TOL
 
 
+def test_1080p_tile_invertibility(dev):
+    """BASELINE config 5 shape (7x3x1080x1920, latent 270x480: not a multiple of the 16x16 tile):
+    the stack inverts its own output on the device and the LR channels stay finite."""
+    from selfc_amd import runtime as rt, _lib
+    g = load_golden("g8_large_stack")
+    net = _large_net(dev, g)
+    x = torch.rand(T, 3, 1080, 1920, generator=torch.Generator().manual_seed(99)).to(dev)
+    with torch.no_grad():
+        z, _ = net(x=x, rev=False)
+        assert torch.isfinite(z).all()
+        ws = net._workspace(x, T, 270, 480)
+        arr, nblk = net._stack()
+        rt.call("selfc_invstack_run", arr, nblk, ws.latent(), 1, _lib.stream_ptr())
+        z0 = rt.latent_to_nchw(ws)
+        fa = net.operations[0](x)
+    assert rel_err(z0.cpu(), fa.cpu()) < TOL
+
+
+def test_freq_k2_and_clip_len_3(dev):
+    """FrequencyAnalyzer(k=2) (the codec variant's split, SelfC_Codec_arch_inv.py:78-98) and a 3-frame clip length."""
+    from selfc_amd import GlobalVar
+    from selfc_amd.modules.SelfC_GMM_arch_inv import FrequencyAnalyzer
+    x = torch.rand(3, 3, 16, 24, generator=torch.Generator().manual_seed(3))
+    fa2 = FrequencyAnalyzer(3, k=2)
+    assert torch.equal(fa2(x.to(dev)).cpu(), O.freq_fwd(x, 2))
+    z = torch.randn(3, 15, 8, 12, generator=torch.Generator().manual_seed(4))
+    assert torch.equal(fa2(z.to(dev), rev=True).cpu(), O.freq_inv(z, 2))
+    g = load_golden("g8_large_stack")
+    net = _large_net(dev, g)
+    xx = torch.rand(6, 3, 32, 48, generator=torch.Generator().manual_seed(8))
+    try:
+        GlobalVar.set_Temporal_LEN(3)
+        with torch.no_grad():
+            zz, _ = net(x=xx.to(dev), rev=False)
+        assert rel_err(zz.cpu(), O.large_fwd(g, xx, 3)) < TOL
+    finally:
+        GlobalVar.set_Temporal_LEN(T)
+
+
 def test_rejects_bad_arguments(dev):
     from selfc_amd import _lib
     L = _lib.lib()
