@@ -506,6 +506,27 @@ __global__ __launch_bounds__(512) void tconv5_kernel(const T5Args a) {
     if (HASX) xd = *reinterpret_cast<const float4*>(a.x1 + pix * 4);
   };
 
+  // biases are fetched once, and the x2 rows an epilogue needs are prefetched before the MFMA phase of
+  // the frame in which it runs: no global load sits in front of its consumer inside the epilogue
+  float4 ebias[NETS][OT];
+#pragma unroll
+  for (int q = 0; q < NETS; ++q)
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+      const int oc = o * 16 + kq * 4;
+      ebias[q][o] = *reinterpret_cast<const float4*>((q ? a.bias[1] : a.bias[0]) + oc);
+    }
+  float4 xrow[OT];
+  auto prefetch_x2 = [&](const int t) __attribute__((always_inline)) {
+    if (EPI != EPI_GH) return;
+    const size_t pix = (size_t)(b * a.T + t) * a.HW + pc;
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+      const int oc = min(o * 16 + kq * 4, a.c2p - 4);
+      xrow[o] = *reinterpret_cast<const float4*>(a.x2io + pix * a.c2p + oc);
+    }
+  };
+
   auto epilogue = [&](const int t, f32x4 (&acc)[NETS][OT]) __attribute__((always_inline)) {
     if (!pvalid) return;
     const size_t pix = (size_t)(b * a.T + t) * a.HW + pl;
@@ -514,14 +535,14 @@ __global__ __launch_bounds__(512) void tconv5_kernel(const T5Args a) {
       for (int o = 0; o < OT; ++o) {
         const int oc = o * 16 + kq * 4;
         if (oc < a.coutp) {
-          const float4 bb = *reinterpret_cast<const float4*>(a.bias[0] + oc);
+          const float4 bb = ebias[0][o];
           *reinterpret_cast<float4*>(a.plain + pix * a.coutp + oc) =
               make_float4(acc[0][o][0] + bb.x, acc[0][o][1] + bb.y, acc[0][o][2] + bb.z, acc[0][o][3] + bb.w);
         }
       }
     } else if (EPI == EPI_F) {
       if (kq == 0) {
-        const float4 bb = *reinterpret_cast<const float4*>(a.bias[0]);
+        const float4 bb = ebias[0][0];
         float4 v = *reinterpret_cast<float4*>(a.x1io + pix * 4);
         const float sgn = a.rev ? -1.f : 1.f;
         v.x += sgn * (acc[0][0][0] + bb.x);
@@ -535,9 +556,9 @@ __global__ __launch_bounds__(512) void tconv5_kernel(const T5Args a) {
       for (int o = 0; o < OT; ++o) {
         const int oc = o * 16 + kq * 4;
         if (oc < a.c2p) {
-          const float4 bg = *reinterpret_cast<const float4*>(a.bias[0] + oc);
-          const float4 bh = *reinterpret_cast<const float4*>(a.bias[NETS - 1] + oc);
-          const float4 xv = *reinterpret_cast<const float4*>(a.x2io + pix * a.c2p + oc);
+          const float4 bg = ebias[0][o];
+          const float4 bh = ebias[NETS - 1][o];
+          const float4 xv = xrow[o];
           const float xin[4] = {xv.x, xv.y, xv.z, xv.w};
           const float gb[4] = {bg.x, bg.y, bg.z, bg.w}, hb[4] = {bh.x, bh.y, bh.z, bh.w};
           float yo[4], so[4];
@@ -565,6 +586,7 @@ __global__ __launch_bounds__(512) void tconv5_kernel(const T5Args a) {
   load_frame(bcur, xcur, 0);
   for (int t = 0; t < a.T; ++t) {
     if (t + 1 < a.T) load_frame(bnxt, xnxt, t + 1);
+    if (t >= 1) prefetch_x2(t - 1);
 #pragma unroll
     for (int q = 0; q < NETS; ++q) {
 #pragma unroll
@@ -611,6 +633,7 @@ __global__ __launch_bounds__(512) void tconv5_kernel(const T5Args a) {
       for (int ks = 0; ks < KD; ++ks) bcur[q][ks] = bnxt[q][ks];
     xcur = xnxt;
   }
+  prefetch_x2(a.T - 1);
   epilogue(a.T - 1, accp);
 }
 
