@@ -334,3 +334,34 @@ def stp_v2_gmm_sample(raw: torch.Tensor, eps: torch.Tensor, hf_dim: int = 48, k:
     ls = torch.clamp(r[:, :, :, 1], -7, 7)
     mu = r[:, :, :, 2]
     return (pi * (eps * torch.exp(ls) + mu)).sum(2)
+
+
+# ----------------------------------------------------------------------------
+# a9  STPNet v1, condition_func == "D2DTNet", l2 head  (models/modules/SelfC_arch_inv.py:90-198)
+# ----------------------------------------------------------------------------
+
+def stp_v1_parameters(params: Params, lr: torch.Tensor, t: int) -> torch.Tensor:
+    """lr (B*T,3,h,w) -> (B*T,9,h,w): blk1 = 3 x D2DTInput (3->12->24->48), blk2 = D2DTInput(48->c)
+    (:99-105,141-142), tail = LeakyReLU + Conv3d(c,9,1) (:110-116,148)."""
+    x = lr
+    for i in range(3):
+        x = d2dt(_sub(params, f"blk1.{i}"), x, t)
+    x = d2dt(_sub(params, "blk2"), x, t)
+    wgt = params["tail.1.weight"]
+    return F.conv2d(lrelu(x), wgt.reshape(wgt.shape[0], wgt.shape[1], 1, 1), params["tail.1.bias"])
+
+
+def selfc_haar_fwd(params: Params, x: torch.Tensor, block_num: Sequence[int], t: int = 7,
+                   kind: str = "DBNet") -> Tuple[torch.Tensor, torch.Tensor]:
+    """SelfC_arch_inv.SelfCInvNet.forward(rev=False) (:300-314): op loop, then STP on the LR channels and
+    neg_llh = mean((hf - stp)^2) over the HF channels (l2 head, :189-190)."""
+    z = haar_net_fwd(params, x, block_num, t, kind)
+    pred = stp_v1_parameters(_sub(params, "stp_net"), z[:, :3], t)
+    return z, torch.mean((z[:, 3:] - pred) ** 2)
+
+
+def selfc_haar_rev(params: Params, lr: torch.Tensor, block_num: Sequence[int], t: int = 7,
+                   kind: str = "DBNet") -> Tuple[torch.Tensor, torch.Tensor]:
+    """forward(rev=True) (:315-333): hf = STP(lr); reversed op loop on cat(lr, hf)."""
+    hf = stp_v1_parameters(_sub(params, "stp_net"), lr, t)
+    return haar_net_inv(params, torch.cat((lr, hf), 1), block_num, t, kind), hf

@@ -359,7 +359,7 @@ int selfc_pwconv_run(const void* in, int in_is_f32, void* out, int out_is_f32, c
     if (out_is_f32) return launch_pw<KS_, false, true>(in, out, w, bias, npix, cin, cout, cout_stride, lrelu_in, lrelu_out, s); \
     return launch_pw<KS_, false, false>(in, out, w, bias, npix, cin, cout, cout_stride, lrelu_in, lrelu_out, s); \
   }
-  SELFC_PW(2) SELFC_PW(4) SELFC_PW(8)
+  SELFC_PW(1) SELFC_PW(2) SELFC_PW(4) SELFC_PW(8)
 #undef SELFC_PW
   return SELFC_EINVAL;
 }

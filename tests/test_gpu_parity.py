@@ -255,6 +255,26 @@ def test_full_size_properties(dev):
     assert rel_err(z[:T].cpu(), z_ref) < TOL
 
 
+def test_selfc_haar_variant(dev):
+    """model "SelfC": Haar + InvBlockExp(DBNet) + STP v1 (D2DTNet conditioner, l2 head), fwd (incl. neg_llh) and rev."""
+    from selfc_amd.modules.SelfC_arch_inv import SelfCInvNet
+    g = load_golden("g8_selfc_haar")
+    opt1 = {"stp_d2d_inner_c": 32, "stp_temporal_c": 32, "fh_loss": "l2", "gmm_mixture_num": 5,
+            "stp_blk_num": 2, "condition_func": "D2DTNet"}
+    net = SelfCInvNet(opt1, 3, 3, "DBNet", [1], 1)
+    net.load_state_dict({k: v for k, v in g.items() if k.startswith(("operations.", "stp_net."))}, strict=True)
+    net.to(dev).eval()
+    with torch.no_grad():
+        z, loss = net(x=g["x"].to(dev), rev=False)
+        assert rel_err(z.cpu(), g["z"]) < TOL
+        assert abs(loss.item() - g["loss_c"].item()) < 5e-3 * g["loss_c"].item()
+        xr, hf = net(x=g["lr"].to(dev), rev=True)
+        assert rel_err(hf.cpu(), g["hf"]) < 2e-3
+        assert rel_err(xr.cpu(), g["x_rev"]) < 2e-3
+    with pytest.raises(NotImplementedError):
+        SelfCInvNet(dict(opt1, condition_func="FeatureCalapseBlock"), 3, 3, "DBNet", [1], 1)
+
+
 def test_1080p_tile_invertibility(dev):
     """BASELINE config 5 shape (7x3x1080x1920, latent 270x480: not a multiple of the 16x16 tile):
     the stack inverts its own output on the device and the LR channels stay finite."""

@@ -122,3 +122,13 @@ def test_stp_l2_full_reverse():
     assert rel_err(hf, g["hf"]) < 2e-5
     xr = O.large_inv_from_latent(ops, torch.cat((g["lr"], hf), 1), T)
     assert rel_err(xr, g["x_rev"]) < 5e-5
+
+
+def test_selfc_haar_variant_with_stp_v1():
+    g = load_golden("g8_selfc_haar")
+    z, loss = O.selfc_haar_fwd(g, g["x"], [1], T, "DBNet")
+    assert rel_err(z, g["z"]) < FTOL
+    assert abs(loss.item() - g["loss_c"].item()) < 1e-5 * abs(g["loss_c"].item()) + 1e-7
+    xr, hf = O.selfc_haar_rev(g, g["lr"], [1], T, "DBNet")
+    assert rel_err(hf, g["hf"]) < 1e-5
+    assert rel_err(xr, g["x_rev"]) < 1e-5

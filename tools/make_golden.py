@@ -172,6 +172,22 @@ def main():
         save("g8_haar_net", x=x.numpy(), lr=lr.numpy(), hf_meansq=hfm.numpy(), z=zfull.numpy(),
              x_rev=xinv.numpy(), **sd_np(irn))
 
+        # ---- G8 Haar-variant SelfCInvNet (model "SelfC", SelfC_arch_inv.py:276-338) with the D2DTNet-conditioned
+        # STP v1 (l2 head).  Its forward also runs STP + neg_llh (:312-313).
+        import models.modules.SelfC_arch_inv as SA
+        torch.manual_seed(18)
+        opt1 = {"stp_d2d_inner_c": 32, "stp_temporal_c": 32, "fh_loss": "l2", "gmm_mixture_num": 5,
+                "stp_blk_num": 2, "condition_func": "D2DTNet"}
+        hnet = SA.SelfCInvNet(opt1, 3, 3, "DBNet", [1], 1).eval()
+        for sub in (hnet.operations[1].F, hnet.operations[1].G, hnet.operations[1].H):
+            rerandomise_conv5(sub, g)
+        x = torch.rand(T, 3, 32, 32, generator=g)
+        out, loss = hnet(x=x, rev=False)
+        lrq = Quantization()(out[:, :3])
+        xr, hf = hnet(x=lrq, rev=True)
+        save("g8_selfc_haar", x=x.numpy(), z=out.numpy(), loss_c=loss.numpy(), lr=lrq.numpy(), x_rev=xr.numpy(),
+             hf=hf.numpy(), **sd_np(hnet))
+
         # ---- G9 Quantization
         q = Quantization()
         v = torch.tensor([-0.3, 0.0, 0.001, 0.00196, 0.00197, 0.5, 0.50196, 0.998, 1.0, 1.7,
