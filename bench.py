@@ -167,6 +167,16 @@ def main():
         kern[name] = {"bound": "mfma", "kernel": label, "achieved": round(tf, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                       "frac": round(tf / PEAK_F16_TFLOPS, 4), "traffic": None, "avg_launch_us": round(avg_ms * 1e3, 2),
                       "launches": cls_n[name], "flops_per_launch": fl, "ms_per_step": round(cls_ms[name] / args.steps, 3)}
+    # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/README.md)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")) as fh:
+            traffic = json.load(fh)
+        for k in kern:
+            if k in traffic:
+                kern[k]["traffic"] = traffic[k]["hbm_bytes_per_launch"]
+                kern[k]["traffic_source"] = "profiles/r1/pmc_traffic.json (rocprofv3 --pmc passes of this workload, not re-measured in this run)"
+    except (OSError, ValueError):
+        pass
     dominant = max(kern, key=lambda k: kern[k]["ms_per_step"])
     roofline = kern[dominant]
     sept = B_PER_GPU * world * args.steps

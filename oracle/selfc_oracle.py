@@ -365,3 +365,21 @@ def selfc_haar_rev(params: Params, lr: torch.Tensor, block_num: Sequence[int], t
     """forward(rev=True) (:315-333): hf = STP(lr); reversed op loop on cat(lr, hf)."""
     hf = stp_v1_parameters(_sub(params, "stp_net"), lr, t)
     return haar_net_inv(params, torch.cat((lr, hf), 1), block_num, t, kind), hf
+
+
+# ----------------------------------------------------------------------------
+# quality metric of test_rescaling.py: Y channel (data/util.py:239-245) and PSNR (utils/util.py:198-221)
+# ----------------------------------------------------------------------------
+
+def rgb_to_y(x: torch.Tensor) -> torch.Tensor:
+    """(N,3,H,W) RGB in [0,1] -> (N,1,H,W): (65.481 R + 128.553 G + 24.966 B + 16) / 255."""
+    return ((x[:, 0:1] * 65.481 + x[:, 1:2] * 128.553 + x[:, 2:3] * 24.966 + 16.0) / 255.0)
+
+
+def psnr_per_frame(a: torch.Tensor, b: torch.Tensor) -> List[float]:
+    """20 log10(1 / sqrt(mean((a-b)^2))) per leading index, as calculate_psnr does."""
+    out = []
+    for i in range(a.shape[0]):
+        mse = torch.mean((a[i].double() - b[i].double()) ** 2)
+        out.append(float("inf") if mse == 0 else (20.0 * torch.log10(1.0 / torch.sqrt(mse))).item())
+    return out

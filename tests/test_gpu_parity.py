@@ -255,6 +255,35 @@ def test_full_size_properties(dev):
     assert rel_err(z[:T].cpu(), z_ref) < TOL
 
 
+def test_psnr_y_parity_on_synthetic_clip(dev):
+    """PSNR within 0.02 dB of the reference.  Vid4 and the pretrained weights are not
+    available offline, so the check runs test_rescaling.py's pipeline (netG fwd -> Quantization -> netG rev,
+    Y-channel PSNR) on a synthetic clip with the golden weights, HIP path vs CPU oracle."""
+    from selfc_amd.modules.Quantization import Quantization
+    g = load_golden("g8_large_stack")
+    s = load_golden("g7_stp_l2_full_rev")
+    net = _large_net(dev, g, "l2", s)
+    gen = torch.Generator().manual_seed(77)
+    low = torch.rand(T, 3, 9, 13, generator=gen)
+    x = torch.nn.functional.interpolate(low, size=(64, 96), mode="bicubic", align_corners=False).clamp(0, 1)
+    x = (x + 0.02 * torch.randn(x.shape, generator=gen)).clamp(0, 1)
+    with torch.no_grad():
+        z, _ = net(x=x.to(dev), rev=False)
+        lr = Quantization()(z[:, :3])
+        xr, _ = net(x=lr, rev=True)
+    z_ref = O.large_fwd(g, x, T)
+    lr_ref = O.quantize(z_ref[:, :3])
+    hf_ref = O.stp_v2_parameters(subdict(s, "stp_net"), lr_ref, T)
+    xr_ref = O.large_inv_from_latent(g, torch.cat((lr_ref, hf_ref), 1), T)
+    p_hip = O.psnr_per_frame(O.rgb_to_y(xr.cpu()), O.rgb_to_y(x))
+    p_ref = O.psnr_per_frame(O.rgb_to_y(xr_ref), O.rgb_to_y(x))
+    assert max(abs(a - b) for a, b in zip(p_hip, p_ref)) < 0.02, (p_hip, p_ref)
+    assert abs(sum(p_hip) / T - sum(p_ref) / T) < 0.02
+    # the LR frames themselves: at most a handful of 1/255 steps may flip across the quantiser
+    assert (lr.cpu() - lr_ref).abs().max() <= 1.0 / 255 + 1e-6
+    assert ((lr.cpu() - lr_ref).abs() > 1e-6).float().mean() < 0.01
+
+
 def test_selfc_haar_variant(dev):
     """model "SelfC": Haar + InvBlockExp(DBNet) + STP v1 (D2DTNet conditioner, l2 head), fwd (incl. neg_llh) and rev."""
     from selfc_amd.modules.SelfC_arch_inv import SelfCInvNet
