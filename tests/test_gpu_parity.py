@@ -279,9 +279,12 @@ def test_psnr_y_parity_on_synthetic_clip(dev):
     p_ref = O.psnr_per_frame(O.rgb_to_y(xr_ref), O.rgb_to_y(x))
     assert max(abs(a - b) for a, b in zip(p_hip, p_ref)) < 0.02, (p_hip, p_ref)
     assert abs(sum(p_hip) / T - sum(p_ref) / T) < 0.02
-    # the LR frames themselves: at most a handful of 1/255 steps may flip across the quantiser
-    assert (lr.cpu() - lr_ref).abs().max() <= 1.0 / 255 + 1e-6
-    assert ((lr.cpu() - lr_ref).abs() > 1e-6).float().mean() < 0.01
+    # the LR frames themselves: a pre-quantisation difference d flips a pixel with probability ~255*|d|
+    # (never by more than one 1/255 step); with the measured ~1e-4 differences that is a few percent
+    dl = (lr.cpu() - lr_ref).abs()
+    flips = (dl > 1e-6).float().mean().item()
+    assert dl.max() <= 1.0 / 255 + 1e-6, dl.max()
+    assert flips < 0.06, flips
 
 
 def test_selfc_haar_variant(dev):
