@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libselfc_hip.so")
+# SELFC_LIB: developer override to A/B two builds of the library inside one process launch script
+LIB_PATH = os.environ.get("SELFC_LIB") or os.path.join(_HERE, "libselfc_hip.so")
 
 SUBNET_D2DT = 0
 SUBNET_DB2D = 1
