@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-path", action="store_true", help="also time netG(x) + Quantization + netG(LR, rev=True) incl. the STP sampler")
     ap.add_argument("--streams", type=int, default=4, help="split the septuplets of a step over this many HIP streams")
     args = ap.parse_args()
 
@@ -195,6 +196,33 @@ def main():
         "stack_tflops": round(whole_flops * world * args.steps / dt / 1e12, 1),
         "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in cls_ms.items()},
     }
+    if args.full_path:
+        # SelfCModel.test()'s two netG calls through the module API (eager, NCHW in/out, STP + GMM sampler on the reverse)
+        from selfc_amd.modules.Quantization import Quantization
+        quant = Quantization()
+        with torch.no_grad():
+            def full():
+                z, _ = net(x=x, rev=False)
+                return net(x=quant(z[:, :3]), rev=True)[0]
+            for _ in range(3):
+                full()
+            L.selfc_profile_reset()
+            L.selfc_profile_enable(1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                full()
+            torch.cuda.synchronize()
+            tf = (time.perf_counter() - t0) / 5
+            L.selfc_profile_enable(0)
+            fp = {}
+            for cls, name in [(0, "conv3x3"), (1, "conv5_F"), (2, "conv5_GH"), (3, "transforms"), (4, "conv5_plain"), (5, "stp"), (6, "fused_gh")]:
+                ms, n = C.c_double(), C.c_longlong()
+                L.selfc_profile_read(cls, C.byref(ms), C.byref(n))
+                fp[name] = round(ms.value / 5, 3)
+            L.selfc_profile_reset()
+        out["full_test_path"] = {"septuplets_per_s": round(B_PER_GPU / tf, 1), "ms_per_batch": round(tf * 1e3, 3),
+                                 "kernel_ms": fp, "note": "module API, eager, single stream, fh_loss gmm with device RNG"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, z_ref, zq_ref, xr_ref = cpu_baseline(net, x_cpu[:T])
         out["cpu_baseline"] = cb
