@@ -125,6 +125,16 @@ int selfc_invstack_run(const selfc_invblock_w* blks, int nblk, const selfc_laten
 int selfc_subnet_run(const selfc_subnet_w* w, int kind, const float* xin, float* yout, void* dense,
                      int N, int T, int H, int W, int cin, int cout, void* stream);
 
+/* Generic dense-block conv on a plane-blocked f16 buffer [P][N][H][W][32] (used for FeatureCalapseBlock,
+ * Subnet_constructor.py:280-324: gc = 128, (3,3,3) conv1 / conv5): reads planes [0, nplanes_in), kt = 1
+ * ((1,3,3) Conv3d) or 3 ((3,3,3): frames n-1, n, n+1 of a T-frame clip, zero outside), cout a multiple of
+ * 32.  out_plane >= 0: LeakyReLU(0.2) output appended as f16 planes out_plane .. out_plane + cout/32 - 1;
+ * out_plane < 0: no activation, fp32 NHWC rows of stride cout into `plain`.  `w`: pack_conv_planes. */
+int selfc_conv_planes_run(void* dense, int nplanes_in, int kt, const void* w, const float* bias, int cout,
+                          int out_plane, float* plain, int N, int T, int H, int W, void* stream);
+/* fp32 NHWC rows (stride roundup(cin,4)) -> f16 planes [0, roundup(cin,32)/32) of a plane-blocked buffer. */
+int selfc_nhwc_to_planes(const float* x, void* dense, size_t npix, int cin, void* stream);
+
 /* NHWC(4-padded) fp32 <-> NCHW fp32 helpers for the stand-alone subnet entry. */
 int selfc_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, void* stream);
 int selfc_nhwc4_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream);

@@ -340,13 +340,36 @@ def stp_v2_gmm_sample(raw: torch.Tensor, eps: torch.Tensor, hf_dim: int = 48, k:
 # a9  STPNet v1, condition_func == "D2DTNet", l2 head  (models/modules/SelfC_arch_inv.py:90-198)
 # ----------------------------------------------------------------------------
 
+def feature_calapse_block(p: Params, x: torch.Tensor, t: int, scale: int = 4, is_res: bool = False) -> torch.Tensor:
+    """FeatureCalapseBlock.forward (Subnet_constructor.py:306-324): SpaceToDepth (:242-257, channel
+    (sy*S+sx)*C + c), 3-D dense block with (3,3,3) conv1 / conv5 and (1,3,3) conv2-4, PixelShuffle."""
+    bt, c, hh, ww = x.shape
+    xs = pixel_unshuffle_ref(x, scale) if scale > 1 else x
+    h, w = xs.shape[2], xs.shape[3]
+    v = xs.reshape(bt // t, t, xs.shape[1], h, w).transpose(1, 2)          # (b, C, t, h, w)
+    feats = [v]
+    for i in range(1, 5):
+        inp = feats[0] if i == 1 else torch.cat(feats, dim=1)
+        pad = (1, 1, 1) if i == 1 else (0, 1, 1)
+        feats.append(lrelu(F.conv3d(inp, p[f"conv{i}.weight"], p.get(f"conv{i}.bias"), 1, pad)))
+    y = F.conv3d(torch.cat(feats, dim=1), p["conv5.weight"], p.get("conv5.bias"), 1, (1, 1, 1))
+    y = y.transpose(1, 2).reshape(bt, -1, h, w)
+    y = F.pixel_shuffle(y, scale) if scale > 1 else y
+    return y + x if is_res else y
+
+
 def stp_v1_parameters(params: Params, lr: torch.Tensor, t: int) -> torch.Tensor:
-    """lr (B*T,3,h,w) -> (B*T,9,h,w): blk1 = 3 x D2DTInput (3->12->24->48), blk2 = D2DTInput(48->c)
-    (:99-105,141-142), tail = LeakyReLU + Conv3d(c,9,1) (:110-116,148)."""
+    """lr (B*T,3,h,w) -> (B*T,9,h,w).  condition_func "D2DTNet": blk1 = 3 x D2DTInput (3->12->24->48),
+    blk2 = D2DTInput(48->c) (:99-105); default: blk1 = FeatureCalapseBlock(3,12), blk2 =
+    FeatureCalapseBlock(12,c) (:107-108); tail = LeakyReLU + Conv3d(c,9,1) (:110-116,148)."""
     x = lr
-    for i in range(3):
-        x = d2dt(_sub(params, f"blk1.{i}"), x, t)
-    x = d2dt(_sub(params, "blk2"), x, t)
+    if "blk1.0.conv1.weight" in params:
+        for i in range(3):
+            x = d2dt(_sub(params, f"blk1.{i}"), x, t)
+        x = d2dt(_sub(params, "blk2"), x, t)
+    else:
+        x = feature_calapse_block(_sub(params, "blk1"), x, t)
+        x = feature_calapse_block(_sub(params, "blk2"), x, t)
     wgt = params["tail.1.weight"]
     return F.conv2d(lrelu(x), wgt.reshape(wgt.shape[0], wgt.shape[1], 1, 1), params["tail.1.bias"])
 

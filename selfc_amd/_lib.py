@@ -23,6 +23,7 @@ SYMBOLS = [
     "selfc_nchw_to_nhwc4", "selfc_nhwc4_to_nchw",
     "selfc_profile_enable", "selfc_profile_read", "selfc_profile_reset",
     "selfc_globalagg_run", "selfc_globalagg_partial_floats", "selfc_pwconv_run", "selfc_gmm_sample",
+    "selfc_conv_planes_run", "selfc_nhwc_to_planes",
 ]
 
 
@@ -78,6 +79,8 @@ def lib():
             "selfc_globalagg_run": [vp, vp, vp, f, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
             "selfc_pwconv_run": [vp, i, vp, i, vp, vp, sz, i, i, i, i, i, vp],
             "selfc_gmm_sample": [vp, vp, vp, sz, i, i, vp],
+            "selfc_conv_planes_run": [vp, i, i, vp, vp, i, i, vp, i, i, i, i, vp],
+            "selfc_nhwc_to_planes": [vp, vp, sz, i, vp],
         }
         for name, args in sigs.items():
             fn = getattr(L, name)

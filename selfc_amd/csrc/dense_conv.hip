@@ -47,6 +47,7 @@ struct C3Stage {
   int coff;   // first channel of the stage in the dense buffer
   int width;  // 16 or 32 channels
   int kind;   // 0: 9-tap stage of the dense buffer; 1: im2col stage built from x1 (K = 9*c1 <= 32)
+  int dt;     // generic mode: frame offset of a temporal tap (-1, 0, +1), 0 otherwise
 };
 
 // The stage list of a conv is regular, so it is described by four integers and
@@ -69,6 +70,11 @@ struct C3Args {
   int out_coff;
   int tiles_x, tiles_y;
   int has_im2col, cin16, n_in, fbase;
+  // generic mode (gen_planes > 0): the conv reads planes [0, gen_planes) of dense[0], optionally at
+  // three temporal taps (gen_tt == 3: frames n-1, n, n+1 inside a clip of T frames, zero outside), and
+  // blockIdx.z selects a 32-channel output group (weights w[0] + z*wz_stride, bias[0] + 32 z).
+  int gen_planes, gen_tt, T;
+  size_t wz_stride;
   // coupling / plain epilogue (EPI != LRELU)
   float* x1io;           // EPI_F: y1 = x1 +- F, in place          [N][H][W][4]
   float* x2io;           // EPI_GH: y2, in place                   [N][H][W][c2p]
@@ -87,9 +93,13 @@ struct C3Args {
 // prefetch of stage s+1 is issued before the MFMAs of stage s).
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ C3Stage stage_of(const C3Args& a, const int s) {
-  if (a.has_im2col) return s == 0 ? C3Stage{0, 32, 1} : C3Stage{a.fbase + 32 * (s - 1), 32, 0};
-  if (s < a.n_in) return C3Stage{32 * s, (a.cin16 - 32 * s >= 32) ? 32 : 16, 0};
-  return C3Stage{a.fbase + 32 * (s - a.n_in), 32, 0};
+  if (a.gen_planes > 0) {
+    const int ti = s / a.gen_planes;
+    return C3Stage{32 * (s - ti * a.gen_planes), 32, 0, a.gen_tt == 3 ? ti - 1 : 0};
+  }
+  if (a.has_im2col) return s == 0 ? C3Stage{0, 32, 1, 0} : C3Stage{a.fbase + 32 * (s - 1), 32, 0, 0};
+  if (s < a.n_in) return C3Stage{32 * s, (a.cin16 - 32 * s >= 32) ? 32 : 16, 0, 0};
+  return C3Stage{a.fbase + 32 * (s - a.n_in), 32, 0, 0};
 }
 
 template <int TH, int TW, int NW, int MT, int EPI>
@@ -140,9 +150,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
       for (int r = 0; r < 16; ++r) acc[q][m][r] = 0.f;
 
   // conv1-4 epilogue biases: fetched now so their latency hides behind the whole K loop
+  const int zg = a.gen_planes > 0 ? (int)blockIdx.z : 0;     // generic mode: 32-channel output group
   float4 ebias[4];
   if (EPI == EPI_LRELU) {
-    const float* __restrict__ bias = blockIdx.z ? a.bias[1] : a.bias[0];
+    const float* __restrict__ bias = a.gen_planes > 0 ? a.bias[0] + 32 * zg : (blockIdx.z ? a.bias[1] : a.bias[0]);
 #pragma unroll
     for (int g = 0; g < 4; ++g) ebias[g] = *reinterpret_cast<const float4*>(bias + 8 * g + 4 * (lane >> 5));
   }
@@ -164,10 +175,13 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
 
 #pragma unroll
   for (int net_i = 0; net_i < NNETS; ++net_i) {
-    const int net = (EPI == EPI_GH) ? net_i : (int)blockIdx.z;
+    const bool gen = a.gen_planes > 0;
+    const int net = (EPI == EPI_GH) ? net_i : (gen ? 0 : (int)blockIdx.z);
     // ternaries, not a.dense[net]: a dynamically indexed by-value array goes to scratch
     const f16* __restrict__ dense = net ? a.dense[1] : a.dense[0];
-    const u32x4* __restrict__ wsrc = reinterpret_cast<const u32x4*>(net ? a.w[1] : a.w[0]);
+    const u32x4* __restrict__ wsrc = reinterpret_cast<const u32x4*>((net ? a.w[1] : a.w[0]) + (gen ? (size_t)blockIdx.z * a.wz_stride : 0));
+    const int tclip = gen ? n % a.T : 0;                 // frame index inside its clip (temporal taps)
+    const long frame_stride = (long)H * W * 32;           // halfs per frame inside a plane
 
     u32x4 areg[AITER];
     u32x4 wreg[WITER];
@@ -180,7 +194,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
     // A 16-wide stage simply stages the (zero) pad half of its plane as well.
     auto load_stage = [&](const C3Stage st, const int fb) __attribute__((always_inline)) {
       if (a.ablate & 2) return;
-      const f16* __restrict__ src = dense + (size_t)(st.coff >> 5) * a.plane;
+      const bool tv = (tclip + st.dt >= 0) & (tclip + st.dt < (gen ? a.T : 1 << 30));
+      const f16* __restrict__ src = dense + (size_t)(st.coff >> 5) * a.plane + (tv ? st.dt * frame_stride : 0);
       if (!(a.ablate & 64))
 #pragma unroll
       for (int it = 0; it < AITER; ++it) areg[it] = *reinterpret_cast<const u32x4*>(src + gofs[it]);
@@ -194,12 +209,14 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
     };
     auto store_stage = [&](const C3Stage st) __attribute__((always_inline)) {
       if (a.ablate & 4) return;
+      const bool tv = (tclip + st.dt >= 0) & (tclip + st.dt < (gen ? a.T : 1 << 30));
+      const unsigned okm = tv ? okmask : 0u;               // a temporal tap outside the clip is zero padding too
 #pragma unroll
       for (int it = 0; it < AITER; ++it) {
         // out-of-image pixels become the conv's zero padding here (a select right after the load
         // would make the compiler drain the prefetch before the MFMA phase)
         if (tid + it * NT < NPIX * 4)
-          *reinterpret_cast<u32x4*>(lact + lofs[it]) = ((okmask >> it) & 1u) ? areg[it] : u32x4{0u, 0u, 0u, 0u};
+          *reinterpret_cast<u32x4*>(lact + lofs[it]) = ((okm >> it) & 1u) ? areg[it] : u32x4{0u, 0u, 0u, 0u};
       }
       const int nfr = 9 * (st.width >> 4);
 #pragma unroll
@@ -359,7 +376,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
     if (EPI == EPI_LRELU) {
       // lanes l and l+32 own the same pixel and interleaved 4-channel groups; one half-swap per
       // dword hands each lane 8 contiguous channels -> two 16-byte stores per M-tile
-      f16* dst = (blockIdx.z ? a.out[1] : a.out[0]) + (size_t)(a.out_coff >> 5) * a.plane + pix * 32 + 8 * half;
+      f16* dst = ((blockIdx.z && !zg) ? a.out[1] : a.out[0]) + (size_t)((a.out_coff >> 5) + zg) * a.plane + pix * 32 + 8 * half;
       uint32_t r[4][2];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -384,7 +401,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
       const float* __restrict__ bias = a.bias[0];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int oc = 8 * g + 4 * half;
+        const int oc = 32 * zg + 8 * g + 4 * half;
         if (oc < a.coutp) {
           const float4 b = *reinterpret_cast<const float4*>(bias + oc);
           *reinterpret_cast<float4*>(a.plain + pix * a.coutp + oc) =
@@ -882,6 +899,39 @@ int selfc_subnet_run(const selfc_subnet_w* w, int kind, const float* xin, float*
   build_stages(a, cin, 5);
   a.plain = yout; a.coutp = coutp;
   return launch_conv3x3<EPI_PLAIN>(a, 1, s);
+}
+
+
+int selfc_nhwc_to_planes(const float* x, void* dense, size_t npix, int cin, void* stream) {
+  if (!x || !dense || npix == 0 || cin < 1) return SELFC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(PROF_TRANSFORM, s);
+  hipLaunchKernelGGL(nhwc_to_dense_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s,
+                     x, (f16*)dense, npix, cin, (cin + 3) & ~3, (cin + 31) & ~31);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_conv_planes_run(void* dense, int nplanes_in, int kt, const void* w, const float* bias, int cout,
+                          int out_plane, float* plain, int N, int T, int H, int W, void* stream) {
+  if (!dense || !w || !bias || nplanes_in < 1 || (kt != 1 && kt != 3) || cout < 32 || cout % 32) return SELFC_EINVAL;
+  if (N <= 0 || T <= 0 || N % T || H <= 0 || W <= 0) return SELFC_EINVAL;
+  if ((out_plane < 0) == (plain == nullptr)) return SELFC_EINVAL;      // exactly one kind of output
+  if (out_plane >= 0 && out_plane < nplanes_in) return SELFC_EINVAL;    // appended planes must not alias the inputs
+  hipStream_t s = (hipStream_t)stream;
+  C3Args a{};
+  a.dense[0] = (const f16*)dense; a.out[0] = (f16*)dense;
+  a.w[0] = (const f16*)w; a.bias[0] = bias;
+  a.N = N; a.H = H; a.W = W; a.plane = (size_t)N * H * W * 32;
+  a.gen_planes = nplanes_in; a.gen_tt = kt; a.T = T;
+  a.nstages = nplanes_in * kt;
+  a.wz_stride = (size_t)a.nstages * 18 * 512;          // halfs of one 32-channel output group's fragments
+  const int zg = cout / 32;
+  if (out_plane >= 0) {
+    a.out_coff = out_plane * 32;
+    return launch_conv3x3<EPI_LRELU>(a, zg, s);
+  }
+  a.plain = plain; a.coutp = cout;
+  return launch_conv3x3<EPI_PLAIN>(a, zg, s);
 }
 
 }  // extern "C"

@@ -5,9 +5,9 @@ Mirrors codes/models/modules/SelfC_arch_inv.py: ``STPNet`` v1 (:90-198) and ``Se
 net only works for one Haar level (scale 2).  The reference's temporal length for this file is the module
 constant ``TEMP_LEN = 7`` (:6); here GlobalVar is used when set, else 7.
 
-Covered natively: ``condition_func: "D2DTNet"`` (a chain of D2DTInput subnets) with the ``fh_loss: "l2"``
-head.  The default conditioner, ``FeatureCalapseBlock`` (space-to-depth + (3,3,3) Conv3d with gc=128,
-Subnet_constructor.py:280-324), has no kernels yet and raises.
+Both conditioners are built: ``condition_func: "D2DTNet"`` (a chain of D2DTInput subnets) and the default
+``FeatureCalapseBlock`` pair (space-to-depth + (3,3,3) Conv3d with gc=128, Subnet_constructor.py:280-324),
+with the ``fh_loss: "l2"`` head (the reference's GMM branch of this file is CUDA-only, :161).
 """
 import torch
 import torch.nn as nn
@@ -15,7 +15,7 @@ import torch.nn as nn
 from .. import _lib, runtime as rt
 from ..global_var import GlobalVar
 from .Inv_arch import HaarDownsampling, InvBlockExp
-from .Subnet_constructor import D2DTInput, subnet
+from .Subnet_constructor import D2DTInput, FeatureCalapseBlock, subnet
 
 TEMP_LEN = 7
 
@@ -33,15 +33,16 @@ class STPNet(nn.Module):
         self.K = opt["gmm_mixture_num"]
         self.stp_blk_num = opt["stp_blk_num"]
         self.condition_func = opt["condition_func"]
-        if self.condition_func != "D2DTNet":
-            raise NotImplementedError("selfc_amd builds STP v1 for condition_func 'D2DTNet'; the FeatureCalapseBlock "
-                                      "conditioner ((3,3,3) Conv3d, gc=128) has no HIP kernels yet")
         if self.fh_loss != "l2":
             raise NotImplementedError("selfc_amd builds the l2 head of STP v1 (its GMM branch is CUDA-only in the reference, :161)")
         if self.stp_temporal_c % 32 or not 32 <= self.stp_temporal_c <= 64:
             raise NotImplementedError("stp_temporal_c must be 32 or 64 for the pointwise head kernel")
-        self.blk1 = nn.Sequential(D2DTInput(3, 12), D2DTInput(12, 24), D2DTInput(24, 48))
-        self.blk2 = D2DTInput(48, self.stp_temporal_c)
+        if self.condition_func == "D2DTNet":
+            self.blk1 = nn.Sequential(D2DTInput(3, 12), D2DTInput(12, 24), D2DTInput(24, 48))
+            self.blk2 = D2DTInput(48, self.stp_temporal_c)
+        else:
+            self.blk1 = FeatureCalapseBlock(3, 12)
+            self.blk2 = FeatureCalapseBlock(12, self.stp_temporal_c)
         self.hf_dim = 9
         self.tail = nn.Sequential(nn.LeakyReLU(negative_slope=0.2, inplace=True),
                                   nn.Conv3d(self.stp_temporal_c, self.hf_dim, 1, 1, 0, bias=True))
@@ -60,9 +61,7 @@ class STPNet(nn.Module):
         b, c, t, h, w = x.size()
         temp = x.transpose(1, 2).reshape(b * t, c, h, w)
         rt.no_autograd_guard(temp, *self.parameters())
-        for m in self.blk1:
-            temp = m(temp)
-        temp = self.blk2(temp)
+        temp = self.blk2(self.blk1(temp))
         n, cc = b * t, self.stp_temporal_c
         sp = _lib.stream_ptr()
         feat = torch.empty((n, h, w, cc), dtype=torch.float32, device=temp.device)

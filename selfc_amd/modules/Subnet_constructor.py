@@ -117,6 +117,94 @@ class D2DTInput(_DenseSubnet):
         return self._run(x, t)
 
 
+class SpaceToDepth(nn.Module):
+    """(N,C,H,W) -> (N,C*S*S,H/S,W/S), out channel (sy*S+sx)*C + c (Subnet_constructor.py:242-257); pure view shuffle."""
+
+    def __init__(self, block_size=4):
+        super().__init__()
+        assert block_size in {2, 4}, "Space2Depth only supports blocks size = 4 or 2"
+        self.block_size = block_size
+
+    def forward(self, x):
+        n, c, h, w = x.size()
+        s = self.block_size
+        x = x.view(n, c, h // s, s, w // s, s).permute(0, 3, 5, 1, 2, 4).contiguous()
+        return x.view(n, c * s * s, h // s, w // s)
+
+
+class FeatureCalapseBlock(nn.Module):
+    """Space-to-depth dense block of STP v1 (Subnet_constructor.py:280-324): at 1/scale resolution, channels
+    scale^2*cin -> [4 x (scale*gc) features] -> scale^2*cout, conv1 and conv5 are (3,3,3) Conv3d, conv2-4
+    (1,3,3); then PixelShuffle back.  The five convs run on selfc_conv_planes_run (dense_conv.hip in its
+    generic plane-list mode: temporal taps + 32-channel output groups); the two shuffles are views."""
+
+    def __init__(self, channel_in, channel_out, scale=4, init='xavier', gc=32, bias=True, INN_init=True, is_res=False):
+        super().__init__()
+        self.scale = scale
+        self.is_res = is_res
+        if scale > 1:
+            self.ds = SpaceToDepth(scale)
+            self.us = nn.PixelShuffle(scale)
+        self.cin = (scale ** 2) * channel_in
+        self.cout = (scale ** 2) * channel_out
+        self.gc = scale * gc
+        ci, co, g = self.cin, self.cout, self.gc
+        self.conv1 = nn.Conv3d(ci, g, (3, 3, 3), 1, (1, 1, 1), bias=bias)
+        self.conv2 = nn.Conv3d(ci + g, g, (1, 3, 3), 1, (0, 1, 1), bias=bias)
+        self.conv3 = nn.Conv3d(ci + 2 * g, g, (1, 3, 3), 1, (0, 1, 1), bias=bias)
+        self.conv4 = nn.Conv3d(ci + 3 * g, g, (1, 3, 3), 1, (0, 1, 1), bias=bias)
+        self.conv5 = nn.Conv3d(ci + 4 * g, co, (3, 3, 3), 1, (1, 1, 1), bias=bias)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.2, inplace=True)
+        if INN_init:   # only matches nn.Conv2d in the reference's helpers: a no-op for these Conv3d layers
+            first4 = [self.conv1, self.conv2, self.conv3, self.conv4]
+            (mutil.initialize_weights_xavier if init == 'xavier' else mutil.initialize_weights)(first4, 0.1)
+            mutil.initialize_weights(self.conv5, 0)
+
+    def _packed(self):
+        key = rt.params_key(self)
+        if getattr(self, "_pk_key", None) != key:
+            from ..packing import pack_conv_planes, pad_bias
+            if self.gc % 32 or self.cout % 32:
+                raise NotImplementedError("FeatureCalapseBlock kernels need scale*gc and scale^2*cout to be multiples of 32")
+            convs = [getattr(self, f"conv{i}") for i in range(1, 6)]
+            self._pk = [(pack_conv_planes(c.weight, self.cin), pad_bias(c.bias, c.out_channels, c.weight.device)) for c in convs]
+            self._pk_key = key
+        return self._pk
+
+    def forward(self, x, io_type="2d"):
+        if io_type != "2d":
+            raise NotImplementedError("FeatureCalapseBlock: only the io_type='2d' call of the reference's STPNet is built")
+        x = rt.as_input(x)
+        rt.no_autograd_guard(x, *self.parameters())
+        res = x
+        xs = self.ds(x) if self.scale > 1 else x
+        t = GlobalVar.get_Temporal_LEN() or 7
+        n, c, h, w = xs.shape
+        if c != self.cin or n % t:
+            raise RuntimeError(f"FeatureCalapseBlock expects (b*{t},{self.cin // self.scale ** 2},H,W), got {tuple(x.shape)}")
+        dev, sp = x.device, _lib.stream_ptr()
+        pk = self._packed()
+        pin = roundup(self.cin, 32) // 32
+        gp = self.gc // 32
+        nhwc = torch.empty((n, h, w, roundup(c, 4)), dtype=torch.float32, device=dev)
+        rt.call("selfc_nchw_to_nhwc4", xs.data_ptr(), nhwc.data_ptr(), n, c, h, w, sp)
+        dense = torch.zeros((pin + 4 * gp, n, h, w, 32), dtype=torch.float16, device=dev)
+        rt.call("selfc_nhwc_to_planes", nhwc.data_ptr(), dense.data_ptr(), n * h * w, c, sp)
+        for i in range(4):          # conv1 (3,3,3), conv2-4 (1,3,3); LeakyReLU fused, features appended as planes
+            wp, bp = pk[i]
+            nin = pin + i * gp
+            rt.call("selfc_conv_planes_run", dense.data_ptr(), nin, 3 if i == 0 else 1, wp.data_ptr(), bp.data_ptr(),
+                    self.gc, nin, None, n, t, h, w, sp)
+        wp, bp = pk[4]
+        out = torch.empty((n, h, w, self.cout), dtype=torch.float32, device=dev)
+        rt.call("selfc_conv_planes_run", dense.data_ptr(), pin + 4 * gp, 3, wp.data_ptr(), bp.data_ptr(),
+                self.cout, -1, out.data_ptr(), n, t, h, w, sp)
+        y = torch.empty((n, self.cout, h, w), dtype=torch.float32, device=dev)
+        rt.call("selfc_nhwc4_to_nchw", out.data_ptr(), y.data_ptr(), n, self.cout, h, w, sp)
+        y = self.us(y) if self.scale > 1 else y
+        return y + res if self.is_res else y
+
+
 def subnet(net_structure, init='xavier'):
     """String-keyed factory, Subnet_constructor.py:719-788.  Live names of the
     shipped configs: 'DBNet' and 'D2DTNet'; any other name returns None exactly

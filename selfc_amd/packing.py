@@ -161,3 +161,24 @@ def pack_fused_gh(weights: Sequence[torch.Tensor], cin: int = 3) -> torch.Tensor
     out = torch.cat(frags, dim=0)
     assert out.shape[0] == 120
     return out.to(F16).contiguous()
+
+
+def pack_conv_planes(weight: torch.Tensor, cin: int) -> torch.Tensor:
+    """Conv3d weight (cout, cin + 128*j, kt, 3, 3), kt in {1, 3}, of a FeatureCalapseBlock-style dense block
+    (inputs first, then 128-channel features) -> f16 [cout/32, nstages*18, 64, 8] for selfc_conv_planes_run.
+    Buffer planes: the cin inputs zero-padded to whole 32-channel planes, then the features (32 | 128).
+    K order per output group: for temporal tap: for plane: for spatial tap: for 32 channels."""
+    w = weight.detach().float()
+    cout, ctot, kt = w.shape[0], w.shape[1], w.shape[2]
+    assert w.shape[3:] == (3, 3) and kt in (1, 3) and cout % 32 == 0 and (ctot - cin) % 32 == 0
+    pin = roundup(cin, 32) // 32
+    nplanes = pin + (ctot - cin) // 32
+    wp = torch.zeros(cout, nplanes * 32, kt, 9, dtype=torch.float32, device=w.device)
+    wp[:, :cin] = w[:, :cin].reshape(cout, cin, kt, 9)
+    wp[:, pin * 32:] = w[:, cin:].reshape(cout, ctot - cin, kt, 9)
+    # (cout, plane, 32, kt, 9) -> (cout, kt, plane, 9, 32)
+    wk = wp.reshape(cout, nplanes, 32, kt, 9).permute(0, 3, 1, 4, 2).reshape(cout, kt * nplanes * 9 * 32)
+    nfrag = wk.shape[1] // 16
+    z = cout // 32
+    frag = wk.reshape(z, 32, nfrag, 2, 8).permute(0, 2, 3, 1, 4).reshape(z, nfrag, 64, 8)
+    return frag.to(F16).contiguous()

@@ -34,3 +34,18 @@ def golden():
 def rel_err(a, b):
     """max |a-b| / max |b|  (the "1e-3 relative fp32" metric of BASELINE.json, written down here)."""
     return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+def seeded_fill(named_tensors, seed):
+    """Deterministically fill parameters too large to store as fixtures (used identically by
+    tools/make_golden.py on the reference module and by the tests on ours): names in sorted order,
+    N(0, 1/fan_in) weights, N(0, 0.01^2) biases, drawn from one seeded CPU generator."""
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name in sorted(named_tensors):
+            t = named_tensors[name]
+            if t.dim() > 1:
+                fan_in = int(np.prod(t.shape[1:]))
+                t.copy_((torch.randn(t.shape, generator=gen) / fan_in ** 0.5).to(t.device))
+            else:
+                t.copy_((torch.randn(t.shape, generator=gen) * 0.01).to(t.device))

@@ -5,7 +5,7 @@ max|a-b| / max|b| (conftest.rel_err).  Run with `-m gpu` on the MI355X box."""
 import pytest
 import torch
 
-from conftest import load_golden, rel_err, subdict
+from conftest import load_golden, rel_err, seeded_fill, subdict
 from oracle import selfc_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -303,8 +303,30 @@ def test_selfc_haar_variant(dev):
         xr, hf = net(x=g["lr"].to(dev), rev=True)
         assert rel_err(hf.cpu(), g["hf"]) < 2e-3
         assert rel_err(xr.cpu(), g["x_rev"]) < 2e-3
-    with pytest.raises(NotImplementedError):
-        SelfCInvNet(dict(opt1, condition_func="FeatureCalapseBlock"), 3, 3, "DBNet", [1], 1)
+
+
+def test_selfc_haar_variant_feature_calapse_block(dev):
+    """The default STP v1 conditioner: FeatureCalapseBlock = SpaceToDepth + dense block with gc = 128 and
+    (3,3,3) conv1 / conv5 (generic plane-list conv kernel) + PixelShuffle.  16 M STP parameters are filled
+    with the fixture's seeded routine instead of being stored."""
+    from selfc_amd.modules.SelfC_arch_inv import SelfCInvNet
+    g = load_golden("g8_selfc_haar_fcb")
+    opt2 = {"stp_d2d_inner_c": 32, "stp_temporal_c": 32, "fh_loss": "l2", "gmm_mixture_num": 5,
+            "stp_blk_num": 2, "condition_func": "FeatureCalapseBlock"}
+    net = SelfCInvNet(opt2, 3, 3, "DBNet", [1], 1)
+    missing, unexpected = net.load_state_dict({k: v for k, v in g.items() if k.startswith("operations.")}, strict=False)
+    assert not unexpected and all(k.startswith("stp_net.") for k in missing)
+    seeded_fill(dict(net.stp_net.named_parameters()), int(g["stp_fill_seed"]))
+    net.to(dev).eval()
+    with torch.no_grad():
+        y1 = net.stp_net.blk1(g["lr"].to(dev))
+        assert rel_err(y1.cpu(), g["blk1_y"]) < TOL
+        z, loss = net(x=g["x"].to(dev), rev=False)
+        assert rel_err(z.cpu(), g["z"]) < TOL
+        assert abs(loss.item() - g["loss_c"].item()) < 5e-3 * g["loss_c"].item()
+        xr, hf = net(x=g["lr"].to(dev), rev=True)
+        assert rel_err(hf.cpu(), g["hf"]) < 2e-3
+        assert rel_err(xr.cpu(), g["x_rev"]) < 2e-3
 
 
 def test_1080p_tile_invertibility(dev):

@@ -4,7 +4,7 @@ shuffles (Haar, FrequencyAnalyzer, Quantization), <=2e-6 relative for float
 paths (different but equivalent summation orders of the same fp32 convs)."""
 import torch
 
-from conftest import load_golden, rel_err, subdict
+from conftest import load_golden, rel_err, seeded_fill, subdict
 from oracle import selfc_oracle as O
 
 T = 7
@@ -132,3 +132,35 @@ def test_selfc_haar_variant_with_stp_v1():
     xr, hf = O.selfc_haar_rev(g, g["lr"], [1], T, "DBNet")
     assert rel_err(hf, g["hf"]) < 1e-5
     assert rel_err(xr, g["x_rev"]) < 1e-5
+
+
+def _fcb_stp_params(seed, c=32):
+    """state_dict-shaped parameters of STP v1 with the FeatureCalapseBlock conditioner, filled like the fixture."""
+    shapes = {}
+    for blk, (ci, co) in {"blk1": (48, 192), "blk2": (192, 16 * c)}.items():
+        for i in range(1, 5):
+            kt = 3 if i == 1 else 1
+            shapes[f"{blk}.conv{i}.weight"] = (128, ci + 128 * (i - 1), kt, 3, 3)
+            shapes[f"{blk}.conv{i}.bias"] = (128,)
+        shapes[f"{blk}.conv5.weight"] = (co, ci + 512, 3, 3, 3)
+        shapes[f"{blk}.conv5.bias"] = (co,)
+    shapes["tail.1.weight"] = (9, c, 1, 1, 1)
+    shapes["tail.1.bias"] = (9,)
+    params = {k: torch.empty(v) for k, v in shapes.items()}
+    seeded_fill(params, seed)
+    return params
+
+
+def test_selfc_haar_variant_with_feature_calapse_block():
+    g = load_golden("g8_selfc_haar_fcb")
+    stp = _fcb_stp_params(int(g["stp_fill_seed"]))
+    y1 = O.feature_calapse_block(subdict(stp, "blk1"), g["lr"], T)
+    assert rel_err(y1, g["blk1_y"]) < 1e-5
+    params = dict(g)
+    params.update({"stp_net." + k: v for k, v in stp.items()})
+    z, loss = O.selfc_haar_fwd(params, g["x"], [1], T, "DBNet")
+    assert rel_err(z, g["z"]) < FTOL
+    assert abs(loss.item() - g["loss_c"].item()) < 1e-4 * abs(g["loss_c"].item()) + 1e-7
+    xr, hf = O.selfc_haar_rev(params, g["lr"], [1], T, "DBNet")
+    assert rel_err(hf, g["hf"]) < 2e-5
+    assert rel_err(xr, g["x_rev"]) < 2e-5

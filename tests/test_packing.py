@@ -183,3 +183,36 @@ def test_pack_fused_gh_stream(layer):
     assert ak.shape[-1] == wk.shape[1]
     out = torch.einsum("ok,nhwk->nohw", wk, ak)
     assert torch.allclose(out, ref, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("cin,nfeat,kt,cout", [(48, 0, 3, 128), (48, 2, 1, 128), (192, 4, 3, 64)])
+def test_pack_conv_planes(cin, nfeat, kt, cout):
+    """generic plane-list conv (FeatureCalapseBlock): K order = temporal tap, plane, spatial tap, 32 channels."""
+    g = torch.Generator().manual_seed(cin + nfeat + kt)
+    ctot = cin + 128 * nfeat
+    w = torch.randn(cout, ctot, kt, 3, 3, generator=g) * 0.05
+    frag = P.pack_conv_planes(w, cin)
+    pin = P.roundup(cin, 32) // 32
+    nplanes = pin + 4 * nfeat
+    assert frag.shape == (cout // 32, kt * nplanes * 18, 64, 8)
+    B, T, h, wd = 1, 3, 4, 5
+    x = torch.randn(B, ctot, T, h, wd, generator=g)
+    pad = (1, 1, 1) if kt == 3 else (0, 1, 1)
+    ref = F.conv3d(x, w.half().float(), None, 1, pad)                       # (B, cout, T, h, w)
+    # plane buffer: inputs zero padded to whole planes, then features
+    buf = torch.zeros(B, T, h, wd, nplanes * 32)
+    buf[..., :cin] = x[:, :cin].permute(0, 2, 3, 4, 1)
+    buf[..., pin * 32:] = x[:, cin:].permute(0, 2, 3, 4, 1)
+    bp = F.pad(buf, (0, 0, 1, 1, 1, 1, 1, 1) if kt == 3 else (0, 0, 1, 1, 1, 1))
+    cols = []
+    for ti in range(kt):
+        for pl in range(nplanes):
+            for tap in range(9):
+                ky, kx = divmod(tap, 3)
+                src = bp[:, ti:ti + T] if kt == 3 else bp
+                cols.append(src[:, :, ky:ky + h, kx:kx + wd, 32 * pl:32 * pl + 32])
+    ak = torch.cat(cols, -1)
+    for z in range(cout // 32):
+        wk = unpack_a32(frag[z])
+        out = torch.einsum("ok,bthwk->bothw", wk, ak)
+        assert torch.allclose(out, ref[:, 32 * z:32 * z + 32], atol=2e-4, rtol=1e-4)

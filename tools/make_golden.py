@@ -188,6 +188,25 @@ def main():
         save("g8_selfc_haar", x=x.numpy(), z=out.numpy(), loss_c=loss.numpy(), lr=lrq.numpy(), x_rev=xr.numpy(),
              hf=hf.numpy(), **sd_np(hnet))
 
+        # ---- G8b the same net with the default FeatureCalapseBlock conditioner (space-to-depth + (3,3,3) convs).
+        # Its STP has ~16 M parameters: they are not stored but filled by tests/conftest.py:seeded_fill(seed).
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+        from conftest import seeded_fill
+        torch.manual_seed(19)
+        opt2 = dict(opt1, condition_func="FeatureCalapseBlock")
+        fnet = SA.SelfCInvNet(opt2, 3, 3, "DBNet", [1], 1).eval()
+        for sub in (fnet.operations[1].F, fnet.operations[1].G, fnet.operations[1].H):
+            rerandomise_conv5(sub, g)
+        seeded_fill(dict(fnet.stp_net.named_parameters()), 4242)
+        x = torch.rand(T, 3, 48, 32, generator=g)             # LR 24x16 -> space-to-depth 6x4
+        out, loss = fnet(x=x, rev=False)
+        lrq = Quantization()(out[:, :3])
+        xr, hf = fnet(x=lrq, rev=True)
+        blk1_y = fnet.stp_net.blk1(lrq)
+        save("g8_selfc_haar_fcb", x=x.numpy(), z=out.numpy(), loss_c=loss.numpy(), lr=lrq.numpy(), x_rev=xr.numpy(),
+             hf=hf.numpy(), blk1_y=blk1_y.numpy(), stp_fill_seed=np.int64(4242),
+             **{k: v for k, v in sd_np(fnet).items() if k.startswith("operations.")})
+
         # ---- G9 Quantization
         q = Quantization()
         v = torch.tensor([-0.3, 0.0, 0.001, 0.00196, 0.00197, 0.5, 0.50196, 0.998, 1.0, 1.7,
