@@ -50,6 +50,10 @@ def lib():
     """The loaded library; raises RuntimeError when it has not been built."""
     global _lib
     if _lib is None:
+        # torch must be loaded first: it bundles its own libamdhip64, and libselfc_hip.so has to bind to
+        # THAT runtime (same soname) - loading our library first pulls in /opt/rocm's copy and the process
+        # ends up with two HIP runtimes (kernel launches then fail with hipErrorNoDevice).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
