@@ -77,6 +77,12 @@ int selfc_latent_to_nchw(const float* x1, const float* x2, float* y,
  * (clamp to [0,1], round-half-even(x*255)/255). n = number of floats. */
 int selfc_quantize_inplace(float* x, size_t n, void* stream);
 
+/* Y-channel squared error of test_rescaling.py's PSNR (rgb_to_ycbcr data/util.py:239-245, calculate_psnr
+ * utils/util.py:198-221): a, b NCHW (N,3,H,W) RGB in [0,1]; partial[n][blk] (double, selfc_y_sse_blocks(HW)
+ * per frame) = partial sums of (Ya - Yb)^2; PSNR_n = 10 log10(HW / sum_blk partial[n][blk]). Deterministic. */
+int selfc_y_sse_blocks(int HW);
+int selfc_y_sse(const float* a, const float* b, double* partial, int N, int HW, void* stream);
+
 /* ---- dense-block subnets --------------------------------------------------- */
 
 typedef struct {

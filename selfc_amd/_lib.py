@@ -23,7 +23,7 @@ SYMBOLS = [
     "selfc_nchw_to_nhwc4", "selfc_nhwc4_to_nchw",
     "selfc_profile_enable", "selfc_profile_read", "selfc_profile_reset",
     "selfc_globalagg_run", "selfc_globalagg_partial_floats", "selfc_pwconv_run", "selfc_gmm_sample",
-    "selfc_conv_planes_run", "selfc_nhwc_to_planes",
+    "selfc_conv_planes_run", "selfc_nhwc_to_planes", "selfc_y_sse", "selfc_y_sse_blocks",
 ]
 
 
@@ -85,11 +85,14 @@ def lib():
             "selfc_gmm_sample": [vp, vp, vp, sz, i, i, vp],
             "selfc_conv_planes_run": [vp, i, i, vp, vp, i, i, vp, i, i, i, i, vp],
             "selfc_nhwc_to_planes": [vp, vp, sz, i, vp],
+            "selfc_y_sse": [vp, vp, vp, i, i, vp],
+            "selfc_y_sse_blocks": [i],
         }
         for name, args in sigs.items():
             fn = getattr(L, name)
             fn.restype = i
             fn.argtypes = args
+        L.selfc_y_sse_blocks.restype = i
         L.selfc_globalagg_partial_floats.restype = sz
         L.selfc_globalagg_partial_floats.argtypes = [i, i]
         _lib = L

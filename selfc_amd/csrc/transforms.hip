@@ -253,9 +253,57 @@ __global__ void quantize_kernel(float* __restrict__ x, size_t n4) {
   reinterpret_cast<float4*>(x)[i] = v;
 }
 
+// Every product and sum is rounded separately, as the reference's torch expression evaluates it.  hipcc's
+// default -ffp-contract=fast may fuse EITHER product of a*b + c*d into the FMA, and it picked different ones
+// for the two SLP-packed lanes (Y(a) != Y(a) by half an ulp); HIP's __fmul_rn / __fadd_rn are plain * and +
+// and do not stop that, the pragma does.
+__device__ __forceinline__ float y_of(float r, float g, float b) {
+#pragma clang fp contract(off)
+  float s = r * 65.481f;
+  s = s + g * 128.553f;
+  s = s + b * 24.966f;
+  s = s + 16.0f;
+  return s / 255.0f;
+}
+
+// Y-channel squared error of test_rescaling.py's metric (data/util.py:239-245, utils/util.py:198-221):
+// Y = (65.481 R + 128.553 G + 24.966 B + 16) / 255; partial[n][blk] = sum over the block's pixels of (Ya - Yb)^2.
+__global__ __launch_bounds__(256) void y_sse_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                    double* __restrict__ partial, int HW, int nblk) {
+  __shared__ double red[256];
+  const int n = blockIdx.y;
+  const float* pa = a + (size_t)n * 3 * HW;
+  const float* pb = b + (size_t)n * 3 * HW;
+  double acc = 0.0;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += nblk * 256) {
+    // every product and sum rounded separately, as the reference's torch expression does (no FMA contraction)
+    const float ya = y_of(pa[p], pa[HW + p], pa[2 * HW + p]);
+    const float yb = y_of(pb[p], pb[HW + p], pb[2 * HW + p]);
+    const double d = (double)ya - (double)yb;
+    acc += d * d;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[(size_t)n * nblk + blockIdx.x] = red[0];
+}
+
 }  // namespace
 
 extern "C" {
+
+int selfc_y_sse_blocks(int HW) { const int nb = (HW + 256 * 8 - 1) / (256 * 8); return nb < 1 ? 1 : (nb > 256 ? 256 : nb); }
+
+int selfc_y_sse(const float* a, const float* b, double* partial, int N, int HW, void* stream) {
+  if (!a || !b || !partial || N <= 0 || HW <= 0) return SELFC_EINVAL;
+  const int nblk = selfc_y_sse_blocks(HW);
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
+  hipLaunchKernelGGL(y_sse_kernel, dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, a, b, partial, HW, nblk);
+  return hip_rc(hipGetLastError());
+}
 
 int selfc_haar_fwd_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return SELFC_EINVAL;

@@ -1,0 +1,73 @@
+"""Caller-side restatement of the reference's evaluation loop on the HIP path.
+
+``rescale_test`` follows ``SelfCModel.test()`` (codes/models/SelfC_model.py:185-250): the clip is cut into
+GOPs of 7 frames, each GOP goes through ``netG(x)`` -> ``Quantization`` of the three LR channels ->
+``netG(x=LR, rev=True)``; a trailing partial GOP is padded by repeating the last frame.  When the length is
+a multiple of 7 the reference still runs one extra pass on seven copies of the last frame and discards it
+(:203-209,236-243) - reproduced only on request (``reference_tail_pass``), the outputs are identical.
+``psnr_y`` is test_rescaling.py's metric (Y channel, per frame) with the reduction on the device.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Tuple
+
+import torch
+
+from . import _lib, runtime as rt
+from .modules.Quantization import Quantization
+
+GOP = 7   # SelfC_model.py:196,199 hard-code t = 7 and gop = 7
+
+
+def rescale_test(net, real_H: torch.Tensor, reference_tail_pass: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """real_H (b*7, 3, h, w) on the device -> (forw_L (b*7,3,h/4,w/4), fake_H (b*7,3,h,w))."""
+    real_H = rt.as_input(real_H)
+    bt, c, h, w = real_H.shape
+    t = GOP
+    if bt % t:
+        raise RuntimeError(f"{bt} frames are not a multiple of {t} (SelfCModel.test reshapes to (b,7,c,h,w))")
+    b = bt // t
+    clip = real_H.reshape(b, t, c, h, w)
+    quant = Quantization()
+    n_gop = t // GOP
+    forw_L: List[torch.Tensor] = []
+    fake_H: List[torch.Tensor] = []
+    with torch.no_grad():
+        for i in range(n_gop + 1):
+            if i == n_gop:
+                keep = t % GOP
+                if keep == 0 and not reference_tail_pass:
+                    continue
+                idx = [i * GOP + j for j in range(keep)] + [t - 1] * (GOP - keep)
+                inp = clip[:, idx]
+            else:
+                keep = GOP
+                inp = clip[:, i * GOP:(i + 1) * GOP]
+            _b, _t, _c, _h, _w = inp.shape
+            out, _ = net(x=inp.reshape(_b * _t, _c, _h, _w))
+            lr = quant(out[:, :3])
+            rec, _ = net(x=lr, rev=True)
+            lr5 = lr.reshape(b, _t, c, h // 4, w // 4)
+            rec5 = rec[:, :3].reshape(b, _t, c, h, w)
+            for j in range(keep):
+                forw_L.append(lr5[:, j])
+                fake_H.append(rec5[:, j])
+    fl = torch.stack(forw_L, dim=1)
+    fh = torch.stack(fake_H, dim=1)
+    return fl.reshape(b * t, c, h // 4, w // 4), fh.reshape(b * t, c, h, w)
+
+
+def psnr_y(img1: torch.Tensor, img2: torch.Tensor) -> List[float]:
+    """Per-frame Y-channel PSNR of two (N,3,H,W) RGB tensors in [0,1] (rgb_to_ycbcr + calculate_psnr of the
+    reference); squared-error reduction by selfc_y_sse, deterministic two-stage sum."""
+    a, b = rt.as_input(img1), rt.as_input(img2)
+    if a.shape != b.shape or a.shape[1] != 3:
+        raise RuntimeError(f"psnr_y expects two (N,3,H,W) tensors, got {tuple(a.shape)} and {tuple(b.shape)}")
+    n, _, h, w = a.shape
+    L = _lib.lib()
+    nblk = L.selfc_y_sse_blocks(h * w)
+    partial = torch.empty((n, nblk), dtype=torch.float64, device=a.device)
+    rt.call("selfc_y_sse", a.data_ptr(), b.data_ptr(), partial.data_ptr(), n, h * w, _lib.stream_ptr())
+    mse = (partial.sum(dim=1) / (h * w)).cpu().tolist()
+    return [float("inf") if m == 0 else 20.0 * math.log10(1.0 / math.sqrt(m)) for m in mse]

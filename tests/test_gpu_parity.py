@@ -287,6 +287,30 @@ def test_psnr_y_parity_on_synthetic_clip(dev):
     assert flips < 0.06, flips
 
 
+def test_harness_test_loop_and_device_psnr(dev):
+    """selfc_amd.harness: SelfCModel.test()'s GOP loop (with and without the reference's redundant tail pass)
+    and the device-side Y-PSNR against the oracle's restatement of the metric."""
+    from selfc_amd import harness
+    g = load_golden("g8_large_stack")
+    s = load_golden("g7_stp_l2_full_rev")
+    net = _large_net(dev, g, "l2", s)
+    x = torch.rand(2 * T, 3, 32, 48, generator=torch.Generator().manual_seed(21))
+    fl, fh = harness.rescale_test(net, x.to(dev))
+    fl2, fh2 = harness.rescale_test(net, x.to(dev), reference_tail_pass=True)
+    assert torch.equal(fl, fl2) and torch.equal(fh, fh2)           # the extra pass is discarded
+    z_ref = O.large_fwd(g, x, T)
+    lr_ref = O.quantize(z_ref[:, :3])
+    hf_ref = O.stp_v2_parameters(subdict(s, "stp_net"), lr_ref, T)
+    xr_ref = O.large_inv_from_latent(g, torch.cat((lr_ref, hf_ref), 1), T)
+    assert (fl.cpu() - lr_ref).abs().max() <= 1.0 / 255 + 1e-6
+    p_dev = harness.psnr_y(fh, x.to(dev))
+    p_ora = O.psnr_per_frame(O.rgb_to_y(fh.cpu()), O.rgb_to_y(x))
+    assert max(abs(a - b) for a, b in zip(p_dev, p_ora)) < 1e-4      # same images: the metric kernel itself
+    p_ref = O.psnr_per_frame(O.rgb_to_y(xr_ref), O.rgb_to_y(x))
+    assert max(abs(a - b) for a, b in zip(p_dev, p_ref)) < 0.05      # HIP path vs oracle path through the quantiser
+    assert harness.psnr_y(x.to(dev), x.to(dev))[0] == float("inf")
+
+
 def test_selfc_haar_variant(dev):
     """model "SelfC": Haar + InvBlockExp(DBNet) + STP v1 (D2DTNet conditioner, l2 head), fwd (incl. neg_llh) and rev."""
     from selfc_amd.modules.SelfC_arch_inv import SelfCInvNet
