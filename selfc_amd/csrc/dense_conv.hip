@@ -33,6 +33,7 @@ struct FGArgs {
   int tiles_x, tiles_y, ntiles;
   size_t plane;
   int ablate;
+  unsigned long long* stamps;
 };
 int launch_fused_gh(FGArgs& a, hipStream_t s);
 }  // namespace selfc

@@ -19,6 +19,7 @@
 // Weights: the packed fragment stream of the four convs (120 KiB per net) is read in chunks of
 // <= 21 fragments through an LDS double buffer; the stream wraps around from conv4 to the next
 // tile's conv1, so the prefetch never stalls at a tile boundary.  One barrier per chunk.
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 #include "common.hpp"
@@ -37,7 +38,8 @@ struct FGArgs {
   int N, H, W;
   int tiles_x, tiles_y, ntiles;
   size_t plane;
-  int ablate;               // developer timing aid (env SELFC_ABLATE_F): 1 no MFMA, 2 no epilogue, 4 no weight stream, 8 no operand reads
+  int ablate;               // unused (kept for ABI stability of the internal struct)
+  unsigned long long* stamps;   // diagnostic build only (-DSELFC_STAMPS): per wave 4 phase-cycle sums
 };
 
 namespace {
@@ -68,7 +70,18 @@ template <> struct FeatGeom<3> { static constexpr int off = OFF_F3, pitch = P3; 
 constexpr int LAYER_OFF[5] = {0, 0, 3, 24, 63};
 constexpr int STREAM_FRAGS = 120;
 
+#ifdef SELFC_STAMPS
+#define STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#define STAMP_ADD(k, a, b) c.phase[k] += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(k, a, b)
+#endif
+
 struct Ctx {
+#ifdef SELFC_STAMPS
+  unsigned long long phase[4];   // 0 setup/prefetch, 1 MFMA loop, 2 epilogue, 3 commit + barrier
+#endif
   unsigned char* smem;
   const u32x4* wsrc;
   int tid, lane, wave, half;
@@ -145,6 +158,7 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
 
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
+    STAMP(ts0);
     // ---- prefetch the chunk that follows (compile-time position in the stream)
     if (ch + 1 < NCH) {
       if (ch == 0) w_prefetch<LAYER_OFF[K] + 21, 18>(c);
@@ -192,6 +206,8 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
           B[m] = *reinterpret_cast<const f16x8*>(fb + pb[m] + (tap / 3) * pitch + (tap % 3) * PS + ks * 32);
       }
     };
+    STAMP(ts1);
+    STAMP_ADD(0, ts0, ts1);
     load_step(0, ringA[0], ringB[0]);
     if (NS > 1) load_step(1, ringA[1], ringB[1]);
 #pragma unroll
@@ -204,6 +220,8 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    STAMP(ts2);
+    STAMP_ADD(1, ts1, ts2);
     if (ch == NCH - 1) {
       // ---- epilogue: bias + LeakyReLU, zero outside the image, f16 -> LDS feature image (+ HBM crop)
       f16* __restrict__ dplane = a.dense[net] + (size_t)(K - 1) * a.plane;
@@ -246,6 +264,8 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
         }
       }
     }
+    STAMP(ts3);
+    STAMP_ADD(2, ts2, ts3);
     // ---- hand the weight buffers over: next chunk -> the other buffer, one barrier per chunk
     if (ch + 1 < NCH) w_commit<18>(c);
     else if (K == 4) w_commit<3>(c);
@@ -253,6 +273,8 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
     if (K == 4 && ch == NCH - 1) return;   // the tile loop stores the next X halo before its barrier
     __syncthreads();
     c.par ^= 1;
+    STAMP(ts4);
+    STAMP_ADD(3, ts3, ts4);
   }
 }
 
@@ -265,6 +287,10 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
   c.wave = c.tid >> 6;
   c.half = c.lane >> 5;
   c.par = 0;
+#ifdef SELFC_STAMPS
+  c.phase[0] = c.phase[1] = c.phase[2] = c.phase[3] = 0;
+  STAMP(tk0);
+#endif
   const int net = blockIdx.y;
   c.wsrc = reinterpret_cast<const u32x4*>(net ? a.w[1] : a.w[0]);
   const int total = a.ntiles * a.N;
@@ -325,11 +351,21 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
     conv_fused<2>(c, a, net, xbuf, n, ty * TS, tx * TS);
     conv_fused<3>(c, a, net, xbuf, n, ty * TS, tx * TS);
     conv_fused<4>(c, a, net, xbuf, n, ty * TS, tx * TS);
+    STAMP(tt0);
     if (more) x_store(xbuf ^ 1);
     __syncthreads();
     c.par ^= 1;
     xbuf ^= 1;
+    STAMP(tt1);
+    STAMP_ADD(3, tt0, tt1);
   }
+#ifdef SELFC_STAMPS
+  STAMP(tk1);
+  if (a.stamps && c.lane == 0) {
+    unsigned long long* o = a.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NWAVE + c.wave) * 5;
+    o[0] = c.phase[0]; o[1] = c.phase[1]; o[2] = c.phase[2]; o[3] = c.phase[3]; o[4] = tk1 - tk0;
+  }
+#endif
 }
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 1000; }
@@ -355,8 +391,22 @@ int launch_fused_gh(FGArgs& a, hipStream_t s) {
   // kernels of other streams
   const int rounds = (total + 127) / 128;
   const int gx = (total + rounds - 1) / rounds;
-  static const int ablate = getenv("SELFC_ABLATE_F") ? atoi(getenv("SELFC_ABLATE_F")) : 0;
-  a.ablate = ablate;
+#ifdef SELFC_STAMPS
+  static unsigned long long* dbg = nullptr;
+  if (!dbg) (void)hipMalloc(&dbg, 256 * NWAVE * 5 * sizeof(unsigned long long));
+  a.stamps = dbg;
+  if (getenv("SELFC_STAMP_DUMP")) {      // diagnostic: dump the previous launch's sums, then continue
+    static unsigned long long host[256 * NWAVE * 5];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
+    FILE* f = fopen(getenv("SELFC_STAMP_DUMP"), "w");
+    if (f) {
+      for (int i = 0; i < 256 * NWAVE; ++i)
+        fprintf(f, "%llu %llu %llu %llu %llu\n", host[5 * i], host[5 * i + 1], host[5 * i + 2], host[5 * i + 3], host[5 * i + 4]);
+      fclose(f);
+    }
+  }
+#endif
   ProfScope prof(PROF_FUSED_GH, s);
   hipLaunchKernelGGL(fused_gh_kernel, dim3((unsigned)gx, 2), dim3(NTHR), FG_LDS, s, a);
   return hip_rc(hipGetLastError());
