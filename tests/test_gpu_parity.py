@@ -392,6 +392,25 @@ def test_freq_k2_and_clip_len_3(dev):
         GlobalVar.set_Temporal_LEN(T)
 
 
+@pytest.mark.parametrize("h,w", [(16, 16), (20, 28), (4, 8), (68, 4)])
+def test_tiny_and_odd_latent_sizes(dev, h, w):
+    """latent sizes below / across the 16x16 conv tile, the 128-pixel temporal strip and the pooling bins
+    (HR = 4 x latent): forward, inverse and the STP reverse against the oracle."""
+    g = load_golden("g8_large_stack")
+    s = load_golden("g7_stp_l2_full_rev")
+    net = _large_net(dev, g, "l2", s)
+    x = torch.rand(T, 3, 4 * h, 4 * w, generator=torch.Generator().manual_seed(h * 31 + w))
+    z_ref = O.large_fwd(g, x, T)
+    with torch.no_grad():
+        z, _ = net(x=x.to(dev), rev=False)
+        assert rel_err(z.cpu(), z_ref) < TOL
+        lr = O.quantize(z_ref[:, :3])
+        xr, hf = net(x=lr.to(dev), rev=True)
+    hf_ref = O.stp_v2_parameters(subdict(s, "stp_net"), lr, T)
+    assert rel_err(hf.cpu(), hf_ref) < 2e-3
+    assert rel_err(xr.cpu(), O.large_inv_from_latent(g, torch.cat((lr, hf_ref), 1), T)) < 2e-3
+
+
 def test_rejects_bad_arguments(dev):
     from selfc_amd import _lib
     L = _lib.lib()
