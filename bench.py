@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--full-path", action="store_true", help="also time netG(x) + Quantization + netG(LR, rev=True) incl. the STP sampler")
+    ap.add_argument("--no-full-path", action="store_true", help="skip the extra netG(x) + Quantization + netG(LR, rev=True) timing (incl. STP sampler)")
     ap.add_argument("--streams", type=int, default=4, help="split the septuplets of a step over this many HIP streams")
     args = ap.parse_args()
 
@@ -196,7 +196,7 @@ def main():
         "stack_tflops": round(whole_flops * world * args.steps / dt / 1e12, 1),
         "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in cls_ms.items()},
     }
-    if args.full_path:
+    if not args.no_full_path and world == 1:
         # SelfCModel.test()'s two netG calls through the module API (eager, NCHW in/out, STP + GMM sampler on the reverse)
         from selfc_amd.modules.Quantization import Quantization
         quant = Quantization()

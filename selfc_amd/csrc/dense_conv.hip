@@ -42,6 +42,15 @@ namespace {
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 1000; }
 
+// Developer timing aid: with -DSELFC_DEV the env var SELFC_ABLATE switches parts of conv3x3_kernel off
+// (1 MFMA loop, 2 global loads, 4 LDS staging, 8 epilogue stores, 16 im2col fill, 32 weight loads, 64 activation
+// loads) - results are then wrong, only the timing is meaningful.  Compiled out of the production library.
+#ifdef SELFC_DEV
+#define ABL(a, bit) ((a).ablate & (bit))
+#else
+#define ABL(a, bit) false
+#endif
+
 enum { EPI_LRELU = 0, EPI_PLAIN = 1, EPI_F = 2, EPI_GH = 3 };
 
 struct C3Stage {
@@ -84,7 +93,7 @@ struct C3Args {
   float* plain;          // EPI_PLAIN: fp32 NHWC output, stride coutp
   int c2p, coutp, rev;
   float clamp;
-  int ablate;            // developer timing aid (env SELFC_ABLATE): 1 skip MFMA loop, 2 skip global loads, 4 skip LDS staging
+  int ablate;            // -DSELFC_DEV only (see ABL above)
 };
 
 // ---------------------------------------------------------------------------------
@@ -93,8 +102,9 @@ struct C3Args {
 // <=32 channels and the stage's weight fragments are staged in LDS (register
 // prefetch of stage s+1 is issued before the MFMAs of stage s).
 // ---------------------------------------------------------------------------------
+template <bool GEN>
 __device__ __forceinline__ C3Stage stage_of(const C3Args& a, const int s) {
-  if (a.gen_planes > 0) {
+  if (GEN) {
     const int ti = s / a.gen_planes;
     return C3Stage{32 * (s - ti * a.gen_planes), 32, 0, a.gen_tt == 3 ? ti - 1 : 0};
   }
@@ -103,7 +113,9 @@ __device__ __forceinline__ C3Stage stage_of(const C3Args& a, const int s) {
   return C3Stage{a.fbase + 32 * (s - a.n_in), 32, 0, 0};
 }
 
-template <int TH, int TW, int NW, int MT, int EPI>
+// GEN: generic plane-list mode (temporal taps, output groups) as a template parameter so that the hot
+// non-generic instantiations keep their register budget (as a runtime flag it cost 21 VGPRs = one wave/SIMD).
+template <int TH, int TW, int NW, int MT, int EPI, bool GEN>
 __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
   static_assert(TH * TW == NW * MT * 32, "tile must be covered by the waves' M-tiles");
   static_assert(TW % 16 == 0 && TH % 2 == 0, "M-tiles are 2 rows x 16 cols");
@@ -150,13 +162,13 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][m][r] = 0.f;
 
-  // conv1-4 epilogue biases: fetched now so their latency hides behind the whole K loop
-  const int zg = a.gen_planes > 0 ? (int)blockIdx.z : 0;     // generic mode: 32-channel output group
-  float4 ebias[4];
-  if (EPI == EPI_LRELU) {
-    const float* __restrict__ bias = a.gen_planes > 0 ? a.bias[0] + 32 * zg : (blockIdx.z ? a.bias[1] : a.bias[0]);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) ebias[g] = *reinterpret_cast<const float4*>(bias + 8 * g + 4 * (lane >> 5));
+  // conv1-4 epilogue biases: copied to LDS now (no global latency in the epilogue, no long-lived registers -
+  // holding them in VGPRs cost the kernel its third wave per SIMD)
+  const int zg = GEN ? (int)blockIdx.z : 0;     // generic mode: 32-channel output group
+  float* const lbias = reinterpret_cast<float*>(smem + ACT_BYTES + 18 * 1024);
+  if (EPI == EPI_LRELU && tid < 32) {
+    const float* __restrict__ bias = GEN ? a.bias[0] + 32 * zg : (blockIdx.z ? a.bias[1] : a.bias[0]);
+    lbias[tid] = bias[tid];
   }
   unsigned gofs[AITER];   // halfs, inside one plane
   int lofs[AITER];        // bytes, inside the LDS halo image
@@ -176,7 +188,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
 
 #pragma unroll
   for (int net_i = 0; net_i < NNETS; ++net_i) {
-    const bool gen = a.gen_planes > 0;
+    constexpr bool gen = GEN;
     const int net = (EPI == EPI_GH) ? net_i : (gen ? 0 : (int)blockIdx.z);
     // ternaries, not a.dense[net]: a dynamically indexed by-value array goes to scratch
     const f16* __restrict__ dense = net ? a.dense[1] : a.dense[0];
@@ -194,14 +206,14 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
     // are computed once (the per-stage address math was as expensive to issue as the stage's MFMAs).
     // A 16-wide stage simply stages the (zero) pad half of its plane as well.
     auto load_stage = [&](const C3Stage st, const int fb) __attribute__((always_inline)) {
-      if (a.ablate & 2) return;
+      if (ABL(a, 2)) return;
       const bool tv = (tclip + st.dt >= 0) & (tclip + st.dt < (gen ? a.T : 1 << 30));
       const f16* __restrict__ src = dense + (size_t)(st.coff >> 5) * a.plane + (tv ? st.dt * frame_stride : 0);
-      if (!(a.ablate & 64))
+      if (!ABL(a, 64))
 #pragma unroll
       for (int it = 0; it < AITER; ++it) areg[it] = *reinterpret_cast<const u32x4*>(src + gofs[it]);
       const int nfr = 9 * (st.width >> 4);
-      if (!(a.ablate & 32))
+      if (!ABL(a, 32))
 #pragma unroll
       for (int it = 0; it < WITER; ++it) {
         const int i = min(tid + it * NT, nfr * 64 - 1);  // unconditional (clamped): keeps wreg in registers
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
       }
     };
     auto store_stage = [&](const C3Stage st) __attribute__((always_inline)) {
-      if (a.ablate & 4) return;
+      if (ABL(a, 4)) return;
       const bool tv = (tclip + st.dt >= 0) & (tclip + st.dt < (gen ? a.T : 1 << 30));
       const unsigned okm = tv ? okmask : 0u;               // a temporal tap outside the clip is zero padding too
 #pragma unroll
@@ -231,7 +243,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
     // x1 goes to LDS as 4 x f16 per pixel (parked in the weight area, which is filled last),
     // (2) rows are assembled LDS -> LDS.
     auto fill_im2col = [&]() __attribute__((always_inline)) {
-      if (a.ablate & 16) return;
+      if (ABL(a, 16)) return;
       const int c1 = a.c1;
       constexpr int XITER = (NPIX + NT - 1) / NT;
       unsigned char* const lx = lw + 4096;          // 8 B per halo pixel, after the 2 im2col weight fragments
@@ -301,20 +313,20 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
     if (a.has_im2col) {
       fill_im2col();
     } else {
-      const C3Stage st0 = stage_of(a, 0);
+      const C3Stage st0 = stage_of<GEN>(a, 0);
       load_stage(st0, 0);
       store_stage(st0);
     }
     __syncthreads();
 
     for (int s = 0; s < a.nstages; ++s) {
-      const C3Stage st = stage_of(a, s);
-      const C3Stage stn = stage_of(a, s + 1);
+      const C3Stage st = stage_of<GEN>(a, s);
+      const C3Stage stn = stage_of<GEN>(a, s + 1);
       const int nfr = st.kind == 1 ? 2 : 9 * (st.width >> 4);
       const bool more = s + 1 < a.nstages;
       if (more) load_stage(stn, fragbase + nfr);
 
-      if (a.ablate & 1) {
+      if (ABL(a, 1)) {
       } else if (st.kind == 1) {
         constexpr int CTR = ROWB + PS;  // centre tap
 #pragma unroll
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
   // -- epilogue -------------------------------------------------------------------
   // acc[..][m][r]: pixel = lane&31 of M-tile m, outch = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int half = lane >> 5;
-  if (a.ablate & 8) {   // keep the accumulators alive without the stores
+  if (ABL(a, 8)) {   // keep the accumulators alive without the stores
     float keep = 0.f;
 #pragma unroll
     for (int m = 0; m < MT; ++m) keep += acc[0][m][0] + acc[NNETS - 1][m][5];
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
       uint32_t r[4][2];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 b = ebias[g];
+        const float4 b = *reinterpret_cast<const float4*>(lbias + 8 * g + 4 * half);
         r[g][0] = pack2(lrelu02(acc[0][m][4 * g + 0] + b.x), lrelu02(acc[0][m][4 * g + 1] + b.y));
         r[g][1] = pack2(lrelu02(acc[0][m][4 * g + 2] + b.z), lrelu02(acc[0][m][4 * g + 3] + b.w));
       }
@@ -679,17 +691,19 @@ __global__ void nhwc_to_dense_kernel(const float* __restrict__ x, f16* __restric
 // host-side launch helpers
 // ---------------------------------------------------------------------------------
 constexpr int C3_TH = 16, C3_TW = 16, C3_NW = 4, C3_MT = 2;
-constexpr int C3_LDS = (C3_TH + 2) * ((((C3_TW + 2) * PS + 255) / 256) * 256) + 18 * 1024;
+constexpr int C3_LDS = (C3_TH + 2) * ((((C3_TW + 2) * PS + 255) / 256) * 256) + 18 * 1024 + 128;   // halo image + weight stage + 32 biases
 
-template <int EPI>
+template <int EPI, bool GEN = false>
 int launch_conv3x3(C3Args& a, int nets_z, hipStream_t s) {
   a.tiles_x = (a.W + C3_TW - 1) / C3_TW;
   a.tiles_y = (a.H + C3_TH - 1) / C3_TH;
+#ifdef SELFC_DEV
   static const int ablate = getenv("SELFC_ABLATE") ? atoi(getenv("SELFC_ABLATE")) : 0;
   a.ablate = ablate;
+#endif
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), 1, (unsigned)nets_z);
   ProfScope prof(EPI == EPI_LRELU ? PROF_CONV3X3 : EPI == EPI_F ? PROF_CONV5_F : EPI == EPI_GH ? PROF_CONV5_GH : PROF_CONV5_PLAIN, s);
-  hipLaunchKernelGGL((conv3x3_kernel<C3_TH, C3_TW, C3_NW, C3_MT, EPI>), grid, dim3(C3_NW * 64), C3_LDS, s, a);
+  hipLaunchKernelGGL((conv3x3_kernel<C3_TH, C3_TW, C3_NW, C3_MT, EPI, GEN>), grid, dim3(C3_NW * 64), C3_LDS, s, a);
   return hip_rc(hipGetLastError());
 }
 
@@ -929,10 +943,10 @@ int selfc_conv_planes_run(void* dense, int nplanes_in, int kt, const void* w, co
   const int zg = cout / 32;
   if (out_plane >= 0) {
     a.out_coff = out_plane * 32;
-    return launch_conv3x3<EPI_LRELU>(a, zg, s);
+    return launch_conv3x3<EPI_LRELU, true>(a, zg, s);
   }
   a.plain = plain; a.coutp = cout;
-  return launch_conv3x3<EPI_PLAIN>(a, zg, s);
+  return launch_conv3x3<EPI_PLAIN, true>(a, zg, s);
 }
 
 }  // extern "C"
