@@ -186,7 +186,7 @@ def main():
     out = {
         "metric": "septuplets/sec (7x3x256x448) fwd+inv InvBlock stack", "value": round(value, 2), "unit": "septuplets/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": _lib.OPERAND, "data": "synthetic",
         "config": {"workload": "SelfC-large FrequencyAnalyzer + 8 InvBlockExp(D2DTNet) fwd, Quantization, 8 InvBlockExp rev, "
                                "FrequencyAnalyzer rev; 4 septuplets 7x3x256x448 per GPU, inputs resident in HBM, seeded default-init weights",
                    "septuplets_per_gpu": B_PER_GPU, "launch": "hipGraph replay" if use_graph else "eager", "streams": args.streams,

@@ -8,8 +8,19 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+#: MFMA operand type of the loaded library: "f16" (default, parity-grade) or "bf16" (SELFC_OPERAND=bf16 selects
+#: libselfc_hip_bf16.so, the same kernels built with bfloat16 operands; per process, fixed at import)
+OPERAND = os.environ.get("SELFC_OPERAND", "f16").lower()
+if OPERAND not in ("f16", "bf16"):
+    raise RuntimeError(f"SELFC_OPERAND must be 'f16' or 'bf16', got {OPERAND!r}")
 # SELFC_LIB: developer override to A/B two builds of the library inside one process launch script
-LIB_PATH = os.environ.get("SELFC_LIB") or os.path.join(_HERE, "libselfc_hip.so")
+LIB_PATH = os.environ.get("SELFC_LIB") or os.path.join(_HERE, "libselfc_hip.so" if OPERAND == "f16" else "libselfc_hip_bf16.so")
+
+
+def operand_dtype():
+    """torch dtype of packed weights and dense feature buffers (matches the loaded library)."""
+    import torch
+    return torch.float16 if OPERAND == "f16" else torch.bfloat16
 
 SUBNET_D2DT = 0
 SUBNET_DB2D = 1
@@ -95,6 +106,8 @@ def lib():
         L.selfc_y_sse_blocks.restype = i
         L.selfc_globalagg_partial_floats.restype = sz
         L.selfc_globalagg_partial_floats.argtypes = [i, i]
+        if ("operands=" + OPERAND).encode() not in L.selfc_version():
+            raise RuntimeError(f"{LIB_PATH} was not built for {OPERAND} operands: {L.selfc_version()!r}")
         _lib = L
     return _lib
 

@@ -5,7 +5,16 @@
 
 namespace selfc {
 
+// MFMA operand type.  `f16` is the name used throughout for "the 16-bit operand type": IEEE half by default
+// (the parity-grade build); -DSELFC_OPERAND_BF16 builds the same kernels with bfloat16
+// operands (libselfc_hip_bf16.so) - same MFMA rate, ~7x the rounding error.
+#ifdef SELFC_OPERAND_BF16
+typedef __bf16 f16;
+#define SELFC_OPERAND_NAME "bf16"
+#else
 typedef _Float16 f16;
+#define SELFC_OPERAND_NAME "f16"
+#endif
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));
@@ -32,6 +41,21 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + (bid >> 3);
+}
+
+__device__ __forceinline__ f32x16 mfma_32x32x16(const f16x8 a, const f16x8 b, const f32x16 c) {
+#ifdef SELFC_OPERAND_BF16
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ f32x4 mfma_16x16x32(const f16x8 a, const f16x8 b, const f32x4 c) {
+#ifdef SELFC_OPERAND_BF16
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
 }
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) {

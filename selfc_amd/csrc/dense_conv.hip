@@ -335,7 +335,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
             const f16x8 bf = *reinterpret_cast<const f16x8*>(lact + pbase[m] + CTR + ks * 32);
-            acc[net_i][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[net_i][m], 0, 0, 0);
+            acc[net_i][m] = mfma_32x32x16(af, bf, acc[net_i][m]);
           }
         }
       } else if (st.width == 32) {
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
               const f16x8 bf = *reinterpret_cast<const f16x8*>(lact + pbase[m] + (tap / 3) * ROWB + (tap % 3) * PS + ks * 32);
-              acc[net_i][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[net_i][m], 0, 0, 0);
+              acc[net_i][m] = mfma_32x32x16(af, bf, acc[net_i][m]);
             }
           }
         }
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
             const f16x8 bf = *reinterpret_cast<const f16x8*>(lact + pbase[m] + (tap / 3) * ROWB + (tap % 3) * PS);
-            acc[net_i][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[net_i][m], 0, 0, 0);
+            acc[net_i][m] = mfma_32x32x16(af, bf, acc[net_i][m]);
           }
         }
       }
@@ -640,9 +640,9 @@ __global__ __launch_bounds__(512) void tconv5_kernel(const T5Args a) {
           const f16x8 a0 = *reinterpret_cast<const f16x8*>(wb);
           const f16x8 a1 = *reinterpret_cast<const f16x8*>(wb + TAPSTRIDE);
           const f16x8 a2 = *reinterpret_cast<const f16x8*>(wb + 2 * TAPSTRIDE);
-          accn[q][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bf, accn[q][o], 0, 0, 0);  // -> out[t+1]
-          accc[q][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf, accc[q][o], 0, 0, 0);  // -> out[t]
-          accp[q][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bf, accp[q][o], 0, 0, 0);  // -> out[t-1]
+          accn[q][o] = mfma_16x16x32(a0, bf, accn[q][o]);  // -> out[t+1]
+          accc[q][o] = mfma_16x16x32(a1, bf, accc[q][o]);  // -> out[t]
+          accp[q][o] = mfma_16x16x32(a2, bf, accp[q][o]);  // -> out[t-1]
         }
         // keep the scheduler from hoisting every k-step's weight reads (it spills at 90 fragments)
         __builtin_amdgcn_sched_barrier(0);
@@ -852,7 +852,7 @@ int run_GH(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStrea
 
 extern "C" {
 
-const char* selfc_version(void) { return "selfc_hip gfx950 abi2"; }
+const char* selfc_version(void) { return "selfc_hip gfx950 abi2 operands=" SELFC_OPERAND_NAME; }
 int selfc_abi_version(void) { return 2; }
 
 int selfc_invblock_run(const selfc_invblock_w* blk, const selfc_latent* lat, int rev, void* stream) {

@@ -216,7 +216,7 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ringA[st % 3], ringB[st % 3][m], acc[m], 0, 0, 0);
+        acc[m] = mfma_32x32x16(ringA[st % 3], ringB[st % 3][m], acc[m]);
       __builtin_amdgcn_sched_barrier(0);
     }
 

@@ -153,8 +153,8 @@ __global__ __launch_bounds__(256) void gagg_mix_kernel(const float* __restrict__
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[o][0], bf[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[o][1], bf[1], acc, 0, 0, 0);
+      acc = mfma_16x16x32(wf[o][0], bf[0], acc);
+      acc = mfma_16x16x32(wf[o][1], bf[1], acc);
       const int oc = o * 16 + kq * 4;
       const float4 xr = *reinterpret_cast<const float4*>(x + pix * 64 + oc);
       const float4 bb = *reinterpret_cast<const float4*>(b1 + oc);
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const void* __restrict__ in
       for (int ks = 0; ks < KS; ++ks) {
         const f16x8 af = *reinterpret_cast<const f16x8*>(smem + ((size_t)(o * KS + ks) * 64 + lane) * 16);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[m][ks], acc[m], 0, 0, 0);
+        for (int m = 0; m < MT; ++m) acc[m] = mfma_16x16x32(af, bf[m][ks], acc[m]);
       }
       const int oc = (ob + o) * 16 + kq * 4;
       const float4 bb = *reinterpret_cast<const float4*>(bias + oc);

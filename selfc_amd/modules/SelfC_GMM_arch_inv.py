@@ -192,8 +192,8 @@ class STPNet(nn.Module):
             sc.clear()
             sc["key"] = shape_key
             sc["feat"] = [torch.empty((n, h * w, 64), dtype=torch.float32, device=dev) for _ in range(2)]
-            sc["dense4"] = torch.zeros((4, n, h, w, 32), dtype=torch.float16, device=dev)
-            sc["dense6"] = torch.zeros((6, n, h, w, 32), dtype=torch.float16, device=dev)
+            sc["dense4"] = torch.zeros((4, n, h, w, 32), dtype=_lib.operand_dtype(), device=dev)
+            sc["dense6"] = torch.zeros((6, n, h, w, 32), dtype=_lib.operand_dtype(), device=dev)
         cur, nxt = None, 0
         for m in self._chain():
             dst = sc["feat"][nxt]
@@ -215,8 +215,8 @@ class STPNet(nn.Module):
                     npix, cin, cout, cout, 1, 0, sp)
             return hf_out if keep_raw else None
         if "h1" not in sc:
-            sc["h1"] = torch.empty((npix, tail[0][3]), dtype=torch.float16, device=dev)
-            sc["h2"] = torch.empty((npix, tail[1][3]), dtype=torch.float16, device=dev)
+            sc["h1"] = torch.empty((npix, tail[0][3]), dtype=_lib.operand_dtype(), device=dev)
+            sc["h2"] = torch.empty((npix, tail[1][3]), dtype=_lib.operand_dtype(), device=dev)
             sc["raw"] = torch.empty((npix, tail[2][3]), dtype=torch.float32, device=dev)
         (w0, b0, ci0, co0), (w1_, b1_, ci1, co1), (w2_, b2_, ci2, co2) = tail
         # tail_gmm = [lrelu, conv, lrelu, conv, lrelu, conv]: each LeakyReLU is fused into the producer's epilogue

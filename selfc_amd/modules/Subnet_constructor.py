@@ -47,7 +47,7 @@ class _DenseSubnet(nn.Module):
         cinp, coutp = roundup(cin, 4), roundup(self.channel_out, 4)
         xin = torch.empty((n, h, w, cinp), dtype=torch.float32, device=dev)
         rt.call("selfc_nchw_to_nhwc4", x.data_ptr(), xin.data_ptr(), n, cin, h, w, sp)
-        dense = torch.zeros((dense_channels(cin) // 32, n, h, w, 32), dtype=torch.float16, device=dev)
+        dense = torch.zeros((dense_channels(cin) // 32, n, h, w, 32), dtype=_lib.operand_dtype(), device=dev)
         yout = torch.empty((n, h, w, coutp), dtype=torch.float32, device=dev)
         sw = pk.struct()
         rt.call("selfc_subnet_run", sw, self.kind, xin.data_ptr(), yout.data_ptr(), dense.data_ptr(),
@@ -188,7 +188,7 @@ class FeatureCalapseBlock(nn.Module):
         gp = self.gc // 32
         nhwc = torch.empty((n, h, w, roundup(c, 4)), dtype=torch.float32, device=dev)
         rt.call("selfc_nchw_to_nhwc4", xs.data_ptr(), nhwc.data_ptr(), n, c, h, w, sp)
-        dense = torch.zeros((pin + 4 * gp, n, h, w, 32), dtype=torch.float16, device=dev)
+        dense = torch.zeros((pin + 4 * gp, n, h, w, 32), dtype=_lib.operand_dtype(), device=dev)
         rt.call("selfc_nhwc_to_planes", nhwc.data_ptr(), dense.data_ptr(), n * h * w, c, sp)
         for i in range(4):          # conv1 (3,3,3), conv2-4 (1,3,3); LeakyReLU fused, features appended as planes
             wp, bp = pk[i]

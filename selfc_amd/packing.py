@@ -23,7 +23,9 @@ from typing import List, Sequence
 
 import torch
 
-F16 = torch.float16
+from ._lib import operand_dtype
+
+F16 = operand_dtype()     # MFMA operand dtype of the loaded library (float16, or bfloat16 under SELFC_OPERAND=bf16)
 
 
 def roundup(v: int, m: int) -> int:

@@ -37,7 +37,7 @@ class Workspace:
         self.kind, self.N, self.T, self.H, self.W, self.c1, self.c2 = kind, N, T, H, W, c1, c2
         self.c2p = roundup(c2, 4)
         self.FC = dense_channels(c2)
-        f32, f16 = torch.float32, torch.float16
+        f32, f16 = torch.float32, _lib.operand_dtype()
         self.x1 = torch.zeros((N, H, W, 4), dtype=f32, device=device)
         self.x2 = torch.zeros((N, H, W, self.c2p), dtype=f32, device=device)
         # dense buffers are plane-blocked: [C/32][N][H][W][32] (every 32-channel group contiguous per pixel)

@@ -18,7 +18,12 @@ def test_exports_match_header():
     for name in declared:
         assert hasattr(L, name), name
     assert _lib.lib().selfc_abi_version() == 2
-    assert b"gfx950" in _lib.lib().selfc_version()
+    assert b"gfx950" in _lib.lib().selfc_version() and b"operands=f16" in _lib.lib().selfc_version()
+    bf = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libselfc_hip_bf16.so"))     # the bf16-operand build
+    bf.selfc_version.restype = ctypes.c_char_p
+    assert b"operands=bf16" in bf.selfc_version()
+    for name in declared:
+        assert hasattr(bf, name), name
 
 
 def test_struct_layout_matches_header():

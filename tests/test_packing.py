@@ -76,7 +76,7 @@ def test_pack_conv3x3(cin, layer, cout, conv3d):
     feats = [torch.randn(2, 32, 6, 7, generator=g) for _ in range(layer - 1)]
     ref = F.conv2d(torch.cat([x] + feats, 1), w.half().float(), None, 1, 1)          # f16-rounded weights
     frag = P.pack_conv3x3(w.unsqueeze(2) if conv3d else w, cin, layer)
-    assert frag.dtype == torch.float16 and frag.shape[1:] == (64, 8)
+    assert frag.dtype == P.F16 and frag.shape[1:] == (64, 8)
     wk = unpack_a32(frag)
     x1 = None
     if cin <= 3:
@@ -149,7 +149,7 @@ def test_pack_pointwise_lane_map():
     g = torch.Generator().manual_seed(3)
     w = torch.randn(720, 256, 1, 1, 1, generator=g)
     fr = P.pack_pointwise(w)
-    assert fr.shape == (45, 8, 64, 8) and fr.dtype == torch.float16
+    assert fr.shape == (45, 8, 64, 8) and fr.dtype == P.F16
     # W[16 o + (lane&15)][32 ks + 8 (lane>>4) + j]
     wk = fr.float().reshape(45, 8, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(720, 256)
     assert torch.equal(wk, w.reshape(720, 256).half().float())
