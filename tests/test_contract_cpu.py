@@ -1,0 +1,68 @@
+"""Drop-in contract on CPU (no GPU needed): every mirrored net has exactly the reference's state_dict keys, tensor
+shapes, parameter count and frozen parameters (tests/golden/state_dict_contract.json, written by
+tools/make_golden.py from the reference modules), the init semantics the traps rely on hold, and the product
+path refuses to run on CPU tensors instead of falling back."""
+import json
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN
+from selfc_amd import GlobalVar
+from selfc_amd.modules import Inv_arch, SelfC_GMM_arch_inv, SelfC_arch_inv, Subnet_constructor as SC
+
+CONTRACT = json.load(open(os.path.join(GOLDEN, "state_dict_contract.json")))
+LARGE = {"global_module": "nonlocal", "stp_blk_num": 6, "scale": 4, "gmm_k": 5}
+HAAR = {"stp_d2d_inner_c": 32, "stp_temporal_c": 32, "fh_loss": "l2", "gmm_mixture_num": 5, "stp_blk_num": 2}
+
+
+def build(name):
+    if name == "selfc_large_gmm":
+        return SelfC_GMM_arch_inv.SelfCInvNet(dict(LARGE, fh_loss="gmm"), 3, 3, "D2DTNet", [4, 4], 2)
+    if name == "selfc_large_l2":
+        return SelfC_GMM_arch_inv.SelfCInvNet(dict(LARGE, fh_loss="l2"), 3, 3, "D2DTNet", [4, 4], 2)
+    if name == "irn_dbnet":
+        return Inv_arch.InvRescaleNet(3, 3, SC.subnet("DBNet", "xavier"), [2, 1], 2)
+    if name == "selfc_haar_d2dt":
+        return SelfC_arch_inv.SelfCInvNet(dict(HAAR, condition_func="D2DTNet"), 3, 3, "DBNet", [1], 1)
+    return SelfC_arch_inv.SelfCInvNet(dict(HAAR, condition_func="FeatureCalapseBlock"), 3, 3, "DBNet", [1], 1)
+
+
+@pytest.mark.parametrize("name", [k for k in CONTRACT if k != "init_facts"])
+def test_state_dict_matches_reference(name):
+    ref = CONTRACT[name]
+    net = build(name)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(ref["shapes"].keys()) or sorted(sd.keys()) == sorted(ref["shapes"].keys())
+    for k, shape in ref["shapes"].items():
+        assert list(sd[k].shape) == shape, k
+    assert sum(p.numel() for p in net.parameters()) == ref["n_params"]
+    assert sorted(k for k, p in net.named_parameters() if not p.requires_grad) == ref["frozen"]
+    # a reference checkpoint (optionally with DDP's "module." prefix stripped by base_model.load_network) loads strict
+    net.load_state_dict({k: torch.zeros(s) for k, s in ref["shapes"].items()}, strict=True)
+
+
+def test_init_semantics_trap4():
+    facts = CONTRACT["init_facts"]
+    torch.manual_seed(0)
+    db = SC.DenseBlock(9, 3, "xavier")
+    assert db.conv5.weight.abs().sum().item() == facts["denseblock_conv5_abs_sum"] == 0.0      # identity coupling at init
+    assert sum(getattr(db, f"conv{i}").bias.abs().sum().item() for i in range(1, 6)) == facts["denseblock_bias_abs_sum"] == 0.0
+    ratio = (db.conv1.weight.std() / (2.0 / (9 * 9 + 32 * 9)) ** 0.5).item()
+    assert abs(ratio - 0.1) < 0.02 and abs(facts["denseblock_conv1_std_over_xavier"] - 0.1) < 0.02   # xavier_normal * 0.1
+    d2 = SC.D2DTInput(48, 3, "xavier")
+    assert facts["d2dt_conv5_is_nonzero"] and d2.conv5.weight.abs().sum() > 0    # Conv3d is skipped by the init helpers
+    assert SC.subnet("NoSuchNet")(3, 3) is None                                   # unknown name -> None, as the reference
+
+
+def test_no_cpu_fallback_anywhere():
+    GlobalVar.set_Temporal_LEN(7)
+    x = torch.zeros(7, 3, 16, 16)
+    for name in ("selfc_large_l2", "irn_dbnet", "selfc_haar_d2dt"):
+        with pytest.raises(RuntimeError, match="no CPU fallback|MI355X"):
+            build(name)(x)
+    with pytest.raises(RuntimeError):
+        SelfC_GMM_arch_inv.FrequencyAnalyzer(3)(x)
+    with pytest.raises(RuntimeError):
+        Inv_arch.HaarDownsampling(3)(x)

@@ -241,5 +241,41 @@ def main():
              eps=eps[0].permute(2, 0, 1, 3, 4).numpy(), v=v[0].transpose(0, 1).numpy(), **sd_np(stp))
 
 
+def dump_state_dict_contract():
+    """Checkpoint contract: state_dict keys and shapes of every reference net the drop-in modules
+    mirror, plus the init facts the traps depend on (trap 4)."""
+    import json
+    import models.modules.SelfC_arch_inv as SA
+    GlobalVar.set_Temporal_LEN(T)
+    torch.manual_seed(0)
+    nets = {
+        "selfc_large_gmm": GA.SelfCInvNet({"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": "gmm", "scale": 4, "gmm_k": 5},
+                                          3, 3, "D2DTNet", [4, 4], 2),
+        "selfc_large_l2": GA.SelfCInvNet({"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": "l2", "scale": 4, "gmm_k": 5},
+                                         3, 3, "D2DTNet", [4, 4], 2),
+        "irn_dbnet": IA.InvRescaleNet(3, 3, SC.subnet("DBNet", "xavier"), [2, 1], 2),
+        "selfc_haar_d2dt": SA.SelfCInvNet({"stp_d2d_inner_c": 32, "stp_temporal_c": 32, "fh_loss": "l2", "gmm_mixture_num": 5,
+                                           "stp_blk_num": 2, "condition_func": "D2DTNet"}, 3, 3, "DBNet", [1], 1),
+        "selfc_haar_fcb": SA.SelfCInvNet({"stp_d2d_inner_c": 32, "stp_temporal_c": 32, "fh_loss": "l2", "gmm_mixture_num": 5,
+                                          "stp_blk_num": 2, "condition_func": "FeatureCalapseBlock"}, 3, 3, "DBNet", [1], 1),
+    }
+    out = {}
+    for name, net in nets.items():
+        sd = net.state_dict()
+        out[name] = {"shapes": {k: list(v.shape) for k, v in sd.items()},
+                     "n_params": int(sum(p.numel() for p in net.parameters())),
+                     "frozen": sorted(k for k, p in net.named_parameters() if not p.requires_grad)}
+    db = SC.DenseBlock(9, 3, "xavier")
+    d2 = SC.D2DTInput(48, 3, "xavier")
+    out["init_facts"] = {"denseblock_conv5_abs_sum": float(db.conv5.weight.abs().sum()),
+                         "denseblock_bias_abs_sum": float(sum(getattr(db, f"conv{i}").bias.abs().sum() for i in range(1, 6))),
+                         "d2dt_conv5_is_nonzero": bool(d2.conv5.weight.abs().sum() > 0),
+                         "denseblock_conv1_std_over_xavier": float(db.conv1.weight.std() / (2.0 / (9 * 9 + 32 * 9)) ** 0.5)}
+    with open(os.path.join(OUT, "state_dict_contract.json"), "w") as fh:
+        json.dump(out, fh, indent=0, sort_keys=True)
+    print("state_dict_contract.json:", {k: v.get("n_params") for k, v in out.items() if k != "init_facts"})
+
+
 if __name__ == "__main__":
     main()
+    dump_state_dict_contract()
