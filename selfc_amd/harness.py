@@ -71,3 +71,48 @@ def psnr_y(img1: torch.Tensor, img2: torch.Tensor) -> List[float]:
     rt.call("selfc_y_sse", a.data_ptr(), b.data_ptr(), partial.data_ptr(), n, h * w, _lib.stream_ptr())
     mse = (partial.sum(dim=1) / (h * w)).cpu().tolist()
     return [float("inf") if m == 0 else 20.0 * math.log10(1.0 / math.sqrt(m)) for m in mse]
+
+
+def gop_slices(n_frames: int, gop: int = GOP) -> List[List[int]]:
+    """Frame indices of consecutive GOPs; the last GOP is padded by repeating the final frame (the padding
+    rule of SelfCModel.test, SelfC_model.py:203-209).  100 frames -> 15 GOPs, the last one [98, 99, 99, 99, 99, 99, 99]."""
+    out = []
+    for s in range(0, n_frames, gop):
+        idx = list(range(s, min(s + gop, n_frames)))
+        out.append(idx + [n_frames - 1] * (gop - len(idx)))
+    return out
+
+
+def shard_gops(n_gops: int, rank: int, world: int) -> List[int]:
+    """GOPs are independent units: round-robin over ranks, no exchange step."""
+    return list(range(rank, n_gops, world))
+
+
+def rescale_video(net, frames: torch.Tensor, rank: int = 0, world: int = 1, gops_per_call: int = 4):
+    """frames (F,3,H,W) on the device, any F (e.g. a 100-frame UVG group at 1080p) -> dict with, for this rank's
+    GOPs, the frame indices, the quantised LR frames and the reconstructions (padding frames dropped)."""
+    frames = rt.as_input(frames)
+    n = frames.shape[0]
+    slices = gop_slices(n)
+    mine = shard_gops(len(slices), rank, world)
+    quant = Quantization()
+    idx_out, lr_out, rec_out = [], [], []
+    with torch.no_grad():
+        for s in range(0, len(mine), gops_per_call):
+            batch = [slices[g] for g in mine[s:s + gops_per_call]]
+            flat = [i for g in batch for i in g]
+            x = frames[flat]
+            out, _ = net(x=x)
+            lr = quant(out[:, :3])
+            rec, _ = net(x=lr, rev=True)
+            pos = 0
+            for g in batch:
+                seen = set()
+                for j, fi in enumerate(g):
+                    if fi not in seen:                 # drop the repeated padding frames
+                        seen.add(fi)
+                        idx_out.append(fi)
+                        lr_out.append(lr[pos + j])
+                        rec_out.append(rec[pos + j, :3])
+                pos += len(g)
+    return {"frames": idx_out, "lr": torch.stack(lr_out) if lr_out else None, "rec": torch.stack(rec_out) if rec_out else None}

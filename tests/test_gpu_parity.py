@@ -311,6 +311,25 @@ def test_harness_test_loop_and_device_psnr(dev):
     assert harness.psnr_y(x.to(dev), x.to(dev))[0] == float("inf")
 
 
+def test_rescale_video_ragged_length_and_sharding(dev):
+    """A 17-frame clip (3 GOPs, the last padded) processed whole and as two rank shards gives the same frames."""
+    from selfc_amd import harness
+    g = load_golden("g8_large_stack")
+    s = load_golden("g7_stp_l2_full_rev")
+    net = _large_net(dev, g, "l2", s)
+    v = torch.rand(17, 3, 32, 32, generator=torch.Generator().manual_seed(31)).to(dev)
+    whole = harness.rescale_video(net, v)
+    assert whole["frames"] == list(range(17)) and whole["rec"].shape == (17, 3, 32, 32)
+    parts = [harness.rescale_video(net, v, rank=r, world=2) for r in range(2)]
+    assert sorted(parts[0]["frames"] + parts[1]["frames"]) == list(range(17))
+    for p in parts:
+        for j, fi in enumerate(p["frames"]):
+            assert torch.equal(p["rec"][j], whole["rec"][fi]) and torch.equal(p["lr"][j], whole["lr"][fi])
+    # first GOP equals the plain 7-frame test loop
+    fl, fh = harness.rescale_test(net, v[:7])
+    assert torch.equal(fh, whole["rec"][:7])
+
+
 def test_selfc_haar_variant(dev):
     """model "SelfC": Haar + InvBlockExp(DBNet) + STP v1 (D2DTNet conditioner, l2 head), fwd (incl. neg_llh) and rev."""
     from selfc_amd.modules.SelfC_arch_inv import SelfCInvNet
