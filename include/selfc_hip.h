@@ -83,6 +83,11 @@ int selfc_quantize_inplace(float* x, size_t n, void* stream);
 int selfc_y_sse_blocks(int HW);
 int selfc_y_sse(const float* a, const float* b, double* partial, int N, int HW, void* stream);
 
+/* Guassian_downsample(x, scale=4) of feed_data's "sr_bd" LR target (models/Guassian.py:7-52, SelfC_model.py:128):
+ * per plane, 13x13 Gaussian g169 (sigma 1.6, row-major) at stride 4 with reflect padding; x (planes,H,W) ->
+ * y (planes,H/4,W/4); H, W multiples of 4 and >= 8. */
+int selfc_gauss_down4(const float* x, float* y, const float* g169, int planes, int H, int W, void* stream);
+
 /* ---- dense-block subnets --------------------------------------------------- */
 
 typedef struct {

@@ -406,3 +406,28 @@ def psnr_per_frame(a: torch.Tensor, b: torch.Tensor) -> List[float]:
         mse = torch.mean((a[i].double() - b[i].double()) ** 2)
         out.append(float("inf") if mse == 0 else (20.0 * torch.log10(1.0 / torch.sqrt(mse))).item())
     return out
+
+
+# ----------------------------------------------------------------------------
+# Guassian_downsample (models/Guassian.py:7-52), scale 4: the "sr_bd" LR target of SelfCModel.feed_data
+# ----------------------------------------------------------------------------
+
+def gaussian_kernel_13(sigma: float = 1.6) -> torch.Tensor:
+    """scipy.ndimage.gaussian_filter of a 13x13 dirac (Guassian.py:16-22): truncate 4 sigma -> radius 6, so the
+    mask is the outer product of the normalised 1-D weights exp(-k^2 / (2 sigma^2)), k = -6..6 (float64)."""
+    k = torch.arange(-6, 7, dtype=torch.float64)
+    w = torch.exp(-0.5 * (k / sigma) ** 2)
+    w = w / w.sum()
+    return torch.outer(w, w)
+
+
+def gaussian_downsample(x: torch.Tensor) -> torch.Tensor:
+    """x (P,H,W) or (..,H,W) planes -> (..,H/4,W/4): reflect-pad 14, 13x13 Gaussian (sigma 1.6) at stride 4,
+    crop 2 (Guassian.py:34-51); equivalently out[oy,ox] = sum_ij g[i,j] x[refl(4oy+i-6), refl(4ox+j-6)]."""
+    shp = x.shape
+    h, w = shp[-2], shp[-1]
+    v = x.reshape(-1, 1, h, w)
+    v = F.pad(v, [14, 14, 14, 14], "reflect")
+    k = gaussian_kernel_13().to(x.dtype).reshape(1, 1, 13, 13)
+    y = F.conv2d(v, k, stride=4)[:, :, 2:-2, 2:-2]
+    return y.reshape(*shp[:-2], y.shape[-2], y.shape[-1])

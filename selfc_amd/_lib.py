@@ -34,7 +34,7 @@ SYMBOLS = [
     "selfc_nchw_to_nhwc4", "selfc_nhwc4_to_nchw",
     "selfc_profile_enable", "selfc_profile_read", "selfc_profile_reset",
     "selfc_globalagg_run", "selfc_globalagg_partial_floats", "selfc_pwconv_run", "selfc_gmm_sample",
-    "selfc_conv_planes_run", "selfc_nhwc_to_planes", "selfc_y_sse", "selfc_y_sse_blocks",
+    "selfc_conv_planes_run", "selfc_nhwc_to_planes", "selfc_y_sse", "selfc_y_sse_blocks", "selfc_gauss_down4",
 ]
 
 
@@ -98,6 +98,7 @@ def lib():
             "selfc_nhwc_to_planes": [vp, vp, sz, i, vp],
             "selfc_y_sse": [vp, vp, vp, i, i, vp],
             "selfc_y_sse_blocks": [i],
+            "selfc_gauss_down4": [vp, vp, vp, i, i, i, vp],
         }
         for name, args in sigs.items():
             fn = getattr(L, name)

@@ -291,9 +291,44 @@ __global__ __launch_bounds__(256) void y_sse_kernel(const float* __restrict__ a,
   if (threadIdx.x == 0) partial[(size_t)n * nblk + blockIdx.x] = red[0];
 }
 
+// Guassian_downsample (models/Guassian.py:34-51, scale 4): out[oy][ox] = sum_{i,j in [-6,6]} g[i][j] *
+// x[reflect(4 oy + i)][reflect(4 ox + j)] per plane ('reflect' = mirror without repeating the edge sample).
+__global__ __launch_bounds__(256) void gauss_down4_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          const float* __restrict__ g, int planes, int H, int W) {
+  __shared__ float gk[169];
+  if (threadIdx.x < 169) gk[threadIdx.x] = g[threadIdx.x];
+  __syncthreads();
+  const int h = H / 4, w = W / 4;
+  const size_t total = (size_t)planes * h * w;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int ox = (int)(i % w), oy = (int)((i / w) % h);
+  const size_t pl = i / ((size_t)w * h);
+  const float* p = x + pl * (size_t)H * W;
+  float acc = 0.f;
+  for (int a = -6; a <= 6; ++a) {
+    int yy = 4 * oy + a;
+    yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy);
+    for (int b = -6; b <= 6; ++b) {
+      int xx = 4 * ox + b;
+      xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
+      acc += gk[(a + 6) * 13 + (b + 6)] * p[(size_t)yy * W + xx];
+    }
+  }
+  y[i] = acc;
+}
+
 }  // namespace
 
 extern "C" {
+
+int selfc_gauss_down4(const float* x, float* y, const float* g169, int planes, int H, int W, void* stream) {
+  if (!x || !y || !g169 || planes <= 0 || H < 8 || W < 8 || (H & 3) || (W & 3)) return SELFC_EINVAL;   // reflect needs 6 < H, W
+  const size_t total = (size_t)planes * (H / 4) * (W / 4);
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
+  hipLaunchKernelGGL(gauss_down4_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, g169, planes, H, W);
+  return hip_rc(hipGetLastError());
+}
 
 int selfc_y_sse_blocks(int HW) { const int nb = (HW + 256 * 8 - 1) / (256 * 8); return nb < 1 ? 1 : (nb > 256 ? 256 : nb); }
 

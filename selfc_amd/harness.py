@@ -116,3 +116,23 @@ def rescale_video(net, frames: torch.Tensor, rank: int = 0, world: int = 1, gops
                         rec_out.append(rec[pos + j, :3])
                 pos += len(g)
     return {"frames": idx_out, "lr": torch.stack(lr_out) if lr_out else None, "rec": torch.stack(rec_out) if rec_out else None}
+
+
+_GK = {}
+
+
+def gaussian_downsample(x: torch.Tensor) -> torch.Tensor:
+    """(N,C,H,W) -> (N,C,H/4,W/4): the reference's Guassian_downsample(scale=4) (models/Guassian.py:7-52), i.e. the
+    "sr_bd" LR target ref_L that SelfCModel.feed_data builds (SelfC_model.py:128).  13x13 mask = outer product of
+    the normalised 1-D weights exp(-k^2/(2*1.6^2)), k = -6..6 (scipy's gaussian_filter of a dirac, 4-sigma truncation)."""
+    x = rt.as_input(x)
+    n, c, h, w = x.shape
+    key = str(x.device)
+    if key not in _GK:
+        k = torch.arange(-6, 7, dtype=torch.float64)
+        w1 = torch.exp(-0.5 * (k / 1.6) ** 2)
+        w1 = w1 / w1.sum()
+        _GK[key] = torch.outer(w1, w1).float().reshape(169).contiguous().to(x.device)
+    y = torch.empty((n, c, h // 4, w // 4), dtype=torch.float32, device=x.device)
+    rt.call("selfc_gauss_down4", x.data_ptr(), y.data_ptr(), _GK[key].data_ptr(), n * c, h, w, _lib.stream_ptr())
+    return y

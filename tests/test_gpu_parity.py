@@ -330,6 +330,16 @@ def test_rescale_video_ragged_length_and_sharding(dev):
     assert torch.equal(fh, whole["rec"][:7])
 
 
+def test_gaussian_downsample_ref_L(dev):
+    from selfc_amd import harness
+    g = load_golden("g10_gauss")
+    x = g["x"]                                          # [C,T,H,W] planes
+    y = harness.gaussian_downsample(x.reshape(1, -1, x.shape[2], x.shape[3]).to(dev)).reshape(g["y"].shape)
+    assert rel_err(y.cpu(), g["y"]) < 1e-5
+    with pytest.raises(RuntimeError):
+        harness.gaussian_downsample(torch.zeros(1, 3, 6, 8, device=dev))     # not a multiple of 4 / too small
+
+
 def test_selfc_haar_variant(dev):
     """model "SelfC": Haar + InvBlockExp(DBNet) + STP v1 (D2DTNet conditioner, l2 head), fwd (incl. neg_llh) and rev."""
     from selfc_amd.modules.SelfC_arch_inv import SelfCInvNet

@@ -164,3 +164,9 @@ def test_selfc_haar_variant_with_feature_calapse_block():
     xr, hf = O.selfc_haar_rev(params, g["lr"], [1], T, "DBNet")
     assert rel_err(hf, g["hf"]) < 2e-5
     assert rel_err(xr, g["x_rev"]) < 2e-5
+
+
+def test_gaussian_downsample():
+    g = load_golden("g10_gauss")
+    y = O.gaussian_downsample(g["x"])
+    assert y.shape == g["y"].shape and rel_err(y, g["y"]) < 2e-6

@@ -207,6 +207,11 @@ def main():
              hf=hf.numpy(), blk1_y=blk1_y.numpy(), stp_fill_seed=np.int64(4242),
              **{k: v for k, v in sd_np(fnet).items() if k.startswith("operations.")})
 
+        # ---- G10 Guassian_downsample (models/Guassian.py:7-52): the LR target ref_L of feed_data (SelfC_model.py:128)
+        from models.Guassian import Guassian_downsample
+        xg = torch.rand(3, 5, 32, 48, generator=g)                 # [C, T, H, W]
+        save("g10_gauss", x=xg.numpy(), y=Guassian_downsample(xg).numpy())
+
         # ---- G9 Quantization
         q = Quantization()
         v = torch.tensor([-0.3, 0.0, 0.001, 0.00196, 0.00197, 0.5, 0.50196, 0.998, 1.0, 1.7,
