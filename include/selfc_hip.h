@@ -150,6 +150,37 @@ int selfc_nhwc_to_planes(const float* x, void* dense, size_t npix, int cin, void
 int selfc_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, void* stream);
 int selfc_nhwc4_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream);
 
+/* ---- training: gradients of the dense-block subnets and the coupling (csrc/backward.hip) --------------
+ *
+ * The reference trains through stock autograd (SelfC_model.py:153-176 optimize_parameters); these entry points are
+ * what the autograd.Functions of the boundary modules call.  Gradients pass through the MFMA as f16 scaled by a
+ * power of two taken from max|dout| of the call; all results are fp32 and unscaled. */
+typedef struct {
+  const void* wt5;      /* conv5^T  : dOut planes -> [x groups | f1 f2 f3 f4]   (packing.py:pack_subnet_bwd) */
+  const void* wtd[3];   /* conv_k^T : [dpre4 ..] -> f3, f2, f1 */
+  const void* wtx;      /* conv_k^T : [dpre4 dpre3 dpre2 dpre1] -> x */
+} selfc_subnet_bw;
+
+size_t selfc_subnet_bwd_scratch_bytes(int N, int H, int W, int cin, int cout);
+/* Backward of DenseBlock.forward / D2DTInput.forward (Subnet_constructor.py:26-34,119-133) given the dense buffer
+ * the forward left behind (`dense`: [x planes when cin > 3 | f1..f4], see selfc_subnet_run) and, when cin <= 3,
+ * the fp32 NHWC(4) input `xin`.  `dout`: fp32 NHWC rows of stride roundup(cout,4), used as sign*dout.
+ * dx (optional): fp32 NHWC rows of stride roundup(cin,4), overwritten or (accumulate_dx) added to.
+ * wgrad[k] / bgrad[k] (k = 0..4, each optional): gradients of conv{k+1}.weight / .bias in the reference's own
+ * layout ((32|cout, cin+32k, [1|3,] 3|1, 3|1) contiguous fp32), written as beta*old + new. */
+int selfc_subnet_bwd(const selfc_subnet_bw* bw, int kind, const void* dense, const float* xin, const float* dout, float sign,
+                     float* dx, int accumulate_dx, float* const* wgrad, float* const* bgrad, float beta,
+                     void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout, void* stream);
+/* Gradient of the affine coupling of InvBlockExp (Inv_arch.py:24-32) w.r.t. its x2 path and H's output, n = npix*c2p
+ * fp32 elements: rev == 0: v = x2 (input), dx2 = dy2*e^s, dh = dx2*x2*ds/dh (dG = dy2);
+ * rev != 0: v = y2 (output), dx2 = dy2*e^-s, dh = -dy2*y2*ds/dh (dG = -dx2); ds/dh = clamp*(1-(s/clamp)^2)/2. */
+int selfc_coupling_bwd(int rev, const float* v, const float* s, const float* dy2, float* dx2, float* dh, float clamp,
+                       size_t n, void* stream);
+/* Adjoint of selfc_freq_fwd (latent grads d1 [N][h][w][4], d2 [N][h][w][48] -> dx NCHW (N,3,H,W)) and of selfc_freq_inv
+ * (dout NCHW -> d1, d2). */
+int selfc_freq_fwd_bwd(const float* d1, const float* d2, float* dx, int N, int H, int W, void* stream);
+int selfc_freq_inv_bwd(const float* dout, float* d1, float* d2, int N, int H, int W, void* stream);
+
 /* ---- STP (self-conditioned latent predictor), activations fp32 NHWC [N][H*W][64] -------------
  *
  * GlobalAgg.forward: SelfC_GMM_arch_inv.py:265-285.  y = x + (proj1(x) viewed (b,C*h*w,T)) @ A,

@@ -35,12 +35,17 @@ SYMBOLS = [
     "selfc_profile_enable", "selfc_profile_read", "selfc_profile_reset",
     "selfc_globalagg_run", "selfc_globalagg_partial_floats", "selfc_pwconv_run", "selfc_gmm_sample",
     "selfc_conv_planes_run", "selfc_nhwc_to_planes", "selfc_y_sse", "selfc_y_sse_blocks", "selfc_gauss_down4",
+    "selfc_subnet_bwd_scratch_bytes", "selfc_subnet_bwd", "selfc_coupling_bwd", "selfc_freq_fwd_bwd", "selfc_freq_inv_bwd",
 ]
 
 
 class SubnetW(C.Structure):
     _fields_ = [("w3", C.c_void_p * 4), ("b3", C.c_void_p * 4), ("w5", C.c_void_p), ("b5", C.c_void_p),
                 ("wfused", C.c_void_p)]
+
+
+class SubnetBW(C.Structure):
+    _fields_ = [("wt5", C.c_void_p), ("wtd", C.c_void_p * 3), ("wtx", C.c_void_p)]
 
 
 class InvBlockW(C.Structure):
@@ -99,12 +104,19 @@ def lib():
             "selfc_y_sse": [vp, vp, vp, i, i, vp],
             "selfc_y_sse_blocks": [i],
             "selfc_gauss_down4": [vp, vp, vp, i, i, i, vp],
+            "selfc_subnet_bwd": [C.POINTER(SubnetBW), i, vp, vp, vp, f, vp, i, C.POINTER(vp), C.POINTER(vp), f,
+                                 vp, sz, i, i, i, i, i, i, vp],
+            "selfc_coupling_bwd": [i, vp, vp, vp, vp, vp, f, sz, vp],
+            "selfc_freq_fwd_bwd": [vp, vp, vp, i, i, i, vp],
+            "selfc_freq_inv_bwd": [vp, vp, vp, i, i, i, vp],
         }
         for name, args in sigs.items():
             fn = getattr(L, name)
             fn.restype = i
             fn.argtypes = args
         L.selfc_y_sse_blocks.restype = i
+        L.selfc_subnet_bwd_scratch_bytes.restype = sz
+        L.selfc_subnet_bwd_scratch_bytes.argtypes = [i, i, i, i, i]
         L.selfc_globalagg_partial_floats.restype = sz
         L.selfc_globalagg_partial_floats.argtypes = [i, i]
         if ("operands=" + OPERAND).encode() not in L.selfc_version():

@@ -37,6 +37,7 @@ struct FGArgs {
 };
 int launch_fused_gh(FGArgs& a, hipStream_t s);
 }  // namespace selfc
+#include "bwd_internal.hpp"
 
 namespace {
 
@@ -51,7 +52,7 @@ inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 
 #define ABL(a, bit) false
 #endif
 
-enum { EPI_LRELU = 0, EPI_PLAIN = 1, EPI_F = 2, EPI_GH = 3 };
+enum { EPI_LRELU = 0, EPI_PLAIN = 1, EPI_F = 2, EPI_GH = 3, EPI_BWD = 4 };
 
 struct C3Stage {
   int coff;   // first channel of the stage in the dense buffer
@@ -85,6 +86,16 @@ struct C3Args {
   // blockIdx.z selects a 32-channel output group (weights w[0] + z*wz_stride, bias[0] + 32 z).
   int gen_planes, gen_tt, T;
   size_t wz_stride;
+  int gen_sp1;           // generic mode: centre spatial tap only ((kt,1,1) kernels: 2 fragments per stage)
+  // EPI_BWD (generic mode, csrc/backward.hip): v = acc + add[z] (f16 plane, optional); group z == bw_mask_z is
+  // multiplied by LeakyReLU'(bw_mask) (1 where the saved feature is > 0, else 0.2).  Output: f16 plane
+  // out[0] + (out_coff/32 + z) planes (group bw_mask_z goes to bw_alt when that is set), or, with `plain`,
+  // fp32 NHWC rows of stride coutp scaled by 1/grad_scale(*bw_amax), added to the old value when bw_acc.
+  const f16* bw_add;
+  const f16* bw_mask;
+  f16* bw_alt;
+  const float* bw_amax;
+  int bw_mask_z, bw_acc;
   // coupling / plain epilogue (EPI != LRELU)
   float* x1io;           // EPI_F: y1 = x1 +- F, in place          [N][H][W][4]
   float* x2io;           // EPI_GH: y2, in place                   [N][H][W][c2p]
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
       if (!ABL(a, 64))
 #pragma unroll
       for (int it = 0; it < AITER; ++it) areg[it] = *reinterpret_cast<const u32x4*>(src + gofs[it]);
-      const int nfr = 9 * (st.width >> 4);
+      const int nfr = (GEN && a.gen_sp1) ? 2 : 9 * (st.width >> 4);
       if (!ABL(a, 32))
 #pragma unroll
       for (int it = 0; it < WITER; ++it) {
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
         if (tid + it * NT < NPIX * 4)
           *reinterpret_cast<u32x4*>(lact + lofs[it]) = ((okm >> it) & 1u) ? areg[it] : u32x4{0u, 0u, 0u, 0u};
       }
-      const int nfr = 9 * (st.width >> 4);
+      const int nfr = (GEN && a.gen_sp1) ? 2 : 9 * (st.width >> 4);
 #pragma unroll
       for (int it = 0; it < WITER; ++it) {
         const int i = tid + it * NT;
@@ -322,12 +333,12 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
     for (int s = 0; s < a.nstages; ++s) {
       const C3Stage st = stage_of<GEN>(a, s);
       const C3Stage stn = stage_of<GEN>(a, s + 1);
-      const int nfr = st.kind == 1 ? 2 : 9 * (st.width >> 4);
+      const int nfr = (st.kind == 1 || (GEN && a.gen_sp1)) ? 2 : 9 * (st.width >> 4);
       const bool more = s + 1 < a.nstages;
       if (more) load_stage(stn, fragbase + nfr);
 
       if (ABL(a, 1)) {
-      } else if (st.kind == 1) {
+      } else if (st.kind == 1 || (GEN && a.gen_sp1)) {
         constexpr int CTR = ROWB + PS;  // centre tap
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -409,6 +420,57 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
           v[2 + d] = sw[1];
         }
         *reinterpret_cast<u32x4*>(dst + 16 * gp) = v;
+      }
+    } else if (EPI == EPI_BWD) {
+      const bool masked = a.bw_mask && zg == a.bw_mask_z;
+      float v[4][4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[g][j] = acc[0][m][4 * g + j];
+      if (a.bw_add) {
+        const f16* __restrict__ ad = a.bw_add + (size_t)zg * a.plane + pix * 32 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f16x4 t = *reinterpret_cast<const f16x4*>(ad + 8 * g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[g][j] += (float)t[j];
+        }
+      }
+      if (masked) {
+        const f16* __restrict__ mk = a.bw_mask + pix * 32 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f16x4 t = *reinterpret_cast<const f16x4*>(mk + 8 * g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[g][j] *= ((float)t[j] > 0.f) ? 1.f : 0.2f;
+        }
+      }
+      if (a.plain) {
+        const float am = *a.bw_amax;
+        const float inv = 1.f / grad_scale(am);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int oc = 32 * zg + 8 * g + 4 * half;
+          if (oc < a.coutp) {
+            float4* dst = reinterpret_cast<float4*>(a.plain + pix * a.coutp + oc);
+            float4 o = make_float4(v[g][0] * inv, v[g][1] * inv, v[g][2] * inv, v[g][3] * inv);
+            if (a.bw_acc) {
+              const float4 old = *dst;
+              o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            }
+            *dst = o;
+          }
+        }
+      } else {
+        f16* dst = ((a.bw_alt && zg == a.bw_mask_z) ? a.bw_alt : a.out[0] + (size_t)((a.out_coff >> 5) + zg) * a.plane) + pix * 32 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 u;
+          u.x = pack2(v[g][0], v[g][1]);
+          u.y = pack2(v[g][2], v[g][3]);
+          *reinterpret_cast<uint2*>(dst + 8 * g) = u;
+        }
       }
     } else if (EPI == EPI_PLAIN) {
       const float* __restrict__ bias = a.bias[0];
@@ -702,7 +764,7 @@ int launch_conv3x3(C3Args& a, int nets_z, hipStream_t s) {
   a.ablate = ablate;
 #endif
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), 1, (unsigned)nets_z);
-  ProfScope prof(EPI == EPI_LRELU ? PROF_CONV3X3 : EPI == EPI_F ? PROF_CONV5_F : EPI == EPI_GH ? PROF_CONV5_GH : PROF_CONV5_PLAIN, s);
+  ProfScope prof(EPI == EPI_LRELU ? PROF_CONV3X3 : EPI == EPI_F ? PROF_CONV5_F : EPI == EPI_GH ? PROF_CONV5_GH : EPI == EPI_BWD ? -1 : PROF_CONV5_PLAIN, s);
   hipLaunchKernelGGL((conv3x3_kernel<C3_TH, C3_TW, C3_NW, C3_MT, EPI, GEN>), grid, dim3(C3_NW * 64), C3_LDS, s, a);
   return hip_rc(hipGetLastError());
 }
@@ -849,6 +911,28 @@ int run_GH(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStrea
 }
 
 }  // namespace
+
+namespace selfc {
+
+// Generic plane-list conv with the EPI_BWD epilogue (see C3Args); used by csrc/backward.hip for the data
+// gradients of a dense block.  `in` = first of nplanes_in contiguous f16 planes; kt temporal taps (1 | 3);
+// sp1: (kt,1,1) kernel instead of (kt,3,3); ngroups 32-channel output groups.
+int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s) {
+  C3Args a{};
+  a.dense[0] = (const f16*)c.in; a.out[0] = (f16*)c.out_planes;
+  a.w[0] = (const f16*)c.w;
+  a.N = N; a.H = H; a.W = W; a.plane = (size_t)N * H * W * 32;
+  a.gen_planes = c.nplanes_in; a.gen_tt = c.kt; a.T = T; a.gen_sp1 = c.sp1;
+  a.nstages = c.nplanes_in * c.kt;
+  a.wz_stride = (size_t)a.nstages * (c.sp1 ? 2 : 18) * 512;
+  a.out_coff = 0;
+  a.bw_add = (const f16*)c.add; a.bw_mask = (const f16*)c.mask; a.bw_mask_z = c.mask_z; a.bw_alt = (f16*)c.alt;
+  a.bw_amax = c.amax; a.bw_acc = c.accumulate;
+  a.plain = c.plain; a.coutp = c.coutp;
+  return launch_conv3x3<EPI_BWD, true>(a, c.ngroups, s);
+}
+
+}  // namespace selfc
 
 extern "C" {
 

@@ -38,13 +38,15 @@ class InvBlockExp(nn.Module):
 
     def forward(self, x, rev=False):
         x = rt.as_input(x)
-        rt.no_autograd_guard(x, *self.parameters())
         n, c, h, w = x.shape
         if c != self.split_len1 + self.split_len2:
             raise RuntimeError(f"InvBlockExp expects {self.split_len1 + self.split_len2} channels, got {c}")
         t = self._temporal_len()
         if n % t:
             raise RuntimeError(f"{n} frames are not a multiple of the temporal length {t}")
+        from .. import autograd as ag
+        if ag.needs_grad(x, *self.parameters()):          # training: buffers kept for the HIP backward (autograd.py)
+            return ag.InvBlockFn.apply(x, self, bool(rev), t, *ag.block_params(self))
         ws = rt.workspace(x.device, self.F.kind, n, t, h, w, self.split_len1, self.split_len2)
         pb = rt.packed_block(self)
         rt.nchw_to_latent(x, ws)

@@ -39,6 +39,14 @@ class FrequencyAnalyzer(nn.Module):
         self.channel_in = channel_in
 
     def forward(self, x, rev=False):
+        from .. import autograd as ag
+        if ag.needs_grad(x):
+            if self.k != 4:
+                raise NotImplementedError("FrequencyAnalyzer backward is built for k = 4")
+            return ag.FreqFn.apply(x, self, bool(rev))
+        return self._run(x, rev)
+
+    def _run(self, x, rev=False):
         x = rt.as_input(x)
         k, sp = self.k, _lib.stream_ptr()
         c2 = 3 * k * k

@@ -36,12 +36,14 @@ class _DenseSubnet(nn.Module):
     def _run(self, x: torch.Tensor, T: int) -> torch.Tensor:
         """x NCHW (N,cin,H,W) -> NCHW (N,cout,H,W) through selfc_subnet_run."""
         x = rt.as_input(x)
-        rt.no_autograd_guard(x, *self.parameters())
         n, cin, h, w = x.shape
         if cin != self.channel_in:
             raise RuntimeError(f"expected {self.channel_in} input channels, got {cin}")
         if n % T:
             raise RuntimeError(f"{n} frames are not a multiple of the temporal length {T}")
+        from .. import autograd as ag
+        if ag.needs_grad(x, *self.parameters()):          # training: same kernels, buffers kept for the HIP backward
+            return ag.SubnetFn.apply(x, self, T, *ag.subnet_params(self))
         pk = self.packed()
         dev, sp = x.device, _lib.stream_ptr()
         cinp, coutp = roundup(cin, 4), roundup(self.channel_out, 4)

@@ -184,3 +184,72 @@ def pack_conv_planes(weight: torch.Tensor, cin: int) -> torch.Tensor:
     z = cout // 32
     frag = wk.reshape(z, 32, nfrag, 2, 8).permute(0, 2, 3, 1, 4).reshape(z, nfrag, 64, 8)
     return frag.to(F16).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# backward (csrc/backward.hip): transposed, tap-flipped weights for the generic plane-list conv
+# ----------------------------------------------------------------------------------------------------------
+
+def pack_planes_generic(wt: torch.Tensor) -> torch.Tensor:
+    """wt (G*32 out, P*32 in, kt, ks) fp32, ks = 9 (3x3 taps) or 1 (centre tap only) -> f16
+    [G][kt*P*(18|2)][64][8]: per 32-channel output group, K order = temporal tap, input plane, spatial tap,
+    32 channels (the stage order of conv3x3_kernel's generic mode)."""
+    cout, cin, kt, ks = wt.shape
+    assert cout % 32 == 0 and cin % 32 == 0 and ks in (1, 9) and kt in (1, 3)
+    z, pl = cout // 32, cin // 32
+    wk = wt.reshape(z, 32, pl, 32, kt, ks).permute(0, 1, 4, 2, 5, 3).reshape(z, 32, kt * pl * ks * 32)
+    nfrag = wk.shape[2] // 16
+    frag = wk.reshape(z, 32, nfrag, 2, 8).permute(0, 2, 3, 1, 4).reshape(z, nfrag, 64, 8)
+    return frag.to(F16).contiguous()
+
+
+def pack_subnet_bwd(weights: Sequence[torch.Tensor], cin: int, cout: int, temporal: bool):
+    """conv1..conv5 weights of a DenseBlock (temporal=False) / D2DTInput (temporal=True) -> the five packed
+    data-gradient convs of selfc_subnet_bwd: (wt5, [wtd3, wtd2, wtd1], wtx).
+
+    y[o][p] = sum W[o][c][tap] x[c][p + off(tap)]  =>  dx[c][q] = sum W[o][c][ntap-1-tap'] dy[o][q + off(tap')]:
+    the gradient conv swaps in/out channels and reverses the taps.  Gradient planes are ordered
+    [dpre4, dpre3, dpre2, dpre1] (plane p <-> conv 4-p); output channel groups of conv5^T are
+    [x (cin, zero padded to 32s) | f1 | f2 | f3 | f4]."""
+    dev = weights[0].device
+    nx, ng = roundup(cin, 32) // 32, roundup(cout, 32) // 32
+    w3 = []
+    for k in range(1, 5):
+        w = weights[k - 1].detach().float()
+        if w.dim() == 5:
+            w = w[:, :, 0]
+        assert w.shape == (32, cin + 32 * (k - 1), 3, 3), tuple(w.shape)
+        w3.append(w.reshape(32, -1, 9).flip(2))                      # [o][c][tap'] = W[o][c][8 - tap']
+    w5 = weights[4].detach().float()
+    if temporal:
+        assert w5.shape == (cout, cin + 128, 3, 1, 1), tuple(w5.shape)
+        w5 = w5[:, :, :, 0, 0].flip(2)                                # (cout, C, 3) temporal taps reversed
+        kt, ks = 3, 1
+    else:
+        assert w5.shape == (cout, cin + 128, 3, 3), tuple(w5.shape)
+        w5 = w5.reshape(cout, cin + 128, 9).flip(2)
+        kt, ks = 1, 9
+    # conv5^T: out (nx+4)*32, in ng*32
+    t5 = torch.zeros((nx + 4) * 32, ng * 32, kt, ks, dtype=torch.float32, device=dev)
+    w5t = w5.permute(1, 0, 2)                                         # (C, cout, taps)
+    w5t = w5t.reshape(cin + 128, cout, kt, ks)
+    t5[:cin, :cout] = w5t[:cin]
+    t5[nx * 32:, :cout] = w5t[cin:]
+    wt5 = pack_planes_generic(t5)
+    # dpre_j, j = 3, 2, 1: in planes dpre4..dpre_{j+1}
+    wtd = []
+    for j in (3, 2, 1):
+        npl = 4 - j
+        t = torch.zeros(32, npl * 32, 1, 9, dtype=torch.float32, device=dev)
+        for pl_i in range(npl):
+            k = 4 - pl_i
+            sl = w3[k - 1][:, cin + 32 * (j - 1): cin + 32 * j, :]    # (o, r, tap')
+            t[:, pl_i * 32:(pl_i + 1) * 32, 0, :] = sl.permute(1, 0, 2)
+        wtd.append(pack_planes_generic(t))
+    # dx: in planes dpre4..dpre1, out nx*32
+    t = torch.zeros(nx * 32, 4 * 32, 1, 9, dtype=torch.float32, device=dev)
+    for pl_i in range(4):
+        k = 4 - pl_i
+        t[:cin, pl_i * 32:(pl_i + 1) * 32, 0, :] = w3[k - 1][:, :cin, :].permute(1, 0, 2)
+    wtx = pack_planes_generic(t)
+    return wt5, wtd, wtx

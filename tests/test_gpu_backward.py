@@ -1,0 +1,209 @@
+"""Gradients of the HIP training path (csrc/backward.hip through the C ABI and selfc_amd/autograd.py) against
+torch autograd through the CPU oracle on the same seeded inputs.
+
+Two bars.  (1) Kernel exactness: with the LeakyReLU masks and layer inputs frozen to the f16 features the HIP
+forward saved, autograd through the oracle's convs is exactly what the kernels must produce; the only difference
+left is the f16 rounding of gradient operands -> max|a-b|/max|b| < 3e-3.  (2) End to end against the fp32 oracle
+the two forwards differ by f16 operand rounding, so a pre-activation within ~1e-3 of zero can land on the other
+side of the LeakyReLU kink and its gradient changes by 5x at that pixel: a max-norm is meaningless there, the bar
+is the relative L2 error < 3e-2.  Index shuffles (FrequencyAnalyzer) are fp32: 1e-6."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_err, subdict
+from oracle import selfc_oracle as O
+
+pytestmark = pytest.mark.gpu
+STRICT = 3e-3
+L2TOL = 3e-2
+T = 7
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from selfc_amd import _lib
+    _lib.lib()
+    from selfc_amd import GlobalVar
+    GlobalVar.set_Temporal_LEN(T)
+    return torch.device("cuda:0")
+
+
+def _oracle_grads(fn, params, x, gy):
+    """autograd through the oracle: returns (y, dx, {name: dparam})."""
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xr = x.clone().requires_grad_(True)
+    y = fn(p, xr)
+    y.backward(gy)
+    return y.detach(), xr.grad, {k: v.grad for k, v in p.items()}
+
+
+def _check_module_grads(mod, ref_grads, prefix="", tol=L2TOL, metric=rel_l2, scale=1.0):
+    worst = 0.0
+    for name, prm in mod.named_parameters():
+        key = prefix + name
+        if key not in ref_grads or ref_grads[key] is None:
+            continue
+        assert prm.grad is not None, f"no gradient for {name}"
+        e = metric(prm.grad.cpu(), scale * ref_grads[key])
+        assert e < tol, f"{name}: {e}"
+        worst = max(worst, e)
+    return worst
+
+
+def _frozen_subnet(p, x, saved, temporal):
+    """The oracle's dense block with LeakyReLU masks and layer inputs frozen to the saved f16 features: values are the
+    saved ones, gradients flow through the convs (what csrc/backward.hip computes)."""
+    import torch.nn.functional as F
+    feats = [x]
+    for k in range(1, 5):
+        w = p[f"conv{k}.weight"]
+        pre = F.conv2d(torch.cat(feats, 1), w[:, :, 0] if w.dim() == 5 else w, p[f"conv{k}.bias"], 1, 1)
+        f = pre * torch.where(saved[k - 1] > 0, 1.0, 0.2)
+        feats.append(saved[k - 1] + (f - f.detach()))
+    d = torch.cat(feats, 1)
+    if not temporal:
+        return F.conv2d(d, p["conv5.weight"], p["conv5.bias"], 1, 1)
+    n, c, h, w_ = d.shape
+    d5 = d.reshape(n // T, T, c, h, w_).transpose(1, 2)
+    return F.conv3d(d5, p["conv5.weight"], p["conv5.bias"], 1, (1, 0, 0)).transpose(1, 2).reshape(n, -1, h, w_)
+
+
+@pytest.mark.parametrize("cls,ci,co,hw", [("D2DTInput", 48, 3, (12, 20)), ("D2DTInput", 3, 48, (12, 20)),
+                                          ("DenseBlock", 9, 3, (16, 16)), ("DenseBlock", 3, 9, (16, 16)),
+                                          ("D2DTInput", 3, 64, (36, 36)), ("D2DTInput", 64, 64, (20, 12))])
+def test_subnet_backward(dev, cls, ci, co, hw):
+    from selfc_amd.modules import Subnet_constructor as S
+    torch.manual_seed(5)
+    h, w = hw
+    n = T * 2 if cls == "D2DTInput" else 3
+    m = getattr(S, cls)(ci, co, "xavier")
+    with torch.no_grad():                       # non-trivial conv5 / biases (the 2-D block zero-inits conv5)
+        for prm in m.parameters():
+            prm.copy_(torch.randn_like(prm) * (0.05 if prm.dim() > 1 else 0.1))
+    params = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(n, ci, h, w)
+    gy = torch.randn(n, co, h, w) * 0.01
+    fn = (lambda p, xx: O.d2dt(p, xx, T)) if cls == "D2DTInput" else (lambda p, xx: O.dense_block(p, xx))
+    y_ref, dx_ref, g_ref = _oracle_grads(fn, params, x, gy)
+    m.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    y = m(xd)
+    assert rel_err(y.detach().cpu(), y_ref) < 1e-3
+    dense = y.grad_fn.dense.float().cpu()                       # [planes][N][H][W][32]
+    y.backward(gy.to(dev))
+    # (2) end to end against the fp32 oracle
+    assert rel_l2(xd.grad.cpu(), dx_ref) < L2TOL
+    _check_module_grads(m, g_ref)
+    # (1) kernel exactness with frozen masks / inputs
+    nx = 0 if ci <= 3 else (ci + 31) // 32
+    saved = [dense[nx + k].permute(0, 3, 1, 2) for k in range(4)]
+    xs = x if ci <= 3 else torch.cat([dense[i] for i in range(nx)], -1)[..., :ci].permute(0, 3, 1, 2).contiguous()
+    _, dx_fz, g_fz = _oracle_grads(lambda p, xx: _frozen_subnet(p, xx, saved, cls == "D2DTInput"), params, xs, gy)
+    assert rel_err(xd.grad.cpu(), dx_fz) < STRICT
+    _check_module_grads(m, g_fz, tol=STRICT, metric=rel_err)
+
+
+@pytest.mark.parametrize("name,kind,cnum", [("g5_invblock_d2dt", "D2DTNet", 51), ("g5_invblock_dbnet", "DBNet", 12)])
+@pytest.mark.parametrize("rev", [False, True])
+def test_invblock_backward(dev, name, kind, cnum, rev):
+    from selfc_amd.modules.Inv_arch import InvBlockExp
+    from selfc_amd.modules.Subnet_constructor import subnet
+    g = load_golden(name)
+    torch.manual_seed(11)
+    blk = InvBlockExp(subnet(kind, "xavier"), cnum, 3)
+    sd = {k: v for k, v in g.items() if k[:2] in ("F.", "G.", "H.")}
+    blk.load_state_dict(sd, strict=True)
+    x = g["x"]
+    gy = torch.randn_like(x) * 0.02
+    y_ref, dx_ref, g_ref = _oracle_grads(lambda p, xx: O.invblock(kind, p, xx, 3, T, rev=rev)[0], sd, x, gy)
+    blk.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    y = blk(xd, rev=rev)
+    assert rel_err(y.detach().cpu(), y_ref) < 1e-3
+    y.backward(gy.to(dev))
+    assert rel_l2(xd.grad.cpu(), dx_ref) < L2TOL
+    _check_module_grads(blk, g_ref)
+    # parameters only (input does not require grad), twice: gradients accumulate like stock autograd
+    first = {n_: p_.grad.clone() for n_, p_ in blk.named_parameters()}
+    blk.zero_grad()
+    for _ in range(2):
+        blk(x.to(dev), rev=rev).backward(gy.to(dev))
+    for nme, prm in blk.named_parameters():
+        assert rel_err(prm.grad, 2 * first[nme]) < 1e-5, nme
+
+
+@pytest.mark.parametrize("rev", [False, True])
+def test_freq_backward(dev, rev):
+    from selfc_amd.modules.SelfC_GMM_arch_inv import FrequencyAnalyzer
+    torch.manual_seed(2)
+    fa = FrequencyAnalyzer(3)
+    x = torch.randn(3, 51, 6, 10) if rev else torch.randn(3, 3, 24, 40)
+    xr = x.clone().requires_grad_(True)
+    y_ref = O.freq_inv(xr) if rev else O.freq_fwd(xr)
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+    xd = x.to(dev).requires_grad_(True)
+    y = fa(xd, rev=rev)
+    assert torch.equal(y.detach().cpu(), y_ref.detach())
+    y.backward(gy.to(dev))
+    assert rel_err(xd.grad.cpu(), xr.grad) < 1e-6
+
+
+def test_stack_backward_chain(dev):
+    """FrequencyAnalyzer + 2 InvBlockExp forward, quantise (identity gradient), the same blocks reversed: the
+    gradient of an l2 + l1 loss w.r.t. every weight, as SelfCModel.optimize_parameters composes it
+    (SelfC_model.py:153-171) minus the STP sampling."""
+    from selfc_amd.modules.Inv_arch import InvBlockExp
+    from selfc_amd.modules.Quantization import Quantization
+    from selfc_amd.modules.SelfC_GMM_arch_inv import FrequencyAnalyzer
+    from selfc_amd.modules.Subnet_constructor import subnet
+    torch.manual_seed(3)
+    blocks = torch.nn.ModuleList([InvBlockExp(subnet("D2DTNet", "xavier"), 51, 3) for _ in range(2)])
+    sd = {k: v.detach().clone() for k, v in blocks.state_dict().items()}
+    x = torch.rand(T, 3, 48, 32)
+    ref_l = torch.rand(T, 3, 12, 8)
+    noise = torch.randn(T, 48, 12, 8) * 0.05       # stands in for the STP sample: keeps |rec - x| away from the l1 kink
+
+    def loss_fn(fwd_blk, quant, freq_f, freq_r, xx):
+        z = freq_f(xx)
+        for i in range(2):
+            z = fwd_blk(i, z, False)
+        lr = z[:, :3]
+        l_fit = ((lr - ref_l.to(xx.device)) ** 2).mean()
+        zq = torch.cat((quant(lr), z[:, 3:] * 0.7 + noise.to(xx.device)), 1)
+        for i in (1, 0):
+            zq = fwd_blk(i, zq, True)
+        rec = freq_r(zq)
+        d = rec - xx
+        l_rec = torch.sqrt(d * d + 1e-6).mean()
+        return (l_fit + l_rec) * 144 * 144 * 3
+
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+
+    class STE(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, v):
+            return O.quantize(v)
+
+        @staticmethod
+        def backward(ctx, gg):
+            return gg
+
+    loss_ref = loss_fn(lambda i, z, rev: O.invblock("D2DTNet", {k[len(f"{i}."):]: v for k, v in p.items() if k.startswith(f"{i}.")}, z, 3, T, rev=rev)[0],
+                       STE.apply, O.freq_fwd, O.freq_inv, x)
+    loss_ref.backward()
+    blocks.to(dev)
+    fa, q = FrequencyAnalyzer(3), Quantization()
+    loss = loss_fn(lambda i, z, rev: blocks[i](z, rev=rev), q, lambda v: fa(v), lambda v: fa(v, rev=True), x.to(dev))
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 2e-3 * abs(float(loss_ref.detach()))
+    loss.backward()
+    gref = {k: v.grad for k, v in p.items()}
+    errs = {n_: rel_l2(p_.grad.cpu(), gref[n_]) for n_, p_ in blocks.named_parameters()}
+    print("worst", sorted(errs.items(), key=lambda kv: -kv[1])[:5])
+    assert max(errs.values()) < 5e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
