@@ -181,6 +181,25 @@ int selfc_coupling_bwd(int rev, const float* v, const float* s, const float* dy2
 int selfc_freq_fwd_bwd(const float* d1, const float* d2, float* dx, int N, int H, int W, void* stream);
 int selfc_freq_inv_bwd(const float* dout, float* d1, float* d2, int N, int H, int W, void* stream);
 
+/* Building blocks of the host-orchestrated gradients (STP head: selfc_amd/autograd.py).  A "plane" is a 32-channel
+ * f16 slab [N*H*W][32]; gradient planes are scaled by S = grad scale of *amax (selfc_bwd_scale), fp32 results are not. */
+int selfc_bwd_scale(const float* g, size_t n, float* amax, void* stream);                 /* *amax = max|g| (device) */
+/* fp32 rows (stride cs, c channels) -> roundup(c,32)/32 planes: sign * S * (lrelu ? LeakyReLU(x) : x); amax NULL: S = 1 */
+int selfc_bwd_to_planes(const float* x, void* planes, size_t npix, int c, int cs, int lrelu, float sign, const float* amax, void* stream);
+int selfc_f16_rows_to_planes(const void* rows, void* planes, size_t npix, int C, void* stream);   /* f16 [npix][C] -> planes */
+/* Generic plane-list conv with the gradient epilogue: in = nplanes_in contiguous planes, (kt, sp1 ? 1x1 : 3x3) kernel
+ * packed by packing.py:pack_planes_generic, ngroups 32-channel output groups.  v = acc + add[z] (optional planes);
+ * v *= LeakyReLU'(mask) for group mask_z (mask = one plane) or for every group (mask_z == -2, mask = ngroups planes).
+ * Output: f16 planes out_planes[z], or (plain) fp32 rows of stride coutp holding v / S (+ old when accumulate). */
+int selfc_bwd_conv_planes(const void* in, int nplanes_in, int kt, int sp1, const void* w, int ngroups, void* out_planes,
+                          const void* add, const void* mask, int mask_z, float* plain, int coutp, int accumulate,
+                          const float* amax, int N, int T, int H, int W, void* stream);
+size_t selfc_bwd_wgrad_scratch_bytes(int N, int H, int W, int Pn, int Qn, int taps);
+/* wout (O, Ctot, taps) = beta*wout + sum_px P[px][o] * Q[px + tap][c] / S;  bout (O) likewise from column sums of P.
+ * P: Pn gradient planes, Q: Qn activation planes, taps 9 (3x3) or 1. */
+int selfc_bwd_wgrad(const void* P, int Pn, const void* Q, int Qn, int taps, float* wout, int O, int Ctot, float* bout, float beta,
+                    const float* amax, void* scratch, size_t scratch_bytes, int N, int T, int H, int W, void* stream);
+
 /* ---- STP (self-conditioned latent predictor), activations fp32 NHWC [N][H*W][64] -------------
  *
  * GlobalAgg.forward: SelfC_GMM_arch_inv.py:265-285.  y = x + (proj1(x) viewed (b,C*h*w,T)) @ A,
@@ -215,6 +234,21 @@ int selfc_gmm_sample(const float* raw, const float* eps, float* v, size_t npix, 
 int selfc_profile_enable(int on);
 int selfc_profile_read(int cls, double* total_ms, long long* launches);   /* waits for the recorded events */
 int selfc_profile_reset(void);
+
+/* ---- STP gradients (csrc/stp.hip) ---- */
+/* d raw of selfc_gmm_sample given dv: raw/draw [npix][hf_dim*K*3], eps [npix][hf_dim*K], dv [npix][hf_dim]. */
+int selfc_gmm_sample_bwd(const float* raw, const float* eps, const float* dv, float* draw, size_t npix, int hf_dim, int K, void* stream);
+int selfc_lrelu_bwd(float* dx, const float* x, size_t n, void* stream);       /* dx *= (x > 0 ? 1 : 0.2), n % 4 == 0 */
+size_t selfc_globalagg_bwd_scratch_bytes(int N, int T, int H, int W);
+/* Backward of selfc_globalagg_run (GlobalAgg.forward, SelfC_GMM_arch_inv.py:265-285): x, dy, dx fp32 [N][H*W][64];
+ * w1t = pack_planes_generic(proj1.weight^T).  Parameter gradients: dw1 (64,64) complete; the others per clip
+ * ([B][64], [B][64*64], [B], dwmap_clip [B][H*W]) - the caller sums over clips and folds dwmap through the pooling
+ * map (packing.py:pool_weight_map) into fc.weight. */
+int selfc_globalagg_bwd(const float* x, const float* dy, float* dx, const float* wmap, float fc_bias, const void* w1t,
+                        const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                        float* dw1, float* db1_clip, float* dw2_clip, float* db2_clip, float* dw3_clip, float* db3_clip,
+                        float* dfcb_clip, float* dwmap_clip, void* scratch, size_t scratch_bytes,
+                        int N, int T, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

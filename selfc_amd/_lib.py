@@ -36,6 +36,9 @@ SYMBOLS = [
     "selfc_globalagg_run", "selfc_globalagg_partial_floats", "selfc_pwconv_run", "selfc_gmm_sample",
     "selfc_conv_planes_run", "selfc_nhwc_to_planes", "selfc_y_sse", "selfc_y_sse_blocks", "selfc_gauss_down4",
     "selfc_subnet_bwd_scratch_bytes", "selfc_subnet_bwd", "selfc_coupling_bwd", "selfc_freq_fwd_bwd", "selfc_freq_inv_bwd",
+    "selfc_bwd_scale", "selfc_bwd_to_planes", "selfc_f16_rows_to_planes", "selfc_bwd_conv_planes",
+    "selfc_bwd_wgrad_scratch_bytes", "selfc_bwd_wgrad", "selfc_gmm_sample_bwd", "selfc_lrelu_bwd",
+    "selfc_globalagg_bwd_scratch_bytes", "selfc_globalagg_bwd",
 ]
 
 
@@ -109,12 +112,24 @@ def lib():
             "selfc_coupling_bwd": [i, vp, vp, vp, vp, vp, f, sz, vp],
             "selfc_freq_fwd_bwd": [vp, vp, vp, i, i, i, vp],
             "selfc_freq_inv_bwd": [vp, vp, vp, i, i, i, vp],
+            "selfc_bwd_scale": [vp, sz, vp, vp],
+            "selfc_bwd_to_planes": [vp, vp, sz, i, i, i, f, vp, vp],
+            "selfc_f16_rows_to_planes": [vp, vp, sz, i, vp],
+            "selfc_bwd_conv_planes": [vp, i, i, i, vp, i, vp, vp, vp, i, vp, i, i, vp, i, i, i, i, vp],
+            "selfc_bwd_wgrad": [vp, i, vp, i, i, vp, i, i, vp, f, vp, vp, sz, i, i, i, i, vp],
+            "selfc_gmm_sample_bwd": [vp, vp, vp, vp, sz, i, i, vp],
+            "selfc_lrelu_bwd": [vp, vp, sz, vp],
+            "selfc_globalagg_bwd": [vp, vp, vp, vp, f, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, i, vp],
         }
         for name, args in sigs.items():
             fn = getattr(L, name)
             fn.restype = i
             fn.argtypes = args
         L.selfc_y_sse_blocks.restype = i
+        L.selfc_bwd_wgrad_scratch_bytes.restype = sz
+        L.selfc_bwd_wgrad_scratch_bytes.argtypes = [i, i, i, i, i, i]
+        L.selfc_globalagg_bwd_scratch_bytes.restype = sz
+        L.selfc_globalagg_bwd_scratch_bytes.argtypes = [i, i, i, i]
         L.selfc_subnet_bwd_scratch_bytes.restype = sz
         L.selfc_subnet_bwd_scratch_bytes.argtypes = [i, i, i, i, i]
         L.selfc_globalagg_partial_floats.restype = sz

@@ -13,7 +13,8 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _lib, runtime as rt
-from .packing import dense_channels, pack_subnet_bwd, roundup
+from .packing import (dense_channels, pack_planes_generic, pack_pointwise_T, pack_subnet_bwd, pool_weight_map_grad,
+                      roundup)
 
 _SCRATCH: Dict[Tuple, torch.Tensor] = {}
 
@@ -229,3 +230,221 @@ class FreqFn(torch.autograd.Function):
 
 def needs_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# STP (SelfC_GMM_arch_inv.py:289-430): GlobalAgg, the 1x1x1 head and the GMM sampler
+# ------------------------------------------------------------------------------------------------------------
+
+def _buf(cache: Dict, name: str, nbytes: int, device) -> torch.Tensor:
+    b = cache.get(name)
+    if b is None or b.numel() < nbytes or b.device != device:
+        b = cache[name] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return b
+
+
+_STP_CACHE: Dict = {}
+
+
+def globalagg_bwd(m, x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, n: int, t: int, h: int, w: int) -> Dict[str, torch.Tensor]:
+    """Backward of GlobalAgg.run_nhwc: x, dy, dx fp32 [n][h*w][64]; returns {parameter name: gradient}."""
+    pk = m._packed(h, w)
+    key = rt.params_key(m)
+    if getattr(m, "_w1t_key", None) != key:
+        m._w1t = pack_planes_generic(m.proj1.weight.detach().float().reshape(64, 64).t().reshape(64, 64, 1, 1).contiguous())
+        m._w1t_key = key
+    dev, b = x.device, n // t
+    f32 = dict(dtype=torch.float32, device=dev)
+    dw1 = torch.empty((64, 64), **f32)
+    db1c, db2c, db3c = (torch.empty((b, 64), **f32) for _ in range(3))
+    dw2c, dw3c = (torch.empty((b, 64 * 64), **f32) for _ in range(2))
+    dfcbc = torch.empty((b,), **f32)
+    dwmapc = torch.empty((b, h * w), **f32)
+    need = _lib.lib().selfc_globalagg_bwd_scratch_bytes(n, t, h, w)
+    sc = _buf(_STP_CACHE, "gagg", need, dev)
+    rt.call("selfc_globalagg_bwd", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), pk["wmap"].data_ptr(), pk["fcb"],
+            m._w1t.data_ptr(), pk["b1"].data_ptr(), pk["w2"].data_ptr(), pk["b2"].data_ptr(), pk["w3"].data_ptr(), pk["b3"].data_ptr(),
+            dw1.data_ptr(), db1c.data_ptr(), dw2c.data_ptr(), db2c.data_ptr(), dw3c.data_ptr(), db3c.data_ptr(),
+            dfcbc.data_ptr(), dwmapc.data_ptr(), sc.data_ptr(), sc.numel(), n, t, h, w, _lib.stream_ptr())
+    return {"proj1.weight": dw1.reshape(64, 64, 1, 1), "proj1.bias": db1c.sum(0),
+            "proj2.weight": dw2c.sum(0).reshape(64, 64), "proj2.bias": db2c.sum(0),
+            "proj3.weight": dw3c.sum(0).reshape(64, 64), "proj3.bias": db3c.sum(0),
+            "fc.weight": pool_weight_map_grad(dwmapc.sum(0), h, w), "fc.bias": dfcbc.sum().reshape(1)}
+
+
+class GlobalAggFn(torch.autograd.Function):
+    """GlobalAgg.forward (SelfC_GMM_arch_inv.py:265-285), NCHW in/out."""
+
+    @staticmethod
+    def forward(ctx, x, mod, t, *params):
+        x = rt.as_input(x)
+        n, c, h, w = x.shape
+        sp = _lib.stream_ptr()
+        xin = torch.empty((n, h * w, 64), dtype=torch.float32, device=x.device)
+        rt.call("selfc_nchw_to_nhwc4", x.data_ptr(), xin.data_ptr(), n, 64, h, w, sp)
+        yout = torch.empty_like(xin)
+        mod.run_nhwc(xin, yout, n, t, h, w, mod.__dict__.setdefault("_scratch", {}))
+        y = torch.empty_like(x)
+        rt.call("selfc_nhwc4_to_nchw", yout.data_ptr(), y.data_ptr(), n, 64, h, w, sp)
+        ctx.mod, ctx.t, ctx.xin, ctx.shape = mod, t, xin, (n, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        mod, t, xin = ctx.mod, ctx.t, ctx.xin
+        n, h, w = ctx.shape
+        gy = gy.contiguous().float()
+        sp = _lib.stream_ptr()
+        dy = torch.empty_like(xin)
+        rt.call("selfc_nchw_to_nhwc4", gy.data_ptr(), dy.data_ptr(), n, 64, h, w, sp)
+        dxl = torch.empty_like(xin)
+        g = globalagg_bwd(mod, xin, dy, dxl, n, t, h, w)
+        dx = torch.empty((n, 64, h, w), dtype=torch.float32, device=gy.device)
+        rt.call("selfc_nhwc4_to_nchw", dxl.data_ptr(), dx.data_ptr(), n, 64, h, w, sp)
+        return (dx, None, None, *[g[name] for name, _ in mod.named_parameters()])
+
+
+def _head_convs(stp):
+    return [m for m in stp.tail_gmm if isinstance(m, torch.nn.Conv3d)]
+
+
+def _head_bwd(stp, feat, acts, dlast, n, t, h, w) -> Tuple[torch.Tensor, Dict[int, Tuple[torch.Tensor, torch.Tensor]]]:
+    """Backward of tail_gmm = [lrelu, conv1x1x1]* given d(last conv output) `dlast` fp32 [npix][Cl].
+    feat: fp32 [npix][64] (input of the head), acts: the saved post-LeakyReLU f16 rows of the hidden layers.
+    Returns (dfeat fp32 [npix][64], {conv index: (dweight, dbias)})."""
+    convs = _head_convs(stp)
+    dev, sp = feat.device, _lib.stream_ptr()
+    npix = n * h * w
+    F16 = _lib.operand_dtype()
+    L = _lib.lib()
+    amax = torch.zeros(64, dtype=torch.float32, device=dev)
+    rt.call("selfc_bwd_scale", dlast.data_ptr(), dlast.numel(), amax.data_ptr(), sp)
+    cl = convs[-1].out_channels
+    gp = torch.empty((roundup(cl, 32) // 32, npix, 32), dtype=F16, device=dev)
+    rt.call("selfc_bwd_to_planes", dlast.data_ptr(), gp.data_ptr(), npix, cl, dlast.shape[-1], 0, 1.0, amax.data_ptr(), sp)
+    # activation planes: lrelu(feat), then the hidden activations
+    inputs = [torch.empty((2, npix, 32), dtype=F16, device=dev)]
+    rt.call("selfc_bwd_to_planes", feat.data_ptr(), inputs[0].data_ptr(), npix, 64, 64, 1, 1.0, None, sp)
+    for a in acts:
+        c = a.shape[-1]
+        pl = torch.empty((c // 32, npix, 32), dtype=F16, device=dev)
+        rt.call("selfc_f16_rows_to_planes", a.data_ptr(), pl.data_ptr(), npix, c, sp)
+        inputs.append(pl)
+    grads: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+    dfeat = torch.empty((npix, 64), dtype=torch.float32, device=dev)
+    for li in range(len(convs) - 1, -1, -1):
+        conv, q = convs[li], inputs[li]
+        cout, cin = conv.out_channels, conv.in_channels
+        pn, qn = gp.shape[0], q.shape[0]
+        need = L.selfc_bwd_wgrad_scratch_bytes(n, h, w, pn, qn, 1)
+        sc = _buf(_STP_CACHE, "wgrad", need, dev)
+        gw = torch.empty((cout, cin), dtype=torch.float32, device=dev)
+        gb = torch.empty((cout,), dtype=torch.float32, device=dev)
+        rt.call("selfc_bwd_wgrad", gp.data_ptr(), pn, q.data_ptr(), qn, 1, gw.data_ptr(), cout, cin, gb.data_ptr(), 0.0,
+                amax.data_ptr(), sc.data_ptr(), sc.numel(), n, t, h, w, sp)
+        grads[li] = (gw.reshape(conv.weight.shape), gb)
+        wt = pack_pointwise_T(conv.weight)
+        if li > 0:
+            nxt = torch.empty((cin // 32, npix, 32), dtype=F16, device=dev)
+            rt.call("selfc_bwd_conv_planes", gp.data_ptr(), pn, 1, 1, wt.data_ptr(), cin // 32, nxt.data_ptr(), None,
+                    q.data_ptr(), -2, None, 0, 0, amax.data_ptr(), n, t, h, w, sp)
+            gp = nxt
+        else:
+            rt.call("selfc_bwd_conv_planes", gp.data_ptr(), pn, 1, 1, wt.data_ptr(), 2, None, None, None, -1,
+                    dfeat.data_ptr(), 64, 0, amax.data_ptr(), n, t, h, w, sp)
+            rt.call("selfc_lrelu_bwd", dfeat.data_ptr(), feat.data_ptr(), dfeat.numel(), sp)
+    return dfeat, grads
+
+
+class STPSampleFn(torch.autograd.Function):
+    """STPNet.forward + sample() (SelfC_GMM_arch_inv.py:358-394) as one differentiable op:
+    lr (N,3,h,w) -> predicted HF (N,48,h,w) ('gmm': the reparameterised sample, 'l2': the head output)."""
+
+    @staticmethod
+    def forward(ctx, lr, stp, t, eps, *params):
+        from .modules.Subnet_constructor import D2DTInput
+        lr = rt.as_input(lr)
+        n, _, h, w = lr.shape
+        dev, sp = lr.device, _lib.stream_ptr()
+        F16 = _lib.operand_dtype()
+        npix = n * h * w
+        x1 = torch.empty((n, h, w, 4), dtype=torch.float32, device=dev)
+        rt.call("selfc_nchw_to_nhwc4", lr.data_ptr(), x1.data_ptr(), n, 3, h, w, sp)
+        stages, cur = [], x1
+        scratch = stp.__dict__.setdefault("_scratch_train", {})
+        for m in stp._chain():
+            dst = torch.empty((n, h * w, 64), dtype=torch.float32, device=dev)
+            if isinstance(m, D2DTInput):
+                dense = torch.zeros((dense_channels(m.channel_in) // 32, n, h, w, 32), dtype=F16, device=dev)
+                sw = m.packed().struct()
+                rt.call("selfc_subnet_run", sw, m.kind, cur.data_ptr(), dst.data_ptr(), dense.data_ptr(),
+                        n, t, h, w, m.channel_in, m.channel_out, sp)
+                stages.append((m, cur if m.channel_in <= 3 else None, dense))
+            else:
+                m.run_nhwc(cur, dst, n, t, h, w, scratch)
+                stages.append((m, cur, None))
+            cur = dst
+        feat = cur
+        tail = stp._tail_packed()
+        hf = torch.empty((npix, stp.hf_dim), dtype=torch.float32, device=dev)
+        acts, raw = [], None
+        if stp.fh_loss == "l2":
+            wp, bp, cin, cout = tail[0]
+            rt.call("selfc_pwconv_run", feat.data_ptr(), 1, hf.data_ptr(), 1, wp.data_ptr(), bp.data_ptr(), npix, cin, cout, cout, 1, 0, sp)
+        else:
+            (w0, b0, ci0, co0), (w1_, b1_, ci1, co1), (w2_, b2_, ci2, co2) = tail
+            h1 = torch.empty((npix, co0), dtype=F16, device=dev)
+            h2 = torch.empty((npix, co1), dtype=F16, device=dev)
+            raw = torch.empty((npix, co2), dtype=torch.float32, device=dev)
+            rt.call("selfc_pwconv_run", feat.data_ptr(), 1, h1.data_ptr(), 0, w0.data_ptr(), b0.data_ptr(), npix, ci0, co0, co0, 1, 1, sp)
+            rt.call("selfc_pwconv_run", h1.data_ptr(), 0, h2.data_ptr(), 0, w1_.data_ptr(), b1_.data_ptr(), npix, ci1, co1, co1, 0, 1, sp)
+            rt.call("selfc_pwconv_run", h2.data_ptr(), 0, raw.data_ptr(), 1, w2_.data_ptr(), b2_.data_ptr(), npix, ci2, co2, co2, 0, 0, sp)
+            if eps is None:
+                eps = torch.randn((npix, stp.hf_dim * stp.K), dtype=torch.float32, device=dev)
+            rt.call("selfc_gmm_sample", raw.data_ptr(), eps.data_ptr(), hf.data_ptr(), npix, stp.hf_dim, stp.K, sp)
+            acts = [h1, h2]
+        y = torch.empty((n, stp.hf_dim, h, w), dtype=torch.float32, device=dev)
+        rt.call("selfc_nhwc4_to_nchw", hf.data_ptr(), y.data_ptr(), n, stp.hf_dim, h, w, sp)
+        ctx.stp, ctx.t, ctx.shape = stp, t, (n, h, w)
+        ctx.stages, ctx.feat, ctx.acts, ctx.raw, ctx.eps = stages, feat, acts, raw, eps
+        ctx.nparams = len(params)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .modules.Subnet_constructor import D2DTInput
+        stp, t = ctx.stp, ctx.t
+        n, h, w = ctx.shape
+        gy = gy.contiguous().float()
+        dev, sp = gy.device, _lib.stream_ptr()
+        npix = n * h * w
+        dv = torch.empty((npix, stp.hf_dim), dtype=torch.float32, device=dev)
+        rt.call("selfc_nchw_to_nhwc4", gy.data_ptr(), dv.data_ptr(), n, stp.hf_dim, h, w, sp)
+        if stp.fh_loss == "l2":
+            dlast = dv
+        else:
+            dlast = torch.empty_like(ctx.raw)
+            rt.call("selfc_gmm_sample_bwd", ctx.raw.data_ptr(), ctx.eps.data_ptr(), dv.data_ptr(), dlast.data_ptr(), npix, stp.hf_dim, stp.K, sp)
+        d, head_grads = _head_bwd(stp, ctx.feat, ctx.acts, dlast, n, t, h, w)
+        grads: Dict[int, torch.Tensor] = {}
+        for conv, (gw, gb) in zip(_head_convs(stp), [head_grads[i] for i in range(len(head_grads))]):
+            grads[id(conv.weight)], grads[id(conv.bias)] = gw, gb
+        d = d.reshape(n, h * w, 64)
+        for m, xin, dense in reversed(ctx.stages):
+            if isinstance(m, D2DTInput):
+                dxl = torch.empty((n, h, w, roundup(m.channel_in, 4)), dtype=torch.float32, device=dev)
+                g = subnet_bwd(m, dense, xin, d, 1.0, dxl, False, n, t, h, w, True)
+                for prm, gg in zip(subnet_params(m), g):
+                    grads[id(prm)] = gg
+                d = dxl
+            else:
+                dxl = torch.empty_like(d)
+                g = globalagg_bwd(m, xin, d.reshape(n, h * w, 64), dxl, n, t, h, w)
+                for name, prm in m.named_parameters():
+                    grads[id(prm)] = g[name]
+                d = dxl
+        dlr = None
+        if ctx.needs_input_grad[0]:
+            dlr = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
+            rt.call("selfc_nhwc4_to_nchw", d.data_ptr(), dlr.data_ptr(), n, 3, h, w, sp)
+        return (dlr, None, None, None, *[grads.get(id(p)) for p in stp.parameters()])

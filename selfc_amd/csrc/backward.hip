@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g
 
 // item = (pixel, 8-channel chunk of the padded planes): 16-byte stores
 __global__ __launch_bounds__(256) void grad_to_planes_kernel(const float* __restrict__ g, f16* __restrict__ planes, size_t npix,
-                                                             int c, int cs, int nplanes, float sign, const float* __restrict__ amax) {
-  const float sc = sign * grad_scale(*amax);
+                                                             int c, int cs, int nplanes, int lrelu, float sign, const float* __restrict__ amax) {
+  const float sc = amax ? sign * grad_scale(*amax) : sign;
   const size_t total = npix * (size_t)nplanes * 4;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256) void grad_to_planes_kernel(const float* __rest
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int ch = ch0 + e;
-    o[e] = (f16)((ch < c) ? g[pix * cs + ch] * sc : 0.f);
+    float v = (ch < c) ? g[pix * cs + ch] : 0.f;
+    if (lrelu) v = lrelu02(v);
+    o[e] = (f16)(v * sc);
   }
   *reinterpret_cast<f16x8*>(planes + (size_t)(ch0 >> 5) * npix * 32 + pix * 32 + (ch0 & 31)) = o;
 }
@@ -314,8 +316,9 @@ BwdLayout bwd_layout(int N, int H, int W, int cin, int cout) {
   const size_t npix = (size_t)N * H * W;
   L.plane_b = npix * 64;
   const int ntiles = N * ((H + 15) / 16) * ((W + 15) / 16);
-  L.nsplit = ntiles < 24 ? ntiles : 24;
-  L.bsplit = 32;
+  (void)ntiles;
+  L.nsplit = bwd_wgrad_nsplit(N, H, W);
+  L.bsplit = BWD_BSPLIT;
   L.off_g = 4 * L.plane_b;
   L.off_t5 = L.off_g + (size_t)L.ng * L.plane_b;
   L.off_xplane = L.off_t5 + (size_t)(L.nx + 3) * L.plane_b;
@@ -335,6 +338,71 @@ int launch_wgrad(const WgArgs& a, int nsplit, int Qn, int Pn, hipStream_t s) {
 }
 
 }  // namespace
+
+namespace selfc {
+
+int bwd_absmax(const float* g, size_t n, float* amax, hipStream_t s) {
+  int rc = hip_rc(hipMemsetAsync(amax, 0, sizeof(float), s));
+  if (rc) return rc;
+  const size_t nb = (n + 256 * 16 - 1) / (256 * 16);
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb))), dim3(256), 0, s, g, n, (unsigned*)amax);
+  return hip_rc(hipGetLastError());
+}
+
+int bwd_to_planes(const float* x, void* planes, size_t npix, int c, int cs, int nplanes, int lrelu, float sign,
+                  const float* amax, hipStream_t s) {
+  const size_t items = npix * (size_t)nplanes * 4;
+  hipLaunchKernelGGL(grad_to_planes_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
+                     x, (f16*)planes, npix, c, cs, nplanes, lrelu, sign, amax);
+  return hip_rc(hipGetLastError());
+}
+
+int bwd_wgrad_nsplit(int N, int H, int W) {
+  const long ntiles = (long)N * ((H + 15) / 16) * ((W + 15) / 16);
+  return (int)(ntiles < 24 ? ntiles : 24);
+}
+
+size_t bwd_wgrad_part_bytes(int nsplit, int Pn, int qtot, int ttot) {
+  return (size_t)nsplit * 4 * Pn * qtot * ttot * 4096;
+}
+
+int bwd_wgrad(const WgradJob& j, const float* amax, float* part, float* partb, int nsplit, int N, int T, int H, int W, hipStream_t s) {
+  const size_t npix = (size_t)N * H * W, plane = npix * 32;
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+  const int qtot = j.Qn[0] + j.Qn[1];
+  const int ttot = j.taps == 9 ? 9 : (j.temporal ? 3 : 1);
+  int rc;
+  if (j.wout) {
+    for (int dt = j.temporal ? -1 : 0; dt <= (j.temporal ? 1 : 0); ++dt) {
+      WgArgs a{};
+      a.P = (const f16*)j.P; a.part = part; a.plane = plane;
+      a.N = N; a.T = T; a.H = H; a.W = W; a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.ntiles = N * tiles_x * tiles_y;
+      a.dt = dt; a.qtot = qtot; a.ttot = ttot; a.tap0 = j.temporal ? dt + 1 : 0;
+      int q0 = 0;
+      for (int r = 0; r < 2; ++r) {
+        if (j.Qn[r] <= 0) continue;
+        a.Q = (const f16*)j.Q[r]; a.q0 = q0;
+        rc = j.taps == 9 ? launch_wgrad<9>(a, nsplit, j.Qn[r], j.Pn, s) : launch_wgrad<1>(a, nsplit, j.Qn[r], j.Pn, s);
+        if (rc) return rc;
+        q0 += j.Qn[r];
+      }
+    }
+    FinArgs f{};
+    f.part = part; f.out = j.wout; f.nW = nsplit * 4; f.Pn = j.Pn; f.qtot = qtot; f.ttot = ttot;
+    f.O = j.O; f.Ctot = j.Ctot; f.cin = j.cin; f.nx = j.nx; f.amax = amax; f.beta = j.beta;
+    const size_t per = (size_t)j.Pn * qtot * ttot * 1024;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, f);
+    if ((rc = hip_rc(hipGetLastError()))) return rc;
+  }
+  if (j.bout) {
+    hipLaunchKernelGGL(bias_partial_kernel, dim3((unsigned)BWD_BSPLIT, (unsigned)j.Pn), dim3(256), 0, s, (const f16*)j.P, plane, npix, partb);
+    hipLaunchKernelGGL(bias_finish_kernel, dim3((unsigned)((j.O + 63) / 64)), dim3(64), 0, s, partb, BWD_BSPLIT, j.Pn, j.O, j.bout, amax, j.beta);
+    if ((rc = hip_rc(hipGetLastError()))) return rc;
+  }
+  return SELFC_OK;
+}
+
+}  // namespace selfc
 
 extern "C" {
 
@@ -370,16 +438,8 @@ int selfc_subnet_bwd(const selfc_subnet_bw* bw, int kind, const void* dense, con
   int rc;
 
   // 1. scale + scaled f16 planes of dOut
-  if ((rc = hip_rc(hipMemsetAsync(amax, 0, sizeof(float), s)))) return rc;
-  {
-    const size_t n = npix * coutp;
-    const unsigned nb = (unsigned)((n + 256 * 16 - 1) / (256 * 16));
-    hipLaunchKernelGGL(absmax_kernel, dim3(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb)), dim3(256), 0, s, dout, n, (unsigned*)amax);
-    const size_t items = npix * (size_t)L.ng * 4;
-    hipLaunchKernelGGL(grad_to_planes_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
-                       dout, gpl, npix, cout, coutp, L.ng, sign, amax);
-    if ((rc = hip_rc(hipGetLastError()))) return rc;
-  }
+  if ((rc = bwd_absmax(dout, npix * coutp, amax, s))) return rc;
+  if ((rc = bwd_to_planes(dout, gpl, npix, cout, coutp, L.ng, 0, sign, amax, s))) return rc;
   if (L.hasx && (rc = selfc_nhwc_to_planes(xin, xpl, npix, cin, stream))) return rc;
 
   // 2. conv5^T(dOut): x-groups and f1..f3 as addend planes, f4 masked straight into dpre4
@@ -412,49 +472,20 @@ int selfc_subnet_bwd(const selfc_subnet_bw* bw, int kind, const void* dense, con
   if (!wgrad && !bgrad) return SELFC_OK;
 
   // 5. weight / bias gradients
-  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
   for (int k = 1; k <= 5; ++k) {
-    const f16* P = k <= 4 ? gb + (size_t)(4 - k) * plane : gpl;
-    const int Pn = k <= 4 ? 1 : L.ng;
     const int nfeat = k <= 4 ? k - 1 : 4;
-    const int qtot = L.nx + nfeat;
-    const bool temporal = k == 5 && d2dt;
-    const int ttot = temporal ? 3 : 9;
-    if (wgrad && wgrad[k - 1]) {
-      for (int dt = temporal ? -1 : 0; dt <= (temporal ? 1 : 0); ++dt) {
-        WgArgs a{};
-        a.P = P; a.part = part; a.plane = plane;
-        a.N = N; a.T = T; a.H = H; a.W = W; a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.ntiles = N * tiles_x * tiles_y;
-        a.dt = dt; a.qtot = qtot; a.ttot = ttot; a.tap0 = temporal ? dt + 1 : 0;
-        // input planes: [x planes][f1..]; with cin <= 3 the x plane is the scratch copy, the features start `dense`
-        if (L.hasx) {
-          a.Q = xpl; a.q0 = 0;
-          rc = temporal ? launch_wgrad<1>(a, L.nsplit, 1, Pn, s) : launch_wgrad<9>(a, L.nsplit, 1, Pn, s);
-          if (rc) return rc;
-          if (nfeat) {
-            a.Q = feat; a.q0 = 1;
-            rc = temporal ? launch_wgrad<1>(a, L.nsplit, nfeat, Pn, s) : launch_wgrad<9>(a, L.nsplit, nfeat, Pn, s);
-            if (rc) return rc;
-          }
-        } else {
-          a.Q = dn; a.q0 = 0;
-          rc = temporal ? launch_wgrad<1>(a, L.nsplit, qtot, Pn, s) : launch_wgrad<9>(a, L.nsplit, qtot, Pn, s);
-          if (rc) return rc;
-        }
-      }
-      FinArgs f{};
-      f.part = part; f.out = wgrad[k - 1]; f.nW = L.nsplit * 4; f.Pn = Pn; f.qtot = qtot; f.ttot = ttot;
-      f.O = k <= 4 ? 32 : cout; f.Ctot = cin + 32 * nfeat; f.cin = cin; f.nx = L.nx; f.amax = amax; f.beta = beta;
-      const size_t per = (size_t)Pn * qtot * ttot * 1024;
-      hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, f);
-      if ((rc = hip_rc(hipGetLastError()))) return rc;
-    }
-    if (bgrad && bgrad[k - 1]) {
-      hipLaunchKernelGGL(bias_partial_kernel, dim3((unsigned)L.bsplit, (unsigned)Pn), dim3(256), 0, s, P, plane, npix, partb);
-      const int O = k <= 4 ? 32 : cout;
-      hipLaunchKernelGGL(bias_finish_kernel, dim3((unsigned)((O + 63) / 64)), dim3(64), 0, s, partb, L.bsplit, Pn, O, bgrad[k - 1], amax, beta);
-      if ((rc = hip_rc(hipGetLastError()))) return rc;
-    }
+    WgradJob j{};
+    j.P = k <= 4 ? gb + (size_t)(4 - k) * plane : gpl;
+    j.Pn = k <= 4 ? 1 : L.ng;
+    // input planes: [x planes][f1..]; with cin <= 3 the x plane is the scratch copy and the features start `dense`
+    if (L.hasx) { j.Q[0] = xpl; j.Qn[0] = 1; j.Q[1] = feat; j.Qn[1] = nfeat; }
+    else { j.Q[0] = dn; j.Qn[0] = L.nx + nfeat; }
+    j.temporal = (k == 5 && d2dt) ? 1 : 0;
+    j.taps = j.temporal ? 1 : 9;
+    j.wout = wgrad ? wgrad[k - 1] : nullptr;
+    j.bout = bgrad ? bgrad[k - 1] : nullptr;
+    j.O = k <= 4 ? 32 : cout; j.Ctot = cin + 32 * nfeat; j.cin = cin; j.nx = L.nx; j.beta = beta;
+    if ((rc = bwd_wgrad(j, amax, part, partb, L.nsplit, N, T, H, W, s))) return rc;
   }
   return SELFC_OK;
 }
@@ -483,6 +514,51 @@ int selfc_freq_inv_bwd(const float* dout, float* d1, float* d2, int N, int H, in
   const size_t total = (size_t)N * (H / 4) * (W / 4) * 3;
   hipLaunchKernelGGL(freq_inv_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, d1, d2, N, H, W, 48);
   return hip_rc(hipGetLastError());
+}
+
+// ---- building blocks for gradients that are orchestrated from the host side (STP head, selfc_amd/autograd.py) ----
+int selfc_bwd_scale(const float* g, size_t n, float* amax, void* stream) {
+  if (!g || !amax || n == 0) return SELFC_EINVAL;
+  ProfScope prof(PROF_BWD, (hipStream_t)stream);
+  return bwd_absmax(g, n, amax, (hipStream_t)stream);
+}
+
+int selfc_bwd_to_planes(const float* x, void* planes, size_t npix, int c, int cs, int lrelu, float sign, const float* amax, void* stream) {
+  if (!x || !planes || npix == 0 || c < 1 || cs < c) return SELFC_EINVAL;
+  ProfScope prof(PROF_BWD, (hipStream_t)stream);
+  return bwd_to_planes(x, planes, npix, c, cs, (c + 31) / 32, lrelu, sign, amax, (hipStream_t)stream);
+}
+
+int selfc_bwd_conv_planes(const void* in, int nplanes_in, int kt, int sp1, const void* w, int ngroups, void* out_planes,
+                          const void* add, const void* mask, int mask_z, float* plain, int coutp, int accumulate,
+                          const float* amax, int N, int T, int H, int W, void* stream) {
+  if (!in || !w || nplanes_in < 1 || (kt != 1 && kt != 3) || ngroups < 1 || N <= 0 || T <= 0 || N % T || H <= 0 || W <= 0) return SELFC_EINVAL;
+  if ((out_planes == nullptr) == (plain == nullptr)) return SELFC_EINVAL;
+  if (plain && (!amax || coutp < 4 || (coutp & 3))) return SELFC_EINVAL;
+  ProfScope prof(PROF_BWD, (hipStream_t)stream);
+  BwdConv c{};
+  c.in = in; c.nplanes_in = nplanes_in; c.kt = kt; c.sp1 = sp1; c.w = w; c.ngroups = ngroups; c.out_planes = out_planes;
+  c.add = add; c.mask = mask; c.mask_z = mask_z; c.plain = plain; c.coutp = coutp; c.accumulate = accumulate; c.amax = amax;
+  return bwd_conv_planes(c, N, T, H, W, (hipStream_t)stream);
+}
+
+size_t selfc_bwd_wgrad_scratch_bytes(int N, int H, int W, int Pn, int Qn, int taps) {
+  if (N <= 0 || H <= 0 || W <= 0 || Pn < 1 || Qn < 1 || (taps != 1 && taps != 9)) return 0;
+  return up256((size_t)BWD_BSPLIT * Pn * 32 * sizeof(float)) + bwd_wgrad_part_bytes(bwd_wgrad_nsplit(N, H, W), Pn, Qn, taps);
+}
+
+int selfc_bwd_wgrad(const void* P, int Pn, const void* Q, int Qn, int taps, float* wout, int O, int Ctot, float* bout, float beta,
+                    const float* amax, void* scratch, size_t scratch_bytes, int N, int T, int H, int W, void* stream) {
+  if (!P || !Q || !amax || !scratch || Pn < 1 || Qn < 1 || (taps != 1 && taps != 9)) return SELFC_EINVAL;
+  if (O < 1 || O > 32 * Pn || Ctot < 1 || Ctot > 32 * Qn || N <= 0 || T <= 0 || N % T || H <= 0 || W <= 0) return SELFC_EINVAL;
+  if (scratch_bytes < selfc_bwd_wgrad_scratch_bytes(N, H, W, Pn, Qn, taps)) return SELFC_EINVAL;
+  ProfScope prof(PROF_BWD, (hipStream_t)stream);
+  unsigned char* sb = (unsigned char*)scratch;
+  WgradJob j{};
+  j.P = P; j.Pn = Pn; j.Q[0] = Q; j.Qn[0] = Qn; j.taps = taps; j.temporal = 0;
+  j.wout = wout; j.O = O; j.Ctot = Ctot; j.cin = Ctot; j.nx = Qn; j.bout = bout; j.beta = beta;
+  return bwd_wgrad(j, amax, (float*)(sb + up256((size_t)BWD_BSPLIT * Pn * 32 * sizeof(float))), (float*)sb,
+                   bwd_wgrad_nsplit(N, H, W), N, T, H, W, (hipStream_t)stream);
 }
 
 }  // extern "C"

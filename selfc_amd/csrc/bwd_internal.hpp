@@ -27,4 +27,25 @@ struct BwdConv {
 };
 int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s);
 
+// csrc/backward.hip building blocks (also used by the STP gradients in csrc/stp.hip)
+int bwd_absmax(const float* g, size_t n, float* amax, hipStream_t s);    // *amax = max|g| (zeroed first)
+// fp32 rows (stride cs, c valid channels) -> f16 planes [nplanes][npix][32]: sign * S(*amax) * (lrelu ? LeakyReLU(x) : x);
+// amax == nullptr: no scaling (activations)
+int bwd_to_planes(const float* x, void* planes, size_t npix, int c, int cs, int nplanes, int lrelu, float sign,
+                  const float* amax, hipStream_t s);
+
+struct WgradJob {
+  const void* P; int Pn;            // gradient planes (scaled f16)
+  const void* Q[2]; int Qn[2];      // activation planes: two contiguous runs (the second may be empty)
+  int taps;                         // 9: 3x3 spatial taps; 1: pointwise
+  int temporal;                     // taps == 1 only: three launches at frame offsets -1, 0, +1 -> weight (O, Ctot, 3)
+  float* wout; int O, Ctot, cin, nx; // output layout (O, Ctot, ttot); channel map: first nx planes = cin inputs, rest features
+  float* bout;                      // optional bias gradient (O)
+  float beta;
+};
+size_t bwd_wgrad_part_bytes(int nsplit, int Pn, int qtot, int ttot);
+int bwd_wgrad_nsplit(int N, int H, int W);
+constexpr int BWD_BSPLIT = 32;      // pixel splits of the bias reduction: partb holds BWD_BSPLIT * Pn * 32 floats
+int bwd_wgrad(const WgradJob& j, const float* amax, float* part, float* partb, int nsplit, int N, int T, int H, int W, hipStream_t s);
+
 }  // namespace selfc

@@ -422,7 +422,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
         *reinterpret_cast<u32x4*>(dst + 16 * gp) = v;
       }
     } else if (EPI == EPI_BWD) {
-      const bool masked = a.bw_mask && zg == a.bw_mask_z;
+      const bool masked = a.bw_mask && (a.bw_mask_z == -2 || zg == a.bw_mask_z);     // -2: every group, mask planes z
       float v[4][4];
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
         }
       }
       if (masked) {
-        const f16* __restrict__ mk = a.bw_mask + pix * 32 + 4 * half;
+        const f16* __restrict__ mk = a.bw_mask + (a.bw_mask_z == -2 ? (size_t)zg * a.plane : 0) + pix * 32 + 4 * half;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f16x4 t = *reinterpret_cast<const f16x4*>(mk + 8 * g);

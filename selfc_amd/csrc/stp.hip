@@ -12,6 +12,7 @@
 //                   temporal mix in fp32 registers, then ONE 64x64 MFMA contraction per frame.
 #include "common.hpp"
 #include "prof.hpp"
+#include "bwd_internal.hpp"
 #include "../../include/selfc_hip.h"
 
 using namespace selfc;
@@ -292,6 +293,341 @@ __global__ __launch_bounds__(256) void gmm_sample_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// gradients (training): GMM sampler, GlobalAgg, small elementwise helpers
+// ---------------------------------------------------------------------------------------------------------
+// d raw of v[c] = sum_k pi[c][k] (eps exp(clamp(ls)) + mu), pi = softmax over c: same lane layout as the sampler
+template <int K>
+__global__ __launch_bounds__(256) void gmm_sample_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ eps,
+                                                             const float* __restrict__ dv, float* __restrict__ draw, size_t npix) {
+  constexpr int HF = 48, CP = HF / 16;
+  const size_t px = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int j = threadIdx.x & 15;
+  const bool ok = px < npix;
+  const size_t pc = ok ? px : npix - 1;
+  float r[CP][K * 3], e[CP][K], g[CP];
+#pragma unroll
+  for (int i = 0; i < CP; ++i) {
+    const int c = j + 16 * i;
+    const float* p = raw + pc * (HF * K * 3) + (size_t)c * K * 3;
+#pragma unroll
+    for (int q = 0; q < K * 3; ++q) r[i][q] = p[q];
+    const float* pe = eps + pc * (HF * K) + (size_t)c * K;
+#pragma unroll
+    for (int q = 0; q < K; ++q) e[i][q] = pe[q];
+    g[i] = dv[pc * HF + c];
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float mx = r[0][3 * k];
+#pragma unroll
+    for (int i = 1; i < CP; ++i) mx = fmaxf(mx, r[i][3 * k]);
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16));
+    float ex[CP], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CP; ++i) { ex[i] = expf(r[i][3 * k] - mx); s += ex[i]; }
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) s += __shfl_xor(s, d, 16);
+    float pi[CP], dpi[CP], sg[CP], dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < CP; ++i) {
+      pi[i] = ex[i] / s;
+      sg[i] = expf(fminf(fmaxf(r[i][3 * k + 1], -7.f), 7.f));
+      dpi[i] = g[i] * (e[i][k] * sg[i] + r[i][3 * k + 2]);
+      dot += pi[i] * dpi[i];
+    }
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) dot += __shfl_xor(dot, d, 16);
+    if (ok) {
+#pragma unroll
+      for (int i = 0; i < CP; ++i) {
+        float* o = draw + px * (HF * K * 3) + (size_t)(j + 16 * i) * K * 3 + 3 * k;
+        const float lsr = r[i][3 * k + 1];
+        o[0] = pi[i] * (dpi[i] - dot);
+        o[1] = (lsr >= -7.f && lsr <= 7.f) ? g[i] * pi[i] * e[i][k] * sg[i] : 0.f;
+        o[2] = g[i] * pi[i];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(float4* __restrict__ dx, const float4* __restrict__ x, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 d = dx[i];
+  const float4 v = x[i];
+  d.x *= v.x > 0.f ? 1.f : 0.2f; d.y *= v.y > 0.f ? 1.f : 0.2f; d.z *= v.z > 0.f ? 1.f : 0.2f; d.w *= v.w > 0.f ? 1.f : 0.2f;
+  dx[i] = d;
+}
+
+// f16 rows [npix][C] -> f16 planes [C/32][npix][32] (C a multiple of 32): item = (pixel, 16-byte chunk)
+__global__ __launch_bounds__(256) void rows_to_planes_kernel(const f16* __restrict__ rows, f16* __restrict__ planes, size_t npix, int C) {
+  const int cpp = C / 8;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix * (size_t)cpp) return;
+  const int chunk = (int)(i % cpp);
+  const size_t pix = i / cpp;
+  const int ch0 = chunk * 8;
+  *reinterpret_cast<u32x4*>(planes + (size_t)(ch0 >> 5) * npix * 32 + pix * 32 + (ch0 & 31)) =
+      *reinterpret_cast<const u32x4*>(rows + pix * C + ch0);
+}
+
+// GlobalAgg backward, step 1: per clip and 512-pixel chunk, dAx[t1][t2] = sum_{px,c} x[t1] dz[t2] and dyo[t][o] = sum_px dy[t][o]
+__global__ __launch_bounds__(256) void gagg_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dz, const float* __restrict__ dy,
+                                                              float* __restrict__ pdA, float* __restrict__ pdyo, int T, int HW, int nchunk) {
+  __shared__ float redA[16][TMAX * TMAX + 1];
+  __shared__ float redY[16][TMAX][64];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int cq = threadIdx.x & 15, pr = threadIdx.x >> 4;
+  const int p0 = chunk * POOL_CHUNK, p1 = min(p0 + POOL_CHUNK, HW);
+  float accA[TMAX][TMAX];
+  float4 accY[TMAX];
+#pragma unroll
+  for (int t1 = 0; t1 < TMAX; ++t1) {
+    accY[t1] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t2 = 0; t2 < TMAX; ++t2) accA[t1][t2] = 0.f;
+  }
+  for (int p = p0 + pr; p < p1; p += 16) {
+    float4 xv[TMAX], zv[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+      if (t < T) {
+        const size_t o = ((size_t)(b * T + t) * HW + p) * 64 + cq * 4;
+        xv[t] = *reinterpret_cast<const float4*>(x + o);
+        zv[t] = *reinterpret_cast<const float4*>(dz + o);
+        const float4 d = *reinterpret_cast<const float4*>(dy + o);
+        accY[t].x += d.x; accY[t].y += d.y; accY[t].z += d.z; accY[t].w += d.w;
+      } else {
+        xv[t] = zv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int t1 = 0; t1 < TMAX; ++t1)
+#pragma unroll
+      for (int t2 = 0; t2 < TMAX; ++t2)
+        accA[t1][t2] += xv[t1].x * zv[t2].x + xv[t1].y * zv[t2].y + xv[t1].z * zv[t2].z + xv[t1].w * zv[t2].w;
+  }
+  // sum over the 16 channel-quad lanes (consecutive lanes), then over the 16 pixel rows through LDS
+#pragma unroll
+  for (int t1 = 0; t1 < TMAX; ++t1)
+#pragma unroll
+    for (int t2 = 0; t2 < TMAX; ++t2) {
+      float v = accA[t1][t2];
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) v += __shfl_xor(v, d, 16);
+      if (cq == 0) redA[pr][t1 * TMAX + t2] = v;
+    }
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) *reinterpret_cast<float4*>(&redY[pr][t][cq * 4]) = accY[t];
+  __syncthreads();
+  const size_t ob = (size_t)b * nchunk + chunk;
+  if (threadIdx.x < TMAX * TMAX) {
+    float v = 0.f;
+    for (int r = 0; r < 16; ++r) v += redA[r][threadIdx.x];
+    pdA[ob * 64 + threadIdx.x] = v;
+  }
+  for (int i = threadIdx.x; i < TMAX * 64; i += 256) {
+    const int t = i >> 6, c = i & 63;
+    float v = 0.f;
+    for (int r = 0; r < 16; ++r) v += redY[r][t][c];
+    pdyo[(ob * TMAX + t) * 64 + c] = v;
+  }
+}
+
+// step 2: per clip - recompute g, q, k, A; then the gradients of everything upstream of A (tiny)
+__global__ __launch_bounds__(64) void gagg_attn_bwd_kernel(const float* __restrict__ partial, int nchunk, float fcb,
+                                                           const float* __restrict__ w2, const float* __restrict__ b2,
+                                                           const float* __restrict__ w3, const float* __restrict__ b3,
+                                                           const float* __restrict__ b1, const float* __restrict__ pdA,
+                                                           const float* __restrict__ pdyo, float* __restrict__ A, float* __restrict__ dg,
+                                                           float* __restrict__ db1c, float* __restrict__ dw2c, float* __restrict__ db2c,
+                                                           float* __restrict__ dw3c, float* __restrict__ db3c, float* __restrict__ dfcbc, int T) {
+  __shared__ float g[TMAX][64], q[TMAX][64], k[TMAX][64], m[TMAX][TMAX], a[TMAX][TMAX], dA[TMAX][TMAX], dm[TMAX][TMAX];
+  __shared__ float dyo[TMAX][64], dq[TMAX][64], dk[TMAX][64], dyb[TMAX], red[64];
+  const int b = blockIdx.x, c = threadIdx.x;
+  for (int t = 0; t < T; ++t) {
+    float s = 0.f, sy = 0.f;
+    const float* p = partial + (size_t)(b * T + t) * nchunk * 64 + c;
+    for (int j = 0; j < nchunk; ++j) {
+      s += p[(size_t)j * 64];
+      sy += pdyo[(((size_t)b * nchunk + j) * TMAX + t) * 64 + c];
+    }
+    g[t][c] = s + fcb;
+    dyo[t][c] = sy;
+  }
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    float sq = b2[c], sk = b3[c];
+    for (int j = 0; j < 64; ++j) {
+      sq += g[t][j] * w2[c * 64 + j];
+      sk += g[t][j] * w3[c * 64 + j];
+    }
+    q[t][c] = sq;
+    k[t][c] = sk;
+  }
+  __syncthreads();
+  if (c < T * T) {
+    const int t1 = c / T, t2 = c % T;
+    float s = 0.f;
+    for (int j = 0; j < 64; ++j) s += q[t1][j] * k[t2][j];
+    m[t1][t2] = s / 64.0f;
+    float d = 0.f;
+    for (int j = 0; j < nchunk; ++j) d += pdA[((size_t)b * nchunk + j) * 64 + t1 * TMAX + t2];
+    dA[t1][t2] = d;
+  }
+  if (c < T) {
+    float s = 0.f;
+    for (int o = 0; o < 64; ++o) s += dyo[c][o] * b1[o];
+    dyb[c] = s;
+  }
+  __syncthreads();
+  if (c < T) {
+    float mx = m[c][0];
+    for (int j = 1; j < T; ++j) mx = fmaxf(mx, m[c][j]);
+    float e[TMAX], s = 0.f;
+    for (int j = 0; j < T; ++j) { e[j] = expf(m[c][j] - mx); s += e[j]; }
+    float dot = 0.f;
+    for (int j = 0; j < T; ++j) {
+      a[c][j] = e[j] / s;
+      A[((size_t)b * T + c) * T + j] = a[c][j];
+      dot += a[c][j] * (dA[c][j] + dyb[j]);
+    }
+    for (int j = 0; j < T; ++j) dm[c][j] = a[c][j] * (dA[c][j] + dyb[j] - dot) / 64.0f;
+  }
+  __syncthreads();
+  {
+    float s = 0.f;                                  // db1[o] = sum_t2 dyo[t2][o] * colsum[t2]
+    for (int t2 = 0; t2 < T; ++t2) {
+      float cs = 0.f;
+      for (int t1 = 0; t1 < T; ++t1) cs += a[t1][t2];
+      s += dyo[t2][c] * cs;
+    }
+    db1c[(size_t)b * 64 + c] = s;
+  }
+  float sq2 = 0.f, sk2 = 0.f;
+  for (int t = 0; t < T; ++t) {
+    float vq = 0.f, vk = 0.f;
+    for (int j = 0; j < T; ++j) {
+      vq += dm[t][j] * k[j][c];
+      vk += dm[j][t] * q[j][c];
+    }
+    dq[t][c] = vq;
+    dk[t][c] = vk;
+    sq2 += vq;
+    sk2 += vk;
+  }
+  db2c[(size_t)b * 64 + c] = sq2;
+  db3c[(size_t)b * 64 + c] = sk2;
+  __syncthreads();
+  for (int j = 0; j < 64; ++j) {
+    float v2 = 0.f, v3 = 0.f;
+    for (int t = 0; t < T; ++t) { v2 += dq[t][c] * g[t][j]; v3 += dk[t][c] * g[t][j]; }
+    dw2c[((size_t)b * 64 + c) * 64 + j] = v2;
+    dw3c[((size_t)b * 64 + c) * 64 + j] = v3;
+  }
+  float tot = 0.f;
+  for (int t = 0; t < T; ++t) {
+    float v = 0.f;
+    for (int o = 0; o < 64; ++o) v += dq[t][o] * w2[o * 64 + c] + dk[t][o] * w3[o * 64 + c];
+    dg[((size_t)b * T + t) * 64 + c] = v;
+    tot += v;
+  }
+  red[c] = tot;
+  __syncthreads();
+  if (c == 0) {
+    float v = 0.f;
+    for (int j = 0; j < 64; ++j) v += red[j];
+    dfcbc[b] = v;
+  }
+}
+
+// step 3: dx[t1] = dy[t1] + sum_t2 A[t1][t2] dz[t2] + dg[t1] wmap[px];  dwmap[b][px] = sum_{t,c} dg[t][c] x[t][px][c];
+// z[t2] = sum_t1 A[t1][t2] x[t1] as f16 planes (the activation operand of proj1's weight gradient)
+__global__ __launch_bounds__(256) void gagg_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dz, const float* __restrict__ dy,
+                                                          const float* __restrict__ A, const float* __restrict__ dg, const float* __restrict__ wmap,
+                                                          float* __restrict__ dx, float* __restrict__ dwmapc, f16* __restrict__ zp, int T, int HW, size_t npix_all) {
+  const int b = blockIdx.y;
+  const int cq = threadIdx.x & 15;
+  const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool ok = p < HW;
+  const int pc = ok ? p : HW - 1;
+  const float* Ab = A + (size_t)b * T * T;
+  float4 xv[TMAX], zv[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) {
+    if (t < T) {
+      const size_t o = ((size_t)(b * T + t) * HW + pc) * 64 + cq * 4;
+      xv[t] = *reinterpret_cast<const float4*>(x + o);
+      zv[t] = *reinterpret_cast<const float4*>(dz + o);
+    } else {
+      xv[t] = zv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float wm = wmap[pc];
+  float dw = 0.f;
+#pragma unroll
+  for (int t1 = 0; t1 < TMAX; ++t1) {
+    if (t1 < T) {
+      const size_t o = ((size_t)(b * T + t1) * HW + pc) * 64 + cq * 4;
+      const float4 d = *reinterpret_cast<const float4*>(dy + o);
+      const float4 gg = *reinterpret_cast<const float4*>(dg + ((size_t)b * T + t1) * 64 + cq * 4);
+      float4 r = make_float4(d.x + gg.x * wm, d.y + gg.y * wm, d.z + gg.z * wm, d.w + gg.w * wm);
+      float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int t2 = 0; t2 < TMAX; ++t2) {
+        if (t2 < T) {
+          const float a12 = Ab[t1 * T + t2], a21 = Ab[t2 * T + t1];
+          r.x += a12 * zv[t2].x; r.y += a12 * zv[t2].y; r.z += a12 * zv[t2].z; r.w += a12 * zv[t2].w;
+          zz.x += a21 * xv[t2].x; zz.y += a21 * xv[t2].y; zz.z += a21 * xv[t2].z; zz.w += a21 * xv[t2].w;   // z[t1] = sum_t A[t][t1] x[t]
+        }
+      }
+      dw += gg.x * xv[t1].x + gg.y * xv[t1].y + gg.z * xv[t1].z + gg.w * xv[t1].w;
+      if (ok) {
+        *reinterpret_cast<float4*>(dx + o) = r;
+        uint2 u;
+        u.x = pack2(zz.x, zz.y);
+        u.y = pack2(zz.z, zz.w);
+        const size_t pix = (size_t)(b * T + t1) * HW + pc;
+        *reinterpret_cast<uint2*>(zp + (size_t)(cq >> 3) * npix_all * 32 + pix * 32 + (cq & 7) * 4) = u;
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) dw += __shfl_xor(dw, d, 16);
+  if (ok && cq == 0) dwmapc[(size_t)b * HW + p] = dw;
+}
+
+struct GaggBwdLayout {
+  size_t plane_b, off_dyp, off_zp, off_dz, off_amax, off_pool, off_A, off_pdA, off_pdyo, off_dg, off_partb, off_part, total;
+  int nchunk, nsplit;
+};
+
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+GaggBwdLayout gagg_bwd_layout(int N, int T, int H, int W) {
+  GaggBwdLayout L{};
+  const int HW = H * W, B = N / T;
+  L.nchunk = (HW + POOL_CHUNK - 1) / POOL_CHUNK;
+  L.nsplit = bwd_wgrad_nsplit(N, H, W);
+  L.plane_b = (size_t)N * HW * 64;
+  size_t o = 0;
+  L.off_dyp = o; o += 2 * L.plane_b;
+  L.off_zp = o; o += 2 * L.plane_b;
+  L.off_dz = o; o += 4 * L.plane_b;
+  L.off_amax = o; o += 256;
+  L.off_pool = o; o = up256(o + (size_t)N * L.nchunk * 64 * 4);
+  L.off_A = o; o = up256(o + (size_t)B * T * T * 4);
+  L.off_pdA = o; o = up256(o + (size_t)B * L.nchunk * 64 * 4);
+  L.off_pdyo = o; o = up256(o + (size_t)B * L.nchunk * TMAX * 64 * 4);
+  L.off_dg = o; o = up256(o + (size_t)N * 64 * 4);
+  L.off_partb = o; o = up256(o + (size_t)BWD_BSPLIT * 2 * 32 * 4);
+  L.off_part = o; o = up256(o + bwd_wgrad_part_bytes(L.nsplit, 2, 2, 1));
+  L.total = o;
+  return L;
+}
+
 template <int KS, bool IN_F32, bool OUT_F32>
 int launch_pw(const void* in, void* out, const void* w, const float* bias, size_t npix, int cin, int cout,
               int cout_stride, int lrelu_in, int lrelu_out, hipStream_t s) {
@@ -374,6 +710,85 @@ int selfc_gmm_sample(const float* raw, const float* eps, float* v, size_t npix, 
   else if (K == 1) hipLaunchKernelGGL(gmm_sample_kernel<1>, dim3(grid), dim3(256), 0, s, raw, eps, v, npix);
   else return SELFC_EINVAL;
   return hip_rc(hipGetLastError());
+}
+
+int selfc_gmm_sample_bwd(const float* raw, const float* eps, const float* dv, float* draw, size_t npix, int hf_dim, int K, void* stream) {
+  if (!raw || !eps || !dv || !draw || npix == 0 || hf_dim != 48) return SELFC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(PROF_BWD, s);
+  const unsigned grid = (unsigned)((npix + 15) / 16);
+  if (K == 5) hipLaunchKernelGGL(gmm_sample_bwd_kernel<5>, dim3(grid), dim3(256), 0, s, raw, eps, dv, draw, npix);
+  else if (K == 3) hipLaunchKernelGGL(gmm_sample_bwd_kernel<3>, dim3(grid), dim3(256), 0, s, raw, eps, dv, draw, npix);
+  else if (K == 1) hipLaunchKernelGGL(gmm_sample_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, raw, eps, dv, draw, npix);
+  else return SELFC_EINVAL;
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_lrelu_bwd(float* dx, const float* x, size_t n, void* stream) {
+  if (!dx || !x || n == 0 || (n & 3)) return SELFC_EINVAL;
+  ProfScope prof(PROF_BWD, (hipStream_t)stream);
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float4*)dx, (const float4*)x, n / 4);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_f16_rows_to_planes(const void* rows, void* planes, size_t npix, int C, void* stream) {
+  if (!rows || !planes || npix == 0 || C < 32 || C % 32) return SELFC_EINVAL;
+  ProfScope prof(PROF_BWD, (hipStream_t)stream);
+  const size_t items = npix * (size_t)(C / 8);
+  hipLaunchKernelGGL(rows_to_planes_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)rows, (f16*)planes, npix, C);
+  return hip_rc(hipGetLastError());
+}
+
+size_t selfc_globalagg_bwd_scratch_bytes(int N, int T, int H, int W) {
+  if (N <= 0 || T <= 0 || T > TMAX || N % T || H <= 0 || W <= 0) return 0;
+  return gagg_bwd_layout(N, T, H, W).total;
+}
+
+int selfc_globalagg_bwd(const float* x, const float* dy, float* dx, const float* wmap, float fc_bias, const void* w1t,
+                        const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                        float* dw1, float* db1_clip, float* dw2_clip, float* db2_clip, float* dw3_clip, float* db3_clip,
+                        float* dfcb_clip, float* dwmap_clip, void* scratch, size_t scratch_bytes,
+                        int N, int T, int H, int W, void* stream) {
+  if (!x || !dy || !dx || !wmap || !w1t || !b1 || !w2 || !b2 || !w3 || !b3 || !scratch) return SELFC_EINVAL;
+  if (!dw1 || !db1_clip || !dw2_clip || !db2_clip || !dw3_clip || !db3_clip || !dfcb_clip || !dwmap_clip) return SELFC_EINVAL;
+  if (N <= 0 || T <= 0 || T > TMAX || N % T || H <= 0 || W <= 0 || x == dx) return SELFC_EINVAL;
+  const GaggBwdLayout L = gagg_bwd_layout(N, T, H, W);
+  if (scratch_bytes < L.total) return SELFC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(PROF_BWD, s);
+  unsigned char* sb = (unsigned char*)scratch;
+  const int HW = H * W, B = N / T;
+  const size_t npix = (size_t)N * HW;
+  f16* dyp = (f16*)(sb + L.off_dyp);
+  f16* zp = (f16*)(sb + L.off_zp);
+  float* dz = (float*)(sb + L.off_dz);
+  float* amax = (float*)(sb + L.off_amax);
+  float* pool = (float*)(sb + L.off_pool);
+  float* A = (float*)(sb + L.off_A);
+  float* pdA = (float*)(sb + L.off_pdA);
+  float* pdyo = (float*)(sb + L.off_pdyo);
+  float* dg = (float*)(sb + L.off_dg);
+  int rc;
+  // dz = W1^T dy on the MFMA (scaled f16 planes in, fp32 rows out)
+  if ((rc = bwd_absmax(dy, npix * 64, amax, s))) return rc;
+  if ((rc = bwd_to_planes(dy, dyp, npix, 64, 64, 2, 0, 1.f, amax, s))) return rc;
+  {
+    BwdConv c{};
+    c.in = dyp; c.nplanes_in = 2; c.kt = 1; c.sp1 = 1; c.w = w1t; c.ngroups = 2; c.mask_z = -1;
+    c.plain = dz; c.coutp = 64; c.accumulate = 0; c.amax = amax;
+    if ((rc = bwd_conv_planes(c, N, T, H, W, s))) return rc;
+  }
+  hipLaunchKernelGGL(gagg_pool_kernel, dim3(L.nchunk, N), dim3(256), 0, s, x, wmap, pool, HW, L.nchunk);
+  hipLaunchKernelGGL(gagg_bwd_reduce_kernel, dim3(L.nchunk, B), dim3(256), 0, s, x, dz, dy, pdA, pdyo, T, HW, L.nchunk);
+  hipLaunchKernelGGL(gagg_attn_bwd_kernel, dim3(B), dim3(64), 0, s, pool, L.nchunk, fc_bias, w2, b2, w3, b3, b1, pdA, pdyo, A, dg,
+                     db1_clip, dw2_clip, db2_clip, dw3_clip, db3_clip, dfcb_clip, T);
+  hipLaunchKernelGGL(gagg_bwd_dx_kernel, dim3((unsigned)((HW + 15) / 16), (unsigned)B), dim3(256), 0, s, x, dz, dy, A, dg, wmap, dx,
+                     dwmap_clip, zp, T, HW, npix);
+  if ((rc = hip_rc(hipGetLastError()))) return rc;
+  WgradJob j{};
+  j.P = dyp; j.Pn = 2; j.Q[0] = zp; j.Qn[0] = 2; j.taps = 1; j.temporal = 0;
+  j.wout = dw1; j.O = 64; j.Ctot = 64; j.cin = 64; j.nx = 2; j.beta = 0.f;
+  return bwd_wgrad(j, amax, (float*)(sb + L.off_part), (float*)(sb + L.off_partb), L.nsplit, N, T, H, W, s);
 }
 
 }  // extern "C"

@@ -108,11 +108,13 @@ class GlobalAgg(nn.Module):
 
     def forward(self, x):
         x = rt.as_input(x)
-        rt.no_autograd_guard(x, *self.parameters())
         t = GlobalVar.get_Temporal_LEN()
         n, c, h, w = x.shape
         if not t or n % t or c != 64:
             raise RuntimeError(f"GlobalAgg expects (b*T,64,h,w) with T={t!r}, got {tuple(x.shape)}")
+        from .. import autograd as ag
+        if ag.needs_grad(x, *self.parameters()):
+            return ag.GlobalAggFn.apply(x, self, t, *self.parameters())
         sp = _lib.stream_ptr()
         xin = torch.empty((n, h, w, 64), dtype=torch.float32, device=x.device)
         rt.call("selfc_nchw_to_nhwc4", x.data_ptr(), xin.data_ptr(), n, 64, h, w, sp)
@@ -240,13 +242,30 @@ class STPNet(nn.Module):
         rt.call("selfc_gmm_sample", sc["raw"].data_ptr(), eps.data_ptr(), hf_out.data_ptr(), npix, self.hf_dim, self.K, sp)
         return sc["raw"] if keep_raw else None
 
+    def _eps_rows(self, n, t, h, w, dev):
+        """Injected noise (b, hf_dim, K, t, h, w) as kernel rows [npix][hf_dim*K], or None (device RNG)."""
+        if self.eps is None:
+            return None
+        eps = self.eps.reshape(n // t, self.hf_dim, self.K, t, h, w).permute(0, 3, 4, 5, 1, 2).reshape(n * h * w, self.hf_dim * self.K)
+        return eps.to(device=dev, dtype=torch.float32).contiguous()
+
     # -- reference-shaped API ---------------------------------------------------------------
     def forward(self, x):
         """x (b,3,t,h,w); side effects as in the reference: ``stp_parameters`` (the reference's
         ``self.parameters``, (b,Cp,t,h,w)) and, for GMM heads, ``gmm_v`` (b,hf_dim,t,h,w)."""
         b, c, t, h, w = x.size()
         xf = rt.as_input(x.transpose(1, 2).reshape(b * t, c, h, w))
-        rt.no_autograd_guard(xf, *self.parameters())
+        from .. import autograd as ag
+        if ag.needs_grad(xf, *self.parameters()):
+            # training: one differentiable op for chain + head + sample; `stp_parameters` (the raw head output) is only
+            # exposed for the l2 head here - the reference's GMM likelihood path (neg_llh) is not used by its trainer
+            v = ag.STPSampleFn.apply(xf, self, t, self._eps_rows(b * t, t, h, w, xf.device), *self.parameters())
+            v5 = v.reshape(b, t, -1, h, w).transpose(1, 2)
+            if self.fh_loss == "l2":
+                self.stp_parameters = v5
+            else:
+                self.gmm_v = v5
+            return
         n, sp = b * t, _lib.stream_ptr()
         x1 = torch.empty((n, h, w, 4), dtype=torch.float32, device=xf.device)
         rt.call("selfc_nchw_to_nhwc4", xf.data_ptr(), x1.data_ptr(), n, 3, h, w, sp)
@@ -307,7 +326,9 @@ class SelfCInvNet(nn.Module):
 
     def forward(self, x, rev=False, cal_jacobian=False, lr_before_distor=None):
         x = rt.as_input(x)
-        rt.no_autograd_guard(x, *[p for b in self._blocks() for p in b.parameters()])
+        from .. import autograd as ag
+        if ag.needs_grad(x, *self.parameters()):
+            return self._forward_train(x, rev)
         sp = _lib.stream_ptr()
         arr, nblk = self._stack()
         k = self.operations[0].k
@@ -335,6 +356,27 @@ class SelfCInvNet(nn.Module):
         rt.call("selfc_invstack_run", arr, nblk, lat, 1, sp)
         out = torch.empty((n, 3, h * k, w * k), dtype=torch.float32, device=x.device)
         rt.call("selfc_freq_inv", ws.x1.data_ptr(), ws.x2.data_ptr(), out.data_ptr(), n, h, w, k, sp)
+        return out, recon_hf
+
+    def _forward_train(self, x, rev):
+        """The reference's op loops (:452-490) composed from the differentiable boundary ops (autograd.py): same HIP
+        kernels as inference, one block per call so that each keeps its buffers for the backward."""
+        from .. import autograd as ag
+        t = GlobalVar.get_Temporal_LEN()
+        if not t or x.shape[0] % t:
+            raise RuntimeError(f"GlobalVar temporal length {t!r} does not divide the {x.shape[0]} input frames")
+        if not rev:
+            out = x
+            for op in self.operations:
+                out = op.forward(out, False)
+            return out, out.new_zeros(())
+        n, c, h, w = x.shape
+        lr = x[:, 0:3]
+        stp = self.stp_net
+        recon_hf = ag.STPSampleFn.apply(lr, stp, t, stp._eps_rows(n, t, h, w, x.device), *stp.parameters())
+        out = torch.cat((lr, recon_hf), dim=1)
+        for op in reversed(self.operations):
+            out = op.forward(out, True)
         return out, recon_hf
 
     def inverse_from_latent(self, z):

@@ -128,16 +128,23 @@ def pool_weight_map(fc_weight: torch.Tensor, h: int, w: int) -> torch.Tensor:
     (h*w,) map: g = sum_px x[px] * wmap[px] + fc.bias.  adaptive_avg_pool2d bin i covers
     [floor(i*L/32), ceil((i+1)*L/32)) - bins overlap when 32 does not divide L and replicate when L < 32."""
     dev = fc_weight.device
-
-    def bins(length):
-        m = torch.zeros(32, length, dtype=torch.float64, device=dev)
-        for i in range(32):
-            s, e = (i * length) // 32, -((-(i + 1) * length) // 32)
-            m[i, s:e] = 1.0 / (e - s)
-        return m
-
     fcw = fc_weight.detach().double().reshape(32, 32)
-    return (bins(h).t() @ fcw @ bins(w)).reshape(h * w).float().contiguous()
+    return (pool_bins(h, dev).t() @ fcw @ pool_bins(w, dev)).reshape(h * w).float().contiguous()
+
+
+def pool_bins(length: int, device) -> torch.Tensor:
+    """(32, length) float64 averaging matrix of adaptive_avg_pool over one axis: bin i = [floor(i*L/32), ceil((i+1)*L/32))."""
+    m = torch.zeros(32, length, dtype=torch.float64, device=device)
+    for i in range(32):
+        s, e = (i * length) // 32, -((-(i + 1) * length) // 32)
+        m[i, s:e] = 1.0 / (e - s)
+    return m
+
+
+def pool_weight_map_grad(dwmap: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """Adjoint of pool_weight_map: gradient of the (h*w,) map -> gradient of fc.weight (1, 1024)."""
+    d = dwmap.double().reshape(h, w)
+    return (pool_bins(h, d.device) @ d @ pool_bins(w, d.device).t()).reshape(1, 32 * 32).float()
 
 
 def pack_fused_gh(weights: Sequence[torch.Tensor], cin: int = 3) -> torch.Tensor:
@@ -253,3 +260,13 @@ def pack_subnet_bwd(weights: Sequence[torch.Tensor], cin: int, cout: int, tempor
         t[:cin, pl_i * 32:(pl_i + 1) * 32, 0, :] = w3[k - 1][:, :cin, :].permute(1, 0, 2)
     wtx = pack_planes_generic(t)
     return wt5, wtd, wtx
+
+
+def pack_pointwise_T(weight: torch.Tensor) -> torch.Tensor:
+    """1x1(x1) conv weight (cout, cin, ...) -> its data-gradient conv for selfc_bwd_conv_planes (sp1): out = cin padded
+    to 32-channel groups, in = cout padded to 32-channel planes."""
+    w = weight.detach().float().reshape(weight.shape[0], -1)
+    cout, cin = w.shape
+    t = torch.zeros(roundup(cin, 32), roundup(cout, 32), 1, 1, dtype=torch.float32, device=w.device)
+    t[:cin, :cout, 0, 0] = w.t()
+    return pack_planes_generic(t)

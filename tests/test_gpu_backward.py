@@ -207,3 +207,79 @@ def test_stack_backward_chain(dev):
     errs = {n_: rel_l2(p_.grad.cpu(), gref[n_]) for n_, p_ in blocks.named_parameters()}
     print("worst", sorted(errs.items(), key=lambda kv: -kv[1])[:5])
     assert max(errs.values()) < 5e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+
+
+OPT = {"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": "l2", "scale": 4, "gmm_k": 5}
+STP_KEYS = ("local_m1", "local_m2", "global_m1", "global_m2", "other_stp_modules", "tail_gmm")
+
+
+def test_globalagg_backward(dev):
+    """No kinks in GlobalAgg: the gradient is smooth, so both a max-norm and an L2 bar apply."""
+    from selfc_amd.modules.SelfC_GMM_arch_inv import GlobalAgg
+    g = load_golden("g6_globalagg")
+    sd = {k: v for k, v in g.items() if k.split(".")[0] in ("fc", "proj1", "proj2", "proj3")}
+    for tag in ("a", "b"):
+        ga = GlobalAgg(64)
+        ga.load_state_dict(sd, strict=True)
+        x = g[f"{tag}_x"]
+        torch.manual_seed(4)
+        gy = torch.randn_like(x) * 0.01
+        y_ref, dx_ref, g_ref = _oracle_grads(lambda p, xx: O.global_agg(p, xx, T), sd, x, gy)
+        ga.to(dev)
+        xd = x.to(dev).requires_grad_(True)
+        y = ga(xd)
+        assert rel_err(y.detach().cpu(), y_ref) < 1e-3
+        y.backward(gy.to(dev))
+        assert rel_err(xd.grad.cpu(), dx_ref) < 5e-3
+        for name, prm in ga.named_parameters():
+            if name == "proj3.bias":
+                # softmax over the key axis is invariant to a shift of every key: the true gradient is exactly zero
+                assert float(prm.grad.abs().max()) < 1e-3 * float(ga.proj2.bias.grad.abs().max())
+                continue
+            e = rel_l2(prm.grad.cpu(), g_ref[name])
+            assert e < 1e-2, f"{tag} {name}: {e}"
+
+
+@pytest.mark.parametrize("fh_loss", ["gmm", "l2"])
+def test_stp_backward(dev, fh_loss):
+    """STPNet chain + head + (GMM) sample as one differentiable op vs autograd through the oracle."""
+    from selfc_amd.modules.SelfC_GMM_arch_inv import STPNet
+    g = load_golden("g7_stp_gmm" if fh_loss == "gmm" else "g7_stp_l2_full_rev")
+    prefix = "" if fh_loss == "gmm" else "stp_net."
+    sd = {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix) and k[len(prefix):].split(".")[0] in STP_KEYS}
+    stp = STPNet(dict(OPT, fh_loss=fh_loss))
+    stp.load_state_dict(sd, strict=True)
+    torch.manual_seed(8)
+    h, w = 8, 12
+    lr = torch.rand(T, 3, h, w)
+    eps = torch.randn(T, 48, 5, h, w)
+    gy = torch.randn(T, 48, h, w) * 0.01
+
+    def fn(p, xx):
+        raw = O.stp_v2_parameters(p, xx, T)
+        return O.stp_v2_gmm_sample(raw, eps) if fh_loss == "gmm" else raw
+
+    y_ref, dx_ref, g_ref = _oracle_grads(fn, sd, lr, gy)
+    stp.to(dev)
+    stp.eps = eps.permute(1, 2, 0, 3, 4).unsqueeze(0).to(dev)            # (1,48,5,T,h,w)
+    xd = lr.to(dev).requires_grad_(True)
+    stp(xd.reshape(1, T, 3, h, w).transpose(1, 2))
+    v = stp.sample()[0].transpose(0, 1)                                   # (T,48,h,w)
+    assert rel_err(v.detach().cpu(), y_ref) < 3e-3
+    v.backward(gy.to(dev))
+    # proj3.bias has an exactly-zero gradient (key shift invariance of the softmax); fc.bias is one scalar obtained
+    # by heavy cancellation, so it is judged together with fc.weight (the same Linear layer) as one vector
+    named = dict(stp.named_parameters())
+    errs = {}
+    for n_, p_ in named.items():
+        if n_.endswith("proj3.bias") or n_.endswith("fc.bias"):
+            continue
+        a, b_ = p_.grad.cpu().reshape(-1), g_ref[n_].reshape(-1)
+        if n_.endswith("fc.weight"):
+            nb = n_[:-len("weight")] + "bias"
+            a, b_ = torch.cat((a, named[nb].grad.cpu().reshape(-1))), torch.cat((b_, g_ref[nb].reshape(-1)))
+        errs[n_] = rel_l2(a, b_)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    print(fh_loss, "dx", rel_l2(xd.grad.cpu(), dx_ref), "worst", worst)
+    assert rel_l2(xd.grad.cpu(), dx_ref) < 5e-2
+    assert worst[0][1] < 5e-2, worst
