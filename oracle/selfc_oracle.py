@@ -431,3 +431,63 @@ def gaussian_downsample(x: torch.Tensor) -> torch.Tensor:
     k = gaussian_kernel_13().to(x.dtype).reshape(1, 1, 13, 13)
     y = F.conv2d(v, k, stride=4)[:, :, 2:-2, 2:-2]
     return y.reshape(*shp[:-2], y.shape[-2], y.shape[-1])
+
+
+# ----------------------------------------------------------------------------
+# f1  one training step of SelfCModel.optimize_parameters (models/SelfC_model.py:153-176), large net, l2 STP head
+# ----------------------------------------------------------------------------
+
+def reconstruction_loss(x: torch.Tensor, target: torch.Tensor, losstype: str = "l2", eps: float = 1e-6) -> torch.Tensor:
+    """ReconstructionLoss.forward (models/modules/loss.py:12-21): mean over all four axes, one after the other."""
+    if losstype == "l2":
+        v = (x - target) ** 2
+    elif losstype == "l1":
+        d = x - target
+        v = torch.sqrt(d * d + eps)
+    else:
+        raise ValueError(losstype)
+    return v.mean(-1).mean(-1).mean(-1).mean(-1)
+
+
+class _QuantSTE(torch.autograd.Function):
+    """Quant (Quantization.py:4-17): clamp + 8-bit rounding forward, identity backward."""
+
+    @staticmethod
+    def forward(ctx, v):
+        return quantize(v)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def large_rev_l2(params: Params, lr: torch.Tensor, t: int = 7) -> Tuple[torch.Tensor, torch.Tensor]:
+    """SelfCInvNet.forward(x=LR, rev=True) with the l2 head (SelfC_GMM_arch_inv.py:470-490): STP predicts the HF
+    channels from the LR frames, then the op loop runs reversed."""
+    hf = stp_v2_parameters(_sub(params, "stp_net"), lr, t)
+    return large_inv_from_latent(params, torch.cat((lr, hf), dim=1), t), hf
+
+
+def train_step_losses(params: Params, real_h: torch.Tensor, ref_l: torch.Tensor, t: int = 7,
+                      lambda_fit_forw: float = 1.0, lambda_rec_back: float = 1.0):
+    """(l_forw_fit, l_back_rec, loss) of optimize_parameters for criterion forw l2 / back l1 (train yml :106-117);
+    loss_c of the large net is identically 0 (SelfC_GMM_arch_inv.py:466)."""
+    z = large_fwd(params, real_h, t)
+    lr_bq = z[:, :3]
+    l_fit = lambda_fit_forw * reconstruction_loss(lr_bq, ref_l.detach(), "l2")
+    x_s, _ = large_rev_l2(params, _QuantSTE.apply(lr_bq), t)
+    l_rec = lambda_rec_back * reconstruction_loss(real_h, x_s[:, :3], "l1")
+    return l_fit, l_rec, (l_fit + l_rec) * 144 * 144 * 3
+
+
+def multistep_lr_restart(base_lr: float, steps: int, milestones: Sequence[int], restarts: Sequence[int] = (0,),
+                         weights: Sequence[float] = (1,), gamma: float = 0.1) -> List[float]:
+    """lr after each of `steps` scheduler.step() calls of MultiStepLR_Restart (models/lr_scheduler.py:8-31)."""
+    lr, out = base_lr, []
+    for epoch in range(1, steps + 1):
+        if epoch in restarts:
+            lr = base_lr * weights[list(restarts).index(epoch)]
+        elif epoch in milestones:
+            lr = lr * gamma ** list(milestones).count(epoch)
+        out.append(lr)
+    return out

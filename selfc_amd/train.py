@@ -1,0 +1,161 @@
+"""Training-step harness: the parts of ``SelfCModel`` (codes/models/SelfC_model.py) that drive the hot path in training.
+
+``SelfCModel`` itself cannot be imported without cv2 / thop / lmdb, so the caller-side logic is restated here with the
+same names and option keys, around the HIP-backed ``SelfCInvNet``:
+
+  feed_data            SelfC_model.py:93-132   pad short clips with the last frame, (B,C,T,H,W) -> (B*T,C,H,W), LR target
+  ReconstructionLoss   modules/loss.py:5-21
+  MultiStepLR_Restart  lr_scheduler.py:8-31
+  RescaleTrainer.optimize_parameters  SelfC_model.py:153-184 (forward fit + quantise + reverse reconstruction, x144*144*3,
+                       clip, Adam step)
+
+Forward, reverse and every gradient run on the HIP kernels (selfc_amd/autograd.py); the loss reductions, the clip and
+Adam are the reference's own torch calls.  Multi-GPU: wrap ``net`` in DistributedDataParallel exactly as the reference
+does (SelfC_model.py:42) - parameter gradients are ordinary ``.grad`` tensors, one 13.46 MB all-reduce per step.
+"""
+from __future__ import annotations
+
+from collections import Counter, OrderedDict, defaultdict
+from typing import Optional
+
+import torch
+import torch.nn as nn
+from torch.optim.lr_scheduler import _LRScheduler
+
+from . import harness
+from .global_var import GlobalVar
+from .modules.Quantization import Quantization
+
+
+class ReconstructionLoss(nn.Module):
+    """loss.py:5-21: 'l2' = (x-t)^2, 'l1' = sqrt((x-t)^2 + eps); mean over the four axes one after the other."""
+
+    def __init__(self, losstype="l2", eps=1e-6):
+        super().__init__()
+        self.losstype = losstype
+        self.eps = eps
+
+    def forward(self, x, target):
+        if self.losstype == "l2":
+            v = (x - target) ** 2
+        elif self.losstype == "l1":
+            diff = x - target
+            v = torch.sqrt(diff * diff + self.eps)
+        else:
+            print("reconstruction loss type error!")
+            return 0
+        return v.mean(-1).mean(-1).mean(-1).mean(-1)
+
+
+class MultiStepLR_Restart(_LRScheduler):
+    """lr_scheduler.py:8-31."""
+
+    def __init__(self, optimizer, milestones, restarts=None, weights=None, gamma=0.1, clear_state=False, last_epoch=-1):
+        self.milestones = Counter(milestones)
+        self.gamma = gamma
+        self.clear_state = clear_state
+        self.restarts = restarts if restarts else [0]
+        self.restart_weights = weights if weights else [1]
+        assert len(self.restarts) == len(self.restart_weights), "restarts and their weights do not match."
+        super().__init__(optimizer, last_epoch)
+
+    def get_lr(self):
+        if self.last_epoch in self.restarts:
+            if self.clear_state:
+                self.optimizer.state = defaultdict(dict)
+            weight = self.restart_weights[self.restarts.index(self.last_epoch)]
+            return [group["initial_lr"] * weight for group in self.optimizer.param_groups]
+        if self.last_epoch not in self.milestones:
+            return [group["lr"] for group in self.optimizer.param_groups]
+        return [group["lr"] * self.gamma ** self.milestones[self.last_epoch] for group in self.optimizer.param_groups]
+
+
+def feed_data(gt: torch.Tensor, distortion: str = "sr_bd", scale: int = 4, lq: Optional[torch.Tensor] = None):
+    """data['GT'] (B,C,T,H,W) -> (real_H (B*T,C,H,W), ref_L (B*T,C,H/scale,W/scale), clip_length) (SelfC_model.py:93-132)."""
+    t_len = GlobalVar.get_Temporal_LEN()
+    clip_length = gt.size(2)
+    if clip_length < t_len:
+        pads = torch.stack([gt[:, :, -1]] * (t_len - clip_length), dim=2)
+        gt = torch.cat([gt, pads], dim=2)
+    real_h = gt.transpose(1, 2).reshape(-1, 3, gt.size(3), gt.size(4)).contiguous()
+    if lq is not None:
+        ref_l = lq.transpose(1, 2).reshape(-1, 3, lq.size(3), lq.size(4))
+    elif distortion == "sr_bd":
+        if scale != 4:
+            raise NotImplementedError("the Gaussian LR target kernel is built for scale 4")
+        ref_l = harness.gaussian_downsample(real_h)                 # Guassian_downsample (models/Guassian.py:7-52)
+    elif distortion == "pytorch_bicubic":                            # (sic) F.upsample(mode='area') in the reference
+        ref_l = torch.nn.functional.avg_pool2d(real_h, scale)
+    else:
+        raise NotImplementedError(f"distortion {distortion!r}")
+    return real_h, ref_l, clip_length
+
+
+class RescaleTrainer:
+    """optimize_parameters of SelfCModel (SelfC_model.py:153-184) around a HIP-backed net.
+
+    train_opt keys are the yml's (train_rescaling_selfc_large.yml:95-121): lr_G, beta1, beta2, weight_decay_G,
+    pixel_criterion_forw/back, lambda_fit_forw, lambda_rec_back, lambda_cond_prob, gradient_clipping, lr_scheme,
+    lr_steps, lr_gamma, restarts, restart_weights, clear_state."""
+
+    def __init__(self, netG: nn.Module, train_opt: dict):
+        self.netG = netG
+        self.train_opt = train_opt
+        self.Quantization = Quantization()
+        self.netG.train()
+        self.Reconstruction_forw = ReconstructionLoss(losstype=train_opt["pixel_criterion_forw"])
+        self.Reconstruction_back = ReconstructionLoss(losstype=train_opt["pixel_criterion_back"])
+        wd = train_opt.get("weight_decay_G") or 0
+        optim_params = [v for k, v in netG.named_parameters() if v.requires_grad and "opticFlow_Net" not in k]
+        self.optim_params = optim_params
+        self.optimizer_G = torch.optim.Adam(optim_params, lr=train_opt["lr_G"], weight_decay=wd,
+                                            betas=(train_opt["beta1"], train_opt["beta2"]))
+        self.schedulers = []
+        if train_opt.get("lr_scheme", "MultiStepLR") == "MultiStepLR":
+            self.schedulers.append(MultiStepLR_Restart(self.optimizer_G, train_opt.get("lr_steps", []),
+                                                       restarts=train_opt.get("restarts"), weights=train_opt.get("restart_weights"),
+                                                       gamma=train_opt.get("lr_gamma", 0.1), clear_state=train_opt.get("clear_state")))
+        else:
+            raise NotImplementedError("MultiStepLR learning rate scheme is enough.")
+        self.log_dict = OrderedDict()
+        self.grad_norm = None
+
+    def loss_forward(self, out, y):
+        return self.train_opt["lambda_fit_forw"] * self.Reconstruction_forw(out, y)
+
+    def loss_backward(self, x, y):
+        x_samples, _ = self.netG(x=y, rev=True)
+        return self.train_opt["lambda_rec_back"] * self.Reconstruction_back(x, x_samples[:, :3, :, :])
+
+    def optimize_parameters(self, real_H: torch.Tensor, ref_L: torch.Tensor, step: int = 0):
+        self.optimizer_G.zero_grad()
+        output, loss_c = self.netG(x=real_H, rev=False)
+        loss_c = loss_c.mean() * self.train_opt.get("lambda_cond_prob", 0)
+        lr_before_quant = output[:, :3, :, :]
+        l_forw_fit = self.loss_forward(lr_before_quant, ref_L.detach())
+        LR = self.Quantization(lr_before_quant)
+        l_back_rec = self.loss_backward(real_H, LR)
+        loss = (l_forw_fit + l_back_rec + loss_c) * 144 * 144 * 3
+        loss.backward()
+        if self.train_opt.get("gradient_clipping"):
+            self.grad_norm = nn.utils.clip_grad_norm_(self.optim_params, self.train_opt["gradient_clipping"])
+        self.optimizer_G.step()
+        self.log_dict["l_forw_fit"] = l_forw_fit.item()
+        self.log_dict["l_back_rec"] = l_back_rec.item()
+        self.log_dict["loss_c"] = float(loss_c)
+        self.log_dict["loss"] = loss.item()
+        return self.log_dict
+
+    def update_learning_rate(self):
+        for s in self.schedulers:
+            s.step()
+
+    def get_current_learning_rate(self):
+        return self.optimizer_G.param_groups[0]["lr"]
+
+
+TRAIN_OPT_LARGE = {   # train_rescaling_selfc_large.yml:95-121
+    "lr_G": 1e-4, "beta1": 0.9, "beta2": 0.999, "lr_scheme": "MultiStepLR", "lr_steps": [100000, 200000, 300000],
+    "lr_gamma": 0.5, "pixel_criterion_forw": "l2", "pixel_criterion_back": "l1", "lambda_cond_prob": 0,
+    "lambda_fit_forw": 1, "lambda_rec_back": 1, "weight_decay_G": 1e-14, "gradient_clipping": 10,
+}

@@ -18,7 +18,7 @@ def pytest_configure(config):
 def load_golden(name):
     """tests/golden/<name>.npz -> {key: torch tensor} (fixtures made by tools/make_golden.py)."""
     with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
-        return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+        return {k: (torch.from_numpy(np.asarray(z[k])) if z[k].dtype.kind != "U" else [str(v) for v in z[k]]) for k in z.files}
 
 
 def subdict(d, prefix):

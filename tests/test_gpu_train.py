@@ -1,0 +1,89 @@
+"""One optimisation step through the HIP path (selfc_amd/train.py: the restated SelfCModel.optimize_parameters) against
+the G11 fixture: the same step run on the reference modules with stock autograd (tools/make_golden.py).  Losses are
+forward quantities (1e-3); gradients see f16 operands in both directions plus LeakyReLU kink flips (see
+test_gpu_backward.py), so their bars are relative L2 errors."""
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+T = 7
+OPT = {"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": "l2", "scale": 4, "gmm_k": 5}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from selfc_amd import _lib, GlobalVar
+    _lib.lib()
+    GlobalVar.set_Temporal_LEN(T)
+    return torch.device("cuda:0")
+
+
+def _net(dev, fh_loss="l2"):
+    from selfc_amd.modules.SelfC_GMM_arch_inv import SelfCInvNet
+    net = SelfCInvNet(dict(OPT, fh_loss=fh_loss), 3, 3, "D2DTNet", [4, 4], 2)
+    sd = {k: v for k, v in load_golden("g8_large_stack").items() if k.startswith("operations.")}
+    if fh_loss == "l2":
+        sd.update({k: v for k, v in load_golden("g7_stp_l2_full_rev").items() if k.startswith("stp_net.")})
+        net.load_state_dict(sd, strict=True)
+    else:
+        net.load_state_dict(sd, strict=False)
+    return net.to(dev)
+
+
+def test_train_step_matches_reference_step(dev):
+    from selfc_amd import train
+    g = load_golden("g11_train_step")
+    x = load_golden("g8_large_stack")["x"]                           # (T,3,32,48) = one clip
+    net = _net(dev)
+    before = {n: p.detach().clone() for n, p in net.named_parameters()}
+    tr = train.RescaleTrainer(net, dict(train.TRAIN_OPT_LARGE))
+    gt = x.reshape(1, T, 3, 32, 48).transpose(1, 2).to(dev)          # data['GT'] (B,C,T,H,W)
+    real_h, ref_l, clip_len = train.feed_data(gt, "sr_bd", 4)
+    assert clip_len == T and torch.equal(real_h.cpu(), x)
+    assert float((ref_l.cpu() - g["ref_l"]).abs().max()) < 1e-5
+    # keep the unclipped gradients: clip_grad_norm_ rescales .grad in place
+    grads = {}
+    hooks = [p.register_hook(lambda gr, n=n: grads.__setitem__(n, gr.detach().clone())) for n, p in net.named_parameters()]
+    log = tr.optimize_parameters(real_h, ref_l)
+    for h_ in hooks:
+        h_.remove()
+    assert abs(log["l_forw_fit"] - float(g["l_forw_fit"])) < 1e-3 * float(g["l_forw_fit"])
+    assert abs(log["l_back_rec"] - float(g["l_back_rec"])) < 1e-3 * float(g["l_back_rec"])
+    assert abs(log["loss"] - float(g["loss"])) < 1e-3 * float(g["loss"])
+    names = g["names"]
+    norms = torch.tensor([float(grads[n].norm()) for n in names], dtype=torch.float64)
+    ref = g["grad_norms"]
+    rel = float((norms - ref).norm() / ref.norm())
+    assert rel < 3e-2, rel
+    assert abs(float(tr.grad_norm) - float(g["grad_norm"])) < 3e-2 * float(g["grad_norm"])
+    # one clipped gradient tensor element-wise, and the Adam step itself: |delta| <= lr, direction = -sign(grad)
+    clipped = net.operations[1].F.conv1.weight.grad.cpu()
+    e = float((clipped - g["grad_F1_conv1_clipped"]).norm() / g["grad_F1_conv1_clipped"].norm())
+    assert e < 5e-2, e
+    for n, p in net.named_parameters():
+        d = (p.detach() - before[n]).cpu()
+        assert float(d.abs().max()) <= 1e-4 * 1.001, n
+    d = (net.operations[1].F.conv1.weight.detach() - before["operations.1.F.conv1.weight"]).cpu()
+    big = g["grad_F1_conv1_clipped"].abs() > 1e-3 * g["grad_F1_conv1_clipped"].abs().max()
+    agree = (torch.sign(d[big]) == -torch.sign(g["grad_F1_conv1_clipped"][big])).float().mean()
+    assert float(agree) > 0.98
+
+
+def test_gmm_training_reduces_loss(dev):
+    """The shipped configuration (fh_loss: gmm, device RNG): a few steps on one fixed clip must reduce the loss."""
+    from selfc_amd import train
+    torch.manual_seed(0)
+    net = _net(dev, "gmm")
+    tr = train.RescaleTrainer(net, dict(train.TRAIN_OPT_LARGE))
+    x = load_golden("g8_large_stack")["x"]
+    gt = x.reshape(1, T, 3, 32, 48).transpose(1, 2).to(dev)
+    real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
+    losses = [tr.optimize_parameters(real_h, ref_l)["loss"] for _ in range(12)]
+    assert all(v == v and abs(v) < 1e9 for v in losses)
+    assert min(losses[-3:]) < 0.9 * losses[0], losses
+    tr.update_learning_rate()
+    assert tr.get_current_learning_rate() == 1e-4

@@ -170,3 +170,28 @@ def test_gaussian_downsample():
     g = load_golden("g10_gauss")
     y = O.gaussian_downsample(g["x"])
     assert y.shape == g["y"].shape and rel_err(y, g["y"]) < 2e-6
+
+
+def test_train_step_losses_and_gradnorm():
+    """G11: the hand restatement of optimize_parameters against the step run on the reference modules."""
+    g = load_golden("g11_train_step")
+    params = {**{k: v for k, v in load_golden("g8_large_stack").items() if k.startswith("operations.")},
+              **{k: v for k, v in load_golden("g7_stp_l2_full_rev").items() if k.startswith("stp_net.")}}
+    x = load_golden("g8_large_stack")["x"]
+    assert rel_err(O.gaussian_downsample(x), g["ref_l"]) < 2e-6
+    p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "haar" not in k) for k, v in params.items()}
+    l_fit, l_rec, loss = O.train_step_losses(p, x, g["ref_l"], 7)
+    assert abs(l_fit.item() - float(g["l_forw_fit"])) < 1e-5 * float(g["l_forw_fit"])
+    assert abs(l_rec.item() - float(g["l_back_rec"])) < 1e-4 * float(g["l_back_rec"])
+    loss.backward()
+    names = g["names"]
+    norms = torch.tensor([float(p[n].grad.norm()) for n in names], dtype=torch.float64)
+    assert rel_err(norms, g["grad_norms"]) < 2e-3
+    total = float(torch.sqrt((norms ** 2).sum()))
+    assert abs(total - float(g["grad_norm"])) < 2e-3 * float(g["grad_norm"])
+
+
+def test_multistep_lr_restart_trace():
+    g = load_golden("g11_lr_trace")
+    lr = O.multistep_lr_restart(1e-4, 12, [3, 6, 9], restarts=[5], weights=[0.5], gamma=0.5)
+    assert rel_err(torch.tensor(lr, dtype=torch.float64), g["lr"]) < 1e-12

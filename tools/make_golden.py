@@ -160,6 +160,48 @@ def main():
         stp_sd = {k: v for k, v in sd_np(net).items() if k.startswith("stp_net.")}
         save("g7_stp_l2_full_rev", lr=lrq.numpy(), x_rev=xs.numpy(), hf=hf.numpy(), **stp_sd)
 
+        # ---- G11 one optimize_parameters step (SelfC_model.py:153-176) on the same net (weights: g8_large_stack +
+        # g7_stp_l2_full_rev), restated by hand around the reference modules because SelfC_model itself needs cv2:
+        # l2 forward fit + l1 (eps 1e-6) reconstruction (loss.py:12-21, train yml :106-107), x 144*144*3, clip 10,
+        # Adam(1e-4, (0.9, 0.999), wd 1e-14), sr_bd LR target (SelfC_model.py:128, Guassian.py).
+        from models.Guassian import Guassian_downsample as _gd
+        from models.lr_scheduler import MultiStepLR_Restart as _MS
+        with torch.enable_grad():
+            net.train()
+            real_h = x
+            ref_l = _gd(real_h.transpose(0, 1)).transpose(0, 1)
+            prms = [p_ for p_ in net.parameters() if p_.requires_grad]
+            optim = torch.optim.Adam(prms, lr=1e-4, weight_decay=1e-14, betas=(0.9, 0.999))
+            optim.zero_grad()
+            out_f, loss_c = net(x=real_h, rev=False)
+            lr_bq = out_f[:, :3]
+            l_fit = 1.0 * ((lr_bq - ref_l.detach()) ** 2).mean(-1).mean(-1).mean(-1).mean(-1)
+            y_ = Quantization()(lr_bq)
+            x_s, _ = net(x=y_, rev=True)
+            d_ = real_h - x_s[:, :3]
+            l_rec = 1.0 * torch.sqrt(d_ * d_ + 1e-6).mean(-1).mean(-1).mean(-1).mean(-1)
+            loss = (l_fit + l_rec + loss_c.mean() * 0) * 144 * 144 * 3
+            loss.backward()
+            names = [n_ for n_, p_ in net.named_parameters() if p_.requires_grad]
+            gnorms = np.array([float(p_.grad.norm()) for p_ in prms], dtype=np.float64)
+            total = float(torch.nn.utils.clip_grad_norm_(prms, 10))
+            before = [p_.detach().clone() for p_ in prms]
+            optim.step()
+            dsum = np.array([float((p_.detach() - b_).double().sum()) for p_, b_ in zip(prms, before)], dtype=np.float64)
+            sample_g = prms[names.index("operations.1.F.conv1.weight")].grad.detach().numpy().copy()   # after clipping
+        save("g11_train_step", ref_l=ref_l.numpy(), l_forw_fit=np.float64(l_fit.item()), l_back_rec=np.float64(l_rec.item()),
+             loss=np.float64(loss.item()), grad_norm=np.float64(total), grad_norms=gnorms, names=np.array(names),
+             step_delta_sum=dsum, grad_F1_conv1_clipped=sample_g)
+        # MultiStepLR_Restart (lr_scheduler.py:8-31): lr trace of a toy schedule incl. a restart
+        po = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
+        sch = _MS(po, [3, 6, 9], restarts=[5], weights=[0.5], gamma=0.5, clear_state=False)
+        trace = []
+        for _ in range(12):
+            po.step()
+            sch.step()
+            trace.append(po.param_groups[0]["lr"])
+        save("g11_lr_trace", lr=np.array(trace, dtype=np.float64))
+
         # ---- G8 Haar nets (config C1)
         torch.manual_seed(8)
         irn = IA.InvRescaleNet(3, 3, SC.subnet("DBNet", "xavier"), [1], 1)
