@@ -13,8 +13,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _lib, runtime as rt
-from .packing import (dense_channels, pack_planes_generic, pack_pointwise_T, pack_subnet_bwd, pool_weight_map_grad,
-                      roundup)
+from .packing import dense_channels, pack_planes_generic, pack_pointwise_T, pool_weight_map_grad, roundup
 
 _SCRATCH: Dict[Tuple, torch.Tensor] = {}
 
@@ -30,31 +29,6 @@ def _scratch(device, n, h, w, cin, cout) -> torch.Tensor:
     return buf
 
 
-class PackedSubnetBwd:
-    def __init__(self, mod):
-        ws = [getattr(mod, f"conv{i}").weight for i in range(1, 6)]
-        self.wt5, self.wtd, self.wtx = pack_subnet_bwd(ws, mod.channel_in, mod.channel_out, mod.kind == rt.SUBNET_D2DT)
-
-    def struct(self) -> _lib.SubnetBW:
-        s = _lib.SubnetBW()
-        s.wt5 = self.wt5.data_ptr()
-        for i in range(3):
-            s.wtd[i] = self.wtd[i].data_ptr()
-        s.wtx = self.wtx.data_ptr()
-        return s
-
-
-def packed_bwd(mod) -> PackedSubnetBwd:
-    key = rt.params_key(mod)
-    if getattr(mod, "_pkb_key", None) != key:
-        mod._check()
-        if mod.channel_out > 96:
-            raise NotImplementedError("subnet backward covers channel_out <= 96")
-        mod._pkb = PackedSubnetBwd(mod)
-        mod._pkb_key = key
-    return mod._pkb
-
-
 def subnet_params(mod) -> List[torch.Tensor]:
     """conv1.weight, conv1.bias, ..., conv5.weight, conv5.bias (the order the Functions take and return)."""
     out = []
@@ -68,11 +42,11 @@ def subnet_params(mod) -> List[torch.Tensor]:
 
 def subnet_bwd(mod, dense: torch.Tensor, xin: Optional[torch.Tensor], dout: torch.Tensor, sign: float,
                dx: Optional[torch.Tensor], accumulate_dx: bool, n: int, t: int, h: int, w: int,
-               want_params: bool = True) -> List[Optional[torch.Tensor]]:
+               want_params: bool = True, pk=None) -> List[Optional[torch.Tensor]]:
     """Backward of one DenseBlock / D2DTInput on kernel-layout buffers; returns the 10 parameter gradients
     (reference layouts) or Nones."""
     cin, cout = mod.channel_in, mod.channel_out
-    pk = packed_bwd(mod)
+    pk = pk if pk is not None else mod.packed()             # inside an InvBlockExp the block's plan owns the tensors
     dev = dout.device
     grads: List[Optional[torch.Tensor]] = [None] * 10
     wg = (C.c_void_p * 5)()
@@ -85,12 +59,19 @@ def subnet_bwd(mod, dense: torch.Tensor, xin: Optional[torch.Tensor], dout: torc
             grads[2 * i], grads[2 * i + 1] = gw, gb
             wg[i], bg[i] = gw.data_ptr(), gb.data_ptr()
     scratch = _scratch(dev, n, h, w, cin, cout)
-    bw = pk.struct()
+    bw = pk.bwd_struct()
     rt.call("selfc_subnet_bwd", bw, mod.kind, dense.data_ptr(), None if xin is None else xin.data_ptr(), dout.data_ptr(),
             float(sign), None if dx is None else dx.data_ptr(), 1 if accumulate_dx else 0,
             wg if want_params else None, bg if want_params else None, 0.0,
             scratch.data_ptr(), scratch.numel(), n, t, h, w, cin, cout, _lib.stream_ptr())
     return grads
+
+
+def _dense_buffer(cin: int, n: int, h: int, w: int, dev) -> torch.Tensor:
+    """Fresh dense feature buffer of a stand-alone subnet call.  Features are fully written by the conv epilogues; a zero
+    fill is only needed for the pad channels of the input planes (cin > 3 and not a multiple of 32)."""
+    mk = torch.zeros if (cin > 3 and cin % 32) else torch.empty
+    return mk((dense_channels(cin) // 32, n, h, w, 32), dtype=_lib.operand_dtype(), device=dev)
 
 
 class SubnetFn(torch.autograd.Function):
@@ -105,7 +86,7 @@ class SubnetFn(torch.autograd.Function):
         cinp, coutp = roundup(cin, 4), roundup(mod.channel_out, 4)
         xin = torch.empty((n, h, w, cinp), dtype=torch.float32, device=dev)
         rt.call("selfc_nchw_to_nhwc4", x.data_ptr(), xin.data_ptr(), n, cin, h, w, sp)
-        dense = torch.zeros((dense_channels(cin) // 32, n, h, w, 32), dtype=_lib.operand_dtype(), device=dev)
+        dense = _dense_buffer(cin, n, h, w, dev)
         yout = torch.empty((n, h, w, coutp), dtype=torch.float32, device=dev)
         sw = pk.struct()
         rt.call("selfc_subnet_run", sw, mod.kind, xin.data_ptr(), yout.data_ptr(), dense.data_ptr(),
@@ -147,7 +128,7 @@ class InvBlockFn(torch.autograd.Function):
         x = rt.as_input(x)
         n, c, h, w = x.shape
         c1, c2 = blk.split_len1, blk.split_len2
-        ws = rt.Workspace(x.device, blk.F.kind, n, t, h, w, c1, c2)      # private: kept for backward
+        ws = rt.Workspace(x.device, blk.F.kind, n, t, h, w, c1, c2, single_use=True)      # private: kept for backward
         pb = rt.packed_block(blk)
         rt.nchw_to_latent(x, ws)
         keep = (ws.x1 if rev else ws.x2).clone()                          # the input side the kernels overwrite
@@ -171,20 +152,21 @@ class InvBlockFn(torch.autograd.Function):
         dh = torch.empty_like(d2)
         nel = d2.numel()
         clamp = float(blk.clamp)
+        pb = rt.packed_block(blk)
         if not rev:
             # y1 = x1 + F(x2); y2 = x2*e^s + G(y1), s = s(H(y1)).  keep = x2 (input), ws.x1 = y1
             rt.call("selfc_coupling_bwd", 0, keep.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel, sp)
-            gG = subnet_bwd(blk.G, ws.gd, ws.x1, d2, 1.0, d1, True, n, t, h, w, want)
-            gH = subnet_bwd(blk.H, ws.hd, ws.x1, dh, 1.0, d1, True, n, t, h, w, want)
+            gG = subnet_bwd(blk.G, ws.gd, ws.x1, d2, 1.0, d1, True, n, t, h, w, want, pb.G)
+            gH = subnet_bwd(blk.H, ws.hd, ws.x1, dh, 1.0, d1, True, n, t, h, w, want, pb.H)
             # the forward's epilogue replaced F's f16 input copy by y2: put x2 back before F's weight gradients
             rt.call("selfc_nhwc_to_planes", keep.data_ptr(), ws.fd.data_ptr(), n * h * w, c2, sp)
-            gF = subnet_bwd(blk.F, ws.fd, None, d1, 1.0, dx2, True, n, t, h, w, want)
+            gF = subnet_bwd(blk.F, ws.fd, None, d1, 1.0, dx2, True, n, t, h, w, want, pb.F)
         else:
             # y2 = (x2 - G(x1))*e^-s, s = s(H(x1)); y1 = x1 - F(y2).  keep = x1 (input), ws.x2 = y2 (also in fd)
-            gF = subnet_bwd(blk.F, ws.fd, None, d1, -1.0, d2, True, n, t, h, w, want)
+            gF = subnet_bwd(blk.F, ws.fd, None, d1, -1.0, d2, True, n, t, h, w, want, pb.F)
             rt.call("selfc_coupling_bwd", 1, ws.x2.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel, sp)
-            gG = subnet_bwd(blk.G, ws.gd, keep, dx2, -1.0, d1, True, n, t, h, w, want)
-            gH = subnet_bwd(blk.H, ws.hd, keep, dh, 1.0, d1, True, n, t, h, w, want)
+            gG = subnet_bwd(blk.G, ws.gd, keep, dx2, -1.0, d1, True, n, t, h, w, want, pb.G)
+            gH = subnet_bwd(blk.H, ws.hd, keep, dh, 1.0, d1, True, n, t, h, w, want, pb.H)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((n, c1 + c2, h, w), dtype=torch.float32, device=dev)
@@ -375,7 +357,7 @@ class STPSampleFn(torch.autograd.Function):
         for m in stp._chain():
             dst = torch.empty((n, h * w, 64), dtype=torch.float32, device=dev)
             if isinstance(m, D2DTInput):
-                dense = torch.zeros((dense_channels(m.channel_in) // 32, n, h, w, 32), dtype=F16, device=dev)
+                dense = _dense_buffer(m.channel_in, n, h, w, dev)
                 sw = m.packed().struct()
                 rt.call("selfc_subnet_run", sw, m.kind, cur.data_ptr(), dst.data_ptr(), dense.data_ptr(),
                         n, t, h, w, m.channel_in, m.channel_out, sp)

@@ -37,10 +37,13 @@ inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g, size_t n, unsigned* __restrict__ amax_bits) {
   float m = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const float v = fabsf(g[i]);
-    m = (v == v) ? fmaxf(m, v) : m;
+  const size_t n4 = n >> 2;                  // fmaxf drops NaNs by itself
+  const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = g4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(g[(n4 << 2) + threadIdx.x]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, __float_as_uint(m));   // non-negative floats order as uints
@@ -71,14 +74,24 @@ __global__ __launch_bounds__(256) void grad_to_planes_kernel(const float* __rest
 // weight gradients
 // ---------------------------------------------------------------------------------------------------------
 struct WgArgs {
-  const f16* P;     // gradient planes (blockIdx.z selects one)
-  const f16* Q;     // activation planes (blockIdx.y selects one)
-  float* part;      // [wave partial][Pn][qtot][ttot][32 o][32 c]
-  size_t plane;     // halfs per plane
+  const f16* P;          // single: gradient planes (blockIdx.z selects one); multi: the dpre planes (conv k reads plane 4-k)
+  const f16* Q0;         // activation planes: a run of nq0 planes, then the run Q1
+  const f16* Q1;
+  float* part;           // [split][pair][taps][32 o][32 c]; pair = z*qtot + q (single) | blockIdx.y (multi)
+  float* bpart;          // optional [split][gridDim.z | 4][32]: column sums of P (bias gradient), written by the q == 0 workgroups
+  size_t plane;          // halfs per plane
   int N, T, H, W, tiles_x, tiles_y, ntiles;
-  int dt;           // TAPS == 1: Q is read at frame n + dt of the clip (zero outside)
-  int q0, qtot, tap0, ttot;
+  int nq0;
+  int multi;             // conv1..4 of one dense block in a single launch: blockIdx.y enumerates (conv k, input plane q)
+  int nqc1;              // multi: input planes of conv1 (conv k has nqc1 + k - 1)
 };
+
+// (conv k, plane q) of pair index y in multi mode
+__device__ __forceinline__ void wg_pair(int y, const int nqc1, int& k, int& q) {
+  k = 1;
+  while (y >= nqc1 + k - 1) { y -= nqc1 + k - 1; ++k; }
+  q = y;
+}
 
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 
@@ -91,23 +104,39 @@ __device__ __forceinline__ f16x8 tr_frag(const unsigned char* lds, const int off
   return __builtin_bit_cast(f16x8, v);
 }
 
+// TAPS = 9: 3x3 spatial taps, 3 waves x 3 taps each.  TAPS = 3: temporal taps (frames n-1, n, n+1 of the clip, zero
+// outside), 3 waves x 1 tap.  TAPS = 1: pointwise, 4 waves x 4 of the tile's 16 patches, reduced through LDS.
+// Every workgroup writes ONE partial per tap, so the finish pass reads nsplit blocks.  The next tile's operands are
+// fetched into registers while the current one is multiplied (the launches are short: exposed load latency per tile
+// was most of their time).
 template <int TAPS>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
+__global__ __launch_bounds__((TAPS == 1 ? 4 : 3) * 64) void wgrad_kernel(const WgArgs a) {
+  constexpr int NW = TAPS == 1 ? 4 : 3, NT = NW * 64;
+  constexpr int TPW = TAPS == 9 ? 3 : 1;                    // taps per wave
   constexpr int HALO = TAPS == 9 ? 1 : 0;
-  constexpr int QW = 16 + 2 * HALO, QPIX = QW * QW;
+  constexpr int QW = 16 + 2 * HALO, QPIX = QW * QW, QF = TAPS == 3 ? 3 : 1;
+  constexpr int PI = (1024 + NT - 1) / NT, QI = (QF * QPIX * 4 + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) unsigned char lp[256 * 64];
-  __shared__ __attribute__((aligned(16))) unsigned char lq[QPIX * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char lq[QF * QPIX * 64];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const f16* __restrict__ P = a.P + (size_t)blockIdx.z * a.plane;
-  const f16* __restrict__ Q = a.Q + (size_t)blockIdx.y * a.plane;
+  int kconv = 0, qi = blockIdx.y;
+  if (a.multi) wg_pair(blockIdx.y, a.nqc1, kconv, qi);
+  const f16* __restrict__ P = a.P + (size_t)(a.multi ? 4 - kconv : (int)blockIdx.z) * a.plane;
+  const f16* __restrict__ Q = qi < a.nq0 ? a.Q0 + (size_t)qi * a.plane : a.Q1 + (size_t)(qi - a.nq0) * a.plane;
   const int H = a.H, W = a.W;
+  const bool want_bias = a.bpart != nullptr && qi == 0;     // workgroup-uniform
 
-  f32x16 acc[TAPS];
+  f32x16 acc[TPW], accb;
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  for (int r = 0; r < 16; ++r) {
+    accb[r] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int t = 0; t < TPW; ++t) acc[t][r] = 0.f;
+  }
+  f16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (f16)1.f;
 
   // ds_read_b64_tr_b16 addressing: lane 16g + 4q + p supplies block row q (a pixel), columns 4p..4p+3 of the
   // group's 16 channels, and receives channel (lane & 15) of the 4 pixels.  Groups g = 0,1 are the two channel
@@ -115,78 +144,169 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
   const int g = lane >> 4, h = g >> 1, q = (lane >> 2) & 3, p = lane & 3;
   const int choff = (16 * (g & 1) + 4 * p) * 2;
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  u32x4 preg[PI], qreg[QI];
+  unsigned okp = 0, okq = 0;
+  auto fetch = [&](const int tile) __attribute__((always_inline)) {
     const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, n = tile / (a.tiles_x * a.tiles_y);
     const int tx0 = tx * 16, ty0 = ty * 16;
-    const int tc = n % a.T + a.dt;
-    const bool tv = (tc >= 0) & (tc < a.T);
-    const int nq = tv ? n + a.dt : n;
-    __syncthreads();                       // the previous tile's fragments have been read
+    const int tclip = n % a.T;
+    okp = 0; okq = 0;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int i = tid + it * 256;
+    for (int it = 0; it < PI; ++it) {
+      const int i = min(tid + it * NT, 1023);
       const int px = i >> 2, ch = i & 3;
       const int y = ty0 + (px >> 4), x = tx0 + (px & 15);
-      const bool ok = (y < H) & (x < W);
+      okp |= (((y < H) & (x < W)) ? 1u : 0u) << it;
       const int yc = min(y, H - 1), xc = min(x, W - 1);
-      const u32x4 v = *reinterpret_cast<const u32x4*>(P + ((size_t)(n * H + yc) * W + xc) * 32 + ch * 8);
-      *reinterpret_cast<u32x4*>(lp + px * 64 + ch * 16) = ok ? v : u32x4{0u, 0u, 0u, 0u};
+      preg[it] = *reinterpret_cast<const u32x4*>(P + ((size_t)(n * H + yc) * W + xc) * 32 + ch * 8);
     }
-    for (int i = tid; i < QPIX * 4; i += 256) {
-      const int px = i >> 2, ch = i & 3;
+#pragma unroll
+    for (int it = 0; it < QI; ++it) {
+      const int i = min(tid + it * NT, QF * QPIX * 4 - 1);
+      const int f = i / (QPIX * 4), j = i - f * (QPIX * 4);
+      const int px = j >> 2, ch = j & 3;
       const int hy = px / QW, hx = px - hy * QW;
       const int y = ty0 + hy - HALO, x = tx0 + hx - HALO;
-      const bool ok = tv & (y >= 0) & (y < H) & (x >= 0) & (x < W);
+      const int dt = TAPS == 3 ? f - 1 : 0;
+      const bool tv = (tclip + dt >= 0) & (tclip + dt < a.T);
+      okq |= ((tv & (y >= 0) & (y < H) & (x >= 0) & (x < W)) ? 1u : 0u) << it;
       const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
-      const u32x4 v = *reinterpret_cast<const u32x4*>(Q + ((size_t)(nq * H + yc) * W + xc) * 32 + ch * 8);
-      *reinterpret_cast<u32x4*>(lq + px * 64 + ch * 16) = ok ? v : u32x4{0u, 0u, 0u, 0u};
+      const int nq = tv ? n + dt : n;
+      qreg[it] = *reinterpret_cast<const u32x4*>(Q + ((size_t)(nq * H + yc) * W + xc) * 32 + ch * 8);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) fetch(tile);
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y;
+    const int tx0 = tx * 16, ty0 = ty * 16;
+    __syncthreads();                       // the previous tile's fragments have been read
+#pragma unroll
+    for (int it = 0; it < PI; ++it) {
+      const int i = tid + it * NT;
+      if (i < 1024) *reinterpret_cast<u32x4*>(lp + (i >> 2) * 64 + (i & 3) * 16) = ((okp >> it) & 1u) ? preg[it] : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int it = 0; it < QI; ++it) {
+      const int i = tid + it * NT;
+      if (i < QF * QPIX * 4) *reinterpret_cast<u32x4*>(lq + (size_t)(i >> 2) * 64 + (i & 3) * 16) = ((okq >> it) & 1u) ? qreg[it] : u32x4{0u, 0u, 0u, 0u};
     }
     __syncthreads();
-    // 16 patches of 4x4 pixels, 4 per wave; patches wholly outside the image are skipped (wave-uniform test:
-    // the transposing read needs EXEC all ones)
-    for (int pi = wave; pi < 16; pi += 4) {
+    if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
+    // 16 patches of 4x4 pixels; patches wholly outside the image are skipped (wave-uniform: the transposing
+    // read needs EXEC all ones).  TAPS == 1: each wave takes 4 of them; otherwise each wave takes all 16 for its taps.
+    for (int pi = (TAPS == 1 ? wave : 0); pi < 16; pi += (TAPS == 1 ? 4 : 1)) {
       const int pr = pi >> 2, pc = pi & 3;
       if (ty0 + 4 * pr >= H || tx0 + 4 * pc >= W) continue;
       const int arow = ((4 * pr + 2 * h) * 16 + 4 * pc + q) * 64 + choff;
       const f16x8 af = tr_frag(lp, arow, arow + 16 * 64);
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        const int dy = TAPS == 9 ? t / 3 : 0, dx = TAPS == 9 ? t % 3 : 0;
-        const int brow = ((4 * pr + 2 * h + dy) * QW + 4 * pc + q + dx) * 64 + choff;
+      for (int t = 0; t < TPW; ++t) {
+        const int tap = TAPS == 9 ? wave * 3 + t : 0;
+        const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap - 3 * (tap / 3) : 0;
+        const int fr = TAPS == 3 ? wave : 0;
+        const int brow = (fr * QPIX + (4 * pr + 2 * h + dy) * QW + 4 * pc + q + dx) * 64 + choff;
         const f16x8 bf = tr_frag(lq, brow, brow + QW * 64);
         acc[t] = mfma_32x32x16(af, bf, acc[t]);
       }
+      if (want_bias && (TAPS == 1 || wave == 0)) accb = mfma_32x32x16(af, ones, accb);
     }
   }
   // D[o][c]: lane owns column c = lane & 31, rows o = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const size_t w = (size_t)blockIdx.x * 4 + wave;
-  float* __restrict__ base = a.part + ((((w * gridDim.z + blockIdx.z) * a.qtot + a.q0 + blockIdx.y) * a.ttot + a.tap0) << 10);
+  const int npairs = a.multi ? (int)gridDim.y : (int)(gridDim.y * gridDim.z);
+  const int pair = a.multi ? (int)blockIdx.y : (int)(blockIdx.z * gridDim.y + blockIdx.y);
+  const size_t blk = (size_t)blockIdx.x * npairs + pair;
+  if (TAPS == 1) {
+    // reduce the 4 waves' accumulators (and bias sums) through LDS, wave 0 writes
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lq);            // 3 x 4 KiB
+    float* redb = reinterpret_cast<float*>(lp);           // 3 x 4 KiB
+    if (wave > 0) {
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      base[(size_t)t * 1024 + o * 32 + (lane & 31)] = acc[t][r];
+      for (int r = 0; r < 16; ++r) {
+        red[(wave - 1) * 1024 + r * 64 + lane] = acc[0][r];
+        if (want_bias) redb[(wave - 1) * 1024 + r * 64 + lane] = accb[r];
+      }
     }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          acc[0][r] += red[w * 1024 + r * 64 + lane];
+          if (want_bias) accb[r] += redb[w * 1024 + r * 64 + lane];
+        }
+    }
+  }
+  if (TAPS != 1 || wave == 0) {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tap = TAPS == 9 ? wave * 3 + t : (TAPS == 3 ? wave : 0);
+      float* __restrict__ base = a.part + ((blk * TAPS + tap) << 10);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        base[o * 32 + (lane & 31)] = acc[t][r];
+      }
+    }
+    if (want_bias && wave == 0 && (lane & 31) == 0) {
+      const int nb = a.multi ? 4 : (int)gridDim.z, pb = a.multi ? kconv - 1 : (int)blockIdx.z;
+      float* __restrict__ bb = a.bpart + ((size_t)blockIdx.x * nb + pb) * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bb[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = accb[r];
+    }
+  }
 }
 
 struct FinArgs {
   const float* part;
-  float* out;            // (O, Ctot, ttot) fp32, PyTorch layout of the conv weight
+  const float* bpart;
+  float* out[4];         // single: out[0] = (O, Ctot, ttot) fp32, PyTorch layout of the conv weight; multi: conv1..4
+  float* bout[4];        // (O) or null
   int nW, Pn, qtot, ttot, O, Ctot, cin, nx;
+  int multi, nqc1, npairs;
   const float* amax;
   float beta;
 };
 
-// thread = one element of the partial block layout (coalesced reads over the nW partials), scattered write
+// thread = one element of the partial block layout (coalesced reads over the nW partials), scattered write;
+// the threads past the weight elements reduce the bias partials
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const FinArgs a) {
-  const size_t per = (size_t)a.Pn * a.qtot * a.ttot * 1024;
+  const size_t per = (size_t)a.npairs * a.ttot * 1024;
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= per) return;
+  const float inv = 1.f / grad_scale(*a.amax);
+  if (e >= per) {
+    const size_t o = e - per;
+    const int nb = a.multi ? 4 : a.Pn;
+    if (o >= (size_t)(a.multi ? 128 : a.O)) return;
+    const int kb = (int)(o >> 5);
+    float* bo = a.multi ? (kb == 0 ? a.bout[0] : kb == 1 ? a.bout[1] : kb == 2 ? a.bout[2] : a.bout[3]) : a.bout[0];
+    if (!bo) return;
+    float t = 0.f;
+    for (int w = 0; w < a.nW; ++w) t += a.bpart[((size_t)w * nb + kb) * 32 + (o & 31)];
+    float* dst = bo + (a.multi ? (o & 31) : o);
+    *dst = (a.beta != 0.f) ? a.beta * *dst + t * inv : t * inv;
+    return;
+  }
   const int c = (int)(e & 31), oo = (int)((e >> 5) & 31);
   const size_t blk = e >> 10;
-  const int tap = (int)(blk % a.ttot), qq = (int)((blk / a.ttot) % a.qtot), pz = (int)(blk / ((size_t)a.ttot * a.qtot));
-  const int o = 32 * pz + oo;
+  const int tap = (int)(blk % a.ttot);
+  const int pair = (int)(blk / a.ttot);
+  int qq, o, Ctot;
+  float* outp;
+  if (a.multi) {
+    int k = 1, y = pair;
+    while (y >= a.nqc1 + k - 1) { y -= a.nqc1 + k - 1; ++k; }
+    qq = y; o = oo; Ctot = a.cin + 32 * (k - 1);
+    outp = k == 1 ? a.out[0] : k == 2 ? a.out[1] : k == 3 ? a.out[2] : a.out[3];
+  } else {
+    qq = pair % a.qtot;
+    o = 32 * (pair / a.qtot) + oo; Ctot = a.Ctot;
+    outp = a.out[0];
+  }
+  if (!outp) return;
   int ci;
   if (qq < a.nx) {
     ci = 32 * qq + c;
@@ -194,43 +314,19 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const FinArgs a) {
   } else {
     ci = a.cin + 32 * (qq - a.nx) + c;
   }
-  if (o >= a.O || ci >= a.Ctot) return;
-  float sum = 0.f;
-  for (int w = 0; w < a.nW; ++w) sum += a.part[(size_t)w * per + e];
-  float* dst = a.out + ((size_t)o * a.Ctot + ci) * a.ttot + tap;
-  const float v = sum / grad_scale(*a.amax);
+  if (o >= a.O || ci >= Ctot) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int w = 0;
+  for (; w + 4 <= a.nW; w += 4) {
+    s0 += a.part[(size_t)w * per + e];
+    s1 += a.part[(size_t)(w + 1) * per + e];
+    s2 += a.part[(size_t)(w + 2) * per + e];
+    s3 += a.part[(size_t)(w + 3) * per + e];
+  }
+  for (; w < a.nW; ++w) s0 += a.part[(size_t)w * per + e];
+  float* dst = outp + ((size_t)o * Ctot + ci) * a.ttot + tap;
+  const float v = ((s0 + s1) + (s2 + s3)) * inv;
   *dst = (a.beta != 0.f) ? a.beta * *dst + v : v;
-}
-
-// bias gradient: column sums of the gradient planes.  grid (nsplit, Pn); partb[(split*Pn + pz)*32 + ch]
-__global__ __launch_bounds__(256) void bias_partial_kernel(const f16* __restrict__ P, size_t plane, size_t npix, float* __restrict__ partb) {
-  __shared__ float red[64][33];
-  const int tid = threadIdx.x, chunk = tid & 3, pl = tid >> 2;
-  const f16* __restrict__ src = P + (size_t)blockIdx.y * plane;
-  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (size_t px = (size_t)blockIdx.x * 64 + pl; px < npix; px += (size_t)gridDim.x * 64) {
-    const f16x8 v = *reinterpret_cast<const f16x8*>(src + px * 32 + chunk * 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
-  }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) red[pl][chunk * 8 + e] = s[e];
-  __syncthreads();
-  if (tid < 32) {
-    float t = 0.f;
-    for (int i = 0; i < 64; ++i) t += red[i][tid];
-    partb[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 32 + tid] = t;
-  }
-}
-
-__global__ void bias_finish_kernel(const float* __restrict__ partb, int nsplit, int Pn, int O, float* __restrict__ out,
-                                   const float* __restrict__ amax, float beta) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= O) return;
-  float t = 0.f;
-  for (int s = 0; s < nsplit; ++s) t += partb[((size_t)s * Pn + (o >> 5)) * 32 + (o & 31)];
-  const float v = t / grad_scale(*amax);
-  out[o] = (beta != 0.f) ? beta * out[o] + v : v;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -303,9 +399,9 @@ __global__ __launch_bounds__(256) void freq_inv_bwd_kernel(const float* __restri
 
 // scratch layout of one selfc_subnet_bwd call
 struct BwdLayout {
-  int nx, ng, hasx, nsplit, bsplit;
+  int nx, ng, hasx;
   size_t plane_b;       // bytes of one f16 plane
-  size_t off_g, off_t5, off_xplane, off_amax, off_partb, off_part, total;
+  size_t off_g, off_t5, off_xplane, off_amax, off_wg, total;
 };
 
 BwdLayout bwd_layout(int N, int H, int W, int cin, int cout) {
@@ -315,26 +411,33 @@ BwdLayout bwd_layout(int N, int H, int W, int cin, int cout) {
   L.hasx = cin <= 3;
   const size_t npix = (size_t)N * H * W;
   L.plane_b = npix * 64;
-  const int ntiles = N * ((H + 15) / 16) * ((W + 15) / 16);
-  (void)ntiles;
-  L.nsplit = bwd_wgrad_nsplit(N, H, W);
-  L.bsplit = BWD_BSPLIT;
   L.off_g = 4 * L.plane_b;
   L.off_t5 = L.off_g + (size_t)L.ng * L.plane_b;
   L.off_xplane = L.off_t5 + (size_t)(L.nx + 3) * L.plane_b;
   L.off_amax = L.off_xplane + (L.hasx ? L.plane_b : 0);
-  L.off_partb = up256(L.off_amax + 256);
-  L.off_part = up256(L.off_partb + (size_t)L.bsplit * L.ng * 32 * sizeof(float));
-  // largest partial: conv4 (1 P plane, nx+3 Q planes, 9 taps) or conv5 (ng P planes, nx+4 Q planes, 9 | 3 taps)
-  const size_t a4 = (size_t)(L.nx + 3) * 9, a5 = (size_t)L.ng * (L.nx + 4) * 9;
-  L.total = up256(L.off_part + (size_t)L.nsplit * 4 * (a4 > a5 ? a4 : a5) * 4096);
+  L.off_wg = up256(L.off_amax + 256);
+  // largest weight-gradient job: conv4 (1 P plane, nx+3 Q planes, 9 taps) or conv5 (ng P planes, nx+4 Q planes, 9 | 3 taps)
+  const size_t a4 = bwd_wgrad14_scratch_bytes(N, H, W, L.nx);
+  const size_t a5 = bwd_wgrad_scratch_bytes(N, H, W, L.ng, L.nx + 4, 9);
+  L.total = up256(L.off_wg + (a4 > a5 ? a4 : a5));
   return L;
 }
 
 template <int TAPS>
 int launch_wgrad(const WgArgs& a, int nsplit, int Qn, int Pn, hipStream_t s) {
-  hipLaunchKernelGGL(wgrad_kernel<TAPS>, dim3((unsigned)nsplit, (unsigned)Qn, (unsigned)Pn), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(wgrad_kernel<TAPS>, dim3((unsigned)nsplit, (unsigned)Qn, (unsigned)Pn), dim3((TAPS == 1 ? 4 : 3) * 64), 0, s, a);
   return hip_rc(hipGetLastError());
+}
+
+// pixel splits of a weight-gradient job: enough workgroups to fill the chip (~2 per CU), bounded by the tile count and
+// by 12 MiB of partials (written once, read once by the finish pass)
+int wgrad_nsplit(int N, int H, int W, int npairs, int ttot) {
+  const long ntiles = (long)N * ((H + 15) / 16) * ((W + 15) / 16);
+  long ns = (768 + (long)npairs - 1) / (long)npairs;
+  const long cap = 3072 / ((long)npairs * ttot);
+  if (ns > cap) ns = cap;
+  if (ns > ntiles) ns = ntiles;
+  return (int)(ns < 1 ? 1 : ns);
 }
 
 }  // namespace
@@ -344,8 +447,8 @@ namespace selfc {
 int bwd_absmax(const float* g, size_t n, float* amax, hipStream_t s) {
   int rc = hip_rc(hipMemsetAsync(amax, 0, sizeof(float), s));
   if (rc) return rc;
-  const size_t nb = (n + 256 * 16 - 1) / (256 * 16);
-  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb))), dim3(256), 0, s, g, n, (unsigned*)amax);
+  const size_t nb = (n + 256 * 32 - 1) / (256 * 32);
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(nb < 1 ? 1 : (nb > 256 ? 256 : nb))), dim3(256), 0, s, g, n, (unsigned*)amax);
   return hip_rc(hipGetLastError());
 }
 
@@ -357,49 +460,73 @@ int bwd_to_planes(const float* x, void* planes, size_t npix, int c, int cs, int 
   return hip_rc(hipGetLastError());
 }
 
-int bwd_wgrad_nsplit(int N, int H, int W) {
-  const long ntiles = (long)N * ((H + 15) / 16) * ((W + 15) / 16);
-  return (int)(ntiles < 24 ? ntiles : 24);
+size_t bwd_wgrad_scratch_bytes(int N, int H, int W, int Pn, int qtot, int ttot) {
+  const int ns = wgrad_nsplit(N, H, W, Pn * qtot, ttot);
+  return up256((size_t)ns * (Pn < 4 ? 4 : Pn) * 32 * sizeof(float)) + (size_t)ns * Pn * qtot * ttot * 4096;
 }
 
-size_t bwd_wgrad_part_bytes(int nsplit, int Pn, int qtot, int ttot) {
-  return (size_t)nsplit * 4 * Pn * qtot * ttot * 4096;
+size_t bwd_wgrad14_scratch_bytes(int N, int H, int W, int nqc1) {
+  const int npairs = 4 * nqc1 + 6;
+  const int ns = wgrad_nsplit(N, H, W, npairs, 9);
+  return up256((size_t)ns * 4 * 32 * sizeof(float)) + (size_t)ns * npairs * 9 * 4096;
 }
 
-int bwd_wgrad(const WgradJob& j, const float* amax, float* part, float* partb, int nsplit, int N, int T, int H, int W, hipStream_t s) {
+namespace {
+template <int TAPS>
+int launch_wgrad_any(const WgArgs& a, int nsplit, int gy, int gz, hipStream_t s) {
+  hipLaunchKernelGGL(wgrad_kernel<TAPS>, dim3((unsigned)nsplit, (unsigned)gy, (unsigned)gz), dim3((TAPS == 1 ? 4 : 3) * 64), 0, s, a);
+  return hip_rc(hipGetLastError());
+}
+}  // namespace
+
+int bwd_wgrad(const WgradJob& j, const float* amax, void* scratch, int N, int T, int H, int W, hipStream_t s) {
   const size_t npix = (size_t)N * H * W, plane = npix * 32;
   const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
   const int qtot = j.Qn[0] + j.Qn[1];
   const int ttot = j.taps == 9 ? 9 : (j.temporal ? 3 : 1);
-  int rc;
-  if (j.wout) {
-    for (int dt = j.temporal ? -1 : 0; dt <= (j.temporal ? 1 : 0); ++dt) {
-      WgArgs a{};
-      a.P = (const f16*)j.P; a.part = part; a.plane = plane;
-      a.N = N; a.T = T; a.H = H; a.W = W; a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.ntiles = N * tiles_x * tiles_y;
-      a.dt = dt; a.qtot = qtot; a.ttot = ttot; a.tap0 = j.temporal ? dt + 1 : 0;
-      int q0 = 0;
-      for (int r = 0; r < 2; ++r) {
-        if (j.Qn[r] <= 0) continue;
-        a.Q = (const f16*)j.Q[r]; a.q0 = q0;
-        rc = j.taps == 9 ? launch_wgrad<9>(a, nsplit, j.Qn[r], j.Pn, s) : launch_wgrad<1>(a, nsplit, j.Qn[r], j.Pn, s);
-        if (rc) return rc;
-        q0 += j.Qn[r];
-      }
-    }
-    FinArgs f{};
-    f.part = part; f.out = j.wout; f.nW = nsplit * 4; f.Pn = j.Pn; f.qtot = qtot; f.ttot = ttot;
-    f.O = j.O; f.Ctot = j.Ctot; f.cin = j.cin; f.nx = j.nx; f.amax = amax; f.beta = j.beta;
-    const size_t per = (size_t)j.Pn * qtot * ttot * 1024;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, f);
-    if ((rc = hip_rc(hipGetLastError()))) return rc;
-  }
-  if (j.bout) {
-    hipLaunchKernelGGL(bias_partial_kernel, dim3((unsigned)BWD_BSPLIT, (unsigned)j.Pn), dim3(256), 0, s, (const f16*)j.P, plane, npix, partb);
-    hipLaunchKernelGGL(bias_finish_kernel, dim3((unsigned)((j.O + 63) / 64)), dim3(64), 0, s, partb, BWD_BSPLIT, j.Pn, j.O, j.bout, amax, j.beta);
-    if ((rc = hip_rc(hipGetLastError()))) return rc;
-  }
-  return SELFC_OK;
+  const int nsplit = wgrad_nsplit(N, H, W, j.Pn * qtot, ttot);
+  float* bpart = (float*)scratch;
+  float* part = (float*)((unsigned char*)scratch + up256((size_t)nsplit * (j.Pn < 4 ? 4 : j.Pn) * 32 * sizeof(float)));
+  if (!j.wout && !j.bout) return SELFC_OK;
+  WgArgs a{};
+  a.P = (const f16*)j.P; a.Q0 = (const f16*)j.Q[0]; a.nq0 = j.Qn[0]; a.Q1 = (const f16*)j.Q[1];
+  a.part = part; a.bpart = j.bout ? bpart : nullptr; a.plane = plane;
+  a.N = N; a.T = T; a.H = H; a.W = W; a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.ntiles = N * tiles_x * tiles_y;
+  int rc = ttot == 9 ? launch_wgrad_any<9>(a, nsplit, qtot, j.Pn, s)
+         : ttot == 3 ? launch_wgrad_any<3>(a, nsplit, qtot, j.Pn, s) : launch_wgrad_any<1>(a, nsplit, qtot, j.Pn, s);
+  if (rc) return rc;
+  FinArgs f{};
+  f.part = part; f.bpart = bpart; f.out[0] = j.wout; f.bout[0] = j.bout; f.nW = nsplit; f.Pn = j.Pn; f.qtot = qtot; f.ttot = ttot;
+  f.O = j.O; f.Ctot = j.Ctot; f.cin = j.cin; f.nx = j.nx; f.npairs = j.Pn * qtot; f.amax = amax; f.beta = j.beta;
+  const size_t per = (size_t)f.npairs * ttot * 1024;
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((per + (j.bout ? j.O : 0) + 255) / 256)), dim3(256), 0, s, f);
+  return hip_rc(hipGetLastError());
+}
+
+// conv1..conv4 of one dense block in one launch + one finish.  dpre: the four gradient planes [dpre4 dpre3 dpre2 dpre1];
+// inputs of conv k = the first (nqc1 + k - 1) planes of the run Q0 (nq0 planes) followed by Q1.
+int bwd_wgrad14(const void* dpre, const void* Q0, int nq0, const void* Q1, int nqc1, int cin, int nx,
+                float* const* wout, float* const* bout, float beta, const float* amax, void* scratch,
+                int N, int T, int H, int W, hipStream_t s) {
+  const size_t npix = (size_t)N * H * W, plane = npix * 32;
+  const int npairs = 4 * nqc1 + 6;
+  const int nsplit = wgrad_nsplit(N, H, W, npairs, 9);
+  float* bpart = (float*)scratch;
+  float* part = (float*)((unsigned char*)scratch + up256((size_t)nsplit * 4 * 32 * sizeof(float)));
+  WgArgs a{};
+  a.P = (const f16*)dpre; a.Q0 = (const f16*)Q0; a.nq0 = nq0; a.Q1 = (const f16*)Q1;
+  a.part = part; a.bpart = bout ? bpart : nullptr; a.plane = plane;
+  a.N = N; a.T = T; a.H = H; a.W = W; a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16; a.ntiles = N * a.tiles_x * a.tiles_y;
+  a.multi = 1; a.nqc1 = nqc1;
+  int rc = launch_wgrad_any<9>(a, nsplit, npairs, 1, s);
+  if (rc) return rc;
+  FinArgs f{};
+  f.part = part; f.bpart = bpart; f.nW = nsplit; f.Pn = 4; f.ttot = 9; f.O = 32; f.cin = cin; f.nx = nx;
+  f.multi = 1; f.nqc1 = nqc1; f.npairs = npairs; f.amax = amax; f.beta = beta;
+  for (int k = 0; k < 4; ++k) { f.out[k] = wout ? wout[k] : nullptr; f.bout[k] = bout ? bout[k] : nullptr; }
+  const size_t per = (size_t)npairs * 9 * 1024;
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((per + (bout ? 128 : 0) + 255) / 256)), dim3(256), 0, s, f);
+  return hip_rc(hipGetLastError());
 }
 
 }  // namespace selfc
@@ -429,8 +556,7 @@ int selfc_subnet_bwd(const selfc_subnet_bw* bw, int kind, const void* dense, con
   f16* t5 = (f16*)(sb + L.off_t5);                     // conv5^T(dOut): nx x-groups, f1, f2, f3
   f16* xpl = (f16*)(sb + L.off_xplane);                // f16 copy of the input when it is not in `dense`
   float* amax = (float*)(sb + L.off_amax);
-  float* partb = (float*)(sb + L.off_partb);
-  float* part = (float*)(sb + L.off_part);
+  void* wgs = sb + L.off_wg;
   const f16* dn = (const f16*)dense;
   const f16* feat = dn + (size_t)(L.hasx ? 0 : L.nx) * plane;      // f1..f4
   const int coutp = (cout + 3) & ~3, cinp = (cin + 3) & ~3;
@@ -471,21 +597,22 @@ int selfc_subnet_bwd(const selfc_subnet_bw* bw, int kind, const void* dense, con
   }
   if (!wgrad && !bgrad) return SELFC_OK;
 
-  // 5. weight / bias gradients
-  for (int k = 1; k <= 5; ++k) {
-    const int nfeat = k <= 4 ? k - 1 : 4;
-    WgradJob j{};
-    j.P = k <= 4 ? gb + (size_t)(4 - k) * plane : gpl;
-    j.Pn = k <= 4 ? 1 : L.ng;
+  // 5. weight / bias gradients: conv1..4 in one launch, conv5 in another
+  {
     // input planes: [x planes][f1..]; with cin <= 3 the x plane is the scratch copy and the features start `dense`
-    if (L.hasx) { j.Q[0] = xpl; j.Qn[0] = 1; j.Q[1] = feat; j.Qn[1] = nfeat; }
-    else { j.Q[0] = dn; j.Qn[0] = L.nx + nfeat; }
-    j.temporal = (k == 5 && d2dt) ? 1 : 0;
-    j.taps = j.temporal ? 1 : 9;
-    j.wout = wgrad ? wgrad[k - 1] : nullptr;
-    j.bout = bgrad ? bgrad[k - 1] : nullptr;
-    j.O = k <= 4 ? 32 : cout; j.Ctot = cin + 32 * nfeat; j.cin = cin; j.nx = L.nx; j.beta = beta;
-    if ((rc = bwd_wgrad(j, amax, part, partb, L.nsplit, N, T, H, W, s))) return rc;
+    const void* q0 = L.hasx ? (const void*)xpl : (const void*)dn;
+    const int nq0 = L.hasx ? 1 : L.nx + 4;
+    if ((rc = bwd_wgrad14(gb, q0, nq0, feat, L.nx, cin, L.nx, wgrad, bgrad, beta, amax, wgs, N, T, H, W, s))) return rc;
+    WgradJob j{};
+    j.P = gpl; j.Pn = L.ng;
+    j.Q[0] = q0; j.Qn[0] = nq0;
+    if (L.hasx) { j.Q[1] = feat; j.Qn[1] = 4; }
+    j.temporal = d2dt ? 1 : 0;
+    j.taps = d2dt ? 1 : 9;
+    j.wout = wgrad ? wgrad[4] : nullptr;
+    j.bout = bgrad ? bgrad[4] : nullptr;
+    j.O = cout; j.Ctot = cin + 128; j.cin = cin; j.nx = L.nx; j.beta = beta;
+    if ((rc = bwd_wgrad(j, amax, wgs, N, T, H, W, s))) return rc;
   }
   return SELFC_OK;
 }
@@ -544,7 +671,7 @@ int selfc_bwd_conv_planes(const void* in, int nplanes_in, int kt, int sp1, const
 
 size_t selfc_bwd_wgrad_scratch_bytes(int N, int H, int W, int Pn, int Qn, int taps) {
   if (N <= 0 || H <= 0 || W <= 0 || Pn < 1 || Qn < 1 || (taps != 1 && taps != 9)) return 0;
-  return up256((size_t)BWD_BSPLIT * Pn * 32 * sizeof(float)) + bwd_wgrad_part_bytes(bwd_wgrad_nsplit(N, H, W), Pn, Qn, taps);
+  return bwd_wgrad_scratch_bytes(N, H, W, Pn, Qn, taps);
 }
 
 int selfc_bwd_wgrad(const void* P, int Pn, const void* Q, int Qn, int taps, float* wout, int O, int Ctot, float* bout, float beta,
@@ -553,12 +680,10 @@ int selfc_bwd_wgrad(const void* P, int Pn, const void* Q, int Qn, int taps, floa
   if (O < 1 || O > 32 * Pn || Ctot < 1 || Ctot > 32 * Qn || N <= 0 || T <= 0 || N % T || H <= 0 || W <= 0) return SELFC_EINVAL;
   if (scratch_bytes < selfc_bwd_wgrad_scratch_bytes(N, H, W, Pn, Qn, taps)) return SELFC_EINVAL;
   ProfScope prof(PROF_BWD, (hipStream_t)stream);
-  unsigned char* sb = (unsigned char*)scratch;
   WgradJob j{};
   j.P = P; j.Pn = Pn; j.Q[0] = Q; j.Qn[0] = Qn; j.taps = taps; j.temporal = 0;
   j.wout = wout; j.O = O; j.Ctot = Ctot; j.cin = Ctot; j.nx = Qn; j.bout = bout; j.beta = beta;
-  return bwd_wgrad(j, amax, (float*)(sb + up256((size_t)BWD_BSPLIT * Pn * 32 * sizeof(float))), (float*)sb,
-                   bwd_wgrad_nsplit(N, H, W), N, T, H, W, (hipStream_t)stream);
+  return bwd_wgrad(j, amax, scratch, N, T, H, W, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -38,14 +38,14 @@ struct WgradJob {
   const void* P; int Pn;            // gradient planes (scaled f16)
   const void* Q[2]; int Qn[2];      // activation planes: two contiguous runs (the second may be empty)
   int taps;                         // 9: 3x3 spatial taps; 1: pointwise
-  int temporal;                     // taps == 1 only: three launches at frame offsets -1, 0, +1 -> weight (O, Ctot, 3)
+  int temporal;                     // taps == 1 only: frames n-1, n, n+1 of the clip -> weight (O, Ctot, 3)
   float* wout; int O, Ctot, cin, nx; // output layout (O, Ctot, ttot); channel map: first nx planes = cin inputs, rest features
   float* bout;                      // optional bias gradient (O)
   float beta;
 };
-size_t bwd_wgrad_part_bytes(int nsplit, int Pn, int qtot, int ttot);
-int bwd_wgrad_nsplit(int N, int H, int W);
-constexpr int BWD_BSPLIT = 32;      // pixel splits of the bias reduction: partb holds BWD_BSPLIT * Pn * 32 floats
-int bwd_wgrad(const WgradJob& j, const float* amax, float* part, float* partb, int nsplit, int N, int T, int H, int W, hipStream_t s);
+// scratch of one job: per-split partial blocks + bias partials (ttot = 9, 3 (temporal) or 1)
+size_t bwd_wgrad_scratch_bytes(int N, int H, int W, int Pn, int qtot, int ttot);
+int bwd_wgrad(const WgradJob& j, const float* amax, void* scratch, int N, int T, int H, int W, hipStream_t s);
+size_t bwd_wgrad14_scratch_bytes(int N, int H, int W, int nqc1);
 
 }  // namespace selfc

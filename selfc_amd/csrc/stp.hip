@@ -600,8 +600,8 @@ __global__ __launch_bounds__(256) void gagg_bwd_dx_kernel(const float* __restric
 }
 
 struct GaggBwdLayout {
-  size_t plane_b, off_dyp, off_zp, off_dz, off_amax, off_pool, off_A, off_pdA, off_pdyo, off_dg, off_partb, off_part, total;
-  int nchunk, nsplit;
+  size_t plane_b, off_dyp, off_zp, off_dz, off_amax, off_pool, off_A, off_pdA, off_pdyo, off_dg, off_wg, total;
+  int nchunk;
 };
 
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -610,7 +610,6 @@ GaggBwdLayout gagg_bwd_layout(int N, int T, int H, int W) {
   GaggBwdLayout L{};
   const int HW = H * W, B = N / T;
   L.nchunk = (HW + POOL_CHUNK - 1) / POOL_CHUNK;
-  L.nsplit = bwd_wgrad_nsplit(N, H, W);
   L.plane_b = (size_t)N * HW * 64;
   size_t o = 0;
   L.off_dyp = o; o += 2 * L.plane_b;
@@ -622,8 +621,7 @@ GaggBwdLayout gagg_bwd_layout(int N, int T, int H, int W) {
   L.off_pdA = o; o = up256(o + (size_t)B * L.nchunk * 64 * 4);
   L.off_pdyo = o; o = up256(o + (size_t)B * L.nchunk * TMAX * 64 * 4);
   L.off_dg = o; o = up256(o + (size_t)N * 64 * 4);
-  L.off_partb = o; o = up256(o + (size_t)BWD_BSPLIT * 2 * 32 * 4);
-  L.off_part = o; o = up256(o + bwd_wgrad_part_bytes(L.nsplit, 2, 2, 1));
+  L.off_wg = o; o = up256(o + bwd_wgrad_scratch_bytes(N, H, W, 2, 2, 1));
   L.total = o;
   return L;
 }
@@ -788,7 +786,7 @@ int selfc_globalagg_bwd(const float* x, const float* dy, float* dx, const float*
   WgradJob j{};
   j.P = dyp; j.Pn = 2; j.Q[0] = zp; j.Qn[0] = 2; j.taps = 1; j.temporal = 0;
   j.wout = dw1; j.O = 64; j.Ctot = 64; j.cin = 64; j.nx = 2; j.beta = 0.f;
-  return bwd_wgrad(j, amax, (float*)(sb + L.off_part), (float*)(sb + L.off_partb), L.nsplit, N, T, H, W, s);
+  return bwd_wgrad(j, amax, sb + L.off_wg, N, T, H, W, s);
 }
 
 }  // extern "C"

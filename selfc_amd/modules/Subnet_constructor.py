@@ -26,12 +26,7 @@ class _DenseSubnet(nn.Module):
             raise NotImplementedError(f"subnet {self.channel_in}->{self.channel_out} is outside the compiled kernel set")
 
     def packed(self) -> rt.PackedSubnet:
-        key = rt.params_key(self)
-        if getattr(self, "_pk_key", None) != key:
-            self._check()
-            self._pk = rt.PackedSubnet(self)
-            self._pk_key = key
-        return self._pk
+        return rt.packed_subnet(self)
 
     def _run(self, x: torch.Tensor, T: int) -> torch.Tensor:
         """x NCHW (N,cin,H,W) -> NCHW (N,cout,H,W) through selfc_subnet_run."""

@@ -27,6 +27,15 @@ from ._lib import operand_dtype
 
 F16 = operand_dtype()     # MFMA operand dtype of the loaded library (float16, or bfloat16 under SELFC_OPERAND=bf16)
 
+# Every pack_* function is a pure re-ordering (gather + zero fill) of its inputs.  PackPlan (below) exploits that: it
+# runs the functions ONCE on index-valued stand-ins with _RAW set (no 16-bit rounding) to learn the gather map, after
+# which re-packing changed weights - every optimizer step in training - is one concatenation, one gather and one cast.
+_RAW = False
+
+
+def _operand(t: torch.Tensor) -> torch.Tensor:
+    return t.contiguous() if _RAW else t.to(F16).contiguous()
+
 
 def roundup(v: int, m: int) -> int:
     return (v + m - 1) // m * m
@@ -74,7 +83,7 @@ def pack_conv3x3(weight: torch.Tensor, cin: int, layer: int) -> torch.Tensor:
     wk = _k_expand_3x3(w, cin, layer - 1)                  # (32, K)
     nfrag = wk.shape[1] // 16
     frag = wk.reshape(32, nfrag, 2, 8).permute(1, 2, 0, 3).reshape(nfrag, 64, 8)
-    return frag.to(F16).contiguous()
+    return _operand(frag)
 
 
 def pack_tconv5(weights: Sequence[torch.Tensor], cin: int) -> torch.Tensor:
@@ -100,7 +109,7 @@ def pack_tconv5(weights: Sequence[torch.Tensor], cin: int) -> torch.Tensor:
             wk[n, :, :cout, :cin] = w3[:, :, :cin]
             wk[n, :, :cout, cin32:cin32 + 128] = w3[:, :, cin:]
     frag = wk.reshape(nets, 3, ot, 16, ks, 4, 8).permute(1, 0, 4, 2, 5, 3, 6).reshape(3, nets, ks, ot, 64, 8)
-    return frag.to(F16).contiguous()
+    return _operand(frag)
 
 
 def pad_bias(bias, n: int = 64, device=None) -> torch.Tensor:
@@ -120,7 +129,7 @@ def pack_pointwise(weight: torch.Tensor) -> torch.Tensor:
     wp = torch.zeros(ot * 16, cin, dtype=torch.float32, device=w.device)
     wp[:cout] = w
     frag = wp.reshape(ot, 16, ks, 4, 8).permute(0, 2, 3, 1, 4).reshape(ot, ks, 64, 8)
-    return frag.to(F16).contiguous()
+    return _operand(frag)
 
 
 def pool_weight_map(fc_weight: torch.Tensor, h: int, w: int) -> torch.Tensor:
@@ -132,13 +141,19 @@ def pool_weight_map(fc_weight: torch.Tensor, h: int, w: int) -> torch.Tensor:
     return (pool_bins(h, dev).t() @ fcw @ pool_bins(w, dev)).reshape(h * w).float().contiguous()
 
 
+_BINS = {}
+
+
 def pool_bins(length: int, device) -> torch.Tensor:
     """(32, length) float64 averaging matrix of adaptive_avg_pool over one axis: bin i = [floor(i*L/32), ceil((i+1)*L/32))."""
-    m = torch.zeros(32, length, dtype=torch.float64, device=device)
-    for i in range(32):
-        s, e = (i * length) // 32, -((-(i + 1) * length) // 32)
-        m[i, s:e] = 1.0 / (e - s)
-    return m
+    key = (length, str(device))
+    if key not in _BINS:
+        m = torch.zeros(32, length, dtype=torch.float64)
+        for i in range(32):
+            s, e = (i * length) // 32, -((-(i + 1) * length) // 32)
+            m[i, s:e] = 1.0 / (e - s)
+        _BINS[key] = m.to(device)
+    return _BINS[key]
 
 
 def pool_weight_map_grad(dwmap: torch.Tensor, h: int, w: int) -> torch.Tensor:
@@ -169,7 +184,7 @@ def pack_fused_gh(weights: Sequence[torch.Tensor], cin: int = 3) -> torch.Tensor
         frags.append(wk.reshape(32, nfrag, 2, 8).permute(1, 2, 0, 3).reshape(nfrag, 64, 8))
     out = torch.cat(frags, dim=0)
     assert out.shape[0] == 120
-    return out.to(F16).contiguous()
+    return _operand(out)
 
 
 def pack_conv_planes(weight: torch.Tensor, cin: int) -> torch.Tensor:
@@ -190,7 +205,7 @@ def pack_conv_planes(weight: torch.Tensor, cin: int) -> torch.Tensor:
     nfrag = wk.shape[1] // 16
     z = cout // 32
     frag = wk.reshape(z, 32, nfrag, 2, 8).permute(0, 2, 3, 1, 4).reshape(z, nfrag, 64, 8)
-    return frag.to(F16).contiguous()
+    return _operand(frag)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -207,7 +222,7 @@ def pack_planes_generic(wt: torch.Tensor) -> torch.Tensor:
     wk = wt.reshape(z, 32, pl, 32, kt, ks).permute(0, 1, 4, 2, 5, 3).reshape(z, 32, kt * pl * ks * 32)
     nfrag = wk.shape[2] // 16
     frag = wk.reshape(z, 32, nfrag, 2, 8).permute(0, 2, 3, 1, 4).reshape(z, nfrag, 64, 8)
-    return frag.to(F16).contiguous()
+    return _operand(frag)
 
 
 def pack_subnet_bwd(weights: Sequence[torch.Tensor], cin: int, cout: int, temporal: bool):
@@ -270,3 +285,83 @@ def pack_pointwise_T(weight: torch.Tensor) -> torch.Tensor:
     t = torch.zeros(roundup(cin, 32), roundup(cout, 32), 1, 1, dtype=torch.float32, device=w.device)
     t[:cin, :cout, 0, 0] = w.t()
     return pack_planes_generic(t)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# gather plans
+# ----------------------------------------------------------------------------------------------------------
+
+class PackPlan:
+    """Kernel-layout tensors of a module as ONE gather from its flat parameter vector.
+
+    build(params) -> {name: (tensor, 'w' | 'b')} must be composed of the pack_* functions of this file ('w': MFMA
+    operand dtype, 'b': fp32).  The plan is learnt once from index-valued stand-ins; run() then costs three device ops
+    whatever the number of packed tensors."""
+
+    ALIGN = 128      # elements: keeps every output segment 256-byte aligned
+
+    def __init__(self, params: Sequence[torch.Tensor], build):
+        global _RAW
+        dev = params[0].device
+        total = sum(p.numel() for p in params)
+        if total + 2 >= (1 << 24):
+            raise ValueError("PackPlan: too many parameters for exact float32 indices")
+        fakes, off = [], 0
+        for p in params:
+            fakes.append(torch.arange(off + 1, off + p.numel() + 1, dtype=torch.float32, device=dev).reshape(p.shape))
+            off += p.numel()
+        prev, _RAW = _RAW, True
+        try:
+            outs = build(fakes)
+        finally:
+            _RAW = prev
+        self.total = total
+        self.items = []                       # (name, kind, start, numel, shape)
+        idx_w, idx_b = [], []
+        cur = {"w": 0, "b": 0}
+        for name, (t, kind) in outs.items():
+            idx = t.reshape(-1).round().long() - 1
+            idx = torch.where(idx < 0, torch.full_like(idx, total), idx)          # zero fill -> the appended 0
+            pad = (-idx.numel()) % self.ALIGN
+            if pad:
+                idx = torch.cat((idx, torch.full((pad,), total, dtype=torch.long, device=dev)))
+            (idx_w if kind == "w" else idx_b).append(idx)
+            self.items.append((name, kind, cur[kind], t.numel(), tuple(t.shape)))
+            cur[kind] += idx.numel()
+        self.nw = cur["w"]
+        self.idx = torch.cat(idx_w + idx_b)
+
+    def run(self, params: Sequence[torch.Tensor]):
+        flat = torch.cat([p.detach().reshape(-1).float() for p in params] + [torch.zeros(1, dtype=torch.float32, device=self.idx.device)])
+        g = flat[self.idx]
+        gw, gb = g[:self.nw].to(F16), g[self.nw:]
+        out = {}
+        for name, kind, start, numel, shape in self.items:
+            src = gw if kind == "w" else gb
+            out[name] = src[start:start + numel].view(shape)
+        return out
+
+
+def subnet_pack_entries(prefix: str, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], cin: int, cout: int,
+                        temporal: bool, partner_w5: torch.Tensor = None, with_bwd: bool = True):
+    """{prefix + name: (tensor, kind)} of everything the kernels need from one DenseBlock / D2DTInput: forward
+    fragments (runtime.PackedSubnet) and, with_bwd, the gradient convs (autograd.PackedSubnetBwd)."""
+    dev = weights[0].device
+    e = {}
+    for i in range(4):
+        e[f"{prefix}w3_{i}"] = (pack_conv3x3(weights[i], cin, i + 1), "w")
+        e[f"{prefix}b3_{i}"] = (pad_bias(biases[i], 64, dev), "b")
+    if temporal:
+        e[f"{prefix}w5"] = (pack_tconv5([weights[4]] + ([partner_w5] if partner_w5 is not None else []), cin), "w")
+    else:
+        e[f"{prefix}w5"] = (pack_conv3x3(weights[4], cin, 5), "w")
+    e[f"{prefix}b5"] = (pad_bias(biases[4], 64, dev), "b")
+    if cin == 3 and temporal:
+        e[f"{prefix}wfused"] = (pack_fused_gh(list(weights[:4]), 3), "w")
+    if with_bwd and cout <= 96:
+        wt5, wtd, wtx = pack_subnet_bwd(weights, cin, cout, temporal)
+        e[f"{prefix}wt5"] = (wt5, "w")
+        for i in range(3):
+            e[f"{prefix}wtd_{i}"] = (wtd[i], "w")
+        e[f"{prefix}wtx"] = (wtx, "w")
+    return e

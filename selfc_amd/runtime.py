@@ -8,7 +8,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import _lib
-from .packing import dense_channels, pack_conv3x3, pack_fused_gh, pack_tconv5, pad_bias, roundup
+from .packing import PackPlan, dense_channels, roundup, subnet_pack_entries
 
 SUBNET_D2DT = _lib.SUBNET_D2DT
 SUBNET_DB2D = _lib.SUBNET_DB2D
@@ -33,23 +33,27 @@ class Workspace:
     Layout: include/selfc_hip.h.  Buffers are zero-initialised once: the pad
     channels of x2 / fd are never written by any kernel and must read as 0."""
 
-    def __init__(self, device, kind: int, N: int, T: int, H: int, W: int, c1: int, c2: int):
+    def __init__(self, device, kind: int, N: int, T: int, H: int, W: int, c1: int, c2: int, single_use: bool = False):
         self.kind, self.N, self.T, self.H, self.W, self.c1, self.c2 = kind, N, T, H, W, c1, c2
         self.c2p = roundup(c2, 4)
         self.FC = dense_channels(c2)
         f32, f16 = torch.float32, _lib.operand_dtype()
-        self.x1 = torch.zeros((N, H, W, 4), dtype=f32, device=device)
-        self.x2 = torch.zeros((N, H, W, self.c2p), dtype=f32, device=device)
+        # single_use (training: one workspace per block call, filled by selfc_nchw_to_latent which writes every element
+        # of x1 / x2 incl. pads, then by the conv epilogues which write every feature channel): only the pad channels of
+        # fd's input planes still need the zero fill
+        mk = torch.empty if single_use else torch.zeros
+        self.x1 = mk((N, H, W, 4), dtype=f32, device=device)
+        self.x2 = mk((N, H, W, self.c2p), dtype=f32, device=device)
         # dense buffers are plane-blocked: [C/32][N][H][W][32] (every 32-channel group contiguous per pixel)
         self.fd = torch.zeros((self.FC // 32, N, H, W, 32), dtype=f16, device=device)
-        self.gd = torch.zeros((4, N, H, W, 32), dtype=f16, device=device)
-        self.hd = torch.zeros((4, N, H, W, 32), dtype=f16, device=device)
+        self.gd = mk((4, N, H, W, 32), dtype=f16, device=device)
+        self.hd = mk((4, N, H, W, 32), dtype=f16, device=device)
         self.s: Optional[torch.Tensor] = None
         self.device = device
 
     def latent(self, want_s: bool = False) -> _lib.Latent:
-        if want_s and self.s is None:
-            self.s = torch.zeros((self.N, self.H, self.W, self.c2p), dtype=torch.float32, device=self.device)
+        if want_s and self.s is None:      # every element (incl. pads) is written by the coupling epilogue
+            self.s = torch.empty((self.N, self.H, self.W, self.c2p), dtype=torch.float32, device=self.device)
         return _lib.Latent(self.kind, self.N, self.T, self.H, self.W, self.c1, self.c2,
                            _ptr(self.x1), _ptr(self.x2), _ptr(self.fd), _ptr(self.gd), _ptr(self.hd),
                            _ptr(self.s) if want_s else None)
@@ -72,24 +76,31 @@ def workspace(device, kind, N, T, H, W, c1, c2) -> Workspace:
     return ws
 
 
-class PackedSubnet:
-    """Kernel-layout weights of one DenseBlock / D2DTInput (kept alive with the struct)."""
+def _conv_params(mod):
+    """conv1.weight, conv1.bias, ..., conv5.weight, conv5.bias of a dense-block subnet."""
+    out = []
+    for i in range(1, 6):
+        conv = getattr(mod, f"conv{i}")
+        if conv.bias is None:
+            raise NotImplementedError("selfc_amd dense-block kernels expect bias=True convs (every shipped config)")
+        out += [conv.weight, conv.bias]
+    return out
 
-    def __init__(self, mod, partner=None):
-        dev = mod.conv1.weight.device
-        self.cin, self.cout, self.kind = mod.channel_in, mod.channel_out, mod.kind
-        self.w3 = [pack_conv3x3(getattr(mod, f"conv{i}").weight, self.cin, i) for i in range(1, 5)]
-        self.b3 = [pad_bias(getattr(mod, f"conv{i}").bias, 64, dev) for i in range(1, 5)]
-        if self.kind == SUBNET_D2DT:
-            ws = [mod.conv5.weight] + ([partner.conv5.weight] if partner is not None else [])
-            self.w5 = pack_tconv5(ws, self.cin)
-        else:
-            self.w5 = pack_conv3x3(mod.conv5.weight, self.cin, 5)
-        self.b5 = pad_bias(mod.conv5.bias, 64, dev)
-        # cin == 3 temporal subnets (G / H of the coupling): fused conv1..4 stream
-        self.wfused = None
-        if self.cin == 3 and self.kind == SUBNET_D2DT:
-            self.wfused = pack_fused_gh([getattr(mod, f"conv{i}").weight for i in range(1, 5)], 3)
+
+class PackedSubnet:
+    """Kernel-layout weights of one DenseBlock / D2DTInput: views into the tensors a PackPlan produced
+    (``d``: name -> tensor, names prefixed with ``prefix``).  Holds the forward fragments and, when present,
+    the gradient convs of csrc/backward.hip."""
+
+    def __init__(self, d, prefix, cin, cout, kind):
+        self.cin, self.cout, self.kind = cin, cout, kind
+        self.w3 = [d[f"{prefix}w3_{i}"] for i in range(4)]
+        self.b3 = [d[f"{prefix}b3_{i}"] for i in range(4)]
+        self.w5, self.b5 = d[f"{prefix}w5"], d[f"{prefix}b5"]
+        self.wfused = d.get(f"{prefix}wfused")
+        self.wt5 = d.get(f"{prefix}wt5")
+        self.wtd = [d.get(f"{prefix}wtd_{i}") for i in range(3)]
+        self.wtx = d.get(f"{prefix}wtx")
 
     def struct(self) -> _lib.SubnetW:
         s = _lib.SubnetW()
@@ -100,6 +111,31 @@ class PackedSubnet:
         s.b5 = _ptr(self.b5)
         s.wfused = _ptr(self.wfused)
         return s
+
+    def bwd_struct(self) -> _lib.SubnetBW:
+        if self.wt5 is None:
+            raise NotImplementedError("subnet backward covers channel_out <= 96")
+        s = _lib.SubnetBW()
+        s.wt5 = _ptr(self.wt5)
+        for i in range(3):
+            s.wtd[i] = _ptr(self.wtd[i])
+        s.wtx = _ptr(self.wtx)
+        return s
+
+
+def packed_subnet(mod) -> PackedSubnet:
+    """Stand-alone subnet (not inside an InvBlockExp): plan learnt once per module, re-run when the weights change."""
+    key = params_key(mod)
+    if getattr(mod, "_pk_key", None) != key:
+        mod._check()
+        params = _conv_params(mod)
+        temporal = mod.kind == SUBNET_D2DT
+        if getattr(mod, "_plan", None) is None or mod._plan_dev != params[0].device:
+            mod._plan = PackPlan(params, lambda ps: subnet_pack_entries("", ps[0::2], ps[1::2], mod.channel_in, mod.channel_out, temporal))
+            mod._plan_dev = params[0].device
+        mod._pk = PackedSubnet(mod._plan.run(params), "", mod.channel_in, mod.channel_out, mod.kind)
+        mod._pk_key = key
+    return mod._pk
 
 
 def params_key(*mods) -> Tuple:
@@ -138,12 +174,13 @@ def as_input(x: torch.Tensor) -> torch.Tensor:
 
 
 class PackedBlock:
-    """Kernel-layout weights of one InvBlockExp (F, G, H) as a selfc_invblock_w."""
+    """Kernel-layout weights of one InvBlockExp (F, G, H) as a selfc_invblock_w; G's temporal conv5 is packed
+    together with H's (one launch computes both)."""
 
-    def __init__(self, blk):
-        self.F = PackedSubnet(blk.F)
-        self.G = PackedSubnet(blk.G, partner=blk.H if blk.G.kind == SUBNET_D2DT else None)
-        self.H = PackedSubnet(blk.H)
+    def __init__(self, blk, d):
+        self.F = PackedSubnet(d, "F.", blk.F.channel_in, blk.F.channel_out, blk.F.kind)
+        self.G = PackedSubnet(d, "G.", blk.G.channel_in, blk.G.channel_out, blk.G.kind)
+        self.H = PackedSubnet(d, "H.", blk.H.channel_in, blk.H.channel_out, blk.H.kind)
         self.clamp = float(blk.clamp)
 
     def struct(self) -> _lib.InvBlockW:
@@ -153,6 +190,16 @@ class PackedBlock:
         return s
 
 
+def _block_entries(blk, ps):
+    f, g, h = ps[0:10], ps[10:20], ps[20:30]
+    temporal = blk.F.kind == SUBNET_D2DT
+    e = subnet_pack_entries("F.", f[0::2], f[1::2], blk.F.channel_in, blk.F.channel_out, temporal)
+    e.update(subnet_pack_entries("G.", g[0::2], g[1::2], blk.G.channel_in, blk.G.channel_out, temporal,
+                                 partner_w5=h[8] if temporal else None))
+    e.update(subnet_pack_entries("H.", h[0::2], h[1::2], blk.H.channel_in, blk.H.channel_out, temporal))
+    return e
+
+
 def packed_block(blk) -> PackedBlock:
     key = params_key(blk) + (float(blk.clamp),)
     if getattr(blk, "_pb_key", None) != key:
@@ -160,7 +207,11 @@ def packed_block(blk) -> PackedBlock:
             sub._check()
         if blk.split_len1 > 3:
             raise NotImplementedError("selfc_amd coupling kernels cover channel_split_num <= 3 (every shipped config uses 3)")
-        blk._pb = PackedBlock(blk)
+        params = _conv_params(blk.F) + _conv_params(blk.G) + _conv_params(blk.H)
+        if getattr(blk, "_plan", None) is None or blk._plan_dev != params[0].device:
+            blk._plan = PackPlan(params, lambda ps: _block_entries(blk, ps))
+            blk._plan_dev = params[0].device
+        blk._pb = PackedBlock(blk, blk._plan.run(params))
         blk._pb_key = key
     return blk._pb
 

@@ -216,3 +216,34 @@ def test_pack_conv_planes(cin, nfeat, kt, cout):
         wk = unpack_a32(frag[z])
         out = torch.einsum("ok,bthwk->bothw", wk, ak)
         assert torch.allclose(out, ref[:, 32 * z:32 * z + 32], atol=2e-4, rtol=1e-4)
+
+
+def test_pack_plan_equals_direct_packing():
+    """PackPlan learns the gather map from index-valued stand-ins; its output must be bit-identical to calling the
+    pack functions on the real weights (forward fragments, biases and the gradient convs)."""
+    import torch
+    from selfc_amd import packing as P
+    torch.manual_seed(0)
+    for cin, cout, temporal, partner in [(48, 3, True, False), (3, 48, True, True), (9, 3, False, False), (3, 9, False, False),
+                                         (64, 64, True, False)]:
+        ws = [torch.randn(32, cin + 32 * k, *((1, 3, 3) if temporal else (3, 3))) for k in range(4)]
+        ws.append(torch.randn(cout, cin + 128, *((3, 1, 1) if temporal else (3, 3))))
+        bs = [torch.randn(32) for _ in range(4)] + [torch.randn(cout)]
+        pw5 = torch.randn_like(ws[4]) if partner else None
+        params = [t for pair in zip(ws, bs) for t in pair] + ([pw5] if partner else [])
+
+        def build(ps):
+            return P.subnet_pack_entries("s.", ps[0:10:2], ps[1:10:2], cin, cout, temporal, partner_w5=ps[10] if partner else None)
+
+        plan = P.PackPlan(params, build)
+        got = plan.run(params)
+        want = build(params)
+        assert set(got) == set(want)
+        for name, (t, kind) in want.items():
+            assert got[name].dtype == (P.F16 if kind == "w" else torch.float32), name
+            assert got[name].shape == t.shape and torch.equal(got[name], t), name
+            assert got[name].data_ptr() % 16 == 0, name
+        # changed weights -> same plan, new values
+        params2 = [p * 0.5 for p in params]
+        got2 = plan.run(params2)
+        assert torch.equal(got2["s.w3_0"], P.pack_conv3x3(params2[0], cin, 1))
