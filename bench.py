@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-path", action="store_true", help="skip the extra netG(x) + Quantization + netG(LR, rev=True) timing (incl. STP sampler)")
     ap.add_argument("--streams", type=int, default=4, help="split the septuplets of a step over this many HIP streams")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the extra training-step timing (config 3: 8 x 7x3x144x144)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -223,6 +224,14 @@ def main():
             L.selfc_profile_reset()
         out["full_test_path"] = {"septuplets_per_s": round(B_PER_GPU / tf, 1), "ms_per_batch": round(tf * 1e3, 3),
                                  "kernel_ms": fp, "note": "module API, eager, single stream, fh_loss gmm with device RNG"}
+    if not args.no_train_step and world == 1:
+        # config 3 of BASELINE.json: one optimize_parameters step (fwd, quantise, STP sample, reverse, backward, clip, Adam)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import bench_train
+        tr = bench_train.run(batch=8, size=144, steps=5, warmup=2, fh_loss="gmm", profile=False)
+        out["train_step"] = {"septuplets_per_s": round(tr["value"], 1), "ms_per_step": round(tr["ms_per_step"], 2),
+                             "config": "8 x 7x3x144x144 crops, fh_loss gmm, l2 + l1 losses, clip 10, Adam; eager, single stream",
+                             "note": "every forward / reverse / gradient kernel is HIP (selfc_amd/autograd.py); losses, clip and Adam are torch"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, z_ref, zq_ref, xr_ref = cpu_baseline(net, x_cpu[:T])
         out["cpu_baseline"] = cb

@@ -16,15 +16,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--size", type=int, default=144)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--fh-loss", default="gmm")
-    ap.add_argument("--profile", action="store_true", help="also report per-class kernel time (adds event overhead)")
-    a = ap.parse_args()
+def run(batch=8, size=144, steps=10, warmup=3, fh_loss="gmm", profile=False):
+    """Time RescaleTrainer.optimize_parameters on one GPU; returns the result dict."""
+    a = argparse.Namespace(batch=batch, size=size, steps=steps, warmup=warmup, fh_loss=fh_loss, profile=profile)
     from selfc_amd import GlobalVar, _lib, train
     from selfc_amd.modules.SelfC_GMM_arch_inv import SelfCInvNet
     dev = torch.device("cuda:0")
@@ -60,7 +54,19 @@ def main():
             L.selfc_profile_read(cls, C.byref(ms), C.byref(n))
             km[name] = {"ms_per_step": ms.value / a.steps, "launches_per_step": n.value / a.steps}
         out["kernel_ms"] = km
-    print(json.dumps(out))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=144)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--fh-loss", default="gmm")
+    ap.add_argument("--profile", action="store_true", help="also report per-class kernel time (adds event overhead)")
+    a = ap.parse_args()
+    print(json.dumps(run(a.batch, a.size, a.steps, a.warmup, a.fh_loss, a.profile)))
 
 
 if __name__ == "__main__":
