@@ -210,6 +210,23 @@ class FreqFn(torch.autograd.Function):
         return dx, None, None
 
 
+class HaarFn(torch.autograd.Function):
+    """HaarDownsampling.forward(x, rev) (Inv_arch.py:60-79).  y = W x / 4 with W^T W = 4 I, reverse x = W^T y, so the
+    adjoints are the opposite-direction kernels: d/dx of forward = haar_inv(dy) / 4, of reverse = 4 haar_fwd(dx)."""
+
+    @staticmethod
+    def forward(ctx, x, mod, rev):
+        ctx.mod, ctx.rev = mod, bool(rev)
+        with torch.no_grad():
+            return mod._run(x, rev)
+
+    @staticmethod
+    def backward(ctx, gy):
+        with torch.no_grad():
+            g = ctx.mod._run(gy.contiguous().float(), not ctx.rev, track=False)
+        return (g * 0.25 if not ctx.rev else g * 4.0), None, None
+
+
 def needs_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 

@@ -75,10 +75,24 @@ class HaarDownsampling(nn.Module):
         self.haar_weights = nn.Parameter(torch.cat([w] * channel_in, 0), requires_grad=False)
 
     def forward(self, x, rev=False):
+        from .. import autograd as ag
+        if ag.needs_grad(x):
+            return ag.HaarFn.apply(x, self, bool(rev))
+        return self._run(x, rev)
+
+    def _run(self, x, rev=False, track=True):
         x = rt.as_input(x)
         n, c, h, w = x.shape
-        self.elements = c * h * w
         sp = _lib.stream_ptr()
+        if not track:               # adjoint evaluation inside a backward: leave elements / last_jac alone
+            if not rev:
+                y = torch.empty((n, 4 * c, h // 2, w // 2), dtype=x.dtype, device=x.device)
+                rt.call("selfc_haar_fwd_nchw", x.data_ptr(), y.data_ptr(), n, c, h, w, sp)
+            else:
+                y = torch.empty((n, c // 4, 2 * h, 2 * w), dtype=x.dtype, device=x.device)
+                rt.call("selfc_haar_inv_nchw", x.data_ptr(), y.data_ptr(), n, c // 4, h, w, sp)
+            return y
+        self.elements = c * h * w
         if not rev:
             if c != self.channel_in:
                 raise RuntimeError(f"HaarDownsampling({self.channel_in}) got {c} channels")

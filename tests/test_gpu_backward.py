@@ -283,3 +283,76 @@ def test_stp_backward(dev, fh_loss):
     print(fh_loss, "dx", rel_l2(xd.grad.cpu(), dx_ref), "worst", worst)
     assert rel_l2(xd.grad.cpu(), dx_ref) < 5e-2
     assert worst[0][1] < 5e-2, worst
+
+
+def test_haar_backward_and_irn_training(dev):
+    """HaarDownsampling adjoints, then InvRescaleNet (Haar + DBNet blocks, Inv_arch.py:87-127) end to end: gradients
+    of its training-style outputs against autograd through the oracle."""
+    from selfc_amd.modules.Inv_arch import HaarDownsampling, InvRescaleNet
+    from selfc_amd.modules.Subnet_constructor import subnet
+    torch.manual_seed(6)
+    hd = HaarDownsampling(3)
+    for rev, shape in ((False, (2, 3, 8, 12)), (True, (2, 12, 4, 6))):
+        x = torch.randn(*shape)
+        xr = x.clone().requires_grad_(True)
+        y_ref = O.haar_inv(xr) if rev else O.haar_fwd(xr)
+        gy = torch.randn_like(y_ref)
+        y_ref.backward(gy)
+        xd = x.to(dev).requires_grad_(True)
+        y = hd.to(dev)(xd, rev=rev)
+        assert torch.equal(y.detach().cpu(), y_ref.detach())
+        y.backward(gy.to(dev))
+        assert rel_err(xd.grad.cpu(), xr.grad) < 1e-6
+    g = load_golden("g8_haar_net")
+    irn = InvRescaleNet(3, 3, subnet("DBNet", "xavier"), [1], 1)
+    sd = {k: v for k, v in g.items() if k.startswith("operations.")}
+    irn.load_state_dict(sd, strict=True)
+    x = g["x"]
+    p = {k: v.clone().requires_grad_(k.endswith(("weight", "bias"))) for k, v in sd.items()}
+    z = O.haar_net_fwd(p, x, [1], T, kind="DBNet")
+    target = torch.rand(T, 3, 32, 32)
+    loss_ref = ((z[:, :3] - target) ** 2).mean() + (z[:, 3:] ** 2).mean()
+    loss_ref.backward()
+    irn.to(dev)
+    lr, hfm = irn(x.to(dev))
+    loss = ((lr - target.to(dev)) ** 2).mean() + hfm
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-3 * float(loss_ref.detach())
+    loss.backward()
+    for name, prm in irn.named_parameters():
+        if prm.requires_grad:
+            e = rel_l2(prm.grad.cpu(), p[name].grad)
+            assert e < L2TOL, f"{name}: {e}"
+
+
+def test_ddp_single_rank_training_step(dev):
+    """The reference wraps netG in DistributedDataParallel (SelfC_model.py:42).  World size 1 over RCCL on this GPU:
+    the autograd.Functions must cooperate with DDP's hooks (every parameter receives its gradient exactly once)."""
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    from selfc_amd import train
+    from selfc_amd.modules.SelfC_GMM_arch_inv import SelfCInvNet
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(10)
+        opt = {"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": "gmm", "scale": 4, "gmm_k": 5}
+        net = SelfCInvNet(opt, 3, 3, "D2DTNet", [4, 4], 2).to(dev)
+        ref = {n: p.detach().clone() for n, p in net.named_parameters()}
+        ddp = DistributedDataParallel(net, device_ids=[dev.index], find_unused_parameters=False)
+        tr = train.RescaleTrainer(ddp, dict(train.TRAIN_OPT_LARGE))
+        gt = torch.rand(1, 3, T, 32, 48, generator=torch.Generator().manual_seed(1)).to(dev)
+        real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
+        log = tr.optimize_parameters(real_h, ref_l)
+        assert log["loss"] == log["loss"] and log["loss"] > 0
+        # GlobalAgg.proj3.bias has an exactly-zero gradient (softmax is invariant to a shift of every key), so Adam
+        # leaves those six tensors where they are; everything else must have moved
+        still = [n for n, p in net.named_parameters() if torch.equal(p.detach(), ref[n])]
+        assert all(n.endswith("proj3.bias") for n in still), still
+        assert len(still) <= 6 and len(ref) == 354
+    finally:
+        if own:
+            dist.destroy_process_group()
