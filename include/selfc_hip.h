@@ -171,6 +171,14 @@ size_t selfc_subnet_bwd_scratch_bytes(int N, int H, int W, int cin, int cout);
 int selfc_subnet_bwd(const selfc_subnet_bw* bw, int kind, const void* dense, const float* xin, const float* dout, float sign,
                      float* dx, int accumulate_dx, float* const* wgrad, float* const* bgrad, float beta,
                      void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout, void* stream);
+/* The same in two phases, so that a caller can put the weight gradients on a second stream: SELFC_BWD_DATA computes dx and
+ * leaves the scaled gradient planes in `scratch`; SELFC_BWD_WEIGHTS (same arguments, same untouched scratch, ordered after
+ * the data phase) produces wgrad / bgrad. */
+#define SELFC_BWD_DATA 1
+#define SELFC_BWD_WEIGHTS 2
+int selfc_subnet_bwd_phase(int phases, const selfc_subnet_bw* bw, int kind, const void* dense, const float* xin, const float* dout,
+                           float sign, float* dx, int accumulate_dx, float* const* wgrad, float* const* bgrad, float beta,
+                           void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout, void* stream);
 /* Gradient of the affine coupling of InvBlockExp (Inv_arch.py:24-32) w.r.t. its x2 path and H's output, n = npix*c2p
  * fp32 elements: rev == 0: v = x2 (input), dx2 = dy2*e^s, dh = dx2*x2*ds/dh (dG = dy2);
  * rev != 0: v = y2 (output), dx2 = dy2*e^-s, dh = -dy2*y2*ds/dh (dG = -dx2); ds/dh = clamp*(1-(s/clamp)^2)/2. */
@@ -207,7 +215,7 @@ int selfc_bwd_wgrad(const void* P, int Pn, const void* Q, int Qn, int taps, floa
  * `wmap` [H*W] is fc folded through the adaptive pooling (host, selfc_amd/packing.py:pool_weight_map),
  * `w1` proj1 as pointwise fragments (pack_pointwise), w2/b2/w3/b3 the fp32 Linear(64,64) params,
  * `partial` selfc_globalagg_partial_floats(N,HW) floats, `attn` (N/T)*T*T floats. C = 64, T <= 8, x != y. */
-int selfc_globalagg_run(const float* x, float* y, const float* wmap, float fc_bias, const void* w1, const float* b1,
+int selfc_globalagg_run(const float* x, float* y, const float* wmap, const float* fc_bias /* device, 1 float */, const void* w1, const float* b1,
                         const float* w2, const float* b2, const float* w3, const float* b3,
                         float* partial, float* attn, int N, int T, int HW, void* stream);
 size_t selfc_globalagg_partial_floats(int N, int HW);
@@ -244,7 +252,7 @@ size_t selfc_globalagg_bwd_scratch_bytes(int N, int T, int H, int W);
  * w1t = pack_planes_generic(proj1.weight^T).  Parameter gradients: dw1 (64,64) complete; the others per clip
  * ([B][64], [B][64*64], [B], dwmap_clip [B][H*W]) - the caller sums over clips and folds dwmap through the pooling
  * map (packing.py:pool_weight_map) into fc.weight. */
-int selfc_globalagg_bwd(const float* x, const float* dy, float* dx, const float* wmap, float fc_bias, const void* w1t,
+int selfc_globalagg_bwd(const float* x, const float* dy, float* dx, const float* wmap, const float* fc_bias, const void* w1t,
                         const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                         float* dw1, float* db1_clip, float* dw2_clip, float* db2_clip, float* dw3_clip, float* db3_clip,
                         float* dfcb_clip, float* dwmap_clip, void* scratch, size_t scratch_bytes,

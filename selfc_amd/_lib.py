@@ -35,7 +35,7 @@ SYMBOLS = [
     "selfc_profile_enable", "selfc_profile_read", "selfc_profile_reset",
     "selfc_globalagg_run", "selfc_globalagg_partial_floats", "selfc_pwconv_run", "selfc_gmm_sample",
     "selfc_conv_planes_run", "selfc_nhwc_to_planes", "selfc_y_sse", "selfc_y_sse_blocks", "selfc_gauss_down4",
-    "selfc_subnet_bwd_scratch_bytes", "selfc_subnet_bwd", "selfc_coupling_bwd", "selfc_freq_fwd_bwd", "selfc_freq_inv_bwd",
+    "selfc_subnet_bwd_scratch_bytes", "selfc_subnet_bwd", "selfc_subnet_bwd_phase", "selfc_coupling_bwd", "selfc_freq_fwd_bwd", "selfc_freq_inv_bwd",
     "selfc_bwd_scale", "selfc_bwd_to_planes", "selfc_f16_rows_to_planes", "selfc_bwd_conv_planes",
     "selfc_bwd_wgrad_scratch_bytes", "selfc_bwd_wgrad", "selfc_gmm_sample_bwd", "selfc_lrelu_bwd",
     "selfc_globalagg_bwd_scratch_bytes", "selfc_globalagg_bwd",
@@ -99,7 +99,7 @@ def lib():
             "selfc_profile_enable": [i],
             "selfc_profile_read": [i, C.POINTER(C.c_double), C.POINTER(C.c_longlong)],
             "selfc_profile_reset": [],
-            "selfc_globalagg_run": [vp, vp, vp, f, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
+            "selfc_globalagg_run": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
             "selfc_pwconv_run": [vp, i, vp, i, vp, vp, sz, i, i, i, i, i, vp],
             "selfc_gmm_sample": [vp, vp, vp, sz, i, i, vp],
             "selfc_conv_planes_run": [vp, i, i, vp, vp, i, i, vp, i, i, i, i, vp],
@@ -109,6 +109,8 @@ def lib():
             "selfc_gauss_down4": [vp, vp, vp, i, i, i, vp],
             "selfc_subnet_bwd": [C.POINTER(SubnetBW), i, vp, vp, vp, f, vp, i, C.POINTER(vp), C.POINTER(vp), f,
                                  vp, sz, i, i, i, i, i, i, vp],
+            "selfc_subnet_bwd_phase": [i, C.POINTER(SubnetBW), i, vp, vp, vp, f, vp, i, C.POINTER(vp), C.POINTER(vp), f,
+                                       vp, sz, i, i, i, i, i, i, vp],
             "selfc_coupling_bwd": [i, vp, vp, vp, vp, vp, f, sz, vp],
             "selfc_freq_fwd_bwd": [vp, vp, vp, i, i, i, vp],
             "selfc_freq_inv_bwd": [vp, vp, vp, i, i, i, vp],
@@ -119,7 +121,7 @@ def lib():
             "selfc_bwd_wgrad": [vp, i, vp, i, i, vp, i, i, vp, f, vp, vp, sz, i, i, i, i, vp],
             "selfc_gmm_sample_bwd": [vp, vp, vp, vp, sz, i, i, vp],
             "selfc_lrelu_bwd": [vp, vp, sz, vp],
-            "selfc_globalagg_bwd": [vp, vp, vp, vp, f, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, i, vp],
+            "selfc_globalagg_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, i, vp],
         }
         for name, args in sigs.items():
             fn = getattr(L, name)

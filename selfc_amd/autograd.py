@@ -8,6 +8,7 @@ back in the reference's own tensor layouts, so optimizers / DDP see ordinary ``.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -18,20 +19,40 @@ from .packing import dense_channels, pack_planes_generic, pack_pointwise_T, pool
 _SCRATCH: Dict[Tuple, torch.Tensor] = {}
 
 
-def _scratch(device, n, h, w, cin, cout) -> torch.Tensor:
+def _scratch(device, n, h, w, cin, cout, slot="") -> torch.Tensor:
+    """Scratch of one subnet backward.  `slot` separates calls whose weight-gradient phase may still be running on the side
+    stream while the next call's data phase starts."""
     need = _lib.lib().selfc_subnet_bwd_scratch_bytes(n, h, w, cin, cout)
     if need == 0:
         raise RuntimeError("selfc_subnet_bwd_scratch_bytes: invalid shape")
-    key = str(device)
+    key = (str(device), slot)
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < need:
         buf = _SCRATCH[key] = torch.empty(need, dtype=torch.uint8, device=device)
     return buf
 
 
+#: weight gradients run on a second HIP stream, overlapping the (latency-bound) data-gradient chain of the next subnet;
+#: SELFC_BWD_STREAMS=1 keeps everything on the caller's stream
+_TWO_STREAMS = os.environ.get("SELFC_BWD_STREAMS", "2") != "1"
+_SIDE: Dict[str, "torch.cuda.Stream"] = {}
+
+
+def side_stream(device):
+    if not _TWO_STREAMS:
+        return None
+    key = str(device)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 def subnet_params(mod) -> List[torch.Tensor]:
     """conv1.weight, conv1.bias, ..., conv5.weight, conv5.bias (the order the Functions take and return)."""
-    out = []
+    cached = mod.__dict__.get("_conv_plist")
+    if cached is not None and cached[0] is mod.conv1.weight:
+        return cached
+    out = mod.__dict__["_conv_plist"] = []
     for i in range(1, 6):
         conv = getattr(mod, f"conv{i}")
         if conv.bias is None:
@@ -42,9 +63,10 @@ def subnet_params(mod) -> List[torch.Tensor]:
 
 def subnet_bwd(mod, dense: torch.Tensor, xin: Optional[torch.Tensor], dout: torch.Tensor, sign: float,
                dx: Optional[torch.Tensor], accumulate_dx: bool, n: int, t: int, h: int, w: int,
-               want_params: bool = True, pk=None) -> List[Optional[torch.Tensor]]:
+               want_params: bool = True, pk=None, side=None, slot: str = "") -> List[Optional[torch.Tensor]]:
     """Backward of one DenseBlock / D2DTInput on kernel-layout buffers; returns the 10 parameter gradients
-    (reference layouts) or Nones."""
+    (reference layouts) or Nones.  With `side` (a stream) the weight-gradient phase is enqueued there, ordered after the
+    data phase; the caller joins the streams before it hands the gradients on and must not reuse `slot` before that."""
     cin, cout = mod.channel_in, mod.channel_out
     pk = pk if pk is not None else mod.packed()             # inside an InvBlockExp the block's plan owns the tensors
     dev = dout.device
@@ -58,12 +80,19 @@ def subnet_bwd(mod, dense: torch.Tensor, xin: Optional[torch.Tensor], dout: torc
             gb = torch.empty(conv.bias.shape, dtype=torch.float32, device=dev)
             grads[2 * i], grads[2 * i + 1] = gw, gb
             wg[i], bg[i] = gw.data_ptr(), gb.data_ptr()
-    scratch = _scratch(dev, n, h, w, cin, cout)
+    scratch = _scratch(dev, n, h, w, cin, cout, slot)
     bw = pk.bwd_struct()
-    rt.call("selfc_subnet_bwd", bw, mod.kind, dense.data_ptr(), None if xin is None else xin.data_ptr(), dout.data_ptr(),
+    args = (bw, mod.kind, dense.data_ptr(), None if xin is None else xin.data_ptr(), dout.data_ptr(),
             float(sign), None if dx is None else dx.data_ptr(), 1 if accumulate_dx else 0,
             wg if want_params else None, bg if want_params else None, 0.0,
-            scratch.data_ptr(), scratch.numel(), n, t, h, w, cin, cout, _lib.stream_ptr())
+            scratch.data_ptr(), scratch.numel(), n, t, h, w, cin, cout)
+    if side is None or not want_params:
+        rt.call("selfc_subnet_bwd", *args, _lib.stream_ptr())
+        return grads
+    rt.call("selfc_subnet_bwd_phase", 1, *args, _lib.stream_ptr())
+    side.wait_event(torch.cuda.current_stream().record_event())
+    with torch.cuda.stream(side):
+        rt.call("selfc_subnet_bwd_phase", 2, *args, _lib.stream_ptr())
     return grads
 
 
@@ -134,7 +163,7 @@ class InvBlockFn(torch.autograd.Function):
         keep = (ws.x1 if rev else ws.x2).clone()                          # the input side the kernels overwrite
         bw, lat = pb.struct(), ws.latent(want_s=True)
         rt.call("selfc_invblock_run", bw, lat, 1 if rev else 0, _lib.stream_ptr())
-        blk.s = rt.s_to_nchw(ws)
+        blk._set_s_lazy(ws)
         ctx.blk, ctx.rev, ctx.t, ctx.ws, ctx.keep = blk, bool(rev), t, ws, keep
         return rt.latent_to_nchw(ws)
 
@@ -153,24 +182,27 @@ class InvBlockFn(torch.autograd.Function):
         nel = d2.numel()
         clamp = float(blk.clamp)
         pb = rt.packed_block(blk)
+        side = side_stream(dev) if want else None
         if not rev:
             # y1 = x1 + F(x2); y2 = x2*e^s + G(y1), s = s(H(y1)).  keep = x2 (input), ws.x1 = y1
             rt.call("selfc_coupling_bwd", 0, keep.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel, sp)
-            gG = subnet_bwd(blk.G, ws.gd, ws.x1, d2, 1.0, d1, True, n, t, h, w, want, pb.G)
-            gH = subnet_bwd(blk.H, ws.hd, ws.x1, dh, 1.0, d1, True, n, t, h, w, want, pb.H)
+            gG = subnet_bwd(blk.G, ws.gd, ws.x1, d2, 1.0, d1, True, n, t, h, w, want, pb.G, side, "G")
+            gH = subnet_bwd(blk.H, ws.hd, ws.x1, dh, 1.0, d1, True, n, t, h, w, want, pb.H, side, "H")
             # the forward's epilogue replaced F's f16 input copy by y2: put x2 back before F's weight gradients
             rt.call("selfc_nhwc_to_planes", keep.data_ptr(), ws.fd.data_ptr(), n * h * w, c2, sp)
-            gF = subnet_bwd(blk.F, ws.fd, None, d1, 1.0, dx2, True, n, t, h, w, want, pb.F)
+            gF = subnet_bwd(blk.F, ws.fd, None, d1, 1.0, dx2, True, n, t, h, w, want, pb.F, side, "F")
         else:
             # y2 = (x2 - G(x1))*e^-s, s = s(H(x1)); y1 = x1 - F(y2).  keep = x1 (input), ws.x2 = y2 (also in fd)
-            gF = subnet_bwd(blk.F, ws.fd, None, d1, -1.0, d2, True, n, t, h, w, want, pb.F)
+            gF = subnet_bwd(blk.F, ws.fd, None, d1, -1.0, d2, True, n, t, h, w, want, pb.F, side, "F")
             rt.call("selfc_coupling_bwd", 1, ws.x2.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel, sp)
-            gG = subnet_bwd(blk.G, ws.gd, keep, dx2, -1.0, d1, True, n, t, h, w, want, pb.G)
-            gH = subnet_bwd(blk.H, ws.hd, keep, dh, 1.0, d1, True, n, t, h, w, want, pb.H)
+            gG = subnet_bwd(blk.G, ws.gd, keep, dx2, -1.0, d1, True, n, t, h, w, want, pb.G, side, "G")
+            gH = subnet_bwd(blk.H, ws.hd, keep, dh, 1.0, d1, True, n, t, h, w, want, pb.H, side, "H")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((n, c1 + c2, h, w), dtype=torch.float32, device=dev)
             rt.call("selfc_latent_to_nchw", d1.data_ptr(), dx2.data_ptr(), dx.data_ptr(), n, c1, c2, h, w, sp)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)          # the parameter gradients are complete from here on
         return (dx, None, None, None, *gF, *gG, *gH)
 
 
@@ -231,6 +263,13 @@ def needs_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
+def module_needs_grad(x, mod) -> bool:
+    """needs_grad(x, *mod.parameters()) on the cached parameter list."""
+    if not torch.is_grad_enabled():
+        return False
+    return (x is not None and x.requires_grad) or any(p.requires_grad for p in rt.plist(mod))
+
+
 # ------------------------------------------------------------------------------------------------------------
 # STP (SelfC_GMM_arch_inv.py:289-430): GlobalAgg, the 1x1x1 head and the GMM sampler
 # ------------------------------------------------------------------------------------------------------------
@@ -261,7 +300,7 @@ def globalagg_bwd(m, x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, n: int
     dwmapc = torch.empty((b, h * w), **f32)
     need = _lib.lib().selfc_globalagg_bwd_scratch_bytes(n, t, h, w)
     sc = _buf(_STP_CACHE, "gagg", need, dev)
-    rt.call("selfc_globalagg_bwd", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), pk["wmap"].data_ptr(), pk["fcb"],
+    rt.call("selfc_globalagg_bwd", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), pk["wmap"].data_ptr(), pk["fcb"].data_ptr(),
             m._w1t.data_ptr(), pk["b1"].data_ptr(), pk["w2"].data_ptr(), pk["b2"].data_ptr(), pk["w3"].data_ptr(), pk["b3"].data_ptr(),
             dw1.data_ptr(), db1c.data_ptr(), dw2c.data_ptr(), db2c.data_ptr(), dw3c.data_ptr(), db3c.data_ptr(),
             dfcbc.data_ptr(), dwmapc.data_ptr(), sc.data_ptr(), sc.numel(), n, t, h, w, _lib.stream_ptr())
@@ -429,10 +468,17 @@ class STPSampleFn(torch.autograd.Function):
         for conv, (gw, gb) in zip(_head_convs(stp), [head_grads[i] for i in range(len(head_grads))]):
             grads[id(conv.weight)], grads[id(conv.bias)] = gw, gb
         d = d.reshape(n, h * w, 64)
+        side = side_stream(dev)
+        ring, turn = [None, None], 0                       # two scratch slots; a slot is reused only after its weight phase
         for m, xin, dense in reversed(ctx.stages):
             if isinstance(m, D2DTInput):
                 dxl = torch.empty((n, h, w, roundup(m.channel_in, 4)), dtype=torch.float32, device=dev)
-                g = subnet_bwd(m, dense, xin, d, 1.0, dxl, False, n, t, h, w, True)
+                if side is not None and ring[turn] is not None:
+                    torch.cuda.current_stream().wait_event(ring[turn])
+                g = subnet_bwd(m, dense, xin, d, 1.0, dxl, False, n, t, h, w, True, None, side, f"stp{turn}")
+                if side is not None:
+                    ring[turn] = side.record_event()
+                    turn ^= 1
                 for prm, gg in zip(subnet_params(m), g):
                     grads[id(prm)] = gg
                 d = dxl
@@ -446,4 +492,6 @@ class STPSampleFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dlr = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
             rt.call("selfc_nhwc4_to_nchw", d.data_ptr(), dlr.data_ptr(), n, 3, h, w, sp)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         return (dlr, None, None, None, *[grads.get(id(p)) for p in stp.parameters()])

@@ -541,6 +541,14 @@ size_t selfc_subnet_bwd_scratch_bytes(int N, int H, int W, int cin, int cout) {
 int selfc_subnet_bwd(const selfc_subnet_bw* bw, int kind, const void* dense, const float* xin, const float* dout, float sign,
                      float* dx, int accumulate_dx, float* const* wgrad, float* const* bgrad, float beta,
                      void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout, void* stream) {
+  return selfc_subnet_bwd_phase(SELFC_BWD_DATA | SELFC_BWD_WEIGHTS, bw, kind, dense, xin, dout, sign, dx, accumulate_dx, wgrad, bgrad,
+                                beta, scratch, scratch_bytes, N, T, H, W, cin, cout, stream);
+}
+
+int selfc_subnet_bwd_phase(int phases, const selfc_subnet_bw* bw, int kind, const void* dense, const float* xin, const float* dout,
+                           float sign, float* dx, int accumulate_dx, float* const* wgrad, float* const* bgrad, float beta,
+                           void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout, void* stream) {
+  if (!(phases & (SELFC_BWD_DATA | SELFC_BWD_WEIGHTS))) return SELFC_EINVAL;
   if (!bw || !dense || !dout || !scratch || !bw->wt5 || !bw->wtx || !bw->wtd[0] || !bw->wtd[1] || !bw->wtd[2]) return SELFC_EINVAL;
   if (N <= 0 || T <= 0 || N % T || H <= 0 || W <= 0 || cin < 1 || cin > 96 || cout < 1 || cout > 96) return SELFC_EINVAL;
   if (kind != SELFC_SUBNET_D2DT && kind != SELFC_SUBNET_DB2D) return SELFC_EINVAL;
@@ -562,6 +570,7 @@ int selfc_subnet_bwd(const selfc_subnet_bw* bw, int kind, const void* dense, con
   const int coutp = (cout + 3) & ~3, cinp = (cin + 3) & ~3;
   const bool d2dt = kind == SELFC_SUBNET_D2DT;
   int rc;
+  if (!(phases & SELFC_BWD_DATA)) goto weights;
 
   // 1. scale + scaled f16 planes of dOut
   if ((rc = bwd_absmax(dout, npix * coutp, amax, s))) return rc;
@@ -595,9 +604,10 @@ int selfc_subnet_bwd(const selfc_subnet_bw* bw, int kind, const void* dense, con
     c.plain = dx; c.coutp = cinp; c.accumulate = accumulate_dx; c.amax = amax;
     if ((rc = bwd_conv_planes(c, N, T, H, W, s))) return rc;
   }
-  if (!wgrad && !bgrad) return SELFC_OK;
+weights:
+  if (!(phases & SELFC_BWD_WEIGHTS) || (!wgrad && !bgrad)) return SELFC_OK;
 
-  // 5. weight / bias gradients: conv1..4 in one launch, conv5 in another
+  // 5. weight / bias gradients: conv1..4 in one launch, conv5 in another (reads only what the data phase left in scratch)
   {
     // input planes: [x planes][f1..]; with cin <= 3 the x plane is the scratch copy and the features start `dense`
     const void* q0 = L.hasx ? (const void*)xpl : (const void*)dn;

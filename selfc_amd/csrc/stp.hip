@@ -51,12 +51,13 @@ __global__ __launch_bounds__(256) void gagg_pool_kernel(const float* __restrict_
 }
 
 // ---- (2) per clip: g = sum(partials) + fc.bias; q = proj2(g), k = proj3(g); A = softmax(q k^T / 64, dim=-1)
-__global__ __launch_bounds__(64) void gagg_attn_kernel(const float* __restrict__ partial, int nchunk, float fcb,
+__global__ __launch_bounds__(64) void gagg_attn_kernel(const float* __restrict__ partial, int nchunk, const float* __restrict__ fcbp,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
                                                        const float* __restrict__ w3, const float* __restrict__ b3,
                                                        float* __restrict__ A, int T) {
   __shared__ float g[TMAX][64], q[TMAX][64], k[TMAX][64], m[TMAX][TMAX];
   const int b = blockIdx.x, c = threadIdx.x;
+  const float fcb = *fcbp;
   for (int t = 0; t < T; ++t) {
     float s = 0.f;
     const float* p = partial + (size_t)(b * T + t) * nchunk * 64 + c;
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(256) void gagg_bwd_reduce_kernel(const float* __res
 }
 
 // step 2: per clip - recompute g, q, k, A; then the gradients of everything upstream of A (tiny)
-__global__ __launch_bounds__(64) void gagg_attn_bwd_kernel(const float* __restrict__ partial, int nchunk, float fcb,
+__global__ __launch_bounds__(64) void gagg_attn_bwd_kernel(const float* __restrict__ partial, int nchunk, const float* __restrict__ fcbp,
                                                            const float* __restrict__ w2, const float* __restrict__ b2,
                                                            const float* __restrict__ w3, const float* __restrict__ b3,
                                                            const float* __restrict__ b1, const float* __restrict__ pdA,
@@ -447,6 +448,7 @@ __global__ __launch_bounds__(64) void gagg_attn_bwd_kernel(const float* __restri
   __shared__ float g[TMAX][64], q[TMAX][64], k[TMAX][64], m[TMAX][TMAX], a[TMAX][TMAX], dA[TMAX][TMAX], dm[TMAX][TMAX];
   __shared__ float dyo[TMAX][64], dq[TMAX][64], dk[TMAX][64], dyb[TMAX], red[64];
   const int b = blockIdx.x, c = threadIdx.x;
+  const float fcb = *fcbp;
   for (int t = 0; t < T; ++t) {
     float s = 0.f, sy = 0.f;
     const float* p = partial + (size_t)(b * T + t) * nchunk * 64 + c;
@@ -648,10 +650,10 @@ int launch_pw(const void* in, void* out, const void* w, const float* bias, size_
 
 extern "C" {
 
-int selfc_globalagg_run(const float* x, float* y, const float* wmap, float fc_bias, const void* w1, const float* b1,
+int selfc_globalagg_run(const float* x, float* y, const float* wmap, const float* fc_bias, const void* w1, const float* b1,
                         const float* w2, const float* b2, const float* w3, const float* b3,
                         float* partial, float* attn, int N, int T, int HW, void* stream) {
-  if (!x || !y || !wmap || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !partial || !attn) return SELFC_EINVAL;
+  if (!x || !y || !wmap || !fc_bias || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !partial || !attn) return SELFC_EINVAL;
   if (N <= 0 || T <= 0 || T > TMAX || N % T || HW <= 0 || x == y) return SELFC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = (HW + POOL_CHUNK - 1) / POOL_CHUNK;
@@ -742,12 +744,12 @@ size_t selfc_globalagg_bwd_scratch_bytes(int N, int T, int H, int W) {
   return gagg_bwd_layout(N, T, H, W).total;
 }
 
-int selfc_globalagg_bwd(const float* x, const float* dy, float* dx, const float* wmap, float fc_bias, const void* w1t,
+int selfc_globalagg_bwd(const float* x, const float* dy, float* dx, const float* wmap, const float* fc_bias, const void* w1t,
                         const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                         float* dw1, float* db1_clip, float* dw2_clip, float* db2_clip, float* dw3_clip, float* db3_clip,
                         float* dfcb_clip, float* dwmap_clip, void* scratch, size_t scratch_bytes,
                         int N, int T, int H, int W, void* stream) {
-  if (!x || !dy || !dx || !wmap || !w1t || !b1 || !w2 || !b2 || !w3 || !b3 || !scratch) return SELFC_EINVAL;
+  if (!x || !dy || !dx || !wmap || !fc_bias || !w1t || !b1 || !w2 || !b2 || !w3 || !b3 || !scratch) return SELFC_EINVAL;
   if (!dw1 || !db1_clip || !dw2_clip || !db2_clip || !dw3_clip || !db3_clip || !dfcb_clip || !dwmap_clip) return SELFC_EINVAL;
   if (N <= 0 || T <= 0 || T > TMAX || N % T || H <= 0 || W <= 0 || x == dx) return SELFC_EINVAL;
   const GaggBwdLayout L = gagg_bwd_layout(N, T, H, W);

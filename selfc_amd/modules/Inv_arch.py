@@ -28,6 +28,26 @@ class InvBlockExp(nn.Module):
         self.G = subnet_constructor(self.split_len1, self.split_len2)
         self.H = subnet_constructor(self.split_len1, self.split_len2)
 
+    # InvBlockExp.s (Inv_arch.py:27,30) is kept in the kernels' NHWC layout and converted to NCHW on first access
+    @property
+    def s(self):
+        v = self.__dict__.get("_s_nchw")
+        if v is None:
+            ws = self.__dict__.get("_s_ws")
+            if ws is None:
+                raise AttributeError("InvBlockExp.s is set by forward()")
+            v = self.__dict__["_s_nchw"] = rt.s_to_nchw(ws)
+        return v
+
+    @s.setter
+    def s(self, value):
+        self.__dict__["_s_nchw"] = value
+        self.__dict__["_s_ws"] = None
+
+    def _set_s_lazy(self, ws):
+        self.__dict__["_s_ws"] = ws
+        self.__dict__["_s_nchw"] = None
+
     def _temporal_len(self):
         if self.F.kind == rt.SUBNET_D2DT:
             t = GlobalVar.get_Temporal_LEN()
@@ -45,7 +65,7 @@ class InvBlockExp(nn.Module):
         if n % t:
             raise RuntimeError(f"{n} frames are not a multiple of the temporal length {t}")
         from .. import autograd as ag
-        if ag.needs_grad(x, *self.parameters()):          # training: buffers kept for the HIP backward (autograd.py)
+        if ag.module_needs_grad(x, self):          # training: buffers kept for the HIP backward (autograd.py)
             return ag.InvBlockFn.apply(x, self, bool(rev), t, *ag.block_params(self))
         ws = rt.workspace(x.device, self.F.kind, n, t, h, w, self.split_len1, self.split_len2)
         pb = rt.packed_block(self)

@@ -86,7 +86,7 @@ class GlobalAgg(nn.Module):
         if getattr(self, "_pk_key", None) != key:
             from ..packing import pack_pointwise, pad_bias, pool_weight_map
             f32 = lambda t: t.detach().float().contiguous()  # noqa: E731
-            self._pk = dict(wmap=pool_weight_map(self.fc.weight, h, w), fcb=float(self.fc.bias.detach().item()),
+            self._pk = dict(wmap=pool_weight_map(self.fc.weight, h, w), fcb=f32(self.fc.bias),
                             w1=pack_pointwise(self.proj1.weight), b1=pad_bias(self.proj1.bias, 64),
                             w2=f32(self.proj2.weight), b2=f32(self.proj2.bias),
                             w3=f32(self.proj3.weight), b3=f32(self.proj3.bias))
@@ -101,7 +101,7 @@ class GlobalAgg(nn.Module):
         if "gagg_partial" not in scratch or scratch["gagg_partial"].numel() < nfl:
             scratch["gagg_partial"] = torch.empty(nfl, dtype=torch.float32, device=x.device)
             scratch["gagg_attn"] = torch.empty((n // t) * t * t, dtype=torch.float32, device=x.device)
-        rt.call("selfc_globalagg_run", x.data_ptr(), y.data_ptr(), pk["wmap"].data_ptr(), pk["fcb"],
+        rt.call("selfc_globalagg_run", x.data_ptr(), y.data_ptr(), pk["wmap"].data_ptr(), pk["fcb"].data_ptr(),
                 pk["w1"].data_ptr(), pk["b1"].data_ptr(), pk["w2"].data_ptr(), pk["b2"].data_ptr(),
                 pk["w3"].data_ptr(), pk["b3"].data_ptr(), scratch["gagg_partial"].data_ptr(),
                 scratch["gagg_attn"].data_ptr(), n, t, h * w, _lib.stream_ptr())
@@ -113,7 +113,7 @@ class GlobalAgg(nn.Module):
         if not t or n % t or c != 64:
             raise RuntimeError(f"GlobalAgg expects (b*T,64,h,w) with T={t!r}, got {tuple(x.shape)}")
         from .. import autograd as ag
-        if ag.needs_grad(x, *self.parameters()):
+        if ag.module_needs_grad(x, self):
             return ag.GlobalAggFn.apply(x, self, t, *self.parameters())
         sp = _lib.stream_ptr()
         xin = torch.empty((n, h, w, 64), dtype=torch.float32, device=x.device)
@@ -256,7 +256,7 @@ class STPNet(nn.Module):
         b, c, t, h, w = x.size()
         xf = rt.as_input(x.transpose(1, 2).reshape(b * t, c, h, w))
         from .. import autograd as ag
-        if ag.needs_grad(xf, *self.parameters()):
+        if ag.module_needs_grad(xf, self):
             # training: one differentiable op for chain + head + sample; `stp_parameters` (the raw head output) is only
             # exposed for the l2 head here - the reference's GMM likelihood path (neg_llh) is not used by its trainer
             v = ag.STPSampleFn.apply(xf, self, t, self._eps_rows(b * t, t, h, w, xf.device), *self.parameters())
@@ -327,7 +327,7 @@ class SelfCInvNet(nn.Module):
     def forward(self, x, rev=False, cal_jacobian=False, lr_before_distor=None):
         x = rt.as_input(x)
         from .. import autograd as ag
-        if ag.needs_grad(x, *self.parameters()):
+        if ag.module_needs_grad(x, self):
             return self._forward_train(x, rev)
         sp = _lib.stream_ptr()
         arr, nblk = self._stack()

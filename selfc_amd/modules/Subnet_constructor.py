@@ -37,7 +37,7 @@ class _DenseSubnet(nn.Module):
         if n % T:
             raise RuntimeError(f"{n} frames are not a multiple of the temporal length {T}")
         from .. import autograd as ag
-        if ag.needs_grad(x, *self.parameters()):          # training: same kernels, buffers kept for the HIP backward
+        if ag.module_needs_grad(x, self):          # training: same kernels, buffers kept for the HIP backward
             return ag.SubnetFn.apply(x, self, T, *ag.subnet_params(self))
         pk = self.packed()
         dev, sp = x.device, _lib.stream_ptr()

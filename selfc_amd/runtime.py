@@ -138,8 +138,19 @@ def packed_subnet(mod) -> PackedSubnet:
     return mod._pk
 
 
+def plist(mod):
+    """list(mod.parameters()), cached on the module (its parameter set does not change after construction; `_apply`
+    - .to() / .cuda() - replaces tensors in place of the same Parameter objects, or re-registers them: the cache is keyed
+    on the first parameter's identity to notice the latter)."""
+    cached = mod.__dict__.get("_plist")
+    first = next(mod.parameters(), None)
+    if cached is None or (cached and cached[0] is not first):
+        cached = mod.__dict__["_plist"] = list(mod.parameters())
+    return cached
+
+
 def params_key(*mods) -> Tuple:
-    return tuple((p.data_ptr(), p._version, str(p.device)) for m in mods for p in m.parameters())
+    return tuple((p.data_ptr(), p._version) for m in mods for p in plist(m))
 
 
 def call(name: str, *args):

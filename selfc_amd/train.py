@@ -98,8 +98,11 @@ class RescaleTrainer:
     pixel_criterion_forw/back, lambda_fit_forw, lambda_rec_back, lambda_cond_prob, gradient_clipping, lr_scheme,
     lr_steps, lr_gamma, restarts, restart_weights, clear_state."""
 
-    def __init__(self, netG: nn.Module, train_opt: dict):
+    def __init__(self, netG: nn.Module, train_opt: dict, capturable: bool = False):
+        """capturable: prepare the optimizer for `capture()` (device-side step counter and learning rate)."""
         self.netG = netG
+        self.capturable = capturable
+        self.graph = None
         self.train_opt = train_opt
         self.Quantization = Quantization()
         self.netG.train()
@@ -108,8 +111,11 @@ class RescaleTrainer:
         wd = train_opt.get("weight_decay_G") or 0
         optim_params = [v for k, v in netG.named_parameters() if v.requires_grad and "opticFlow_Net" not in k]
         self.optim_params = optim_params
-        self.optimizer_G = torch.optim.Adam(optim_params, lr=train_opt["lr_G"], weight_decay=wd,
-                                            betas=(train_opt["beta1"], train_opt["beta2"]))
+        lr = train_opt["lr_G"]
+        if capturable:
+            lr = torch.tensor(float(lr), dtype=torch.float32, device=optim_params[0].device)
+        self.optimizer_G = torch.optim.Adam(optim_params, lr=lr, weight_decay=wd,
+                                            betas=(train_opt["beta1"], train_opt["beta2"]), capturable=capturable)
         self.schedulers = []
         if train_opt.get("lr_scheme", "MultiStepLR") == "MultiStepLR":
             self.schedulers.append(MultiStepLR_Restart(self.optimizer_G, train_opt.get("lr_steps", []),
@@ -127,8 +133,8 @@ class RescaleTrainer:
         x_samples, _ = self.netG(x=y, rev=True)
         return self.train_opt["lambda_rec_back"] * self.Reconstruction_back(x, x_samples[:, :3, :, :])
 
-    def optimize_parameters(self, real_H: torch.Tensor, ref_L: torch.Tensor, step: int = 0):
-        self.optimizer_G.zero_grad()
+    def _step(self, real_H: torch.Tensor, ref_L: torch.Tensor):
+        """optimize_parameters (SelfC_model.py:153-176) up to and including optimizer.step(); returns the loss tensors."""
         output, loss_c = self.netG(x=real_H, rev=False)
         loss_c = loss_c.mean() * self.train_opt.get("lambda_cond_prob", 0)
         lr_before_quant = output[:, :3, :, :]
@@ -140,11 +146,51 @@ class RescaleTrainer:
         if self.train_opt.get("gradient_clipping"):
             self.grad_norm = nn.utils.clip_grad_norm_(self.optim_params, self.train_opt["gradient_clipping"])
         self.optimizer_G.step()
+        return l_forw_fit.detach(), l_back_rec.detach(), loss_c.detach(), loss.detach()
+
+    def _log(self, losses):
+        l_forw_fit, l_back_rec, loss_c, loss = losses
         self.log_dict["l_forw_fit"] = l_forw_fit.item()
         self.log_dict["l_back_rec"] = l_back_rec.item()
         self.log_dict["loss_c"] = float(loss_c)
         self.log_dict["loss"] = loss.item()
         return self.log_dict
+
+    def optimize_parameters(self, real_H: torch.Tensor, ref_L: torch.Tensor, step: int = 0):
+        if self.graph is not None:
+            return self.replay(real_H, ref_L)
+        self.optimizer_G.zero_grad()
+        return self._log(self._step(real_H, ref_L))
+
+    # -- whole-step hipGraph ----------------------------------------------------------------------------------------
+    def capture(self, real_H: torch.Tensor, ref_L: torch.Tensor, warmup: int = 3):
+        """Record one optimisation step (forward, quantise, STP sample, reverse, every gradient kernel on both streams,
+        clip, Adam) into a hipGraph; later `optimize_parameters` calls copy the batch into the captured buffers and
+        replay it - the step stops being bound by ~1,500 host-side launches.  Shapes are fixed by this call; the
+        `warmup` eager steps it runs are real optimisation steps.  Needs `capturable=True` at construction."""
+        if not self.capturable:
+            raise RuntimeError("construct RescaleTrainer(..., capturable=True) to capture the step")
+        self._static_h, self._static_l = real_H.clone(), ref_L.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.optimizer_G.zero_grad(set_to_none=True)
+                self._step(self._static_h, self._static_l)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        self.optimizer_G.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g):
+            self._static_losses = self._step(self._static_h, self._static_l)
+        self.graph = g
+        return self
+
+    def replay(self, real_H: torch.Tensor, ref_L: torch.Tensor):
+        self._static_h.copy_(real_H)
+        self._static_l.copy_(ref_L)
+        self.graph.replay()
+        return self._log(self._static_losses)
 
     def update_learning_rate(self):
         for s in self.schedulers:

@@ -87,3 +87,23 @@ def test_gmm_training_reduces_loss(dev):
     assert min(losses[-3:]) < 0.9 * losses[0], losses
     tr.update_learning_rate()
     assert tr.get_current_learning_rate() == 1e-4
+
+
+def test_captured_step_matches_eager(dev):
+    """RescaleTrainer.capture(): the whole optimisation step as one hipGraph.  With the l2 head (no RNG) the replayed steps
+    must track eager steps from the same start (not bit-identical: Adam is `capturable` and the gradient planes are summed
+    in the same order, but the losses agree far below the step-to-step change)."""
+    from selfc_amd import train
+    x = load_golden("g8_large_stack")["x"]
+    gt = x.reshape(1, T, 3, 32, 48).transpose(1, 2).to(dev)
+    real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
+    eager = train.RescaleTrainer(_net(dev), dict(train.TRAIN_OPT_LARGE))
+    le = [eager.optimize_parameters(real_h, ref_l)["loss"] for _ in range(8)]
+    graphed = train.RescaleTrainer(_net(dev), dict(train.TRAIN_OPT_LARGE), capturable=True)
+    graphed.capture(real_h, ref_l, warmup=3)                       # 3 real steps
+    lg = [graphed.optimize_parameters(real_h, ref_l)["loss"] for _ in range(5)]     # steps 4..8 replayed
+    assert all(v == v for v in lg)
+    for a, b in zip(le[3:], lg):
+        assert abs(a - b) < 2e-2 * abs(a), (le, lg)
+    graphed.update_learning_rate()
+    assert abs(float(graphed.get_current_learning_rate()) - 1e-4) < 1e-10

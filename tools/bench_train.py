@@ -16,9 +16,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch  # noqa: E402
 
 
-def run(batch=8, size=144, steps=10, warmup=3, fh_loss="gmm", profile=False):
+def run(batch=8, size=144, steps=10, warmup=3, fh_loss="gmm", profile=False, graph=False):
     """Time RescaleTrainer.optimize_parameters on one GPU; returns the result dict."""
-    a = argparse.Namespace(batch=batch, size=size, steps=steps, warmup=warmup, fh_loss=fh_loss, profile=profile)
+    a = argparse.Namespace(batch=batch, size=size, steps=steps, warmup=warmup, fh_loss=fh_loss, profile=profile, graph=graph)
     from selfc_amd import GlobalVar, _lib, train
     from selfc_amd.modules.SelfC_GMM_arch_inv import SelfCInvNet
     dev = torch.device("cuda:0")
@@ -26,11 +26,14 @@ def run(batch=8, size=144, steps=10, warmup=3, fh_loss="gmm", profile=False):
     torch.manual_seed(10)
     opt = {"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": a.fh_loss, "scale": 4, "gmm_k": 5}
     net = SelfCInvNet(opt, 3, 3, "D2DTNet", [4, 4], 2).to(dev)
-    tr = train.RescaleTrainer(net, dict(train.TRAIN_OPT_LARGE))
+    tr = train.RescaleTrainer(net, dict(train.TRAIN_OPT_LARGE), capturable=a.graph)
     g = torch.Generator().manual_seed(1234)
     gt = torch.rand(a.batch, 3, 7, a.size, a.size, generator=g).to(dev)
     real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
     for _ in range(a.warmup):
+        tr.optimize_parameters(real_h, ref_l)
+    if a.graph:
+        tr.capture(real_h, ref_l)
         tr.optimize_parameters(real_h, ref_l)
     torch.cuda.synchronize()
     L = _lib.lib()
@@ -44,7 +47,7 @@ def run(batch=8, size=144, steps=10, warmup=3, fh_loss="gmm", profile=False):
     dt = (time.perf_counter() - t0) / a.steps
     out = {"metric": "training septuplets/s (optimize_parameters, 7x3x%dx%d crops)" % (a.size, a.size), "value": a.batch / dt,
            "ms_per_step": dt * 1e3, "batch": a.batch, "fh_loss": a.fh_loss, "loss": log["loss"], "dtype": _lib.OPERAND,
-           "launch": "eager, single stream"}
+           "launch": "hipGraph replay of the whole step" if a.graph else "eager"}
     if a.profile:
         L.selfc_profile_enable(0)
         names = {0: "conv3x3", 1: "conv5_F", 2: "conv5_GH", 3: "transforms", 4: "conv5_plain", 5: "stp", 6: "fused_gh", 7: "backward"}
@@ -65,8 +68,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--fh-loss", default="gmm")
     ap.add_argument("--profile", action="store_true", help="also report per-class kernel time (adds event overhead)")
+    ap.add_argument("--graph", action="store_true", help="capture the whole step into a hipGraph and time replays")
     a = ap.parse_args()
-    print(json.dumps(run(a.batch, a.size, a.steps, a.warmup, a.fh_loss, a.profile)))
+    print(json.dumps(run(a.batch, a.size, a.steps, a.warmup, a.fh_loss, a.profile, a.graph)))
 
 
 if __name__ == "__main__":
