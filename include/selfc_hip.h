@@ -83,6 +83,11 @@ int selfc_quantize_inplace(float* x, size_t n, void* stream);
 int selfc_y_sse_blocks(int HW);
 int selfc_y_sse(const float* a, const float* b, double* partial, int N, int HW, void* stream);
 
+/* Y-channel SSIM sums of calculate_ssim(rgb_to_ycbcr(a), rgb_to_ycbcr(b)) (utils/util.py:396-441,597-605; 11-tap window
+ * win11, no padding, data_range 1): a, b (N,3,H,W) RGB in [0,1]; partial[N][ceil((H-10)/16)][ceil((W-10)/16)] doubles, the
+ * sum over a frame's entries divided by (H-10)*(W-10) is its SSIM. */
+int selfc_y_ssim(const float* a, const float* b, const float* win11, double* partial, int N, int H, int W, void* stream);
+
 /* Guassian_downsample(x, scale=4) of feed_data's "sr_bd" LR target (models/Guassian.py:7-52, SelfC_model.py:128):
  * per plane, 13x13 Gaussian g169 (sigma 1.6, row-major) at stride 4 with reflect padding; x (planes,H,W) ->
  * y (planes,H/4,W/4); H, W multiples of 4 and >= 8. */

@@ -491,3 +491,32 @@ def multistep_lr_restart(base_lr: float, steps: int, milestones: Sequence[int], 
             lr = lr * gamma ** list(milestones).count(epoch)
         out.append(lr)
     return out
+
+
+# ----------------------------------------------------------------------------
+# f2  SSIM on the Y channel (utils/util.py:361-470 `ssim`, called per frame by calculate_ssim :597-605)
+# ----------------------------------------------------------------------------
+
+def ssim_gauss_1d(size: int = 11, sigma: float = 1.5) -> torch.Tensor:
+    """_fspecial_gauss_1d (utils/util.py:362-376)."""
+    c = torch.arange(size, dtype=torch.float32) - size // 2
+    gk = torch.exp(-(c ** 2) / (2 * sigma ** 2))
+    return gk / gk.sum()
+
+
+def ssim_per_frame(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0) -> List[float]:
+    """x, y (N,1,H,W): SSIM of every frame with an 11-tap sigma-1.5 Gaussian window applied separably without padding
+    (gaussian_filter :379-393), K1 = 0.01, K2 = 0.03, mean of the (H-10)x(W-10) map (_ssim :396-441)."""
+    win = ssim_gauss_1d().reshape(1, 1, 1, 11)
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+
+    def blur(v):
+        return F.conv2d(F.conv2d(v, win), win.transpose(2, 3))
+
+    mu1, mu2 = blur(x), blur(y)
+    s1 = blur(x * x) - mu1 * mu1
+    s2 = blur(y * y) - mu2 * mu2
+    s12 = blur(x * y) - mu1 * mu2
+    cs = (2 * s12 + c2) / (s1 + s2 + c2)
+    m = ((2 * mu1 * mu2 + c1) / (mu1 * mu1 + mu2 * mu2 + c1)) * cs
+    return [float(v) for v in m.mean(-1).mean(-1).mean(-1)]

@@ -34,7 +34,7 @@ SYMBOLS = [
     "selfc_nchw_to_nhwc4", "selfc_nhwc4_to_nchw",
     "selfc_profile_enable", "selfc_profile_read", "selfc_profile_reset",
     "selfc_globalagg_run", "selfc_globalagg_partial_floats", "selfc_pwconv_run", "selfc_gmm_sample",
-    "selfc_conv_planes_run", "selfc_nhwc_to_planes", "selfc_y_sse", "selfc_y_sse_blocks", "selfc_gauss_down4",
+    "selfc_conv_planes_run", "selfc_nhwc_to_planes", "selfc_y_sse", "selfc_y_sse_blocks", "selfc_y_ssim", "selfc_gauss_down4",
     "selfc_subnet_bwd_scratch_bytes", "selfc_subnet_bwd", "selfc_subnet_bwd_phase", "selfc_coupling_bwd", "selfc_freq_fwd_bwd", "selfc_freq_inv_bwd",
     "selfc_bwd_scale", "selfc_bwd_to_planes", "selfc_f16_rows_to_planes", "selfc_bwd_conv_planes",
     "selfc_bwd_wgrad_scratch_bytes", "selfc_bwd_wgrad", "selfc_gmm_sample_bwd", "selfc_lrelu_bwd",
@@ -107,6 +107,7 @@ def lib():
             "selfc_y_sse": [vp, vp, vp, i, i, vp],
             "selfc_y_sse_blocks": [i],
             "selfc_gauss_down4": [vp, vp, vp, i, i, i, vp],
+            "selfc_y_ssim": [vp, vp, vp, vp, i, i, i, vp],
             "selfc_subnet_bwd": [C.POINTER(SubnetBW), i, vp, vp, vp, f, vp, i, C.POINTER(vp), C.POINTER(vp), f,
                                  vp, sz, i, i, i, i, i, i, vp],
             "selfc_subnet_bwd_phase": [i, C.POINTER(SubnetBW), i, vp, vp, vp, f, vp, i, C.POINTER(vp), C.POINTER(vp), f,

@@ -291,6 +291,64 @@ __global__ __launch_bounds__(256) void y_sse_kernel(const float* __restrict__ a,
   if (threadIdx.x == 0) partial[(size_t)n * nblk + blockIdx.x] = red[0];
 }
 
+// Y-channel SSIM of test_rescaling.py:110-122 (utils/util.py:396-441 with an 11-tap sigma-1.5 window, no padding,
+// K1 = 0.01, K2 = 0.03, data_range 1): each 16x16 block of the (H-10)x(W-10) SSIM map stages the 26x26 Y patches of both
+// images in LDS, filters the five moments horizontally then vertically (as the reference's two conv2d passes do) and
+// adds its part of the map sum to partial[n][block] (fp64, deterministic two-stage sum).
+__global__ __launch_bounds__(256) void y_ssim_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ win,
+                                                     double* __restrict__ partial, int H, int W, int nbx, int nby) {
+  __shared__ float ya[26][27], yb[26][27];
+  __shared__ float hz[5][26][17];             // horizontally filtered x, y, xx, yy, xy at 26 rows x 16 columns
+  __shared__ float wk[11];
+  __shared__ double red[256];
+  const int n = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
+  const int tid = threadIdx.x;
+  const size_t HW = (size_t)H * W;
+  const float* pa = a + (size_t)n * 3 * HW;
+  const float* pb = b + (size_t)n * 3 * HW;
+  if (tid < 11) wk[tid] = win[tid];
+  for (int i = tid; i < 26 * 26; i += 256) {
+    const int r = i / 26, c = i - r * 26;
+    const int y = min(by * 16 + r, H - 1), x = min(bx * 16 + c, W - 1);
+    const size_t p = (size_t)y * W + x;
+    ya[r][c] = y_of(pa[p], pa[HW + p], pa[2 * HW + p]);
+    yb[r][c] = y_of(pb[p], pb[HW + p], pb[2 * HW + p]);
+  }
+  __syncthreads();
+  for (int i = tid; i < 26 * 16; i += 256) {
+    const int r = i >> 4, c = i & 15;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float u = ya[r][c + k], v = yb[r][c + k], w = wk[k];
+      s0 += w * u; s1 += w * v; s2 += w * (u * u); s3 += w * (v * v); s4 += w * (u * v);
+    }
+    hz[0][r][c] = s0; hz[1][r][c] = s1; hz[2][r][c] = s2; hz[3][r][c] = s3; hz[4][r][c] = s4;
+  }
+  __syncthreads();
+  const int r = tid >> 4, c = tid & 15;
+  double val = 0.0;
+  if (by * 16 + r < H - 10 && bx * 16 + c < W - 10) {
+    float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 11; ++k)
+#pragma unroll
+      for (int q = 0; q < 5; ++q) m[q] += wk[k] * hz[q][r + k][c];
+    const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+    const float mu1 = m[0], mu2 = m[1];
+    const float s1 = m[2] - mu1 * mu1, s2 = m[3] - mu2 * mu2, s12 = m[4] - mu1 * mu2;
+    const float cs = (2.f * s12 + c2) / (s1 + s2 + c2);
+    val = (double)(((2.f * mu1 * mu2 + c1) / (mu1 * mu1 + mu2 * mu2 + c1)) * cs);
+  }
+  red[tid] = val;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) partial[((size_t)n * nby + by) * nbx + bx] = red[0];
+}
+
 // Guassian_downsample (models/Guassian.py:34-51, scale 4): out[oy][ox] = sum_{i,j in [-6,6]} g[i][j] *
 // x[reflect(4 oy + i)][reflect(4 ox + j)] per plane ('reflect' = mirror without repeating the edge sample).
 __global__ __launch_bounds__(256) void gauss_down4_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -327,6 +385,14 @@ int selfc_gauss_down4(const float* x, float* y, const float* g169, int planes, i
   const size_t total = (size_t)planes * (H / 4) * (W / 4);
   ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
   hipLaunchKernelGGL(gauss_down4_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, g169, planes, H, W);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_y_ssim(const float* a, const float* b, const float* win11, double* partial, int N, int H, int W, void* stream) {
+  if (!a || !b || !win11 || !partial || N <= 0 || H < 11 || W < 11) return SELFC_EINVAL;
+  const int nbx = (W - 10 + 15) / 16, nby = (H - 10 + 15) / 16;
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
+  hipLaunchKernelGGL(y_ssim_kernel, dim3(nbx, nby, N), dim3(256), 0, (hipStream_t)stream, a, b, win11, partial, H, W, nbx, nby);
   return hip_rc(hipGetLastError());
 }
 

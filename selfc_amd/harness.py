@@ -73,6 +73,42 @@ def psnr_y(img1: torch.Tensor, img2: torch.Tensor) -> List[float]:
     return [float("inf") if m == 0 else 20.0 * math.log10(1.0 / math.sqrt(m)) for m in mse]
 
 
+_SSIM_WIN = {}
+
+
+def ssim_y(img1: torch.Tensor, img2: torch.Tensor) -> List[float]:
+    """Per-frame Y-channel SSIM of two (N,3,H,W) RGB tensors in [0,1]: rgb_to_ycbcr + calculate_ssim of the reference
+    (data/util.py:239-245, utils/util.py:396-441,597-605; 11-tap sigma-1.5 Gaussian window, no padding, data_range 1)."""
+    a, b = rt.as_input(img1), rt.as_input(img2)
+    if a.shape != b.shape or a.shape[1] != 3:
+        raise RuntimeError(f"ssim_y expects two (N,3,H,W) tensors, got {tuple(a.shape)} and {tuple(b.shape)}")
+    n, _, h, w = a.shape
+    if h < 11 or w < 11:
+        raise RuntimeError("ssim_y needs frames of at least 11x11 pixels")
+    key = str(a.device)
+    if key not in _SSIM_WIN:
+        c = torch.arange(11, dtype=torch.float32) - 5
+        gk = torch.exp(-(c ** 2) / (2 * 1.5 ** 2))
+        _SSIM_WIN[key] = (gk / gk.sum()).to(a.device)
+    nbx, nby = (w - 10 + 15) // 16, (h - 10 + 15) // 16
+    partial = torch.empty((n, nby * nbx), dtype=torch.float64, device=a.device)
+    rt.call("selfc_y_ssim", a.data_ptr(), b.data_ptr(), _SSIM_WIN[key].data_ptr(), partial.data_ptr(), n, h, w, _lib.stream_ptr())
+    return (partial.sum(dim=1) / ((h - 10) * (w - 10))).cpu().tolist()
+
+
+def rescale_metrics(net, real_H: torch.Tensor, ref_L: torch.Tensor = None) -> dict:
+    """The per-batch numbers of test_rescaling.py:82-122 on the device: rescale_test, then Y-channel PSNR / SSIM of the
+    reconstruction against real_H and of the LR video against ref_L (default: the sr_bd Gaussian LR target)."""
+    forw_L, fake_H = rescale_test(net, real_H)
+    if ref_L is None:
+        ref_L = gaussian_downsample(real_H)
+    avg = lambda v: sum(v) / len(v)  # noqa: E731
+    psnr, ssim = psnr_y(fake_H, real_H), ssim_y(fake_H, real_H)
+    lr_psnr, lr_ssim = psnr_y(forw_L, ref_L), ssim_y(forw_L, ref_L)
+    return {"psnr_y": avg(psnr), "ssim_y": avg(ssim), "lr_psnr_y": avg(lr_psnr), "lr_ssim_y": avg(lr_ssim),
+            "per_frame": {"psnr_y": psnr, "ssim_y": ssim, "lr_psnr_y": lr_psnr, "lr_ssim_y": lr_ssim}}
+
+
 def gop_slices(n_frames: int, gop: int = GOP) -> List[List[int]]:
     """Frame indices of consecutive GOPs; the last GOP is padded by repeating the final frame (the padding
     rule of SelfCModel.test, SelfC_model.py:203-209).  100 frames -> 15 GOPs, the last one [98, 99, 99, 99, 99, 99, 99]."""

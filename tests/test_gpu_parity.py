@@ -330,6 +330,39 @@ def test_rescale_video_ragged_length_and_sharding(dev):
     assert torch.equal(fh, whole["rec"][:7])
 
 
+def test_ssim_y(dev):
+    from selfc_amd import harness
+    g = load_golden("g12_ssim_y")
+    got = torch.tensor(harness.ssim_y(g["a"].to(dev), g["b"].to(dev)), dtype=torch.float64)
+    assert rel_err(got, g["ssim"]) < 1e-5
+    assert abs(harness.ssim_y(g["a"].to(dev), g["a"].to(dev))[1] - 1.0) < 1e-6
+    x = torch.rand(2, 3, 37, 61)                       # ragged block edges
+    y = (x + 0.1 * torch.randn_like(x)).clamp(0, 1)
+    ref = O.ssim_per_frame(O.rgb_to_y(x), O.rgb_to_y(y))
+    assert rel_err(torch.tensor(harness.ssim_y(x.to(dev), y.to(dev))), torch.tensor(ref)) < 1e-5
+
+
+def test_rescale_metrics(dev):
+    """test_rescaling.py's per-batch metrics through the harness against the same quantities from the oracle."""
+    from selfc_amd import harness
+    g = load_golden("g8_large_stack")
+    net = _large_net(dev, g, stp=load_golden("g7_stp_l2_full_rev"))
+    x = torch.rand(T, 3, 64, 64, generator=torch.Generator().manual_seed(77))      # LR 16x16: the 11-tap SSIM window fits
+    m = harness.rescale_metrics(net, x.to(dev))
+    z = O.large_fwd(g, x, T)
+    lr = O.quantize(z[:, :3])
+    params = {**{k: v for k, v in g.items() if k.startswith("operations.")},
+              **{k: v for k, v in load_golden("g7_stp_l2_full_rev").items() if k.startswith("stp_net.")}}
+    rec, _ = O.large_rev_l2(params, lr, T)
+    ref_l = O.gaussian_downsample(x)
+    want_psnr = sum(O.psnr_per_frame(O.rgb_to_y(rec), O.rgb_to_y(x))) / T
+    want_ssim = sum(O.ssim_per_frame(O.rgb_to_y(rec), O.rgb_to_y(x))) / T
+    assert abs(m["psnr_y"] - want_psnr) < 0.05 and abs(m["ssim_y"] - want_ssim) < 2e-3
+    want_lr_psnr = sum(O.psnr_per_frame(O.rgb_to_y(lr), O.rgb_to_y(ref_l))) / T
+    want_lr_ssim = sum(O.ssim_per_frame(O.rgb_to_y(lr), O.rgb_to_y(ref_l))) / T
+    assert abs(m["lr_psnr_y"] - want_lr_psnr) < 0.05 and abs(m["lr_ssim_y"] - want_lr_ssim) < 2e-3
+
+
 def test_gaussian_downsample_ref_L(dev):
     from selfc_amd import harness
     g = load_golden("g10_gauss")

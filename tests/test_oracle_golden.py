@@ -195,3 +195,10 @@ def test_multistep_lr_restart_trace():
     g = load_golden("g11_lr_trace")
     lr = O.multistep_lr_restart(1e-4, 12, [3, 6, 9], restarts=[5], weights=[0.5], gamma=0.5)
     assert rel_err(torch.tensor(lr, dtype=torch.float64), g["lr"]) < 1e-12
+
+
+def test_ssim_y():
+    g = load_golden("g12_ssim_y")
+    got = O.ssim_per_frame(O.rgb_to_y(g["a"]), O.rgb_to_y(g["b"]))
+    assert rel_err(torch.tensor(got, dtype=torch.float64), g["ssim"]) < 1e-6
+    assert abs(O.ssim_per_frame(O.rgb_to_y(g["a"]), O.rgb_to_y(g["a"]))[0] - 1.0) < 1e-6

@@ -254,6 +254,33 @@ def main():
         xg = torch.rand(3, 5, 32, 48, generator=g)                 # [C, T, H, W]
         save("g10_gauss", x=xg.numpy(), y=Guassian_downsample(xg).numpy())
 
+        # ---- G12 Y-channel SSIM of test_rescaling.py:110-122 (utils/util.py:361-470 `ssim`, data/util.py:239-245
+        # rgb_to_ycbcr).  utils.util / data.util import cv2 and torchvision.utils at module level only for their image
+        # I/O helpers: stub those names so the pure-torch metric code can be imported.
+        _cv2 = types.ModuleType("cv2")
+        _tvu = types.ModuleType("torchvision.utils")
+        _tvu.make_grid = None
+        sys.modules.setdefault("cv2", _cv2)
+        sys.modules.setdefault("imageio", types.ModuleType("imageio"))
+        sys.modules["torchvision.utils"] = _tvu
+        _tv.utils = _tvu
+        import importlib.util as _ilu
+
+        def _load(name, rel):          # the module file itself: the package __init__ pulls in the image datasets (imageio, lmdb)
+            spec = _ilu.spec_from_file_location(name, os.path.join(REF, rel))
+            m = _ilu.module_from_spec(spec)
+            spec.loader.exec_module(m)
+            return m
+
+        ref_util = _load("ref_utils_util", "utils/util.py")
+        ref_dutil = _load("ref_data_util", "data/util.py")
+        g12 = torch.Generator().manual_seed(1212)         # own stream: the fixtures below keep their historical draws
+        a_img = torch.rand(3, 3, 40, 56, generator=g12)
+        b_img = (a_img + 0.05 * torch.randn(3, 3, 40, 56, generator=g12)).clamp(0, 1)
+        ya, yb = ref_dutil.rgb_to_ycbcr(a_img), ref_dutil.rgb_to_ycbcr(b_img)
+        ssims = [float(ref_util.ssim(ya[i:i + 1], yb[i:i + 1], data_range=1.0)) for i in range(3)]
+        save("g12_ssim_y", a=a_img.numpy(), b=b_img.numpy(), ssim=np.array(ssims, dtype=np.float64))
+
         # ---- G9 Quantization
         q = Quantization()
         v = torch.tensor([-0.3, 0.0, 0.001, 0.00196, 0.00197, 0.5, 0.50196, 0.998, 1.0, 1.7,
