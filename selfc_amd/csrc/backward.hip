@@ -423,12 +423,6 @@ BwdLayout bwd_layout(int N, int H, int W, int cin, int cout) {
   return L;
 }
 
-template <int TAPS>
-int launch_wgrad(const WgArgs& a, int nsplit, int Qn, int Pn, hipStream_t s) {
-  hipLaunchKernelGGL(wgrad_kernel<TAPS>, dim3((unsigned)nsplit, (unsigned)Qn, (unsigned)Pn), dim3((TAPS == 1 ? 4 : 3) * 64), 0, s, a);
-  return hip_rc(hipGetLastError());
-}
-
 // pixel splits of a weight-gradient job: enough workgroups to fill the chip (~2 per CU), bounded by the tile count and
 // by 12 MiB of partials (written once, read once by the finish pass)
 int wgrad_nsplit(int N, int H, int W, int npairs, int ttot) {

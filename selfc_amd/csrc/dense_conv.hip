@@ -752,21 +752,30 @@ __global__ void nhwc_to_dense_kernel(const float* __restrict__ x, f16* __restric
 // ---------------------------------------------------------------------------------
 // host-side launch helpers
 // ---------------------------------------------------------------------------------
-constexpr int C3_TH = 16, C3_TW = 16, C3_NW = 4, C3_MT = 2;
-constexpr int C3_LDS = (C3_TH + 2) * ((((C3_TW + 2) * PS + 255) / 256) * 256) + 18 * 1024 + 128;   // halo image + weight stage + 32 biases
+// Two tile shapes: 16x16 pixels on 4 waves, and 12x16 on 3 waves for frame heights that 12 divides better (training
+// crops: a 36-row LR frame is 3 x 12 exactly but 3 x 16 = 48 rows of tiles, i.e. 25 % fewer MFMAs and workgroups).
+template <int TH, int TW>
+constexpr int c3_lds() { return (TH + 2) * ((((TW + 2) * PS + 255) / 256) * 256) + 18 * 1024 + 128; }   // halo image + weight stage + 32 biases
+
+template <int TH, int TW, int NW, int MT, int EPI, bool GEN>
+int launch_conv3x3_cfg(C3Args& a, int nets_z, hipStream_t s) {
+  a.tiles_x = (a.W + TW - 1) / TW;
+  a.tiles_y = (a.H + TH - 1) / TH;
+  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), 1, (unsigned)nets_z);
+  ProfScope prof(EPI == EPI_LRELU ? PROF_CONV3X3 : EPI == EPI_F ? PROF_CONV5_F : EPI == EPI_GH ? PROF_CONV5_GH : EPI == EPI_BWD ? -1 : PROF_CONV5_PLAIN, s);
+  hipLaunchKernelGGL((conv3x3_kernel<TH, TW, NW, MT, EPI, GEN>), grid, dim3(NW * 64), (c3_lds<TH, TW>()), s, a);
+  return hip_rc(hipGetLastError());
+}
 
 template <int EPI, bool GEN = false>
 int launch_conv3x3(C3Args& a, int nets_z, hipStream_t s) {
-  a.tiles_x = (a.W + C3_TW - 1) / C3_TW;
-  a.tiles_y = (a.H + C3_TH - 1) / C3_TH;
 #ifdef SELFC_DEV
   static const int ablate = getenv("SELFC_ABLATE") ? atoi(getenv("SELFC_ABLATE")) : 0;
   a.ablate = ablate;
 #endif
-  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), 1, (unsigned)nets_z);
-  ProfScope prof(EPI == EPI_LRELU ? PROF_CONV3X3 : EPI == EPI_F ? PROF_CONV5_F : EPI == EPI_GH ? PROF_CONV5_GH : EPI == EPI_BWD ? -1 : PROF_CONV5_PLAIN, s);
-  hipLaunchKernelGGL((conv3x3_kernel<C3_TH, C3_TW, C3_NW, C3_MT, EPI, GEN>), grid, dim3(C3_NW * 64), C3_LDS, s, a);
-  return hip_rc(hipGetLastError());
+  const int rows16 = (a.H + 15) / 16 * 16, rows12 = (a.H + 11) / 12 * 12;
+  if (rows12 < rows16) return launch_conv3x3_cfg<12, 16, 3, 2, EPI, GEN>(a, nets_z, s);
+  return launch_conv3x3_cfg<16, 16, 4, 2, EPI, GEN>(a, nets_z, s);
 }
 
 // stage description of conv `layer` (1..5) of a dense block with `cin` inputs.

@@ -19,12 +19,13 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def no_autograd_guard(*tensors):
-    """The HIP path is forward-only this round: refuse loudly instead of silently
-    returning tensors without a graph."""
+    """For the few modules without a HIP backward yet (STP v1 of the Haar variant, FeatureCalapseBlock): refuse loudly
+    instead of silently returning tensors without a graph."""
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
         raise NotImplementedError(
-            "selfc_amd: backward kernels are not implemented yet - call under torch.no_grad() "
-            "(training through the HIP path is a later milestone, see DESIGN.md)")
+            "selfc_amd: this module has no backward kernels yet - call it under torch.no_grad() "
+            "(differentiable today: DenseBlock, D2DTInput, InvBlockExp, HaarDownsampling, FrequencyAnalyzer, GlobalAgg, "
+            "STPNet v2 / SelfCInvNet large; see DESIGN.md section 4b)")
 
 
 class Workspace:

@@ -76,7 +76,8 @@ def _frozen_subnet(p, x, saved, temporal):
 
 @pytest.mark.parametrize("cls,ci,co,hw", [("D2DTInput", 48, 3, (12, 20)), ("D2DTInput", 3, 48, (12, 20)),
                                           ("DenseBlock", 9, 3, (16, 16)), ("DenseBlock", 3, 9, (16, 16)),
-                                          ("D2DTInput", 3, 64, (36, 36)), ("D2DTInput", 64, 64, (20, 12))])
+                                          ("D2DTInput", 3, 64, (36, 36)), ("D2DTInput", 64, 64, (20, 12)),
+                                          ("D2DTInput", 48, 3, (64, 112)), ("DenseBlock", 12, 3, (18, 50))])
 def test_subnet_backward(dev, cls, ci, co, hw):
     from selfc_amd.modules import Subnet_constructor as S
     torch.manual_seed(5)
