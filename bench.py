@@ -195,6 +195,12 @@ def main():
         "roofline": roofline,
         "roofline_other": {k: v for k, v in kern.items() if k != dominant},
         "stack_tflops": round(whole_flops * world * args.steps / dt / 1e12, 1),
+        # SURVEY 8d reporting rule: the whole unit of work against both rooflines, per GPU.  Layer-granular byte model =
+        # 1,815 16-bit elements per pixel-frame per block and direction (one kernel per conv on a concat-free buffer),
+        # 2.91 GB per septuplet; the north star's ">= 50 % of the HBM roofline" is this fraction.
+        "stack_roofline": {"mfma_frac": round(whole_flops * args.steps / dt / 1e12 / PEAK_F16_TFLOPS, 4),
+                           "hbm_frac_layer_granular": round(2 * 8 * 1815 * 2 * npx * args.steps / dt / 8.0e12, 4),
+                           "hbm_peak_GBps": 8000, "bytes_model": "2*8*1815 f16 elements per LR pixel-frame (SURVEY 8d)"},
         "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in cls_ms.items()},
     }
     if not args.no_full_path and world == 1:

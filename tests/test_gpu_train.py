@@ -107,3 +107,36 @@ def test_captured_step_matches_eager(dev):
         assert abs(a - b) < 2e-2 * abs(a), (le, lg)
     graphed.update_learning_rate()
     assert abs(float(graphed.get_current_learning_rate()) - 1e-4) < 1e-10
+
+
+def test_train_synthetic_script_one_rank(dev):
+    """tools/train_synthetic.py (config 3 launcher) end to end as a child process on this GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "train_synthetic.py"), "--steps", "3", "--warmup", "1",
+                          "--global-batch", "2", "--size", "64"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["loss"] == line["loss"]
+
+
+def test_backward_argument_errors(dev):
+    """The gradient entry points refuse bad arguments with SELFC_EINVAL -> RuntimeError, launching nothing."""
+    from selfc_amd import _lib, runtime as rt
+    L = _lib.lib()
+    assert L.selfc_subnet_bwd_scratch_bytes(0, 8, 8, 3, 48) == 0
+    x = torch.zeros(64, device=dev)
+    with pytest.raises(RuntimeError):
+        rt.call("selfc_coupling_bwd", 0, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 1.0, 63, _lib.stream_ptr())
+    with pytest.raises(RuntimeError):
+        rt.call("selfc_lrelu_bwd", x.data_ptr(), x.data_ptr(), 62, _lib.stream_ptr())
+    with pytest.raises(RuntimeError):
+        rt.call("selfc_freq_fwd_bwd", x.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 6, 8, _lib.stream_ptr())     # H % 4 != 0
+    # a CPU tensor in training mode fails loudly (no CPU fallback)
+    from selfc_amd.modules.Subnet_constructor import D2DTInput
+    m = D2DTInput(3, 48)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(7, 3, 8, 8, requires_grad=True))
