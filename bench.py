@@ -230,6 +230,21 @@ def main():
             L.selfc_profile_reset()
         out["full_test_path"] = {"septuplets_per_s": round(B_PER_GPU / tf, 1), "ms_per_batch": round(tf * 1e3, 3),
                                  "kernel_ms": fp, "note": "module API, eager, single stream, fh_loss gmm with device RNG"}
+        # the same work as a pre-bound pipeline: hipGraph, one septuplet per stream (pipeline.FullTestPath)
+        from selfc_amd.pipeline import FullTestPath
+        with torch.no_grad():
+            ftp = MultiStreamRoundTrip(net, n_frames, H, W, dev, args.streams if args.streams > 1 else 1, part_cls=FullTestPath)
+            ftp.capture(x)
+            for _ in range(3):
+                ftp.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                ftp.replay()
+            torch.cuda.synchronize()
+            tg = (time.perf_counter() - t0) / 10
+        out["full_test_path"]["pipeline"] = {"septuplets_per_s": round(B_PER_GPU / tg, 1), "ms_per_batch": round(tg * 1e3, 3),
+                                              "launch": f"hipGraph replay, {ftp.nstreams} streams"}
     if not args.no_train_step and world == 1:
         # config 3 of BASELINE.json: one optimize_parameters step (fwd, quantise, STP sample, reverse, backward, clip, Adam)
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))

@@ -188,15 +188,17 @@ class STPNet(nn.Module):
             self._tail_key = key
         return self._tail
 
-    def run_nhwc(self, x1, hf_out, n, t, h, w, keep_raw=False):
+    def run_nhwc(self, x1, hf_out, n, t, h, w, keep_raw=False, scratch=None, eps=None):
         """x1: fp32 NHWC4 [n][h*w][4] (LR frames); hf_out: fp32 [n][h*w][hf_dim] (e.g. the latent x2
-        buffer).  Returns the raw head output [n][h*w][Cp] when keep_raw (else None)."""
+        buffer).  Returns the raw head output [n][h*w][Cp] when keep_raw (else None).
+        scratch: a caller-owned dict for the intermediate buffers (one per stream when several calls overlap);
+        eps: pre-allocated noise rows [n*h*w][hf_dim*K] to fill in place (hipGraph capture) instead of a fresh randn."""
         if self.fh_loss == "gmm_thin":
             raise NotImplementedError("fh_loss 'gmm_thin' (ReLU head) has no kernel; the shipped configs use 'gmm' / 'l2'")
         if self.hf_dim != 48:
             raise NotImplementedError("STP head kernels are built for hf_dim = 48 (scale 4)")
         dev, sp = x1.device, _lib.stream_ptr()
-        sc = self.__dict__.setdefault("_scratch", {})
+        sc = scratch if scratch is not None else self.__dict__.setdefault("_scratch", {})
         shape_key = (n, h, w, str(dev))
         if sc.get("key") != shape_key:
             sc.clear()
@@ -237,6 +239,8 @@ class STPNet(nn.Module):
             b = n // t
             eps = self.eps.reshape(b, self.hf_dim, self.K, t, h, w).permute(0, 3, 4, 5, 1, 2).reshape(npix, self.hf_dim * self.K)
             eps = eps.to(device=dev, dtype=torch.float32).contiguous()
+        elif eps is not None:
+            eps.normal_()
         else:
             eps = torch.randn((npix, self.hf_dim * self.K), dtype=torch.float32, device=dev)
         rt.call("selfc_gmm_sample", sc["raw"].data_ptr(), eps.data_ptr(), hf_out.data_ptr(), npix, self.hf_dim, self.K, sp)

@@ -84,6 +84,35 @@ class RescaleRoundTrip:
         return self.out
 
 
+class FullTestPath(RescaleRoundTrip):
+    """SelfCModel.test()'s two netG calls as the reference runs them (SelfC_model.py:213-230): forward stack, Quantization
+    of the LR frames, STP prediction of the HF channels from the quantised LR (fh_loss gmm: a fresh sample per call), reverse
+    stack.  Same latent-layout pipeline as RescaleRoundTrip, plus the STP between the halves; capturable."""
+
+    def __init__(self, net, n_frames: int, H: int, W: int, device):
+        super().__init__(net, n_frames, H, W, device)
+        stp = net.stp_net
+        self.stp_scratch = {}
+        self.eps = None
+        if stp.fh_loss != "l2":
+            self.eps = torch.empty((n_frames * self.h * self.w, stp.hf_dim * stp.K), dtype=torch.float32, device=device)
+        self.lr = torch.empty((n_frames, 3, self.h, self.w), dtype=torch.float32, device=device)
+
+    def run(self, x: torch.Tensor) -> torch.Tensor:
+        ws, L, sp = self.ws, _lib.lib(), _lib.stream_ptr()
+        chk = _lib.check
+        chk(L.selfc_freq_fwd(x.data_ptr(), ws.x1.data_ptr(), ws.x2.data_ptr(), ws.fd.data_ptr(), ws.FC,
+                             self.N, self.H, self.W, self.k, sp), "selfc_freq_fwd")
+        chk(L.selfc_invstack_run(self.arr, self.nblk, C.byref(self.lat), 0, sp), "selfc_invstack_run fwd")
+        chk(L.selfc_quantize_inplace(ws.x1.data_ptr(), ws.x1.numel(), sp), "selfc_quantize_inplace")
+        chk(L.selfc_nhwc4_to_nchw(ws.x1.data_ptr(), self.lr.data_ptr(), self.N, 3, self.h, self.w, sp), "selfc_nhwc4_to_nchw")   # forw_L
+        self.net.stp_net.run_nhwc(ws.x1, ws.x2, self.N, ws.T, self.h, self.w, scratch=self.stp_scratch, eps=self.eps)
+        chk(L.selfc_invstack_run(self.arr, self.nblk, C.byref(self.lat), 1, sp), "selfc_invstack_run rev")
+        chk(L.selfc_freq_inv(ws.x1.data_ptr(), ws.x2.data_ptr(), self.out.data_ptr(), self.N, self.h, self.w, self.k, sp),
+            "selfc_freq_inv")
+        return self.out
+
+
 class MultiStreamRoundTrip:
     """The same unit of work, with the batch of septuplets split over `nstreams` HIP
     streams (whole clips per stream - they are independent).  Each conv launch is
@@ -91,14 +120,15 @@ class MultiStreamRoundTrip:
     exposed; kernels of different streams overlap and fill those gaps.  Fork/join is
     expressed with stream events so the whole step still captures into one hipGraph."""
 
-    def __init__(self, net, n_frames: int, H: int, W: int, device, nstreams: int = 2):
+    def __init__(self, net, n_frames: int, H: int, W: int, device, nstreams: int = 2, part_cls=None):
         t = GlobalVar.get_Temporal_LEN()
         clips = n_frames // t
         if clips % nstreams:
             raise RuntimeError(f"{clips} clips do not split evenly over {nstreams} streams")
         self.nstreams = nstreams
         self.per = n_frames // nstreams
-        self.parts = [RescaleRoundTrip(net, self.per, H, W, device) for _ in range(nstreams)]
+        part_cls = part_cls or RescaleRoundTrip          # e.g. FullTestPath
+        self.parts = [part_cls(net, self.per, H, W, device) for _ in range(nstreams)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(nstreams)]
         self.out = torch.empty((n_frames, 3, H, W), dtype=torch.float32, device=device)
         for i, p in enumerate(self.parts):           # parts write straight into slices of one output

@@ -363,6 +363,27 @@ def test_rescale_metrics(dev):
     assert abs(m["lr_psnr_y"] - want_lr_psnr) < 0.05 and abs(m["lr_ssim_y"] - want_lr_ssim) < 2e-3
 
 
+def test_full_test_path_pipeline(dev):
+    """pipeline.FullTestPath (stack fwd, quantise, STP, stack rev in the latent layout; eager, captured, and split over
+    two streams) against the module API calls SelfCModel.test makes."""
+    from selfc_amd.modules.Quantization import Quantization
+    from selfc_amd.pipeline import FullTestPath, MultiStreamRoundTrip
+    g = load_golden("g8_large_stack")
+    net = _large_net(dev, g, stp=load_golden("g7_stp_l2_full_rev"))          # l2 head: deterministic
+    x = torch.rand(2 * T, 3, 32, 48, generator=torch.Generator().manual_seed(5)).to(dev)
+    with torch.no_grad():
+        z, _ = net(x=x, rev=False)
+        lr = Quantization()(z[:, :3])
+        want, _ = net(x=lr, rev=True)
+        p = FullTestPath(net, 2 * T, 32, 48, dev)
+        got = p.run(x).clone()
+        assert torch.equal(p.lr, lr)
+        assert rel_err(got.cpu(), want.cpu()) < 1e-6
+        ms = MultiStreamRoundTrip(net, 2 * T, 32, 48, dev, 2, part_cls=FullTestPath)
+        ms.capture(x)
+        assert rel_err(ms.replay().cpu(), want.cpu()) < 1e-6
+
+
 def test_gaussian_downsample_ref_L(dev):
     from selfc_amd import harness
     g = load_golden("g10_gauss")
