@@ -357,3 +357,29 @@ def test_ddp_single_rank_training_step(dev):
     finally:
         if own:
             dist.destroy_process_group()
+
+
+def test_gradient_scale_invariance(dev):
+    """Gradients travel through the MFMA as f16 scaled by a power of two taken from max|dOut| on the device: the result must
+    not depend on the magnitude of the incoming gradient (1e-8 would underflow f16 entirely, 1e5 would overflow it)."""
+    from selfc_amd.modules.Inv_arch import InvBlockExp
+    from selfc_amd.modules.Subnet_constructor import subnet
+    g = load_golden("g5_invblock_d2dt")
+    blk = InvBlockExp(subnet("D2DTNet", "xavier"), 51, 3)
+    blk.load_state_dict({k: v for k, v in g.items() if k[:2] in ("F.", "G.", "H.")}, strict=True)
+    blk.to(dev)
+    x = g["x"].to(dev)
+    torch.manual_seed(3)
+    gy = torch.randn_like(x)
+    base = None
+    for scale in (1.0, 1e-8, 1e5):
+        blk.zero_grad()
+        xd = x.clone().requires_grad_(True)
+        blk(xd).backward(gy * scale)
+        cur = [xd.grad / scale] + [p.grad / scale for p in blk.parameters()]
+        assert all(torch.isfinite(c).all() for c in cur)
+        if base is None:
+            base = cur
+        else:
+            for a, b in zip(cur, base):
+                assert rel_err(a, b) < 2e-3, scale
