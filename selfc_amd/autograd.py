@@ -35,13 +35,14 @@ def _scratch(device, n, h, w, cin, cout, slot="") -> torch.Tensor:
 #: weight gradients run on a second HIP stream, overlapping the (latency-bound) data-gradient chain of the next subnet;
 #: SELFC_BWD_STREAMS=1 keeps everything on the caller's stream
 _TWO_STREAMS = os.environ.get("SELFC_BWD_STREAMS", "2") != "1"
-_SIDE: Dict[str, "torch.cuda.Stream"] = {}
+_SIDE: Dict[Tuple, "torch.cuda.Stream"] = {}
 
 
-def side_stream(device):
+def side_stream(device, which: int = 0):
+    """which 0: the weight-gradient stream; 1: the stream that runs H's backward next to G's inside a coupling block."""
     if not _TWO_STREAMS:
         return None
-    key = str(device)
+    key = (str(device), which)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
@@ -63,7 +64,7 @@ def subnet_params(mod) -> List[torch.Tensor]:
 
 def subnet_bwd(mod, dense: torch.Tensor, xin: Optional[torch.Tensor], dout: torch.Tensor, sign: float,
                dx: Optional[torch.Tensor], accumulate_dx: bool, n: int, t: int, h: int, w: int,
-               want_params: bool = True, pk=None, side=None, slot: str = "") -> List[Optional[torch.Tensor]]:
+               want_params: bool = True, pk=None, side=None, slot: str = "", on_data_done=None) -> List[Optional[torch.Tensor]]:
     """Backward of one DenseBlock / D2DTInput on kernel-layout buffers; returns the 10 parameter gradients
     (reference layouts) or Nones.  With `side` (a stream) the weight-gradient phase is enqueued there, ordered after the
     data phase; the caller joins the streams before it hands the gradients on and must not reuse `slot` before that."""
@@ -86,10 +87,17 @@ def subnet_bwd(mod, dense: torch.Tensor, xin: Optional[torch.Tensor], dout: torc
             float(sign), None if dx is None else dx.data_ptr(), 1 if accumulate_dx else 0,
             wg if want_params else None, bg if want_params else None, 0.0,
             scratch.data_ptr(), scratch.numel(), n, t, h, w, cin, cout)
-    if side is None or not want_params:
+    if (side is None or not want_params) and on_data_done is None:
         rt.call("selfc_subnet_bwd", *args, _lib.stream_ptr())
         return grads
     rt.call("selfc_subnet_bwd_phase", 1, *args, _lib.stream_ptr())
+    if on_data_done is not None:
+        on_data_done()
+    if not want_params:
+        return grads
+    if side is None:
+        rt.call("selfc_subnet_bwd_phase", 2, *args, _lib.stream_ptr())
+        return grads
     side.wait_event(torch.cuda.current_stream().record_event())
     with torch.cuda.stream(side):
         rt.call("selfc_subnet_bwd_phase", 2, *args, _lib.stream_ptr())
@@ -183,11 +191,29 @@ class InvBlockFn(torch.autograd.Function):
         clamp = float(blk.clamp)
         pb = rt.packed_block(blk)
         side = side_stream(dev) if want else None
+        side_h = side_stream(dev, 1)
+        main = torch.cuda.current_stream()
+        ev_h = []
+
+        def h_backward(xin_gh):
+            """H's whole backward (data chain, then its weight gradients) next to G's: own stream, own dx buffer."""
+            if side_h is None:
+                return subnet_bwd(blk.H, ws.hd, xin_gh, dh, 1.0, d1, True, n, t, h, w, want, pb.H, side, "H"), None
+            d1h = torch.empty_like(d1)
+            side_h.wait_event(main.record_event())
+            with torch.cuda.stream(side_h):
+                g_ = subnet_bwd(blk.H, ws.hd, xin_gh, dh, 1.0, d1h, False, n, t, h, w, want, pb.H, None, "H",
+                                on_data_done=lambda: ev_h.append(side_h.record_event()))
+            return g_, d1h
+
         if not rev:
             # y1 = x1 + F(x2); y2 = x2*e^s + G(y1), s = s(H(y1)).  keep = x2 (input), ws.x1 = y1
             rt.call("selfc_coupling_bwd", 0, keep.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel, sp)
+            gH, d1h = h_backward(ws.x1)
             gG = subnet_bwd(blk.G, ws.gd, ws.x1, d2, 1.0, d1, True, n, t, h, w, want, pb.G, side, "G")
-            gH = subnet_bwd(blk.H, ws.hd, ws.x1, dh, 1.0, d1, True, n, t, h, w, want, pb.H, side, "H")
+            if d1h is not None:
+                main.wait_event(ev_h[0])
+                d1.add_(d1h)
             # the forward's epilogue replaced F's f16 input copy by y2: put x2 back before F's weight gradients
             rt.call("selfc_nhwc_to_planes", keep.data_ptr(), ws.fd.data_ptr(), n * h * w, c2, sp)
             gF = subnet_bwd(blk.F, ws.fd, None, d1, 1.0, dx2, True, n, t, h, w, want, pb.F, side, "F")
@@ -195,14 +221,19 @@ class InvBlockFn(torch.autograd.Function):
             # y2 = (x2 - G(x1))*e^-s, s = s(H(x1)); y1 = x1 - F(y2).  keep = x1 (input), ws.x2 = y2 (also in fd)
             gF = subnet_bwd(blk.F, ws.fd, None, d1, -1.0, d2, True, n, t, h, w, want, pb.F, side, "F")
             rt.call("selfc_coupling_bwd", 1, ws.x2.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel, sp)
+            gH, d1h = h_backward(keep)
             gG = subnet_bwd(blk.G, ws.gd, keep, dx2, -1.0, d1, True, n, t, h, w, want, pb.G, side, "G")
-            gH = subnet_bwd(blk.H, ws.hd, keep, dh, 1.0, d1, True, n, t, h, w, want, pb.H, side, "H")
+            if d1h is not None:
+                main.wait_event(ev_h[0])
+                d1.add_(d1h)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((n, c1 + c2, h, w), dtype=torch.float32, device=dev)
             rt.call("selfc_latent_to_nchw", d1.data_ptr(), dx2.data_ptr(), dx.data_ptr(), n, c1, c2, h, w, sp)
         if side is not None:
-            torch.cuda.current_stream().wait_stream(side)          # the parameter gradients are complete from here on
+            main.wait_stream(side)                                 # the parameter gradients are complete from here on
+        if side_h is not None:
+            main.wait_stream(side_h)
         return (dx, None, None, None, *gF, *gG, *gH)
 
 
