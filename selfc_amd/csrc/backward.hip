@@ -571,10 +571,14 @@ int selfc_subnet_bwd_phase(int phases, const selfc_subnet_bw* bw, int kind, cons
   if ((rc = bwd_to_planes(dout, gpl, npix, cout, coutp, L.ng, 0, sign, amax, s))) return rc;
   if (L.hasx && (rc = selfc_nhwc_to_planes(xin, xpl, npix, cin, stream))) return rc;
 
-  // 2. conv5^T(dOut): x-groups and f1..f3 as addend planes, f4 masked straight into dpre4
-  {
+  // 2. conv5^T(dOut): x-groups and f1..f3 as addend planes, f4 masked straight into dpre4.  Temporal conv5 (D2DTInput):
+  //    the frame-walking temporal-conv kernel, one 32-channel output plane per blockIdx.y; 3x3 conv5 (DenseBlock): the
+  //    generic plane conv.
+  if (d2dt) {
+    if ((rc = bwd_tconv5T(gpl, L.ng, bw->wt5, L.nx + 4, t5, feat + 3 * plane, L.nx + 3, gb, N, T, H, W, s))) return rc;
+  } else {
     BwdConv c{};
-    c.in = gpl; c.nplanes_in = L.ng; c.kt = d2dt ? 3 : 1; c.sp1 = d2dt ? 1 : 0; c.w = bw->wt5;
+    c.in = gpl; c.nplanes_in = L.ng; c.kt = 1; c.sp1 = 0; c.w = bw->wt5;
     c.ngroups = L.nx + 4; c.out_planes = t5;
     c.mask = feat + 3 * plane; c.mask_z = L.nx + 3; c.alt = gb;
     c.amax = amax;

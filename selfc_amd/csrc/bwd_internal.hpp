@@ -26,6 +26,9 @@ struct BwdConv {
   const float* amax;      // device: max|dOut| of this subnet call (defines S)
 };
 int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s);
+// conv5^T of a temporal dense block on the temporal-conv kernel (weights: packing.pack_t5_bwd)
+int bwd_tconv5T(const void* g, int ng, const void* w, int nplanes_out, void* out_planes, const void* mask, int mask_z, void* alt,
+                int N, int T, int H, int W, hipStream_t s);
 
 // csrc/backward.hip building blocks (also used by the STP gradients in csrc/stp.hip)
 int bwd_absmax(const float* g, size_t n, float* amax, hipStream_t s);    // *amax = max|g| (zeroed first)

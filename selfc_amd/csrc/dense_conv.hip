@@ -52,7 +52,7 @@ inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 
 #define ABL(a, bit) false
 #endif
 
-enum { EPI_LRELU = 0, EPI_PLAIN = 1, EPI_F = 2, EPI_GH = 3, EPI_BWD = 4 };
+enum { EPI_LRELU = 0, EPI_PLAIN = 1, EPI_F = 2, EPI_GH = 3, EPI_BWD = 4, EPI_T5B = 5 };
 
 struct C3Stage {
   int coff;   // first channel of the stage in the dense buffer
@@ -550,6 +550,13 @@ struct T5Args {
   float* plain;
   int c2p, coutp, rev;
   float clamp;
+  // EPI_T5B (csrc/backward.hip: conv5^T of a temporal dense block): blockIdx.y = 32-channel output plane, weights
+  // w + y*wz_stride; f16 planes out (no bias); plane mask_z is multiplied by LeakyReLU'(maskp) and stored to altp
+  f16* outp;
+  const f16* maskp;
+  f16* altp;
+  int mask_z;
+  size_t wz_stride;
 };
 
 template <int NETS, int OT, int KD, int HASX, int EPI>
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(512) void tconv5_kernel(const T5Args a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   {
-    const uint4* __restrict__ wsrc = reinterpret_cast<const uint4*>(a.w);
+    const uint4* __restrict__ wsrc = reinterpret_cast<const uint4*>(a.w + (EPI == EPI_T5B ? (size_t)blockIdx.y * a.wz_stride : 0));
     for (int i = tid; i < NFRAG * 64; i += 512) *reinterpret_cast<uint4*>(smem + (size_t)i * 16) = wsrc[i];
   }
   __syncthreads();
@@ -606,7 +613,7 @@ __global__ __launch_bounds__(512) void tconv5_kernel(const T5Args a) {
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
       const int oc = o * 16 + kq * 4;
-      ebias[q][o] = *reinterpret_cast<const float4*>((q ? a.bias[1] : a.bias[0]) + oc);
+      ebias[q][o] = EPI == EPI_T5B ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>((q ? a.bias[1] : a.bias[0]) + oc);
     }
   float4 xrow[OT];
   auto prefetch_x2 = [&](const int t) __attribute__((always_inline)) {
@@ -622,7 +629,24 @@ __global__ __launch_bounds__(512) void tconv5_kernel(const T5Args a) {
   auto epilogue = [&](const int t, f32x4 (&acc)[NETS][OT]) __attribute__((always_inline)) {
     if (!pvalid) return;
     const size_t pix = (size_t)(b * a.T + t) * a.HW + pl;
-    if (EPI == EPI_PLAIN) {
+    if (EPI == EPI_T5B) {
+      const int zg = blockIdx.y;
+      const bool masked = a.maskp != nullptr && zg == a.mask_z;
+      f16* __restrict__ dst = (masked && a.altp ? a.altp : a.outp + (size_t)zg * a.plane) + pix * 32 + kq * 4;
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+        float v[4] = {acc[0][o][0], acc[0][o][1], acc[0][o][2], acc[0][o][3]};
+        if (masked) {
+          const f16x4 m = *reinterpret_cast<const f16x4*>(a.maskp + pix * 32 + o * 16 + kq * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] *= ((float)m[j] > 0.f) ? 1.f : 0.2f;
+        }
+        uint2 u;
+        u.x = pack2(v[0], v[1]);
+        u.y = pack2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(dst + o * 16) = u;
+      }
+    } else if (EPI == EPI_PLAIN) {
 #pragma unroll
       for (int o = 0; o < OT; ++o) {
         const int oc = o * 16 + kq * 4;
@@ -807,8 +831,8 @@ int launch_t5(const T5Args& a, hipStream_t s) {
     attr_done = true;
   }
   const int tiles = (a.HW + 127) / 128;
-  ProfScope prof(EPI == EPI_F ? PROF_CONV5_F : EPI == EPI_GH ? PROF_CONV5_GH : PROF_CONV5_PLAIN, s);
-  hipLaunchKernelGGL((tconv5_kernel<NETS, OT, KD, HASX, EPI>), dim3((unsigned)(tiles * a.B)), dim3(512), lds, s, a);
+  ProfScope prof(EPI == EPI_F ? PROF_CONV5_F : EPI == EPI_GH ? PROF_CONV5_GH : EPI == EPI_T5B ? -1 : PROF_CONV5_PLAIN, s);
+  hipLaunchKernelGGL((tconv5_kernel<NETS, OT, KD, HASX, EPI>), dim3((unsigned)(tiles * a.B), EPI == EPI_T5B ? (unsigned)a.coutp : 1u), dim3(512), lds, s, a);
   return hip_rc(hipGetLastError());
 }
 
@@ -922,6 +946,22 @@ int run_GH(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStrea
 }  // namespace
 
 namespace selfc {
+
+// conv5^T of a temporal dense block: out plane z (z < nplanes_out) = sum over the three temporal taps of W_z[tap] g[t + tap - 1];
+// g = ng scaled f16 gradient planes; plane mask_z is multiplied by LeakyReLU'(mask) and stored to `alt`.
+int bwd_tconv5T(const void* g, int ng, const void* w, int nplanes_out, void* out_planes, const void* mask, int mask_z, void* alt,
+                int N, int T, int H, int W, hipStream_t s) {
+  T5Args a{};
+  a.dense[0] = (const f16*)g; a.w = (const f16*)w;
+  a.B = N / T; a.T = T; a.HW = H * W; a.plane = (size_t)N * H * W * 32;
+  a.outp = (f16*)out_planes; a.maskp = (const f16*)mask; a.altp = (f16*)alt; a.mask_z = mask_z;
+  a.coutp = nplanes_out;                                  // grid.y
+  a.wz_stride = (size_t)3 * ng * 2 * 512;                 // halfs per output plane: 3 taps x ng k-steps x 2 out tiles
+  if (ng == 1) return launch_t5<1, 2, 1, 0, EPI_T5B>(a, s);
+  if (ng == 2) return launch_t5<1, 2, 2, 0, EPI_T5B>(a, s);
+  if (ng == 3) return launch_t5<1, 2, 3, 0, EPI_T5B>(a, s);
+  return SELFC_EINVAL;
+}
 
 // Generic plane-list conv with the EPI_BWD epilogue (see C3Args); used by csrc/backward.hip for the data
 // gradients of a dense block.  `in` = first of nplanes_in contiguous f16 planes; kt temporal taps (1 | 3);

@@ -225,6 +225,17 @@ def pack_planes_generic(wt: torch.Tensor) -> torch.Tensor:
     return _operand(frag)
 
 
+def pack_t5_bwd(wt: torch.Tensor) -> torch.Tensor:
+    """conv5^T of a temporal dense block for the frame-walking temporal-conv kernel (dense_conv.hip: EPI_T5B).
+    wt (Z*32 out, KS*32 in, 3 taps) -> f16 [Z][3][KS][2][64][8]: per 32-channel output plane, 16x16x32 A fragments
+    W[16 o + (lane & 15)][32 ks + 8 (lane >> 4) + j] of out tile o (0, 1), k-step ks, tap."""
+    cout, cin, kt = wt.shape
+    assert cout % 32 == 0 and cin % 32 == 0 and kt == 3
+    z, ks = cout // 32, cin // 32
+    frag = wt.reshape(z, 2, 16, ks, 4, 8, 3).permute(0, 6, 3, 1, 4, 2, 5).reshape(z, 3, ks, 2, 64, 8)
+    return _operand(frag)
+
+
 def pack_subnet_bwd(weights: Sequence[torch.Tensor], cin: int, cout: int, temporal: bool):
     """conv1..conv5 weights of a DenseBlock (temporal=False) / D2DTInput (temporal=True) -> the five packed
     data-gradient convs of selfc_subnet_bwd: (wt5, [wtd3, wtd2, wtd1], wtx).
@@ -257,7 +268,7 @@ def pack_subnet_bwd(weights: Sequence[torch.Tensor], cin: int, cout: int, tempor
     w5t = w5t.reshape(cin + 128, cout, kt, ks)
     t5[:cin, :cout] = w5t[:cin]
     t5[nx * 32:, :cout] = w5t[cin:]
-    wt5 = pack_planes_generic(t5)
+    wt5 = pack_t5_bwd(t5[:, :, :, 0]) if temporal else pack_planes_generic(t5)
     # dpre_j, j = 3, 2, 1: in planes dpre4..dpre_{j+1}
     wtd = []
     for j in (3, 2, 1):
