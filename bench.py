@@ -231,28 +231,34 @@ def main():
         out["full_test_path"] = {"septuplets_per_s": round(B_PER_GPU / tf, 1), "ms_per_batch": round(tf * 1e3, 3),
                                  "kernel_ms": fp, "note": "module API, eager, single stream, fh_loss gmm with device RNG"}
         # the same work as a pre-bound pipeline: hipGraph, one septuplet per stream (pipeline.FullTestPath)
-        from selfc_amd.pipeline import FullTestPath
-        with torch.no_grad():
-            ftp = MultiStreamRoundTrip(net, n_frames, H, W, dev, args.streams if args.streams > 1 else 1, part_cls=FullTestPath)
-            ftp.capture(x)
-            for _ in range(3):
-                ftp.replay()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                ftp.replay()
-            torch.cuda.synchronize()
-            tg = (time.perf_counter() - t0) / 10
-        out["full_test_path"]["pipeline"] = {"septuplets_per_s": round(B_PER_GPU / tg, 1), "ms_per_batch": round(tg * 1e3, 3),
-                                              "launch": f"hipGraph replay, {ftp.nstreams} streams"}
+        try:
+            from selfc_amd.pipeline import FullTestPath
+            with torch.no_grad():
+                ftp = MultiStreamRoundTrip(net, n_frames, H, W, dev, args.streams if args.streams > 1 else 1, part_cls=FullTestPath)
+                ftp.capture(x)
+                for _ in range(3):
+                    ftp.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    ftp.replay()
+                torch.cuda.synchronize()
+                tg = (time.perf_counter() - t0) / 10
+            out["full_test_path"]["pipeline"] = {"septuplets_per_s": round(B_PER_GPU / tg, 1), "ms_per_batch": round(tg * 1e3, 3),
+                                                  "launch": f"hipGraph replay, {ftp.nstreams} streams"}
+        except Exception as e:  # noqa: BLE001
+            out["full_test_path"]["pipeline"] = {"error": repr(e)[:300]}
     if not args.no_train_step and world == 1:
         # config 3 of BASELINE.json: one optimize_parameters step (fwd, quantise, STP sample, reverse, backward, clip, Adam)
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
-        import bench_train
-        tr = bench_train.run(batch=8, size=144, steps=5, warmup=2, fh_loss="gmm", profile=False)
-        out["train_step"] = {"septuplets_per_s": round(tr["value"], 1), "ms_per_step": round(tr["ms_per_step"], 2),
-                             "config": "8 x 7x3x144x144 crops, fh_loss gmm, l2 + l1 losses, clip 10, Adam; eager, single stream",
-                             "note": "every forward / reverse / gradient kernel is HIP (selfc_amd/autograd.py); losses, clip and Adam are torch"}
+        try:                                          # a secondary leg must never cost the headline line
+            import bench_train
+            tr = bench_train.run(batch=8, size=144, steps=5, warmup=2, fh_loss="gmm", profile=False)
+            out["train_step"] = {"septuplets_per_s": round(tr["value"], 1), "ms_per_step": round(tr["ms_per_step"], 2),
+                                 "config": "8 x 7x3x144x144 crops, fh_loss gmm, l2 + l1 losses, clip 10, Adam; eager, 3 streams",
+                                 "note": "every forward / reverse / gradient kernel is HIP (selfc_amd/autograd.py); losses, clip and Adam are torch"}
+        except Exception as e:  # noqa: BLE001
+            out["train_step"] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, z_ref, zq_ref, xr_ref = cpu_baseline(net, x_cpu[:T])
         out["cpu_baseline"] = cb
