@@ -140,3 +140,17 @@ def test_backward_argument_errors(dev):
     m = D2DTInput(3, 48)
     with pytest.raises(RuntimeError):
         m(torch.zeros(7, 3, 8, 8, requires_grad=True))
+
+
+def test_bench_uvg_script_small(dev):
+    """tools/bench_uvg.py (config 5 launcher: GOP split with last-frame padding, shard-by-clip) on a small clip."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_uvg.py"), "--clips", "1", "--frames", "10",
+                          "--height", "64", "--width", "96"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["gops_per_clip"] == 2 and line["n_gpus"] == 1 and line["frames_per_s"] > 0
