@@ -1,0 +1,147 @@
+"""Frame I/O on the training / test side of the hot path: the reference's video-folder convention, its
+iteration-oriented distributed sampler and its dataloader factory, without cv2 / lmdb.
+
+  DistIterSampler     codes/data/data_sampler.py:12-59
+  get_vid_paths       codes/data/util.py:59-86   (<root>/<list line>/im{1..N}.png, sorted)
+  SeptupletDataset    codes/data/LQGTVID_dataset.py:14-231 for data_type 'img' (GT only; LR targets are generated on the
+                      device by train.feed_data): RGB float [0,1], (C,T,H,W), one random crop / flip / rot90 per clip
+  create_dataloader   codes/data/__init__.py:7-27
+
+PNG decoding uses PIL (cv2.imread + the BGR->RGB swap of the reference yield the same RGB values); a clip directory may
+instead hold one ``clip.npy`` (N,H,W,3) uint8 file, which avoids the PNG decode that starves 8 GPUs at 2 workers each."""
+from __future__ import annotations
+
+import math
+import os
+import random
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.utils.data as tud
+
+from .global_var import GlobalVar
+
+
+class DistIterSampler(tud.Sampler):
+    """data_sampler.py:12-59: every rank takes indices rank::world of one epoch-seeded permutation of `ratio` copies of the
+    dataset (iteration-oriented training: the loader is restarted only every `ratio` passes)."""
+
+    def __init__(self, dataset, num_replicas=None, rank=None, ratio=100):
+        import torch.distributed as dist
+        if num_replicas is None:
+            if not dist.is_available():
+                raise RuntimeError("Requires distributed package to be available")
+            num_replicas = dist.get_world_size()
+        if rank is None:
+            if not dist.is_available():
+                raise RuntimeError("Requires distributed package to be available")
+            rank = dist.get_rank()
+        self.dataset = dataset
+        self.num_replicas = num_replicas
+        self.rank = rank
+        self.epoch = 0
+        self.num_samples = int(math.ceil(len(self.dataset) * ratio / self.num_replicas))
+        self.total_size = self.num_samples * self.num_replicas
+
+    def __iter__(self):
+        g = torch.Generator()
+        g.manual_seed(self.epoch)
+        indices = torch.randperm(self.total_size, generator=g).tolist()
+        dsize = len(self.dataset)
+        indices = [v % dsize for v in indices]
+        indices = indices[self.rank:self.total_size:self.num_replicas]
+        assert len(indices) == self.num_samples
+        return iter(indices)
+
+    def __len__(self):
+        return self.num_samples
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+
+def get_vid_paths(dataroot: str, data_list: str) -> List[List[str]]:
+    """One list of frame paths per line of `data_list`: <dataroot>/<line>/im1.png .. im<N>.png with N = number of entries in
+    that directory; the list of videos is sorted (data/util.py:59-86)."""
+    vids = []
+    with open(data_list) as fh:
+        for line in fh.readlines():
+            d = os.path.join(dataroot, line.strip())
+            n = len(os.listdir(d))
+            vids.append([os.path.join(d, "im" + str(i)) + ".png" for i in range(1, n + 1)])
+    return sorted(vids)
+
+
+def _read_frame(path: str) -> np.ndarray:
+    """float32 HWC RGB in [0,1] (read_img1 + the channel swap of LQGTVID_dataset.py:132-134)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert("RGB"), dtype=np.float32) / 255.0
+
+
+class SeptupletDataset(tud.Dataset):
+    """opt keys as in the yml: dataroot_GT, dataroot_list, phase, GT_size, video_len, use_flip, use_rot, sample_num."""
+
+    def __init__(self, opt: dict):
+        super().__init__()
+        self.opt = opt
+        self.train = opt.get("phase", "train") == "train"
+        self.paths_GT = get_vid_paths(opt["dataroot_GT"], opt["dataroot_list"])
+        if not self.train and opt.get("sample_num"):
+            self.paths_GT = self.paths_GT[0:opt["sample_num"]]
+        GlobalVar.set_Temporal_LEN(opt["video_len"])            # the dataset sets the global clip length (:56)
+
+    def __len__(self):
+        return len(self.paths_GT)
+
+    def _frames(self, paths: List[str]) -> np.ndarray:
+        d = os.path.dirname(paths[0])
+        npy = os.path.join(d, "clip.npy")
+        if os.path.exists(npy):
+            clip = np.load(npy, mmap_mode="r")[: len(paths)]
+            return np.asarray(clip, dtype=np.float32) / 255.0     # (T,H,W,3)
+        return np.stack([_read_frame(p) for p in paths])
+
+    def __getitem__(self, index):
+        paths = self.paths_GT[index]
+        video_len = self.opt["video_len"]
+        sel = paths[0:video_len] if video_len else paths         # video_len 7 / other: the first frames (:208-211)
+        clip = self._frames(sel)                                   # (T,H,W,3) RGB [0,1]
+        if self.train:
+            gt = self.opt["GT_size"]
+            t, h, w, _ = clip.shape
+            if h < gt or w < gt:
+                raise RuntimeError(f"frames of {paths[0]} are smaller than GT_size {gt} (the reference resizes with cv2 here)")
+            rnd_h = random.randint(0, max(0, h - gt))
+            rnd_w = random.randint(0, max(0, w - gt))
+            clip = clip[:, rnd_h:rnd_h + gt, rnd_w:rnd_w + gt, :]
+            # one draw per clip, applied to every frame (gen_aug_params :60-65, util.augment)
+            if self.opt.get("use_flip") and random.random() < 0.5:
+                clip = clip[:, :, ::-1, :]
+            if self.opt.get("use_rot") and random.random() < 0.5:
+                clip = clip[:, ::-1, :, :]
+            if self.opt.get("use_rot") and random.random() < 0.5:
+                clip = clip.transpose(0, 2, 1, 3)
+        vid = torch.from_numpy(np.ascontiguousarray(clip.transpose(3, 0, 1, 2))).float()      # (C,T,H,W)
+        return {"GT": vid, "LQ_path": paths[0], "GT_path": paths[0]}
+
+
+def create_dataloader(dataset, dataset_opt: dict, opt: Optional[dict] = None, sampler=None):
+    """data/__init__.py:7-27: training batch = batch_size // world when distributed, drop_last; test: batch as given."""
+    phase = dataset_opt["phase"]
+    if phase == "train":
+        if opt and opt.get("dist"):
+            world_size = torch.distributed.get_world_size()
+            num_workers = dataset_opt["n_workers"]
+            assert dataset_opt["batch_size"] % world_size == 0
+            batch_size = dataset_opt["batch_size"] // world_size
+            shuffle = False
+        else:
+            num_workers = dataset_opt["n_workers"] * len((opt or {}).get("gpu_ids", [0]))
+            batch_size = dataset_opt["batch_size"]
+            shuffle = True
+        return tud.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, num_workers=num_workers, sampler=sampler,
+                              drop_last=True, pin_memory=False)
+    return tud.DataLoader(dataset, batch_size=dataset_opt["batch_size"], shuffle=False, num_workers=dataset_opt.get("n_workers", 0),
+                          drop_last=False, pin_memory=False)

@@ -1,0 +1,100 @@
+"""Frame I/O (selfc_amd/data.py): the sampler against index streams captured from the reference's DistIterSampler (G13), the
+folder convention / dataset / dataloader on a synthetic directory tree."""
+import os
+import random
+
+import numpy as np
+import torch
+
+from conftest import load_golden
+
+
+def test_dist_iter_sampler_matches_reference_streams():
+    from selfc_amd.data import DistIterSampler
+    g = load_golden("g13_sampler")
+    for i, (n, world, rank, epoch, ratio) in enumerate(g["cfgs"].tolist()):
+        s = DistIterSampler(list(range(n)), num_replicas=world, rank=rank, ratio=ratio)
+        s.set_epoch(epoch)
+        got = torch.tensor(list(iter(s)))
+        assert torch.equal(got, g[f"idx{i}"]), (n, world, rank)
+        assert len(s) == len(got)
+    # the ranks of one epoch partition the enlarged index list
+    parts = []
+    for r in range(4):
+        s = DistIterSampler(list(range(9)), num_replicas=4, rank=r, ratio=2)
+        parts += list(iter(s))
+    assert len(parts) == 4 * 5 and sorted(set(parts)) == list(range(9))
+
+
+def _make_tree(root, nvid=3, nframes=7, h=20, w=24, npy_for=None):
+    from PIL import Image
+    rng = np.random.RandomState(0)
+    lines = []
+    for v in range(nvid):
+        rel = f"{v:05d}/0001"
+        d = os.path.join(root, rel)
+        os.makedirs(d)
+        frames = rng.randint(0, 256, size=(nframes, h, w, 3), dtype=np.uint8)
+        if npy_for is not None and v == npy_for:
+            np.save(os.path.join(d, "clip.npy"), frames)
+            for i in range(1, nframes):              # directory entry count decides N: keep it at nframes
+                open(os.path.join(d, f"pad{i}"), "w").close()
+        else:
+            for i in range(nframes):
+                Image.fromarray(frames[i]).save(os.path.join(d, f"im{i + 1}.png"))
+        lines.append(rel)
+    lst = os.path.join(root, "list.txt")
+    with open(lst, "w") as fh:
+        fh.write("\n".join(reversed(lines)) + "\n")     # unsorted on purpose
+    return lst
+
+
+def test_dataset_folder_convention_and_augmentation(tmp_path):
+    from selfc_amd import GlobalVar
+    from selfc_amd.data import SeptupletDataset, create_dataloader, get_vid_paths
+    root = str(tmp_path)
+    lst = _make_tree(root, npy_for=1)
+    paths = get_vid_paths(root, lst)
+    assert len(paths) == 3 and paths == sorted(paths) and paths[0][0].endswith("00000/0001/im1.png") and len(paths[0]) == 7
+    test = SeptupletDataset({"dataroot_GT": root, "dataroot_list": lst, "phase": "test", "video_len": 7, "GT_size": 16})
+    assert GlobalVar.get_Temporal_LEN() == 7
+    item = test[0]
+    assert item["GT"].shape == (3, 7, 20, 24) and item["GT"].dtype == torch.float32
+    assert 0.0 <= float(item["GT"].min()) and float(item["GT"].max()) <= 1.0
+    assert item["GT_path"] == paths[0][0]
+    # PNG and clip.npy routes give the same kind of tensor; values are k/255
+    npy_item = test[1]
+    assert npy_item["GT"].shape == (3, 7, 20, 24)
+    assert torch.allclose(npy_item["GT"] * 255, (npy_item["GT"] * 255).round(), atol=1e-4)
+    # training: one crop / flip / rot per clip -> every frame is the same window of its source frame
+    random.seed(3)
+    train = SeptupletDataset({"dataroot_GT": root, "dataroot_list": lst, "phase": "train", "video_len": 7, "GT_size": 16,
+                              "use_flip": True, "use_rot": True})
+    full = test[0]["GT"]
+    for _ in range(8):
+        clip = train[0]["GT"]
+        assert clip.shape == (3, 7, 16, 16)
+        cands = []
+        for t in range(7):
+            f = full[:, t]
+            found = None
+            for rot in (False, True):
+                for vf in (False, True):
+                    for hf in (False, True):
+                        for y in range(0, 5):
+                            for x in range(0, 9):
+                                win = f[:, y:y + 16, x:x + 16]
+                                if hf:
+                                    win = win.flip(2)
+                                if vf:
+                                    win = win.flip(1)
+                                if rot:
+                                    win = win.transpose(1, 2)
+                                if torch.equal(win, clip[:, t]):
+                                    found = (rot, vf, hf, y, x)
+            assert found is not None
+            cands.append(found)
+        assert len(set(cands)) == 1, cands
+    loader = create_dataloader(train, {"phase": "train", "batch_size": 2, "n_workers": 0}, {"dist": False, "gpu_ids": [0]})
+    batch = next(iter(loader))
+    assert batch["GT"].shape == (2, 3, 7, 16, 16)                  # data['GT'] (B,C,T,H,W) as feed_data expects

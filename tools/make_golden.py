@@ -281,6 +281,16 @@ def main():
         ssims = [float(ref_util.ssim(ya[i:i + 1], yb[i:i + 1], data_range=1.0)) for i in range(3)]
         save("g12_ssim_y", a=a_img.numpy(), b=b_img.numpy(), ssim=np.array(ssims, dtype=np.float64))
 
+        # ---- G13 DistIterSampler (data/data_sampler.py:12-59): index streams of a few (dataset size, world, rank, epoch, ratio)
+        from data.data_sampler import DistIterSampler as _DIS
+        cfgs = [(10, 2, 0, 0, 3), (10, 2, 1, 0, 3), (7, 4, 3, 5, 2), (64, 8, 5, 1, 1)]
+        streams = {}
+        for i, (n, world, rk, ep, ratio) in enumerate(cfgs):
+            smp = _DIS(list(range(n)), num_replicas=world, rank=rk, ratio=ratio)
+            smp.set_epoch(ep)
+            streams[f"idx{i}"] = np.array(list(iter(smp)), dtype=np.int64)
+        save("g13_sampler", cfgs=np.array(cfgs, dtype=np.int64), **streams)
+
         # ---- G9 Quantization
         q = Quantization()
         v = torch.tensor([-0.3, 0.0, 0.001, 0.00196, 0.00197, 0.5, 0.50196, 0.998, 1.0, 1.7,
