@@ -377,13 +377,13 @@ def _head_convs(stp):
     return [m for m in stp.tail_gmm if isinstance(m, torch.nn.Conv3d)]
 
 
-def _head_bwd(stp, feat, acts, dlast, n, t, h, w) -> Tuple[torch.Tensor, Dict[int, Tuple[torch.Tensor, torch.Tensor]]]:
-    """Backward of tail_gmm = [lrelu, conv1x1x1]* given d(last conv output) `dlast` fp32 [npix][Cl].
-    feat: fp32 [npix][64] (input of the head), acts: the saved post-LeakyReLU f16 rows of the hidden layers.
-    Returns (dfeat fp32 [npix][64], {conv index: (dweight, dbias)})."""
-    convs = _head_convs(stp)
+def _head_bwd(convs, feat, acts, dlast, n, t, h, w) -> Tuple[torch.Tensor, Dict[int, Tuple[torch.Tensor, torch.Tensor]]]:
+    """Backward of a [lrelu, conv1x1x1]* head given d(last conv output) `dlast` fp32 [npix][>= Cl].
+    feat: fp32 [npix][C0] (input of the head, C0 a multiple of 32), acts: the saved post-LeakyReLU f16 rows of the hidden
+    layers.  Returns (dfeat fp32 [npix][C0], {conv index: (dweight, dbias)})."""
     dev, sp = feat.device, _lib.stream_ptr()
     npix = n * h * w
+    c0 = feat.shape[-1]
     F16 = _lib.operand_dtype()
     L = _lib.lib()
     amax = torch.zeros(64, dtype=torch.float32, device=dev)
@@ -392,15 +392,15 @@ def _head_bwd(stp, feat, acts, dlast, n, t, h, w) -> Tuple[torch.Tensor, Dict[in
     gp = torch.empty((roundup(cl, 32) // 32, npix, 32), dtype=F16, device=dev)
     rt.call("selfc_bwd_to_planes", dlast.data_ptr(), gp.data_ptr(), npix, cl, dlast.shape[-1], 0, 1.0, amax.data_ptr(), sp)
     # activation planes: lrelu(feat), then the hidden activations
-    inputs = [torch.empty((2, npix, 32), dtype=F16, device=dev)]
-    rt.call("selfc_bwd_to_planes", feat.data_ptr(), inputs[0].data_ptr(), npix, 64, 64, 1, 1.0, None, sp)
+    inputs = [torch.empty((c0 // 32, npix, 32), dtype=F16, device=dev)]
+    rt.call("selfc_bwd_to_planes", feat.data_ptr(), inputs[0].data_ptr(), npix, c0, c0, 1, 1.0, None, sp)
     for a in acts:
         c = a.shape[-1]
         pl = torch.empty((c // 32, npix, 32), dtype=F16, device=dev)
         rt.call("selfc_f16_rows_to_planes", a.data_ptr(), pl.data_ptr(), npix, c, sp)
         inputs.append(pl)
     grads: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
-    dfeat = torch.empty((npix, 64), dtype=torch.float32, device=dev)
+    dfeat = torch.empty((npix, c0), dtype=torch.float32, device=dev)
     for li in range(len(convs) - 1, -1, -1):
         conv, q = convs[li], inputs[li]
         cout, cin = conv.out_channels, conv.in_channels
@@ -419,8 +419,8 @@ def _head_bwd(stp, feat, acts, dlast, n, t, h, w) -> Tuple[torch.Tensor, Dict[in
                     q.data_ptr(), -2, None, 0, 0, amax.data_ptr(), n, t, h, w, sp)
             gp = nxt
         else:
-            rt.call("selfc_bwd_conv_planes", gp.data_ptr(), pn, 1, 1, wt.data_ptr(), 2, None, None, None, -1,
-                    dfeat.data_ptr(), 64, 0, amax.data_ptr(), n, t, h, w, sp)
+            rt.call("selfc_bwd_conv_planes", gp.data_ptr(), pn, 1, 1, wt.data_ptr(), c0 // 32, None, None, None, -1,
+                    dfeat.data_ptr(), c0, 0, amax.data_ptr(), n, t, h, w, sp)
             rt.call("selfc_lrelu_bwd", dfeat.data_ptr(), feat.data_ptr(), dfeat.numel(), sp)
     return dfeat, grads
 
@@ -494,7 +494,7 @@ class STPSampleFn(torch.autograd.Function):
         else:
             dlast = torch.empty_like(ctx.raw)
             rt.call("selfc_gmm_sample_bwd", ctx.raw.data_ptr(), ctx.eps.data_ptr(), dv.data_ptr(), dlast.data_ptr(), npix, stp.hf_dim, stp.K, sp)
-        d, head_grads = _head_bwd(stp, ctx.feat, ctx.acts, dlast, n, t, h, w)
+        d, head_grads = _head_bwd(_head_convs(stp), ctx.feat, ctx.acts, dlast, n, t, h, w)
         grads: Dict[int, torch.Tensor] = {}
         for conv, (gw, gb) in zip(_head_convs(stp), [head_grads[i] for i in range(len(head_grads))]):
             grads[id(conv.weight)], grads[id(conv.bias)] = gw, gb
@@ -526,3 +526,37 @@ class STPSampleFn(torch.autograd.Function):
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         return (dlr, None, None, None, *[grads.get(id(p)) for p in stp.parameters()])
+
+
+class PointwiseHeadFn(torch.autograd.Function):
+    """LeakyReLU + Conv3d 1x1x1 head of STP v1 (SelfC_arch_inv.py:139-141,170-176): x (N,C,h,w) -> (N,cout,h,w)."""
+
+    @staticmethod
+    def forward(ctx, x, conv, packed, t, weight, bias):
+        x = rt.as_input(x)
+        n, cc, h, w = x.shape
+        dev, sp = x.device, _lib.stream_ptr()
+        cout = conv.out_channels
+        coutp = roundup(cout, 16)
+        feat = torch.empty((n, h, w, cc), dtype=torch.float32, device=dev)
+        rt.call("selfc_nchw_to_nhwc4", x.data_ptr(), feat.data_ptr(), n, cc, h, w, sp)
+        wp, bp = packed
+        outp = torch.empty((n, h, w, coutp), dtype=torch.float32, device=dev)
+        rt.call("selfc_pwconv_run", feat.data_ptr(), 1, outp.data_ptr(), 1, wp.data_ptr(), bp.data_ptr(), n * h * w, cc, coutp, coutp, 1, 0, sp)
+        ctx.conv, ctx.t, ctx.feat, ctx.shape = conv, t, feat, (n, cc, h, w)
+        return outp[..., :cout].permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, gy):
+        conv, t, feat = ctx.conv, ctx.t, ctx.feat
+        n, cc, h, w = ctx.shape
+        dev, sp = gy.device, _lib.stream_ptr()
+        cout = conv.out_channels
+        cs = roundup(cout, 4)
+        dlast = torch.empty((n, h, w, cs), dtype=torch.float32, device=dev)
+        rt.call("selfc_nchw_to_nhwc4", gy.contiguous().float().data_ptr(), dlast.data_ptr(), n, cout, h, w, sp)
+        dfeat, grads = _head_bwd([conv], feat.reshape(n * h * w, cc), [], dlast.reshape(n * h * w, cs), n, t, h, w)
+        dx = torch.empty((n, cc, h, w), dtype=torch.float32, device=dev)
+        rt.call("selfc_nhwc4_to_nchw", dfeat.data_ptr(), dx.data_ptr(), n, cc, h, w, sp)
+        gw, gb = grads[0]
+        return dx, None, None, None, gw, gb

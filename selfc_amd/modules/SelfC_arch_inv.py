@@ -60,7 +60,15 @@ class STPNet(nn.Module):
         """x (b,3,t,h,w); sets ``stp_parameters`` (the reference's ``self.parameters``) = (b,9,t,h,w)."""
         b, c, t, h, w = x.size()
         temp = x.transpose(1, 2).reshape(b * t, c, h, w)
-        rt.no_autograd_guard(temp, *self.parameters())
+        from .. import autograd as ag
+        if ag.module_needs_grad(temp, self):
+            if self.condition_func != "D2DTNet":
+                rt.no_autograd_guard(temp, *self.parameters())      # FeatureCalapseBlock has no backward kernels yet
+            feat = self.blk2(self.blk1(temp))                        # differentiable D2DTInput chain
+            conv = self.tail[1]
+            v = ag.PointwiseHeadFn.apply(feat, conv, self._tail_packed(), t, conv.weight, conv.bias)
+            self.stp_parameters = v.reshape(b, t, self.hf_dim, h, w).transpose(1, 2)
+            return
         temp = self.blk2(self.blk1(temp))
         n, cc = b * t, self.stp_temporal_c
         sp = _lib.stream_ptr()

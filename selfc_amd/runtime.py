@@ -19,8 +19,8 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def no_autograd_guard(*tensors):
-    """For the few modules without a HIP backward yet (STP v1 of the Haar variant, FeatureCalapseBlock): refuse loudly
-    instead of silently returning tensors without a graph."""
+    """For the modules without a HIP backward yet (FeatureCalapseBlock, hence STP v1 with its default conditioner): refuse
+    loudly instead of silently returning tensors without a graph."""
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
         raise NotImplementedError(
             "selfc_amd: this module has no backward kernels yet - call it under torch.no_grad() "

@@ -383,3 +383,41 @@ def test_gradient_scale_invariance(dev):
         else:
             for a, b in zip(cur, base):
                 assert rel_err(a, b) < 2e-3, scale
+
+
+def test_selfc_haar_variant_training_gradients(dev):
+    """model "SelfC" (Haar + InvBlockExp(DBNet) + STP v1 with the D2DTNet conditioner and l2 head, SelfC_arch_inv.py): the
+    training-style objective fit(LR) + neg_llh + reconstruction through rev, every gradient on the HIP path."""
+    from selfc_amd.modules.SelfC_arch_inv import SelfCInvNet
+    g = load_golden("g8_selfc_haar")
+    opt1 = {"stp_d2d_inner_c": 32, "stp_temporal_c": 32, "fh_loss": "l2", "gmm_mixture_num": 5,
+            "stp_blk_num": 2, "condition_func": "D2DTNet"}
+    sd = {k: v for k, v in g.items() if k.startswith(("operations.", "stp_net."))}
+    net = SelfCInvNet(opt1, 3, 3, "DBNet", [1], 1)
+    net.load_state_dict(sd, strict=True)
+    x = g["x"]
+    target = torch.rand(x.shape[0], 3, x.shape[2] // 2, x.shape[3] // 2, generator=torch.Generator().manual_seed(12))
+    noise = torch.randn(x.shape[0], 3, x.shape[2] // 2, x.shape[3] // 2, generator=torch.Generator().manual_seed(13)) * 0.02
+
+    def objective(fwd, rev, xx, tgt, nz):
+        z, nll = fwd(xx)
+        lr = z[:, :3]
+        rec, _ = rev(lr + nz)                      # a perturbed LR keeps |rec - x| away from the l1 kink
+        d = rec - xx
+        return ((lr - tgt) ** 2).mean() + nll + torch.sqrt(d * d + 1e-6).mean()
+
+    p = {k: v.clone().requires_grad_(k.endswith(("weight", "bias"))) for k, v in sd.items()}
+    loss_ref = objective(lambda v: O.selfc_haar_fwd(p, v, [1], T), lambda v: O.selfc_haar_rev(p, v, [1], T), x, target, noise)
+    loss_ref.backward()
+    net.to(dev)
+    loss = objective(lambda v: net(x=v, rev=False), lambda v: net(x=v, rev=True), x.to(dev), target.to(dev), noise.to(dev))
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 2e-3 * abs(float(loss_ref.detach()))
+    loss.backward()
+    errs = {n_: rel_l2(p_.grad.cpu(), p[n_].grad) for n_, p_ in net.named_parameters() if p_.requires_grad}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert worst[0][1] < 5e-2, worst
+    # the default FeatureCalapseBlock conditioner still refuses loudly in training mode
+    opt2 = dict(opt1, condition_func="FeatureCalapseBlock")
+    net2 = SelfCInvNet(opt2, 3, 3, "DBNet", [1], 1).to(dev)
+    with pytest.raises(NotImplementedError):
+        net2(x=x.to(dev), rev=False)
