@@ -84,8 +84,12 @@ def feed_data(gt: torch.Tensor, distortion: str = "sr_bd", scale: int = 4, lq: O
         if scale != 4:
             raise NotImplementedError("the Gaussian LR target kernel is built for scale 4")
         ref_l = harness.gaussian_downsample(real_h)                 # Guassian_downsample (models/Guassian.py:7-52)
-    elif distortion == "pytorch_bicubic":                            # (sic) F.upsample(mode='area') in the reference
-        ref_l = torch.nn.functional.avg_pool2d(real_h, scale)
+    elif distortion == "pytorch_bicubic":                            # (sic) F.upsample(mode='area') in the reference = 4x4 block mean
+        if scale != 4:
+            raise NotImplementedError("the area LR target is built for scale 4")
+        from .modules.SelfC_GMM_arch_inv import FrequencyAnalyzer
+        with torch.no_grad():
+            ref_l = FrequencyAnalyzer(3)(real_h)[:, :3].contiguous()   # the low band of the split kernel is that block mean
     else:
         raise NotImplementedError(f"distortion {distortion!r}")
     return real_h, ref_l, clip_length

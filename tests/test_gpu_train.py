@@ -154,3 +154,14 @@ def test_bench_uvg_script_small(dev):
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["gops_per_clip"] == 2 and line["n_gpus"] == 1 and line["frames_per_s"] > 0
+
+
+def test_feed_data_variants(dev):
+    """feed_data: short clips are padded with their last frame (SelfC_model.py:99-108); 'pytorch_bicubic' (area) LR target."""
+    from selfc_amd import train
+    gt = torch.rand(2, 3, 5, 16, 24).to(dev)                          # 5 < 7 frames
+    real_h, ref_l, clip_len = train.feed_data(gt, "pytorch_bicubic", 4)
+    assert clip_len == 5 and real_h.shape == (14, 3, 16, 24) and ref_l.shape == (14, 3, 4, 6)
+    assert torch.equal(real_h.reshape(2, 7, 3, 16, 24)[:, 6], gt[:, :, 4])
+    want = torch.nn.functional.avg_pool2d(real_h.cpu(), 4)
+    assert float((ref_l.cpu() - want).abs().max()) < 1e-6
