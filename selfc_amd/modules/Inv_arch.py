@@ -45,7 +45,9 @@ class InvBlockExp(nn.Module):
         self.__dict__["_s_ws"] = None
 
     def _set_s_lazy(self, ws):
-        self.__dict__["_s_ws"] = ws
+        # keep only what s_to_nchw needs (the NHWC s buffer and its dims), not the block's whole saved workspace
+        from types import SimpleNamespace
+        self.__dict__["_s_ws"] = SimpleNamespace(s=ws.s, N=ws.N, c2=ws.c2, H=ws.H, W=ws.W, device=ws.device)
         self.__dict__["_s_nchw"] = None
 
     def _temporal_len(self):
