@@ -260,6 +260,105 @@ __global__ __launch_bounds__((TAPS == 1 ? 4 : 3) * 64) void wgrad_kernel(const W
   }
 }
 
+// Temporal weight gradient (conv5 of D2DTInput: dW[o][c][tap] = sum_px g[n][px][o] * in[n + tap - 1][px][c] inside each clip).
+// A workgroup owns (clip, 16x16 spatial tile) units and walks the clip's frames in order with a three-slot ring of
+// activation tiles in LDS, so every frame's tile is loaded once (the generic kernel loaded three per frame) while the next
+// frame's two tiles are prefetched into registers; wave w multiplies with the ring slot of frame t + w - 1.
+__global__ __launch_bounds__(192) void wgrad_temporal_kernel(const WgArgs a) {
+  constexpr int NT = 192, PI = (1024 + NT - 1) / NT;
+  __shared__ __attribute__((aligned(16))) unsigned char lp[256 * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char lq[3 * 256 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qi = blockIdx.y;
+  const f16* __restrict__ P = a.P + (size_t)blockIdx.z * a.plane;
+  const f16* __restrict__ Q = qi < a.nq0 ? a.Q0 + (size_t)qi * a.plane : a.Q1 + (size_t)(qi - a.nq0) * a.plane;
+  const int H = a.H, W = a.W, T = a.T;
+  const bool want_bias = a.bpart != nullptr && qi == 0;
+  f32x16 acc, accb;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
+  f16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (f16)1.f;
+  const int g = lane >> 4, h = g >> 1, q = (lane >> 2) & 3, p = lane & 3;
+  const int choff = (16 * (g & 1) + 4 * p) * 2;
+
+  u32x4 preg[PI], qreg[PI];
+  unsigned okm = 0;
+  // fetch the P tile of frame t and the Q tile of frame t + 1 of the current unit (either may be outside the clip)
+  auto fetch = [&](const int nbase, const int t, const int tx0, const int ty0) __attribute__((always_inline)) {
+    okm = 0;
+    const bool pv = (t >= 0) & (t < T), qv = t + 1 < T;
+    const int np = nbase + max(0, min(t, T - 1)), nq = nbase + min(t + 1, T - 1);
+#pragma unroll
+    for (int it = 0; it < PI; ++it) {
+      const int i = min(tid + it * NT, 1023);
+      const int px = i >> 2, ch = i & 3;
+      const int y = ty0 + (px >> 4), x = tx0 + (px & 15);
+      const bool in = (y < H) & (x < W);
+      okm |= ((in & pv) ? 1u : 0u) << it;
+      okm |= ((in & qv) ? 1u : 0u) << (16 + it);
+      const int yc = min(y, H - 1), xc = min(x, W - 1);
+      preg[it] = *reinterpret_cast<const u32x4*>(P + ((size_t)(np * H + yc) * W + xc) * 32 + ch * 8);
+      qreg[it] = *reinterpret_cast<const u32x4*>(Q + ((size_t)(nq * H + yc) * W + xc) * 32 + ch * 8);
+    }
+  };
+  auto store_q = [&](const int slot, const unsigned mask) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < PI; ++it) {
+      const int i = tid + it * NT;
+      if (i < 1024) *reinterpret_cast<u32x4*>(lq + (size_t)slot * 16384 + (i >> 2) * 64 + (i & 3) * 16) = ((mask >> it) & 1u) ? qreg[it] : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+
+  const int nunits = (a.N / T) * a.tiles_x * a.tiles_y;
+  for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    const int tx = unit % a.tiles_x, ty = (unit / a.tiles_x) % a.tiles_y, clip = unit / (a.tiles_x * a.tiles_y);
+    const int tx0 = tx * 16, ty0 = ty * 16, nbase = clip * T;
+    // ring slots: frame f lives in slot (f + 1) % 3; slot of frame -1 is zero, frame 0 is loaded up front
+    __syncthreads();
+    fetch(nbase, -1 + 0, tx0, ty0);                    // t = -1: P invalid (unused), Q = frame 0
+    // (fetch's P part for t = -1 reads frame 0's P rows harmlessly; only the Q half is stored)
+    store_q(1, okm >> 16);
+    for (int i = tid; i < 1024; i += NT) *reinterpret_cast<u32x4*>(lq + (i >> 2) * 64 + (i & 3) * 16) = u32x4{0u, 0u, 0u, 0u};   // slot 0 = frame -1
+    fetch(nbase, 0, tx0, ty0);                          // P[0], Q[1]
+    for (int t = 0; t < T; ++t) {
+      __syncthreads();                                  // frame t-1's fragments have been read
+#pragma unroll
+      for (int it = 0; it < PI; ++it) {
+        const int i = tid + it * NT;
+        if (i < 1024) *reinterpret_cast<u32x4*>(lp + (i >> 2) * 64 + (i & 3) * 16) = ((okm >> it) & 1u) ? preg[it] : u32x4{0u, 0u, 0u, 0u};
+      }
+      store_q((t + 2) % 3, okm >> 16);                  // frame t+1 (zeros past the clip end)
+      __syncthreads();
+      if (t + 1 < T) fetch(nbase, t + 1, tx0, ty0);     // P[t+1], Q[t+2] while frame t is multiplied
+      const int slot = (t + wave) % 3;                  // frame t + wave - 1
+      for (int pi = 0; pi < 16; ++pi) {
+        const int pr = pi >> 2, pc = pi & 3;
+        if (ty0 + 4 * pr >= H || tx0 + 4 * pc >= W) continue;
+        const int row = ((4 * pr + 2 * h) * 16 + 4 * pc + q) * 64 + choff;
+        const f16x8 af = tr_frag(lp, row, row + 16 * 64);
+        const f16x8 bf = tr_frag(lq + (size_t)slot * 16384, row, row + 16 * 64);
+        acc = mfma_32x32x16(af, bf, acc);
+        if (want_bias && wave == 0) accb = mfma_32x32x16(af, ones, accb);
+      }
+    }
+  }
+  const int npairs = (int)(gridDim.y * gridDim.z);
+  const int pair = (int)(blockIdx.z * gridDim.y + blockIdx.y);
+  float* __restrict__ base = a.part + ((((size_t)blockIdx.x * npairs + pair) * 3 + wave) << 10);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int o = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    base[o * 32 + (lane & 31)] = acc[r];
+  }
+  if (want_bias && wave == 0 && (lane & 31) == 0) {
+    float* __restrict__ bb = a.bpart + ((size_t)blockIdx.x * gridDim.z + blockIdx.z) * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bb[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = accb[r];
+  }
+}
+
 struct FinArgs {
   const float* part;
   const float* bpart;
@@ -478,7 +577,11 @@ int bwd_wgrad(const WgradJob& j, const float* amax, void* scratch, int N, int T,
   const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
   const int qtot = j.Qn[0] + j.Qn[1];
   const int ttot = j.taps == 9 ? 9 : (j.temporal ? 3 : 1);
-  const int nsplit = wgrad_nsplit(N, H, W, j.Pn * qtot, ttot);
+  int nsplit = wgrad_nsplit(N, H, W, j.Pn * qtot, ttot);
+  if (ttot == 3) {                                   // the temporal kernel's units are (clip, tile): never more splits than units
+    const int nunits = (N / T) * tiles_x * tiles_y;
+    if (nsplit > nunits) nsplit = nunits;
+  }
   float* bpart = (float*)scratch;
   float* part = (float*)((unsigned char*)scratch + up256((size_t)nsplit * (j.Pn < 4 ? 4 : j.Pn) * 32 * sizeof(float)));
   if (!j.wout && !j.bout) return SELFC_OK;
@@ -487,7 +590,11 @@ int bwd_wgrad(const WgradJob& j, const float* amax, void* scratch, int N, int T,
   a.part = part; a.bpart = j.bout ? bpart : nullptr; a.plane = plane;
   a.N = N; a.T = T; a.H = H; a.W = W; a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.ntiles = N * tiles_x * tiles_y;
   int rc = ttot == 9 ? launch_wgrad_any<9>(a, nsplit, qtot, j.Pn, s)
-         : ttot == 3 ? launch_wgrad_any<3>(a, nsplit, qtot, j.Pn, s) : launch_wgrad_any<1>(a, nsplit, qtot, j.Pn, s);
+         : ttot == 1 ? launch_wgrad_any<1>(a, nsplit, qtot, j.Pn, s) : SELFC_OK;
+  if (ttot == 3) {
+    hipLaunchKernelGGL(wgrad_temporal_kernel, dim3((unsigned)nsplit, (unsigned)qtot, (unsigned)j.Pn), dim3(192), 0, s, a);
+    rc = hip_rc(hipGetLastError());
+  }
   if (rc) return rc;
   FinArgs f{};
   f.part = part; f.bpart = bpart; f.out[0] = j.wout; f.bout[0] = j.bout; f.nW = nsplit; f.Pn = j.Pn; f.qtot = qtot; f.ttot = ttot;
