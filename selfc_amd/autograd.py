@@ -75,12 +75,17 @@ def subnet_bwd(mod, dense: torch.Tensor, xin: Optional[torch.Tensor], dout: torc
     wg = (C.c_void_p * 5)()
     bg = (C.c_void_p * 5)()
     if want_params:
-        for i in range(5):
-            conv = getattr(mod, f"conv{i + 1}")
-            gw = torch.empty(conv.weight.shape, dtype=torch.float32, device=dev)
-            gb = torch.empty(conv.bias.shape, dtype=torch.float32, device=dev)
-            grads[2 * i], grads[2 * i + 1] = gw, gb
-            wg[i], bg[i] = gw.data_ptr(), gb.data_ptr()
+        # one allocation for the ten gradients (each slice 64-float aligned), handed out as views
+        prm = subnet_params(mod)
+        offs, total = [], 0
+        for p_ in prm:
+            offs.append(total)
+            total += (p_.numel() + 63) & ~63
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        base = flat.data_ptr()
+        for i, p_ in enumerate(prm):
+            grads[i] = flat[offs[i]:offs[i] + p_.numel()].view(p_.shape)
+            (wg if i % 2 == 0 else bg)[i // 2] = base + 4 * offs[i]
     scratch = _scratch(dev, n, h, w, cin, cout, slot)
     bw = pk.bwd_struct()
     args = (bw, mod.kind, dense.data_ptr(), None if xin is None else xin.data_ptr(), dout.data_ptr(),

@@ -104,23 +104,29 @@ class PackedSubnet:
         self.wtx = d.get(f"{prefix}wtx")
 
     def struct(self) -> _lib.SubnetW:
-        s = _lib.SubnetW()
-        for i in range(4):
-            s.w3[i] = _ptr(self.w3[i])
-            s.b3[i] = _ptr(self.b3[i])
-        s.w5 = _ptr(self.w5)
-        s.b5 = _ptr(self.b5)
-        s.wfused = _ptr(self.wfused)
+        s = self.__dict__.get("_struct")          # the tensors of one PackedSubnet never change: build the ctypes view once
+        if s is None:
+            s = _lib.SubnetW()
+            for i in range(4):
+                s.w3[i] = _ptr(self.w3[i])
+                s.b3[i] = _ptr(self.b3[i])
+            s.w5 = _ptr(self.w5)
+            s.b5 = _ptr(self.b5)
+            s.wfused = _ptr(self.wfused)
+            self._struct = s
         return s
 
     def bwd_struct(self) -> _lib.SubnetBW:
-        if self.wt5 is None:
-            raise NotImplementedError("subnet backward covers channel_out <= 96")
-        s = _lib.SubnetBW()
-        s.wt5 = _ptr(self.wt5)
-        for i in range(3):
-            s.wtd[i] = _ptr(self.wtd[i])
-        s.wtx = _ptr(self.wtx)
+        s = self.__dict__.get("_bwd_struct")
+        if s is None:
+            if self.wt5 is None:
+                raise NotImplementedError("subnet backward covers channel_out <= 96")
+            s = _lib.SubnetBW()
+            s.wt5 = _ptr(self.wt5)
+            for i in range(3):
+                s.wtd[i] = _ptr(self.wtd[i])
+            s.wtx = _ptr(self.wtx)
+            self._bwd_struct = s
         return s
 
 
@@ -154,9 +160,16 @@ def params_key(*mods) -> Tuple:
     return tuple((p.data_ptr(), p._version) for m in mods for p in plist(m))
 
 
+_FN: Dict[str, object] = {}
+
+
 def call(name: str, *args):
-    rc = getattr(_lib.lib(), name)(*args)
-    _lib.check(rc, name)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(_lib.lib(), name)
+    rc = fn(*args)
+    if rc:
+        _lib.check(rc, name)
 
 
 def nchw_to_latent(x: torch.Tensor, ws: Workspace, with_fd: bool = True):
@@ -196,9 +209,12 @@ class PackedBlock:
         self.clamp = float(blk.clamp)
 
     def struct(self) -> _lib.InvBlockW:
-        s = _lib.InvBlockW()
-        s.F, s.G, s.H = self.F.struct(), self.G.struct(), self.H.struct()
-        s.clamp = self.clamp
+        s = self.__dict__.get("_struct")
+        if s is None:
+            s = _lib.InvBlockW()
+            s.F, s.G, s.H = self.F.struct(), self.G.struct(), self.H.struct()
+            s.clamp = self.clamp
+            self._struct = s
         return s
 
 
