@@ -55,3 +55,46 @@ def test_bf16_operand_build_runs_and_is_less_accurate_than_f16():
     assert 1e-3 < b["fwd"] < 1e-2 and 1e-3 < b["inv"] < 2e-2      # bf16: works, but outside the bar
     assert b["fwd"] > 3 * f["fwd"]
     print("f16:", f, "bf16:", b)
+
+
+BWD_SCRIPT = r"""
+import json, sys
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+import torch
+from selfc_amd import GlobalVar, _lib
+from selfc_amd.modules.Subnet_constructor import D2DTInput
+from oracle import selfc_oracle as O
+GlobalVar.set_Temporal_LEN(7)
+torch.manual_seed(5)
+m = D2DTInput(48, 3)
+with torch.no_grad():
+    for p in m.parameters():
+        p.copy_(torch.randn_like(p) * (0.05 if p.dim() > 1 else 0.1))
+sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+x = torch.randn(14, 48, 12, 20)
+gy = torch.randn(14, 3, 12, 20) * 0.01
+O.d2dt(sd, x, 7).backward(gy)
+m.cuda()
+m(x.cuda()).backward(gy.cuda())
+l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+print(json.dumps({"operand": _lib.OPERAND, "worst": max(l2(p.grad.cpu(), sd[n].grad) for n, p in m.named_parameters())}))
+""" % (ROOT, os.path.join(ROOT, "tests"))
+
+
+def test_backward_runs_on_both_operand_builds():
+    """The gradient kernels are operand-type generic (scaled 16-bit planes, transposing LDS reads): bf16 works and is
+    ~8x less accurate than f16 here as well."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    res = {}
+    for operand in ("f16", "bf16"):
+        env = dict(os.environ, SELFC_OPERAND=operand)
+        env.pop("SELFC_LIB", None)
+        p = subprocess.run([sys.executable, "-c", BWD_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[operand] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["f16"]["worst"] < 3e-2
+    assert res["bf16"]["worst"] < 2e-1 and res["bf16"]["operand"] == "bf16"
+    print(res)
