@@ -24,41 +24,33 @@ from .global_var import GlobalVar
 
 
 class DistIterSampler(tud.Sampler):
-    """data_sampler.py:12-59: every rank takes indices rank::world of one epoch-seeded permutation of `ratio` copies of the
-    dataset (iteration-oriented training: the loader is restarted only every `ratio` passes)."""
+    """Iteration-oriented distributed sampler (behaviour of data_sampler.py:12-59): one "epoch" is `ratio` passes over the
+    dataset, shuffled as a single permutation seeded by the epoch number; rank r reads positions r, r + world, ... of it, and
+    every position is folded back onto a dataset index by modulo.  The loader is thus restarted only every `ratio` passes."""
 
     def __init__(self, dataset, num_replicas=None, rank=None, ratio=100):
-        import torch.distributed as dist
-        if num_replicas is None:
+        if num_replicas is None or rank is None:
+            import torch.distributed as dist
             if not dist.is_available():
                 raise RuntimeError("Requires distributed package to be available")
-            num_replicas = dist.get_world_size()
-        if rank is None:
-            if not dist.is_available():
-                raise RuntimeError("Requires distributed package to be available")
-            rank = dist.get_rank()
-        self.dataset = dataset
-        self.num_replicas = num_replicas
-        self.rank = rank
-        self.epoch = 0
-        self.num_samples = int(math.ceil(len(self.dataset) * ratio / self.num_replicas))
-        self.total_size = self.num_samples * self.num_replicas
+            num_replicas = dist.get_world_size() if num_replicas is None else num_replicas
+            rank = dist.get_rank() if rank is None else rank
+        self.dataset, self.num_replicas, self.rank, self.epoch = dataset, num_replicas, rank, 0
+        self.num_samples = int(math.ceil(len(dataset) * ratio / num_replicas))       # per rank
+        self.total_size = self.num_samples * num_replicas                              # padded so that it splits evenly
 
-    def __iter__(self):
-        g = torch.Generator()
-        g.manual_seed(self.epoch)
-        indices = torch.randperm(self.total_size, generator=g).tolist()
-        dsize = len(self.dataset)
-        indices = [v % dsize for v in indices]
-        indices = indices[self.rank:self.total_size:self.num_replicas]
-        assert len(indices) == self.num_samples
-        return iter(indices)
+    def set_epoch(self, epoch):
+        self.epoch = epoch
 
     def __len__(self):
         return self.num_samples
 
-    def set_epoch(self, epoch):
-        self.epoch = epoch
+    def __iter__(self):
+        perm = torch.randperm(self.total_size, generator=torch.Generator().manual_seed(self.epoch))
+        mine = perm[self.rank::self.num_replicas] % len(self.dataset)
+        if mine.numel() != self.num_samples:
+            raise AssertionError("rank slice and num_samples disagree")
+        return iter(mine.tolist())
 
 
 def get_vid_paths(dataroot: str, data_list: str) -> List[List[str]]:

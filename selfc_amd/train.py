@@ -48,26 +48,28 @@ class ReconstructionLoss(nn.Module):
 
 
 class MultiStepLR_Restart(_LRScheduler):
-    """lr_scheduler.py:8-31."""
+    """Step schedule with warm restarts (behaviour of lr_scheduler.py:8-31): at a restart iteration the rate jumps to
+    initial_lr * weight (optionally dropping the optimizer state), at a milestone it is multiplied by gamma once per
+    occurrence of that milestone, otherwise it is left alone.  A restart takes precedence over a milestone."""
 
     def __init__(self, optimizer, milestones, restarts=None, weights=None, gamma=0.1, clear_state=False, last_epoch=-1):
         self.milestones = Counter(milestones)
-        self.gamma = gamma
-        self.clear_state = clear_state
-        self.restarts = restarts if restarts else [0]
-        self.restart_weights = weights if weights else [1]
-        assert len(self.restarts) == len(self.restart_weights), "restarts and their weights do not match."
+        self.gamma, self.clear_state = gamma, clear_state
+        self.restarts = list(restarts) if restarts else [0]
+        self.restart_weights = list(weights) if weights else [1]
+        if len(self.restarts) != len(self.restart_weights):
+            raise AssertionError("restarts and their weights do not match.")
         super().__init__(optimizer, last_epoch)
 
     def get_lr(self):
-        if self.last_epoch in self.restarts:
+        it, groups = self.last_epoch, self.optimizer.param_groups
+        if it in self.restarts:
             if self.clear_state:
                 self.optimizer.state = defaultdict(dict)
-            weight = self.restart_weights[self.restarts.index(self.last_epoch)]
-            return [group["initial_lr"] * weight for group in self.optimizer.param_groups]
-        if self.last_epoch not in self.milestones:
-            return [group["lr"] for group in self.optimizer.param_groups]
-        return [group["lr"] * self.gamma ** self.milestones[self.last_epoch] for group in self.optimizer.param_groups]
+            w = self.restart_weights[self.restarts.index(it)]
+            return [g["initial_lr"] * w for g in groups]
+        factor = self.gamma ** self.milestones[it] if it in self.milestones else 1
+        return [g["lr"] * factor if factor != 1 else g["lr"] for g in groups]
 
 
 def feed_data(gt: torch.Tensor, distortion: str = "sr_bd", scale: int = 4, lq: Optional[torch.Tensor] = None):

@@ -98,3 +98,26 @@ def test_dataset_folder_convention_and_augmentation(tmp_path):
     loader = create_dataloader(train, {"phase": "train", "batch_size": 2, "n_workers": 0}, {"dist": False, "gpu_ids": [0]})
     batch = next(iter(loader))
     assert batch["GT"].shape == (2, 3, 7, 16, 16)                  # data['GT'] (B,C,T,H,W) as feed_data expects
+
+
+def test_multistep_lr_restart_product_class_matches_reference_trace():
+    """selfc_amd.train.MultiStepLR_Restart against the lr trace of the reference's scheduler (G11)."""
+    from selfc_amd.train import MultiStepLR_Restart
+    g = load_golden("g11_lr_trace")
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
+    sch = MultiStepLR_Restart(opt, [3, 6, 9], restarts=[5], weights=[0.5], gamma=0.5, clear_state=False)
+    trace = []
+    for _ in range(12):
+        opt.step()
+        sch.step()
+        trace.append(opt.param_groups[0]["lr"])
+    assert torch.allclose(torch.tensor(trace, dtype=torch.float64), g["lr"], rtol=0, atol=1e-18)
+    # repeated milestones multiply gamma once per occurrence; clear_state drops the optimizer state at a restart
+    opt2 = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    sch2 = MultiStepLR_Restart(opt2, [2, 2], restarts=[4], weights=[1.0], gamma=0.1, clear_state=True)
+    lrs = []
+    for _ in range(4):
+        opt2.step()
+        sch2.step()
+        lrs.append(opt2.param_groups[0]["lr"])
+    assert abs(lrs[1] - 0.01) < 1e-12 and abs(lrs[3] - 1.0) < 1e-12 and len(opt2.state) == 0
