@@ -7,34 +7,35 @@ constructor sets it (data/LQGTVID_dataset.py:50).  When the reference's own
 re-exported so both sides see one value.
 """
 import random
+import string
 import sys
 
 
+def _accessor(attr):
+    """(getter, setter) pair over a class attribute of whichever GlobalVar class is exported below; an attribute that was
+    never set reads as None, as in the reference."""
+
+    def getter():
+        return GlobalVar.__dict__.get(attr)
+
+    def setter(value):
+        setattr(GlobalVar, attr, value)
+
+    return staticmethod(getter), staticmethod(setter)
+
+
 class _GlobalVar:
-    VIDEO_T_LEN = None
-    Istrain = None
-
-    @staticmethod
-    def get_Temporal_LEN():
-        return getattr(GlobalVar, "VIDEO_T_LEN", None)
-
-    @staticmethod
-    def set_Temporal_LEN(v):
-        GlobalVar.VIDEO_T_LEN = v
-
-    @staticmethod
-    def get_Istrain():
-        return getattr(GlobalVar, "Istrain", None)
-
-    @staticmethod
-    def set_Istrain(v):
-        GlobalVar.Istrain = v
+    get_Temporal_LEN, set_Temporal_LEN = _accessor("VIDEO_T_LEN")      # frames per clip (7 for septuplets)
+    get_Istrain, set_Istrain = _accessor("Istrain")
 
     @staticmethod
     def get_v_random_name():
-        if not hasattr(GlobalVar, "encode_video_random_name"):
-            GlobalVar.encode_video_random_name = "".join(random.sample("zyxwvutsrqponmlkjihgfedcba", 5))
-        return GlobalVar.encode_video_random_name
+        """Five distinct letters, drawn once per process (temp-file tag of the codec variant)."""
+        name = GlobalVar.__dict__.get("encode_video_random_name")
+        if name is None:
+            name = "".join(random.sample(string.ascii_lowercase[::-1], 5))
+            GlobalVar.encode_video_random_name = name
+        return name
 
 
 _ref = sys.modules.get("global_var")

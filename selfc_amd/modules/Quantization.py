@@ -1,26 +1,36 @@
-"""8-bit rounding between the forward and the reverse pass (codes/models/modules/Quantization.py:4-26)."""
+"""8-bit rounding between the forward and the reverse pass (codes/models/modules/Quantization.py:4-26).
+
+``Quantization()(x)`` clamps to [0, 1] and rounds to the 1/255 grid on the device (``selfc_quantize_inplace``); the
+gradient is the identity (straight-through), as in the reference.  ``quant_v`` / ``is_clip`` stay class-level settings
+shared by every instance, because that is how the reference stores them."""
 import torch
 import torch.nn as nn
 
 from .. import _lib, runtime as rt
 
 
+def _round_to_grid(values: torch.Tensor) -> torch.Tensor:
+    """A quantised copy of `values` (any shape, fp32, on the GPU).  The kernel works on whole float4 groups, so a length
+    that is not a multiple of 4 goes through a zero-padded staging buffer."""
+    if Quantization.quant_v != 255.0 or not Quantization.is_clip:
+        raise NotImplementedError("selfc_quantize_inplace implements the shipped setting quant_v=255, is_clip=True")
+    count = values.numel()
+    padded = (count + 3) // 4 * 4
+    if padded == count:
+        work = values.clone()
+    else:
+        work = values.new_zeros(padded)
+        work[:count].copy_(values.reshape(-1))
+    rt.call("selfc_quantize_inplace", work.data_ptr(), padded, _lib.stream_ptr())
+    return work if padded == count else work[:count].reshape(values.shape)
+
+
 class Quant(torch.autograd.Function):
-    """clamp(x,0,1); round(x*quant_v)/quant_v on the HIP kernel; identity gradient (:15-17)."""
+    """Straight-through estimator: forward = the rounding kernel, backward passes the gradient unchanged (:15-17)."""
 
     @staticmethod
     def forward(ctx, input):
-        x = rt.as_input(input).clone()
-        if Quantization.quant_v != 255.0 or not Quantization.is_clip:
-            raise NotImplementedError("selfc_quantize_inplace implements the shipped setting quant_v=255, is_clip=True")
-        n = x.numel()
-        if n % 4:
-            flat = torch.zeros(n + 4 - n % 4, dtype=x.dtype, device=x.device)
-            flat[:n] = x.reshape(-1)
-            rt.call("selfc_quantize_inplace", flat.data_ptr(), flat.numel(), _lib.stream_ptr())
-            return flat[:n].reshape(x.shape)
-        rt.call("selfc_quantize_inplace", x.data_ptr(), n, _lib.stream_ptr())
-        return x
+        return _round_to_grid(rt.as_input(input))
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -33,8 +43,7 @@ class Quantization(nn.Module):
 
     def __init__(self, quant_v=255.0, is_clip=True):
         super().__init__()
-        Quantization.quant_v = quant_v
-        Quantization.is_clip = is_clip
+        Quantization.quant_v, Quantization.is_clip = quant_v, is_clip
 
     def forward(self, input):
         return Quant.apply(input)
