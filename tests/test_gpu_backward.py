@@ -447,3 +447,27 @@ def test_d2dt_backward_other_clip_lengths(dev, t):
     dx = x5.grad.transpose(1, 2).reshape(b * t, 3, h, w)
     assert rel_l2(dx.cpu(), dx_ref) < L2TOL
     _check_module_grads(m, g_ref)
+
+
+@pytest.mark.parametrize("hw", [(5, 7), (9, 13), (17, 33), (4, 52)])
+def test_invblock_backward_ragged_sizes(dev, hw):
+    """Odd latent sizes: partial 16x16 / 12x16 conv tiles, partial 4x4 weight-gradient patches, single-tile frames."""
+    from selfc_amd.modules.Inv_arch import InvBlockExp
+    from selfc_amd.modules.Subnet_constructor import subnet
+    g = load_golden("g5_invblock_d2dt")
+    sd = {k: v for k, v in g.items() if k[:2] in ("F.", "G.", "H.")}
+    blk = InvBlockExp(subnet("D2DTNet", "xavier"), 51, 3)
+    blk.load_state_dict(sd, strict=True)
+    blk.to(dev)
+    torch.manual_seed(hw[0] * 100 + hw[1])
+    x = torch.randn(T, 51, *hw) * 0.5
+    gy = torch.randn_like(x) * 0.02
+    for rev in (False, True):
+        y_ref, dx_ref, g_ref = _oracle_grads(lambda p, xx: O.invblock("D2DTNet", p, xx, 3, T, rev=rev)[0], sd, x, gy)
+        blk.zero_grad()
+        xd = x.to(dev).requires_grad_(True)
+        y = blk(xd, rev=rev)
+        assert rel_err(y.detach().cpu(), y_ref) < 1e-3
+        y.backward(gy.to(dev))
+        assert rel_l2(xd.grad.cpu(), dx_ref) < 5e-2
+        _check_module_grads(blk, g_ref, tol=6e-2)
