@@ -36,6 +36,8 @@ struct FGArgs {
   unsigned long long* stamps;
 };
 int launch_fused_gh(FGArgs& a, hipStream_t s);
+// csrc/fused_f.hip
+int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, int H, int W, hipStream_t s);
 }  // namespace selfc
 #include "bwd_internal.hpp"
 
@@ -887,7 +889,12 @@ int check_subnet(const selfc_subnet_w* w, bool need5) {
 }
 
 int run_F(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStream_t s) {
-  int rc = run_conv1to4(&blk->F, nullptr, l->fd, nullptr, nullptr, l->c2, l->N, l->H, l->W, s);
+  static const bool no_fuse_f = getenv("SELFC_NO_FUSE_F") != nullptr;     // developer A/B switch
+  int rc;
+  if (blk->F.wfused && l->c2 == 48 && !no_fuse_f)
+    rc = launch_fused_f(l->fd, blk->F.wfused, blk->F.b3, l->N, l->H, l->W, s);   // two pairwise-fused launches
+  else
+    rc = run_conv1to4(&blk->F, nullptr, l->fd, nullptr, nullptr, l->c2, l->N, l->H, l->W, s);
   if (rc) return rc;
   const int FC = dense_channels(l->c2);
   if (l->kind == SELFC_SUBNET_D2DT) {

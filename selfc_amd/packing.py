@@ -187,6 +187,43 @@ def pack_fused_gh(weights: Sequence[torch.Tensor], cin: int = 3) -> torch.Tensor
     return _operand(out)
 
 
+def pack_fused_f(weights: Sequence[torch.Tensor], cin: int = 48) -> torch.Tensor:
+    """conv1..conv4 weights of a cin == 48 dense block -> the fragment stream of csrc/fused_f.hip (two pairwise-fused
+    launches).  Per pair (conv a, conv b) = (1, 2), (3, 4) with nin = cin + 64*pair shared input channels:
+    [merged steps - source group (x2, f1, f2) major, tap-major inside a group, 16-channel k-step minor: fragment of
+    conv a, fragment of conv b (its first nin inputs)]
+    + [conv b's last 32 inputs (the feature conv a produced), tap-major: 18 fragments]  -> f16 [72 + 144, 64, 8]."""
+    assert cin == 48 and len(weights) == 4
+
+    def to_frags(wk):
+        nfrag = wk.shape[1] // 16
+        return wk.reshape(32, nfrag, 2, 8).permute(1, 2, 0, 3).reshape(nfrag, 64, 8)
+
+    out = []
+    for pair in (0, 1):
+        nin = cin + 64 * pair
+        ws = []
+        for j in (0, 1):
+            w = weights[2 * pair + j].detach().float()
+            if w.dim() == 5:
+                w = w[:, :, 0]
+            assert w.shape == (32, nin + 32 * j, 3, 3), tuple(w.shape)
+            ws.append(w.reshape(32, nin + 32 * j, 9))
+        groups = [(0, cin)] + [(cin + 32 * i, cin + 32 * (i + 1)) for i in range(2 * pair)]     # x2, then f1, f2
+
+        def kmajor(w9):          # source group major, tap-major inside a group, channel minor
+            return torch.cat([w9[:, lo:hi].permute(0, 2, 1).reshape(32, 9 * (hi - lo)) for lo, hi in groups], dim=1)
+
+        fa = to_frags(kmajor(ws[0]))
+        fb = to_frags(kmajor(ws[1]))
+        ff = to_frags(ws[1][:, nin:].permute(0, 2, 1).reshape(32, 9 * 32))
+        out.append(torch.stack((fa, fb), dim=1).reshape(2 * fa.shape[0], 64, 8))
+        out.append(ff)
+    res = torch.cat(out, dim=0)
+    assert res.shape[0] == 216
+    return _operand(res)
+
+
 def pack_conv_planes(weight: torch.Tensor, cin: int) -> torch.Tensor:
     """Conv3d weight (cout, cin + 128*j, kt, 3, 3), kt in {1, 3}, of a FeatureCalapseBlock-style dense block
     (inputs first, then 128-channel features) -> f16 [cout/32, nstages*18, 64, 8] for selfc_conv_planes_run.
@@ -369,6 +406,8 @@ def subnet_pack_entries(prefix: str, weights: Sequence[torch.Tensor], biases: Se
     e[f"{prefix}b5"] = (pad_bias(biases[4], 64, dev), "b")
     if cin == 3 and temporal:
         e[f"{prefix}wfused"] = (pack_fused_gh(list(weights[:4]), 3), "w")
+    if cin == 48:
+        e[f"{prefix}wfused"] = (pack_fused_f(list(weights[:4]), 48), "w")
     if with_bwd and cout <= 96:
         wt5, wtd, wtx = pack_subnet_bwd(weights, cin, cout, temporal)
         e[f"{prefix}wt5"] = (wt5, "w")

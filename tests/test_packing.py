@@ -185,6 +185,47 @@ def test_pack_fused_gh_stream(layer):
     assert torch.allclose(out, ref, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("pair", [0, 1])
+def test_pack_fused_f_stream(pair):
+    """pairwise-fused F stream of csrc/fused_f.hip: per pair [merged steps: (conv a, conv b) fragment pairs, source
+    group major / tap-major / 16-channel k-step minor][conv b's 18 FM fragments, tap-major].  The kernel's step decode
+    (merged_steps / fm_steps) is restated here on an image whose pixel holds [x2 48 | f1 32 | f2 32] channels."""
+    g = torch.Generator().manual_seed(70 + pair)
+    ws = [torch.randn(32, 48 + 32 * i, 1, 3, 3, generator=g) * 0.1 for i in range(4)]
+    stream = P.pack_fused_f(ws, 48)
+    assert stream.shape == (216, 64, 8)
+    nin = 48 + 64 * pair
+    s1 = 9 * nin // 16
+    base = 0 if pair == 0 else 72
+    merged = stream[base: base + 2 * s1].reshape(s1, 2, 64, 8)
+    wa, wb = unpack_a32(merged[:, 0].contiguous()), unpack_a32(merged[:, 1].contiguous())       # (32, 16*s1)
+    wf = unpack_a32(stream[base + 2 * s1: base + 2 * s1 + 18])                                    # (32, 288)
+    n, h, w = 2, 5, 6
+    img = torch.randn(n, nin, h, w, generator=g)            # x2 | f1 | f2 in the reference's concat order
+    fm = torch.randn(n, 32, h, w, generator=g)
+    ip = F.pad(img.permute(0, 2, 3, 1), (0, 0, 1, 1, 1, 1))
+    cols = []
+    for st in range(s1):                                    # kernel decode of merged step st
+        if st < 27:
+            tap, ks = st // 3, st % 3
+        elif st < 45:
+            tap, ks = (st - 27) >> 1, 3 + ((st - 27) & 1)
+        else:
+            tap, ks = (st - 45) >> 1, 5 + ((st - 45) & 1)
+        ky, kx = divmod(tap, 3)
+        cols.append(ip[:, ky:ky + h, kx:kx + w, 16 * ks:16 * ks + 16])
+    ak = torch.cat(cols, -1)
+    fp = F.pad(fm.permute(0, 2, 3, 1), (0, 0, 1, 1, 1, 1))
+    fk = torch.cat([fp[:, (st >> 1) // 3:(st >> 1) // 3 + h, (st >> 1) % 3:(st >> 1) % 3 + w, 16 * (st & 1):16 * (st & 1) + 16]
+                    for st in range(18)], -1)
+    out_a = torch.einsum("ok,nhwk->nohw", wa, ak)
+    out_b = torch.einsum("ok,nhwk->nohw", wb, ak) + torch.einsum("ok,nhwk->nohw", wf, fk)
+    ref_a = F.conv2d(img, ws[2 * pair][:, :, 0].half().float(), None, 1, 1)
+    ref_b = F.conv2d(torch.cat((img, fm), 1), ws[2 * pair + 1][:, :, 0].half().float(), None, 1, 1)
+    assert torch.allclose(out_a, ref_a, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(out_b, ref_b, atol=1e-4, rtol=1e-4)
+
+
 @pytest.mark.parametrize("cin,nfeat,kt,cout", [(48, 0, 3, 128), (48, 2, 1, 128), (192, 4, 3, 64)])
 def test_pack_conv_planes(cin, nfeat, kt, cout):
     """generic plane-list conv (FeatureCalapseBlock): K order = temporal tap, plane, spatial tap, 32 channels."""
