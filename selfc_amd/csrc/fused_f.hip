@@ -13,9 +13,10 @@
 // input part of the second conv consume the SAME activation fragment with two weight fragments
 // ("merged" steps: 1 B read feeds 2 MFMAs), the 68 ring pixels of the 18x18 region are three extra
 // M-tiles on waves 0..2; then the second conv's last 18 steps read FM.  Pair 0 keeps its whole 72-KiB
-// weight stream resident in LDS (no per-chunk barrier), pair 1 streams its 144 KiB through an LDS double
-// buffer in 18-fragment chunks like csrc/fused_gh.hip.  The next tile's input halo is prefetched into
-// registers while the current tile computes.
+// weight stream resident in LDS (no per-chunk barrier), pair 1 streams its 144 KiB through three LDS
+// buffers of 12 fragments with the chunk barrier in the MIDDLE of a chunk, so the operand ring never drains
+// at a chunk boundary (see the kernel).  The next tile's input halo is prefetched into registers while the
+// current tile computes.
 //
 // LDS banking (MI355X_MICROARCH.md, LDS): ds_read_b128 is served in lane groups {0-3,12-15,20-27},... -
 // an M-tile is 2 rows x 16 columns; with a row pitch of (16 q + 1) sixteen-byte slots the ring's COLUMN
@@ -23,6 +24,7 @@
 // kappa = (pitch/16)^-1 mod 16 keeps the two rows of a lane group on disjoint slots.
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "common.hpp"
 #include "prof.hpp"
 #include "../../include/selfc_hip.h"
@@ -38,6 +40,7 @@ struct FFArgs {
   int N, H, W;
   int tiles_x, tiles_y, ntiles;
   size_t plane;
+  unsigned long long* stamps;   // diagnostic build only (-DSELFC_STAMPS): per wave 7 phase sums + lifetime
 };
 
 namespace {
@@ -46,6 +49,14 @@ constexpr int TS = 16, IS = 20, FS = 18;
 constexpr int NWAVE = 8, NTHR = NWAVE * 64;
 constexpr int NRING = FS * FS - TS * TS;          // 68 ring pixels
 constexpr int CHF = 18;                           // fragments per streamed weight chunk
+
+#ifdef SELFC_STAMPS
+#define STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#define STAMP_ADD(k, a, b) phase[k] += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(k, a, b)
+#endif
 
 template <int PAIR>
 struct Geo {
@@ -61,7 +72,7 @@ struct Geo {
   static constexpr int NFRAG = 2 * S1 + 18;                // 72 / 144
   static constexpr bool RES = PAIR == 0;                   // whole stream resident in LDS
   static constexpr int RD = 3;                             // operand ring depth (fragments fetched RD-1 steps ahead)
-  static constexpr int W_BYTES = RES ? NFRAG * 1024 : 2 * CHF * 1024;
+  static constexpr int W_BYTES = RES ? NFRAG * 1024 : 3 * 12 * 1024;   // resident stream | three 12-fragment chunk buffers
   static constexpr int OFF_IMG = 0, OFF_FM = IMG_BYTES, OFF_W = OFF_FM + FM_BYTES, OFF_B = OFF_W + W_BYTES;
   static constexpr int LDS = OFF_B + 256;
   static constexpr int NITEM = IS * IS * NCHK;             // 16-byte pieces of one input halo
@@ -71,8 +82,17 @@ struct Geo {
   static_assert(FROW >= FS * PS && (FROW / 16) % 16 == (5 * KAPPA) % 16, "FM row pitch");
   static_assert(((PITCH / 16) * KAPPA) % 16 == 1, "kappa");
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static_assert(NFRAG % CHF == 0 && (2 * S1) % CHF == 0, "chunking");
 };
+
+// compile-time loop: f(integral_constant<int, I>) for I = 0..N-1.  (#pragma unroll gave up on the 63-step body with
+// barriers inside and left the tap / k-step decode to run-time branches.)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 struct Lane {
   int tid, lane, wave, half;
@@ -83,9 +103,13 @@ struct Lane {
 
 // ---- one run of merged steps [G0, G0+NS): acc1c += W1 B, acc2 += W2 B, (RING) acc1r += W1 Br ----------
 // wl: LDS address of the fragment pair of step G0 (+ lane*16); fragments alternate [W1 step][W2 step].
-template <int PAIR, int G0, int NS, bool RING>
+// post(integral_constant<step>) runs behind the MFMAs of every step: the kernels hang their global loads and LDS
+// stores there ONE PER STEP - issued as a burst behind a barrier by all eight waves at once they queue on the
+// CU's address path while the matrix pipes run dry (measured: 23 % of pair 1's time).
+template <int PAIR, int G0, int NS, bool RING, class Post>
 __device__ __forceinline__ void merged_steps(const unsigned char* __restrict__ wl, const unsigned char* __restrict__ bc,
-                                             const unsigned char* __restrict__ br, f32x16& acc1c, f32x16& acc1r, f32x16& acc2) {
+                                             const unsigned char* __restrict__ br, f32x16& acc1c, f32x16& acc1r, f32x16& acc2,
+                                             Post&& post) {
   using G = Geo<PAIR>;
   constexpr int RD = G::RD;
   f16x8 rA1[RD], rA2[RD], rBc[RD], rBr[RD];
@@ -103,21 +127,22 @@ __device__ __forceinline__ void merged_steps(const unsigned char* __restrict__ w
   };
   load_step(0);
   if (RD > 2 && NS > 1) load_step(1);
-#pragma unroll
-  for (int st = 0; st < NS; ++st) {
-    if (st + RD - 1 < NS) load_step(st + RD - 1);
+  static_for<0, NS>([&](auto si) __attribute__((always_inline)) {
+    constexpr int st = decltype(si)::value;
+    if constexpr (st + RD - 1 < NS) load_step(st + RD - 1);
     __builtin_amdgcn_sched_barrier(0);
-    const int s = st % RD;
+    constexpr int s = st % RD;
     acc1c = mfma_32x32x16(rA1[s], rBc[s], acc1c);
     acc2 = mfma_32x32x16(rA2[s], rBc[s], acc2);
     if (RING) acc1r = mfma_32x32x16(rA1[s], rBr[s], acc1r);
     __builtin_amdgcn_sched_barrier(0);
-  }
+    post(std::integral_constant<int, G0 + st>{});
+  });
 }
 
 // ---- the 18 FM steps of the second conv --------------------------------------------------------------
-template <int PAIR>
-__device__ __forceinline__ void fm_steps(const unsigned char* __restrict__ wl, const unsigned char* __restrict__ fb, f32x16& acc2) {
+template <int PAIR, class Post>
+__device__ __forceinline__ void fm_steps(const unsigned char* __restrict__ wl, const unsigned char* __restrict__ fb, f32x16& acc2, Post&& post) {
   using G = Geo<PAIR>;
   f16x8 rA[3], rB[3];
   auto load_step = [&](const int st) __attribute__((always_inline)) {
@@ -127,13 +152,14 @@ __device__ __forceinline__ void fm_steps(const unsigned char* __restrict__ wl, c
   };
   load_step(0);
   load_step(1);
-#pragma unroll
-  for (int st = 0; st < 18; ++st) {
-    if (st + 2 < 18) load_step(st + 2);
+  static_for<0, 18>([&](auto si) __attribute__((always_inline)) {
+    constexpr int st = decltype(si)::value;
+    if constexpr (st + 2 < 18) load_step(st + 2);
     __builtin_amdgcn_sched_barrier(0);
     acc2 = mfma_32x32x16(rA[st % 3], rB[st % 3], acc2);
     __builtin_amdgcn_sched_barrier(0);
-  }
+    post(si);
+  });
 }
 
 __device__ __forceinline__ f32x16 bias_init(const float* bl, const int half) {
@@ -184,98 +210,88 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
     c.rr = q < 18 ? 0 : q < 36 ? 17 : q < 52 ? q - 35 : q - 51;
     c.rc = q < 18 ? q : q < 36 ? q - 18 : q < 52 ? 0 : 17;
   }
-  const int total = a.ntiles * a.N;
-  int t = blockIdx.x;
-  if (t >= total) return;
+  // Frame walk: workgroup b owns ONE spatial tile (b % ntiles) and visits frames f0, f0 + gf, ... - the halo geometry
+  // (global offsets inside a frame, LDS offsets, which pixels fall outside the frame) is then a per-workgroup constant,
+  // computed once, and a tile's 14 halo loads cost one instruction each (the per-tile address arithmetic - ~55 VALU
+  // instructions per 16-byte piece - used to outweigh the MFMAs of the steps it was hung behind).
+  const int stile = blockIdx.x % a.ntiles, f0 = blockIdx.x / a.ntiles, gf = gridDim.x / a.ntiles;
+  if (f0 >= a.N) return;
+  const int ty0 = (stile / a.tiles_x) * TS, tx0 = (stile % a.tiles_x) * TS;
+#ifdef SELFC_STAMPS
+  unsigned long long phase[7] = {0, 0, 0, 0, 0, 0, 0};   // 0 tile setup, 1 merged MFMA, 2 epilogue 1, 3 mid barrier, 4 FM MFMA, 5 epilogue 2 + image store, 6 end barrier
+  STAMP(tk0);
+#endif
   const bool ring = c.wave < 3;
   const u32x4* __restrict__ wsrc = reinterpret_cast<const u32x4*>(a.w);
 
-  // ---- next-tile input halo: global -> registers (x_load), registers -> LDS image (x_store) ----------
-  // Loaded in PARTS that follow the K order (part 0: x2 = planes 0, 1; part 1: f1; part 2: f2): a part of the
-  // image is dead as soon as every wave has finished that source group's steps, so pair 1 refills it and starts
-  // the next part's loads at that chunk barrier - 5 staging registers instead of 11.
-  constexpr int XMAX = 5;
-  u32x4 xv[XMAX];
-  unsigned xok = 0;
-  auto item = [&](const int part, const int it, int& seg, int& piece, int& hy, int& hx) __attribute__((always_inline)) {
-    // pieces are enumerated plane by plane (coalesced 64-byte pixels): plane 0: 4, plane 1: 2, planes 2, 3: 4 per pixel
-    int p;
-    if (part == 0) {
-      const int i = min(c.tid + it * NTHR, 2400 - 1);
-      if (i < 1600) { seg = 0; p = i >> 2; piece = i & 3; }
-      else { seg = 1; p = (i - 1600) >> 1; piece = i & 1; }
-    } else {
-      const int i = min(c.tid + it * NTHR, 1600 - 1);
-      seg = part + 1; p = i >> 2; piece = i & 3;
-    }
-    hy = p / IS;
-    hx = p - hy * IS;
-  };
-  auto x_load = [&](const int part, const int tile) __attribute__((always_inline)) {
-    xok = 0;
-    const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, n = tile / a.ntiles;
-    const int niter = part == 0 ? 5 : 4;
+  // ---- input halo (20x20 pixels) -------------------------------------------------------------------------
+  // map A (64-byte planes: x2 channels 0..31, f1, f2): piece i = tid + 512 it (it < 4, i < 1600) = 16-byte piece i & 3 of
+  // halo pixel i >> 2;  map B (x2 channels 32..47): i = tid + 512 it (it < 2, i < 800) = piece i & 1 of pixel i >> 1.
+  // goff: byte offset inside one frame of a plane; ok: bit it set
+  // when the piece exists and its pixel lies inside the frame - pieces outside are never stored, the image is zeroed once.
+  unsigned goffA[4], goffB[2], okA = 0, okB = 0;
+  {
+    auto geom = [&](const int pix, const bool exists, unsigned& goff) __attribute__((always_inline)) {
+      const int p = min(pix, IS * IS - 1);
+      const int hy = p / IS, hx = p - hy * IS;
+      const int y = ty0 + hy - 2, x = tx0 + hx - 2;
+      const bool ok = exists & (y >= 0) & (y < a.H) & (x >= 0) & (x < a.W);
+      const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
+      goff = (unsigned)(yc * a.W + xc) * 64u;
+      return ok;
+    };
 #pragma unroll
-    for (int it = 0; it < XMAX; ++it) {
-      if (it < niter) {
-        int seg, piece, hy, hx;
-        item(part, it, seg, piece, hy, hx);
-        const int y = ty * TS + hy - 2, x = tx * TS + hx - 2;
-        const bool ok = (y >= 0) & (y < a.H) & (x >= 0) & (x < a.W);
-        const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
-        xv[it] = *reinterpret_cast<const u32x4*>(a.dense + (size_t)seg * a.plane + ((size_t)(n * a.H + yc) * a.W + xc) * 32 + piece * 8);
-        xok |= (ok ? 1u : 0u) << it;
-      }
-    }
-  };
-  auto x_store = [&](const int part) __attribute__((always_inline)) {
-    const int niter = part == 0 ? 5 : 4, nitem = part == 0 ? 2400 : 1600;
-#pragma unroll
-    for (int it = 0; it < XMAX; ++it) {
-      if (it < niter && c.tid + it * NTHR < nitem) {
-        int seg, piece, hy, hx;
-        item(part, it, seg, piece, hy, hx);
-        const int slot = (seg == 0 ? 0 : seg == 1 ? 4 : seg == 2 ? 6 : 10) + piece;
-        *reinterpret_cast<u32x4*>(smem + G::OFF_IMG + hy * G::ROWP + hx * G::PITCH + slot * 16) =
-            ((xok >> it) & 1u) ? xv[it] : u32x4{0u, 0u, 0u, 0u};
-      }
-    }
-  };
-  constexpr int NPART = PAIR ? 3 : 1;
-
-  // ---- weights ------------------------------------------------------------------------------------------
-  constexpr int WITER = (CHF * 64 + NTHR - 1) / NTHR;   // 3 (streamed chunks)
-  u32x4 wreg[WITER];
-  auto w_prefetch = [&](const int chunk) __attribute__((always_inline)) {
-#pragma unroll
-    for (int it = 0; it < WITER; ++it) {
-      const int i = min(c.tid + it * NTHR, CHF * 64 - 1);
-      wreg[it] = wsrc[chunk * CHF * 64 + i];
-    }
-  };
-  auto w_commit = [&](const int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int it = 0; it < WITER; ++it) {
+    for (int it = 0; it < 4; ++it) {
       const int i = c.tid + it * NTHR;
-      if (i < CHF * 64) *reinterpret_cast<u32x4*>(smem + G::OFF_W + buf * CHF * 1024 + i * 16) = wreg[it];
+      const bool ok = geom(i >> 2, i < 1600, goffA[it]);
+      goffA[it] += (i & 3) * 16;
+      okA |= (ok ? 1u : 0u) << it;
     }
-  };
-
-  // ---- prologue ---------------------------------------------------------------------------------------
-  if (c.tid < 64) reinterpret_cast<float*>(smem + G::OFF_B)[c.tid] = (c.tid < 32 ? a.bias[0] : a.bias[1])[c.tid & 31];
-  x_load(0, t);
-  if (G::RES) {
-    for (int i = c.tid; i < G::NFRAG * 64; i += NTHR) *reinterpret_cast<u32x4*>(smem + G::OFF_W + i * 16) = wsrc[i];
-  } else {
-    w_prefetch(0);
-    w_commit(0);
-  }
-  x_store(0);
 #pragma unroll
-  for (int part = 1; part < NPART; ++part) {
-    x_load(part, t);
-    x_store(part);
+    for (int it = 0; it < 2; ++it) {
+      const int i = c.tid + it * NTHR;
+      const bool ok = geom(i >> 1, i < 800, goffB[it]);
+      goffB[it] += (i & 1) * 16;
+      okB |= (ok ? 1u : 0u) << it;
+    }
   }
+  const size_t frame_bytes = (size_t)a.H * a.W * 64;
+  const char* const dbase = reinterpret_cast<const char*>(a.dense);
+  // part 0 = x2: items 0..3 map A on plane 0, items 4, 5 map B on plane 1; part 1 = f1 (plane 2), part 2 = f2 (plane 3)
+  constexpr int XMAX = 6;
+  u32x4 xv[XMAX];
+  const char* lframe = dbase;        // frame the next x_load_item reads (plane 0)
+  auto x_target = [&](const int n) __attribute__((always_inline)) { lframe = dbase + (size_t)n * frame_bytes; };
+  auto x_load_item_to = [&](const int part, const int it, u32x4 (&v)[XMAX]) __attribute__((always_inline)) {
+    const size_t pb = (size_t)a.plane * 2;      // bytes per plane
+    if (part == 0 && it >= 4) v[it] = *reinterpret_cast<const u32x4*>(lframe + pb + goffB[it - 4]);
+    else v[it] = *reinterpret_cast<const u32x4*>(lframe + (part == 0 ? 0 : part + 1) * pb + goffA[it]);
+  };
+  auto x_store_item_from = [&](const int part, const int it, const u32x4 (&v)[XMAX]) __attribute__((always_inline)) {
+    // the LDS offset is recomputed here (a handful of VALU instructions) rather than pinned in registers all kernel long
+    int tidl = c.tid;
+    asm volatile("" : "+v"(tidl));
+    const bool mb = part == 0 && it >= 4;
+    const int i = tidl + (mb ? it - 4 : it) * NTHR;
+    const int p = mb ? i >> 1 : i >> 2, piece = mb ? i & 1 : i & 3;
+    const int hy = p / IS, hx = p - hy * IS;
+    const int loff = hy * G::ROWP + hx * G::PITCH + piece * 16 + (mb ? 64 : part == 0 ? 0 : part == 1 ? 96 : 160);
+    if (((mb ? okB >> (it - 4) : okA >> it) & 1u)) *reinterpret_cast<u32x4*>(smem + G::OFF_IMG + loff) = v[it];
+  };
+  auto x_load_item = [&](const int part, const int it) __attribute__((always_inline)) { x_load_item_to(part, it, xv); };
+  auto x_store_item = [&](const int part, const int it) __attribute__((always_inline)) { x_store_item_from(part, it, xv); };
+  auto x_load_to = [&](const int part, u32x4 (&v)[XMAX]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < XMAX; ++it)
+      if (it < (part == 0 ? 6 : 4)) x_load_item_to(part, it, v);
+  };
+  auto x_store_from = [&](const int part, const u32x4 (&v)[XMAX]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < XMAX; ++it)
+      if (it < (part == 0 ? 6 : 4)) x_store_item_from(part, it, v);
+  };
+  // the image is zeroed once: pieces outside the frame (the convs' zero padding) are never written afterwards
+  for (int i = c.tid; i < G::IMG_BYTES / 16; i += NTHR) *reinterpret_cast<u32x4*>(smem + G::OFF_IMG + i * 16) = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
 
   const unsigned char* const img = smem + G::OFF_IMG;
@@ -283,109 +299,281 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
   const unsigned char* const br = img + c.rr * G::ROWP + c.rc * G::PITCH + c.half * 16;
   const unsigned char* const fb = smem + G::OFF_FM + c.py * G::FROW + c.px * PS + c.half * 16;
   const float* const lb = reinterpret_cast<const float*>(smem + G::OFF_B);
-  int par = 0;   // streamed mode: buffer holding the current chunk
 
-  for (; t < total; t += gridDim.x) {
-    const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, n = t / a.ntiles;
-    const int ty0 = ty * TS, tx0 = tx * TS;
-    const int tnext = t + gridDim.x;
-    const bool more = tnext < total;
-    if (more) x_load(0, tnext);                    // lands while this tile computes
+  // epilogue of the pair's first conv: FM image (zero outside the frame) + centre crop to HBM
+  auto epilogue1 = [&](const f32x16& acc1c, const f32x16& acc1r, const int n, const int ty0, const int tx0) __attribute__((always_inline)) {
+    f16* __restrict__ dplane = a.dense + (size_t)G::OUT1 * a.plane;
+    u32x4 v[2];
+    const int y = ty0 + c.py, x = tx0 + c.px;
+    const bool in = (y < a.H) & (x < a.W);
+    lrelu_pack(acc1c, in, v);
+    unsigned char* fdst = smem + G::OFF_FM + (c.py + 1) * G::FROW + (c.px + 1) * PS + 16 * c.half;
+    *reinterpret_cast<u32x4*>(fdst) = v[0];
+    *reinterpret_cast<u32x4*>(fdst + 32) = v[1];
+    if (in) {
+      f16* d = dplane + ((size_t)(n * a.H + y) * a.W + x) * 32 + 8 * c.half;
+      *reinterpret_cast<u32x4*>(d) = v[0];
+      *reinterpret_cast<u32x4*>(d + 16) = v[1];
+    }
+    if (ring) {
+      const int ry = ty0 + c.rr - 1, rx = tx0 + c.rc - 1;
+      const bool rin = (ry >= 0) & (ry < a.H) & (rx >= 0) & (rx < a.W);
+      lrelu_pack(acc1r, rin, v);
+      if (c.rvalid) {
+        unsigned char* rdst = smem + G::OFF_FM + c.rr * G::FROW + c.rc * PS + 16 * c.half;
+        *reinterpret_cast<u32x4*>(rdst) = v[0];
+        *reinterpret_cast<u32x4*>(rdst + 32) = v[1];
+      }
+    }
+  };
+  auto epilogue2 = [&](const f32x16& acc2, const int n, const int ty0, const int tx0) __attribute__((always_inline)) {
+    const int y = ty0 + c.py, x = tx0 + c.px;
+    u32x4 v[2];
+    lrelu_pack(acc2, true, v);
+    if ((y < a.H) & (x < a.W)) {
+      f16* d = a.dense + (size_t)G::OUT2 * a.plane + ((size_t)(n * a.H + y) * a.W + x) * 32 + 8 * c.half;
+      *reinterpret_cast<u32x4*>(d) = v[0];
+      *reinterpret_cast<u32x4*>(d + 16) = v[1];
+    }
+  };
 
-    f32x16 acc1c = bias_init(lb, c.half), acc1r = acc1c, acc2 = bias_init(lb + 32, c.half);
+  if (c.tid < 64) reinterpret_cast<float*>(smem + G::OFF_B)[c.tid] = (c.tid < 32 ? a.bias[0] : a.bias[1])[c.tid & 31];
 
-    // ---- merged phase -------------------------------------------------------------------------------
-    if (G::RES) {
-      const unsigned char* wl = smem + G::OFF_W + c.lane * 16;
-      if (ring) merged_steps<PAIR, 0, G::S1, true>(wl, bc, br, acc1c, acc1r, acc2);
-      else merged_steps<PAIR, 0, G::S1, false>(wl, bc, br, acc1c, acc1r, acc2);
-    } else {
-      constexpr int NMC = 2 * G::S1 / CHF;         // 7 merged chunks of 9 steps
+  if constexpr (G::RES) {
+    // =====================================================================================================
+    // pair 0: the whole 72-fragment stream is resident.  The first tile starts on the first 18 fragments (9
+    // merged steps); the other 54 are already in flight and are stored behind those steps (a serial 72-KiB
+    // fill was 22 % of the kernel's time).
+    // =====================================================================================================
+    constexpr int RITER = ((G::NFRAG - CHF) * 64 + NTHR - 1) / NTHR;   // 7
+    constexpr int HITER = (CHF * 64 + NTHR - 1) / NTHR;                // 3
+    u32x4 wrest[RITER];
+    {
+      u32x4 whead[HITER];
+      x_target(f0);
+      x_load_to(0, xv);
 #pragma unroll
-      for (int ch = 0; ch < NMC; ++ch) {
-        w_prefetch(ch + 1);
-        const unsigned char* wl = smem + G::OFF_W + par * CHF * 1024 + c.lane * 16;
-        if (ring) {
-          switch (ch) {   // compile-time step base per chunk
-            case 0: merged_steps<PAIR, 0, 9, true>(wl, bc, br, acc1c, acc1r, acc2); break;
-            case 1: merged_steps<PAIR, 9, 9, true>(wl, bc, br, acc1c, acc1r, acc2); break;
-            case 2: merged_steps<PAIR, 18, 9, true>(wl, bc, br, acc1c, acc1r, acc2); break;
-            case 3: merged_steps<PAIR, 27, 9, true>(wl, bc, br, acc1c, acc1r, acc2); break;
-            case 4: merged_steps<PAIR, 36, 9, true>(wl, bc, br, acc1c, acc1r, acc2); break;
-            case 5: merged_steps<PAIR, 45, 9, true>(wl, bc, br, acc1c, acc1r, acc2); break;
-            default: merged_steps<PAIR, 54, 9, true>(wl, bc, br, acc1c, acc1r, acc2); break;
-          }
-        } else {
-          switch (ch) {
-            case 0: merged_steps<PAIR, 0, 9, false>(wl, bc, br, acc1c, acc1r, acc2); break;
-            case 1: merged_steps<PAIR, 9, 9, false>(wl, bc, br, acc1c, acc1r, acc2); break;
-            case 2: merged_steps<PAIR, 18, 9, false>(wl, bc, br, acc1c, acc1r, acc2); break;
-            case 3: merged_steps<PAIR, 27, 9, false>(wl, bc, br, acc1c, acc1r, acc2); break;
-            case 4: merged_steps<PAIR, 36, 9, false>(wl, bc, br, acc1c, acc1r, acc2); break;
-            case 5: merged_steps<PAIR, 45, 9, false>(wl, bc, br, acc1c, acc1r, acc2); break;
-            default: merged_steps<PAIR, 54, 9, false>(wl, bc, br, acc1c, acc1r, acc2); break;
-          }
+      for (int it = 0; it < HITER; ++it) whead[it] = wsrc[min(c.tid + it * NTHR, CHF * 64 - 1)];
+#pragma unroll
+      for (int it = 0; it < RITER; ++it) wrest[it] = wsrc[CHF * 64 + min(c.tid + it * NTHR, (G::NFRAG - CHF) * 64 - 1)];
+      x_store_from(0, xv);
+#pragma unroll
+      for (int it = 0; it < HITER; ++it) {
+        const int i = c.tid + it * NTHR;
+        if (i < CHF * 64) *reinterpret_cast<u32x4*>(smem + G::OFF_W + i * 16) = whead[it];
+      }
+    }
+    __syncthreads();
+    bool first = true;
+    const unsigned char* const wl = smem + G::OFF_W + c.lane * 16;
+
+    for (int n = f0; n < a.N; n += gf) {
+      const bool more = n + gf < a.N;
+      STAMP(ts0);
+      if (more) x_target(n + gf);
+      f32x16 acc1c = bias_init(lb, c.half), acc1r = acc1c, acc2 = bias_init(lb + 32, c.half);
+      STAMP(ts1);
+      STAMP_ADD(0, ts0, ts1);
+      // the next tile's halo: one load behind each of the first six merged steps, one store behind each of the first
+      // six FM steps (the image is dead once every wave has passed the barrier in front of the FM phase)
+      auto post_m = [&](auto gi) __attribute__((always_inline)) {
+        constexpr int g = decltype(gi)::value;
+        if constexpr (g < 6) { if (more) x_load_item(0, g); }
+      };
+      auto post_f = [&](auto si) __attribute__((always_inline)) {
+        constexpr int st = decltype(si)::value;
+        if constexpr (st < 6) { if (more) x_store_item(0, st); }
+      };
+      if (first) {
+        if (ring) merged_steps<PAIR, 0, 9, true>(wl, bc, br, acc1c, acc1r, acc2, post_m);
+        else merged_steps<PAIR, 0, 9, false>(wl, bc, br, acc1c, acc1r, acc2, post_m);
+#pragma unroll
+        for (int it = 0; it < RITER; ++it) {
+          const int i = c.tid + it * NTHR;
+          if (i < (G::NFRAG - CHF) * 64) *reinterpret_cast<u32x4*>(smem + G::OFF_W + CHF * 1024 + i * 16) = wrest[it];
         }
-        if (ch + 1 < NMC) {
-          w_commit(par ^ 1);
+        __syncthreads();
+        first = false;
+        if (ring) merged_steps<PAIR, 9, G::S1 - 9, true>(wl + CHF * 1024, bc, br, acc1c, acc1r, acc2, post_m);
+        else merged_steps<PAIR, 9, G::S1 - 9, false>(wl + CHF * 1024, bc, br, acc1c, acc1r, acc2, post_m);
+      } else {
+        if (ring) merged_steps<PAIR, 0, G::S1, true>(wl, bc, br, acc1c, acc1r, acc2, post_m);
+        else merged_steps<PAIR, 0, G::S1, false>(wl, bc, br, acc1c, acc1r, acc2, post_m);
+      }
+      STAMP(ts2);
+      STAMP_ADD(1, ts1, ts2);
+      epilogue1(acc1c, acc1r, n, ty0, tx0);
+      STAMP(ts3);
+      STAMP_ADD(2, ts2, ts3);
+      __syncthreads();                                // FM complete; every wave is done with the input image
+      STAMP(ts4);
+      STAMP_ADD(3, ts3, ts4);
+      fm_steps<PAIR>(wl + 2 * G::S1 * 1024, fb, acc2, post_f);
+      STAMP(ts5);
+      STAMP_ADD(4, ts4, ts5);
+      epilogue2(acc2, n, ty0, tx0);
+      STAMP(ts6);
+      STAMP_ADD(5, ts5, ts6);
+      __syncthreads();                                // image of the next tile visible; FM free again
+      STAMP(ts7);
+      STAMP_ADD(6, ts6, ts7);
+    }
+  } else {
+    // =====================================================================================================
+    // pair 1: 144 fragments = 12 chunks of 12 through THREE LDS buffers.  The only workgroup barrier of a chunk
+    // sits in its MIDDLE (after 3 of its 6 merged steps): behind barrier c every wave has left chunk c-1, so
+    // chunk c+2 is committed into that buffer there, and it is visible to everybody by barrier c+1 - before any
+    // wave starts chunk c+2.  The operand ring therefore runs across chunk boundaries and across the barrier
+    // (its fragments are already in registers), instead of draining and refilling once per chunk.  Those same
+    // barriers are where a source group's part of the image dies (x2 after step 26 = barrier 4, f1 after step 44
+    // = barrier 7, f2 after step 62 = barrier 10), so the next tile's parts are stored there.
+    // =====================================================================================================
+    constexpr int CH3 = 12, CHI = CH3 * 64;          // fragments / 16-byte items per chunk
+    static_assert(G::NFRAG % CH3 == 0 && (G::NFRAG / CH3) % 3 == 0 && 3 * CH3 * 1024 <= G::W_BYTES, "three-buffer chunking");
+    u32x4 wset[2][2];
+    auto w_prefetch_item = [&](const int chunk, const int set, const int it) __attribute__((always_inline)) {
+      wset[set][it] = wsrc[chunk * CHI + min(c.tid + it * NTHR, CHI - 1)];
+    };
+    auto w_commit_item = [&](const int buf, const int set, const int it) __attribute__((always_inline)) {
+      const int i = c.tid + it * NTHR;
+      if (i < CHI) *reinterpret_cast<u32x4*>(smem + G::OFF_W + buf * CH3 * 1024 + i * 16) = wset[set][it];
+    };
+    {
+      u32x4 xb[XMAX], xc[XMAX];
+      x_target(f0);
+      x_load_to(0, xv);
+      w_prefetch_item(0, 0, 0); w_prefetch_item(0, 0, 1);
+      w_prefetch_item(1, 1, 0); w_prefetch_item(1, 1, 1);
+      x_load_to(1, xb);
+      x_load_to(2, xc);
+      x_store_from(0, xv);
+      w_commit_item(0, 0, 0); w_commit_item(0, 0, 1);
+      w_commit_item(1, 1, 0); w_commit_item(1, 1, 1);
+      w_prefetch_item(2, 0, 0); w_prefetch_item(2, 0, 1);
+      w_prefetch_item(3, 1, 0); w_prefetch_item(3, 1, 1);
+      x_store_from(1, xb);
+      x_store_from(2, xc);
+    }
+    __syncthreads();
+    const unsigned char* const wb = smem + G::OFF_W + c.lane * 16;
+    constexpr int NCHUNK = G::NFRAG / CH3;   // 12
+
+    for (int n = f0; n < a.N; n += gf) {
+      const bool more = n + gf < a.N;
+      STAMP(ts0);
+      if (more) x_target(n + gf);
+      f32x16 acc1c = bias_init(lb, c.half), acc1r = acc1c, acc2 = bias_init(lb + 32, c.half);
+      STAMP(ts1);
+      STAMP_ADD(0, ts0, ts1);
+
+      auto wfrag = [&](const int f) __attribute__((always_inline)) { return wb + ((f / CH3) % 3) * CH3 * 1024 + (f % CH3) * 1024; };
+      // Behind barrier cidx (merged step 6 cidx + 2): steps +1, +2 commit chunk cidx+2, steps +3, +4 prefetch chunk cidx+4.
+      auto chunk_task = [&](const int cidx, const int j) __attribute__((always_inline)) {
+#ifdef SELFC_EXP_NOW        // timing experiment only (results are wrong): what does the weight streaming cost?
+        return;
+#endif
+        if (j == 1 || j == 2) w_commit_item((cidx + 2) % 3, cidx & 1, j - 1);
+        if (j == 3 || j == 4) w_prefetch_item((cidx + 4) % NCHUNK, cidx & 1, j - 3);
+      };
+      auto post_m = [&](auto gi) __attribute__((always_inline)) {
+        constexpr int g = decltype(gi)::value;
+        if constexpr (g % 6 == 2) {
+          if constexpr (g / 6 == 10) epilogue1(acc1c, acc1r, n, ty0, tx0);
+#ifdef SELFC_EXP_NOBAR      // timing experiment only (results are wrong): what do the mid-chunk barriers cost?
+          if constexpr (g / 6 == 10) __syncthreads();
+#else
           __syncthreads();
-          par ^= 1;
-          // x2 steps end with chunk 2, f1 steps with chunk 4: refill that part of the image, start the next part's loads
-          if (ch == 2 && more) { x_store(0); x_load(1, tnext); }
-          if (ch == 4 && more) { x_store(1); x_load(2, tnext); }
+#endif
+        } else if constexpr (g >= 3) {
+          chunk_task((g - 3) / 6, g - (6 * ((g - 3) / 6) + 2));
         }
-      }
-    }
-
-    // ---- epilogue of the first conv: FM image (zero outside the frame) + centre crop to HBM ----------
-    {
-      f16* __restrict__ dplane = a.dense + (size_t)G::OUT1 * a.plane;
-      u32x4 v[2];
-      const int y = ty0 + c.py, x = tx0 + c.px;
-      const bool in = (y < a.H) & (x < a.W);
-      lrelu_pack(acc1c, in, v);
-      unsigned char* fdst = smem + G::OFF_FM + (c.py + 1) * G::FROW + (c.px + 1) * PS + 16 * c.half;
-      *reinterpret_cast<u32x4*>(fdst) = v[0];
-      *reinterpret_cast<u32x4*>(fdst + 32) = v[1];
-      if (in) {
-        f16* d = dplane + ((size_t)(n * a.H + y) * a.W + x) * 32 + 8 * c.half;
-        *reinterpret_cast<u32x4*>(d) = v[0];
-        *reinterpret_cast<u32x4*>(d + 16) = v[1];
-      }
-      if (ring) {
-        const int ry = ty0 + c.rr - 1, rx = tx0 + c.rc - 1;
-        const bool rin = (ry >= 0) & (ry < a.H) & (rx >= 0) & (rx < a.W);
-        lrelu_pack(acc1r, rin, v);
-        if (c.rvalid) {
-          unsigned char* rdst = smem + G::OFF_FM + c.rr * G::FROW + c.rc * PS + 16 * c.half;
-          *reinterpret_cast<u32x4*>(rdst) = v[0];
-          *reinterpret_cast<u32x4*>(rdst + 32) = v[1];
+        if (more) {
+          if constexpr (g < 6) x_load_item(0, g);
+          if constexpr (g >= 27 && g < 33) {                  // x2 died at barrier 4 (step 26)
+            x_store_item(0, g - 27);
+            if constexpr (g - 27 < 4) x_load_item(1, g - 27);
+          }
+          if constexpr (g >= 45 && g < 49) {                  // f1 died at barrier 7 (step 44)
+            x_store_item(1, g - 45);
+            x_load_item(2, g - 45);
+          }
         }
-      }
-    }
-    if (!G::RES) w_commit(par ^ 1);                 // the FM chunk
-    __syncthreads();                                // FM complete; every wave is done with the input image
-    if (!G::RES) par ^= 1;
+      };
+      auto post_f = [&](auto si) __attribute__((always_inline)) {
+        constexpr int st = decltype(si)::value;
+        if constexpr (st < 4) chunk_task(10, st + 1);            // behind barrier 10 (merged step 62)
+        if constexpr (st == 11) __syncthreads();                 // barrier 11
+        if constexpr (st >= 12 && st < 16) chunk_task(11, st - 11);
+        if constexpr (st < 4) { if (more) x_store_item(2, st); } // f2 died at barrier 10
+      };
 
-    // ---- FM phase + epilogue of the second conv -------------------------------------------------------
-    if (!G::RES) w_prefetch(0);                     // wraps to the next tile's first chunk
-    fm_steps<PAIR>(smem + G::OFF_W + (G::RES ? 2 * G::S1 * 1024 : par * CHF * 1024) + c.lane * 16, fb, acc2);
-    {
-      const int y = ty0 + c.py, x = tx0 + c.px;
-      const bool in = (y < a.H) & (x < a.W);
-      u32x4 v[2];
-      lrelu_pack(acc2, true, v);
-      if (in) {
-        f16* d = a.dense + (size_t)G::OUT2 * a.plane + ((size_t)(n * a.H + y) * a.W + x) * 32 + 8 * c.half;
-        *reinterpret_cast<u32x4*>(d) = v[0];
-        *reinterpret_cast<u32x4*>(d + 16) = v[1];
+      auto body = [&](auto ring_tag) __attribute__((always_inline)) {
+        constexpr bool RING = decltype(ring_tag)::value;
+        f16x8 rA1[3], rA2[3], rBc[3], rBr[3];
+        auto load_m = [&](const int g) __attribute__((always_inline)) {
+          const int tap = g < 27 ? g / 3 : g < 45 ? (g - 27) >> 1 : (g - 45) >> 1;
+          const int ks = g < 27 ? g % 3 : g < 45 ? 3 + ((g - 27) & 1) : 5 + ((g - 45) & 1);
+          const int off = (tap / 3) * G::ROWP + (tap % 3) * G::PITCH + ks * 32;
+          const int s = g % 3;
+          rA1[s] = *reinterpret_cast<const f16x8*>(wfrag(2 * g));
+          rA2[s] = *reinterpret_cast<const f16x8*>(wfrag(2 * g + 1));
+          rBc[s] = *reinterpret_cast<const f16x8*>(bc + off);
+          if (RING) rBr[s] = *reinterpret_cast<const f16x8*>(br + off);
+        };
+        load_m(0);
+        load_m(1);
+        static_for<0, G::S1>([&](auto gi) __attribute__((always_inline)) {
+          constexpr int g = decltype(gi)::value;
+          if constexpr (g + 2 < G::S1) load_m(g + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          constexpr int s = g % 3;
+          acc1c = mfma_32x32x16(rA1[s], rBc[s], acc1c);
+          acc2 = mfma_32x32x16(rA2[s], rBc[s], acc2);
+          if (RING) acc1r = mfma_32x32x16(rA1[s], rBr[s], acc1r);
+          __builtin_amdgcn_sched_barrier(0);
+          post_m(gi);
+        });
+      };
+      if (ring) body(std::true_type{});
+      else body(std::false_type{});
+      STAMP(ts2);
+      STAMP_ADD(1, ts1, ts2);
+
+      // FM phase: fragments 126..143 = second half of chunk 10 and chunk 11 (barrier 11 behind FM step 11)
+      {
+        f16x8 rA[3], rB[3];
+        auto load_f = [&](const int st) __attribute__((always_inline)) {
+          const int tap = st >> 1, ks = st & 1;
+          rA[st % 3] = *reinterpret_cast<const f16x8*>(wfrag(2 * G::S1 + st));
+          rB[st % 3] = *reinterpret_cast<const f16x8*>(fb + (tap / 3) * G::FROW + (tap % 3) * PS + ks * 32);
+        };
+        load_f(0);
+        load_f(1);
+        static_for<0, 18>([&](auto si) __attribute__((always_inline)) {
+          constexpr int st = decltype(si)::value;
+          if constexpr (st + 2 < 18) load_f(st + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          acc2 = mfma_32x32x16(rA[st % 3], rB[st % 3], acc2);
+          __builtin_amdgcn_sched_barrier(0);
+          post_f(si);
+        });
       }
+      STAMP(ts5);
+      STAMP_ADD(4, ts2, ts5);
+      epilogue2(acc2, n, ty0, tx0);
+      STAMP(ts6);
+      STAMP_ADD(5, ts5, ts6);
     }
-    if (more) x_store(NPART - 1);
-    if (!G::RES) w_commit(par ^ 1);
-    __syncthreads();                                // image of the next tile visible; FM free again
-    if (!G::RES) par ^= 1;
   }
+#ifdef SELFC_STAMPS
+  STAMP(tk1);
+  if (a.stamps && c.lane == 0) {
+    unsigned long long* o = a.stamps + ((size_t)blockIdx.x * NWAVE + c.wave) * 8;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) o[i] = phase[i];
+    o[7] = tk1 - tk0;
+  }
+#endif
 }
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 1000; }
@@ -399,10 +587,35 @@ int launch_pair(FFArgs& a, int maxwg, hipStream_t s) {
     if (e != hipSuccess) return hip_rc(e);
     attr_done = true;
   }
-  const int total = a.ntiles * a.N;
-  // persistent workgroups, every one walks the same number of tiles (no straggler round)
-  const int rounds = (total + maxwg - 1) / maxwg;
-  const int gx = (total + rounds - 1) / rounds;
+  // Frame walk (see the kernel): gf workgroups per spatial tile, workgroup b visits frames b / ntiles + k gf.  gf is
+  // sized so that about maxwg workgroups exist, every one of them walks (nearly) the same number of frames, and -
+  // when there are frames enough - at least three, which amortises the prologue (weights, first halo).
+  const int gmax = a.ntiles >= maxwg ? 1 : (maxwg / a.ntiles < a.N ? maxwg / a.ntiles : a.N);
+  int rounds = (a.N + gmax - 1) / gmax;
+  if (rounds < 3) rounds = a.N < 3 ? a.N : 3;
+  const int gfr = (a.N + rounds - 1) / rounds;
+  const int gx = gfr * a.ntiles;
+#ifdef SELFC_STAMPS
+  static unsigned long long* dbg = nullptr;
+  constexpr int DBG_WG = 1024;
+  if (!dbg) { (void)hipMalloc(&dbg, DBG_WG * NWAVE * 8 * sizeof(unsigned long long)); (void)hipMemset(dbg, 0, DBG_WG * NWAVE * 8 * sizeof(unsigned long long)); }
+  a.stamps = gx <= DBG_WG ? dbg : nullptr;
+  if (getenv("SELFC_STAMP_DUMP_F")) {      // diagnostic: dump the previous launch's sums (of this pair), then continue
+    static unsigned long long host[DBG_WG * NWAVE * 8];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
+    char fn[512];
+    snprintf(fn, sizeof(fn), "%s.%d", getenv("SELFC_STAMP_DUMP_F"), PAIR);
+    FILE* f = fopen(fn, "w");
+    if (f) {
+      for (int i = 0; i < DBG_WG * NWAVE; ++i) {
+        for (int j = 0; j < 8; ++j) fprintf(f, "%llu ", host[8 * i + j]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
+#endif
   hipLaunchKernelGGL(fused_f_kernel<PAIR>, dim3((unsigned)gx), dim3(NTHR), G::LDS, s, a);
   return hip_rc(hipGetLastError());
 }

@@ -1,0 +1,33 @@
+"""Diagnostic: per-phase time shares of the pairwise-fused F kernels (build with -DSELFC_STAMPS).
+Usage on the GPU box:  SELFC_LIB=$PWD/diag/libselfc_stamps.so SELFC_STAMP_DUMP_F=/tmp/stf python tools/stamp_report_f.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import bench
+from selfc_amd.pipeline import RescaleRoundTrip
+
+dev = torch.device("cuda:0")
+net = bench.build_net(dev)
+x = torch.rand(28, 3, 256, 448, device=dev)
+rt = RescaleRoundTrip(net, 28, 256, 448, dev)
+with torch.no_grad():
+    for _ in range(2):
+        rt.run(x)          # every launch dumps the previous launch's sums of its own pair
+torch.cuda.synchronize()
+names = ["tile setup", "merged MFMA", "epilogue 1", "mid barrier", "FM MFMA", "epilogue 2 + image store", "end barrier", "kernel total"]
+names1 = ["tile setup", "merged + FM steps incl. hooks", "epilogue 1 (hook 10)", "barrier waits (12 hooks)", "(FM steps incl. hook 11)", "prefetch issue + image parts + epilogue 2", "weight commits", "kernel total"]
+for pair in (0, 1):
+    d = np.loadtxt(os.environ["SELFC_STAMP_DUMP_F"] + f".{pair}")
+    d = d[d[:, 7] > 0]
+    print(f"pair {pair}: waves with data {len(d)}; wave lifetime mean {d[:, 7].mean():.0f} ticks (s_memtime, 100 MHz => {d[:, 7].mean() / 100:.1f} us)")
+    tot = d[:, 7].mean()
+    w = np.arange(len(d)) % 8  # rows are (workgroup, wave)
+    for i, n in enumerate((names1 if pair else names)[:7]):
+        ring = d[w < 3, i].mean()
+        rest = d[w >= 3, i].mean()
+        print(f"  {n:26s} {100 * d[:, i].mean() / tot:5.1f} %   (ring waves {100 * ring / tot:5.1f} %, others {100 * rest / tot:5.1f} %)")
+    print("  unaccounted: %.1f %%" % (100 * (1 - d[:, :7].sum(1).mean() / tot)))
