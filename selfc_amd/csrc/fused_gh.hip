@@ -111,7 +111,7 @@ __device__ __forceinline__ void w_commit(Ctx& c) {
 // last chunk in the stream (prefetched during that chunk).
 template <int K>
 __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int net, const int xbuf,
-                                           const int n, const int ty0, const int tx0) {
+                                           const size_t fofs, const int ty0, const int tx0) {
   constexpr int R = TS + 2 * (4 - K);
   constexpr int NPX = R * R;
   constexpr int NTL = (NPX + 31) / 32;
@@ -259,7 +259,7 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
             }
             const bool centre = (ar >= 0) & (ar < TS) & (ac >= 0) & (ac < TS);
             if (centre && inimg)
-              *reinterpret_cast<u32x4*>(dplane + ((size_t)(n * a.H + y) * a.W + x) * 32 + 16 * gp + 8 * c.half) = v;
+              *reinterpret_cast<u32x4*>(dplane + fofs + (unsigned)((y * a.W + x) * 32 + 16 * gp + 8 * c.half)) = v;
           }
         }
       }
@@ -293,26 +293,32 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
 #endif
   const int net = blockIdx.y;
   c.wsrc = reinterpret_cast<const u32x4*>(net ? a.w[1] : a.w[0]);
-  const int total = a.ntiles * a.N;
-  int t = blockIdx.x;
-  if (t >= total) return;
+  // Frame walk: a workgroup owns ONE spatial tile (blockIdx.x % ntiles) and visits frames f0, f0 + gf, ...: everything
+  // that depends on the tile position (halo offsets, border masks, output offsets) is a per-workgroup constant that the
+  // compiler keeps in registers instead of re-deriving ~400 VALU instructions' worth of it per tile.
+  const int stile = blockIdx.x % a.ntiles, f0 = blockIdx.x / a.ntiles, gf = gridDim.x / a.ntiles;
+  if (f0 >= a.N) return;
+  const int ty0 = (stile / a.tiles_x) * TS, tx0 = (stile % a.tiles_x) * TS;
+  const size_t fpix = (size_t)a.H * a.W;
 
   constexpr int XITER = (XS * XS + NTHR - 1) / NTHR;   // 2
   float4 xv[XITER];
+  unsigned xgo[XITER];
   unsigned xok = 0;   // bit it: halo pixel it is inside the image (mask applied at store time, not after the load)
-  auto x_load = [&](const int tile) __attribute__((always_inline)) {
-    xok = 0;
-    const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, n = tile / a.ntiles;
 #pragma unroll
-    for (int it = 0; it < XITER; ++it) {
-      const int p = min(c.tid + it * NTHR, XS * XS - 1);
-      const int hy = p / XS, hx = p - hy * XS;
-      const int y = ty * TS + hy - 4, x = tx * TS + hx - 4;
-      const bool ok = (y >= 0) & (y < a.H) & (x >= 0) & (x < a.W);
-      const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
-      xv[it] = *reinterpret_cast<const float4*>(a.x1 + ((size_t)(n * a.H + yc) * a.W + xc) * 4);
-      xok |= (ok ? 1u : 0u) << it;
-    }
+  for (int it = 0; it < XITER; ++it) {
+    const int p = min(c.tid + it * NTHR, XS * XS - 1);
+    const int hy = p / XS, hx = p - hy * XS;
+    const int y = ty0 + hy - 4, x = tx0 + hx - 4;
+    const bool ok = (y >= 0) & (y < a.H) & (x >= 0) & (x < a.W);
+    const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
+    xgo[it] = (unsigned)(yc * a.W + xc) * 4u;
+    xok |= (ok ? 1u : 0u) << it;
+  }
+  auto x_load = [&](const int n) __attribute__((always_inline)) {
+    const float* fr = a.x1 + (size_t)n * fpix * 4;
+#pragma unroll
+    for (int it = 0; it < XITER; ++it) xv[it] = *reinterpret_cast<const float4*>(fr + xgo[it]);
   };
   auto x_store = [&](const int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
     const float* bsrc = net ? a.bias[1][c.tid >> 5] : a.bias[0][c.tid >> 5];
     reinterpret_cast<float*>(smem + OFF_B)[c.tid] = bsrc[c.tid & 31];
   }
-  x_load(t);
+  x_load(f0);
   w_prefetch<LAYER_OFF[1], 3>(c);
   x_store(0);
   c.par = 1;            // w_commit writes buffer par^1 = 0
@@ -342,15 +348,14 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
   c.par = 0;
 
   int xbuf = 0;
-  for (; t < total; t += gridDim.x) {
-    const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, n = t / a.ntiles;
-    const int tnext = t + gridDim.x;
-    const bool more = tnext < total;
-    if (more) x_load(tnext);                      // lands while this tile computes
-    conv_fused<1>(c, a, net, xbuf, n, ty * TS, tx * TS);
-    conv_fused<2>(c, a, net, xbuf, n, ty * TS, tx * TS);
-    conv_fused<3>(c, a, net, xbuf, n, ty * TS, tx * TS);
-    conv_fused<4>(c, a, net, xbuf, n, ty * TS, tx * TS);
+  for (int n = f0; n < a.N; n += gf) {
+    const bool more = n + gf < a.N;
+    if (more) x_load(n + gf);                     // lands while this tile computes
+    const size_t fofs = (size_t)n * fpix * 32;
+    conv_fused<1>(c, a, net, xbuf, fofs, ty0, tx0);
+    conv_fused<2>(c, a, net, xbuf, fofs, ty0, tx0);
+    conv_fused<3>(c, a, net, xbuf, fofs, ty0, tx0);
+    conv_fused<4>(c, a, net, xbuf, fofs, ty0, tx0);
     STAMP(tt0);
     if (more) x_store(xbuf ^ 1);
     __syncthreads();
@@ -385,16 +390,18 @@ int launch_fused_gh(FGArgs& a, hipStream_t s) {
   a.tiles_y = (a.H + TS - 1) / TS;
   a.ntiles = a.tiles_x * a.tiles_y;
   a.plane = (size_t)a.N * a.H * a.W * 32;
-  const int total = a.ntiles * a.N;
-  // persistent workgroups, at most 128 per net (one per CU overall); sized so that every
-  // workgroup walks the same number of tiles (no straggler round) and unused CUs stay free for
-  // kernels of other streams
-  const int rounds = (total + 127) / 128;
-  const int gx = (total + rounds - 1) / rounds;
+  // persistent workgroups, about 128 per net (one per CU overall): gfr workgroups per spatial tile, each walking
+  // frames f0, f0 + gfr, ... - sized so that every workgroup walks (nearly) the same number of frames (no straggler
+  // round) and unused CUs stay free for kernels of other streams
+  static const int maxwg = getenv("SELFC_FUSEDGH_MAXWG") ? atoi(getenv("SELFC_FUSEDGH_MAXWG")) : 128;
+  const int gmax = a.ntiles >= maxwg ? 1 : (maxwg / a.ntiles < a.N ? maxwg / a.ntiles : a.N);
+  const int rounds = (a.N + gmax - 1) / gmax;
+  const int gfr = (a.N + rounds - 1) / rounds;
+  const int gx = gfr * a.ntiles;
 #ifdef SELFC_STAMPS
   static unsigned long long* dbg = nullptr;
   if (!dbg) (void)hipMalloc(&dbg, 256 * NWAVE * 5 * sizeof(unsigned long long));
-  a.stamps = dbg;
+  a.stamps = 2 * gx <= 256 ? dbg : nullptr;
   if (getenv("SELFC_STAMP_DUMP")) {      // diagnostic: dump the previous launch's sums, then continue
     static unsigned long long host[256 * NWAVE * 5];
     (void)hipDeviceSynchronize();
