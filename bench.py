@@ -159,7 +159,12 @@ def main():
     npx = n_frames * (H // 4) * (W // 4)
     # per-kernel rooflines: algorithmic FLOPs per launch / live HIP-event duration of that launch
     kern = {}
-    for name, mac_px, per_blockdir, label in (("conv3x3", MAC_F14_PX, 4, "conv3x3_kernel (conv1-4 of F, layer-wise)"),
+    # class "conv3x3" = conv1-4 of F: one timed scope per block and direction when the pairwise-fused kernels run
+    # (fused_f_kernel<0> + fused_f_kernel<1>, two launches under one scope), four (one per conv) on the layer-wise path
+    f_scopes = max(1, round(cls_n.get("conv3x3", 0) / (16.0 * args.steps)))
+    f_label = ("fused_f_kernel<0> + <1> (conv1-4 of F, pairwise fused, two launches timed as one)" if f_scopes == 1
+               else "conv3x3_kernel (conv1-4 of F, layer-wise)")
+    for name, mac_px, per_blockdir, label in (("conv3x3", MAC_F14_PX, f_scopes, f_label),
                                               ("fused_gh", MAC_GH14_PX, 1, "fused_gh_kernel (conv1-4 of G+H, fused)")):
         if cls_n.get(name, 0) == 0:
             continue
@@ -173,6 +178,8 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")) as fh:
             traffic = json.load(fh)
+        if f_scopes == 1 and "fused_f" in traffic:
+            traffic["conv3x3"] = traffic["fused_f"]
         for k in kern:
             if k in traffic:
                 kern[k]["traffic"] = traffic[k]["hbm_bytes_per_launch"]

@@ -7,8 +7,8 @@ TAG=${1:-r1}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-TRACE_ARGS="bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-full-path --streams 1"
-PMC_ARGS="bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-full-path --streams 1"
+TRACE_ARGS="bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-full-path --no-train-step --streams 1"
+PMC_ARGS="bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-full-path --no-train-step --streams 1"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $TRACE_ARGS > $OUT/trace.log 2>&1
 python3 tools/prof_summary.py $OUT/trace > $OUT/kernel_trace_summary.txt 2>&1
 tail -1 $OUT/trace.log > $OUT/bench_line_under_trace.json
