@@ -591,8 +591,9 @@ int launch_pair(FFArgs& a, int maxwg, hipStream_t s) {
   // sized so that about maxwg workgroups exist, every one of them walks (nearly) the same number of frames, and -
   // when there are frames enough - at least three, which amortises the prologue (weights, first halo).
   const int gmax = a.ntiles >= maxwg ? 1 : (maxwg / a.ntiles < a.N ? maxwg / a.ntiles : a.N);
+  static const int minrounds = getenv("SELFC_FUSEDF_MINROUNDS") ? atoi(getenv("SELFC_FUSEDF_MINROUNDS")) : 3;
   int rounds = (a.N + gmax - 1) / gmax;
-  if (rounds < 3) rounds = a.N < 3 ? a.N : 3;
+  if (rounds < minrounds) rounds = a.N < minrounds ? a.N : minrounds;
   const int gfr = (a.N + rounds - 1) / rounds;
   const int gx = gfr * a.ntiles;
 #ifdef SELFC_STAMPS

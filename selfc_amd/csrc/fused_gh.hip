@@ -395,7 +395,9 @@ int launch_fused_gh(FGArgs& a, hipStream_t s) {
   // round) and unused CUs stay free for kernels of other streams
   static const int maxwg = getenv("SELFC_FUSEDGH_MAXWG") ? atoi(getenv("SELFC_FUSEDGH_MAXWG")) : 128;
   const int gmax = a.ntiles >= maxwg ? 1 : (maxwg / a.ntiles < a.N ? maxwg / a.ntiles : a.N);
-  const int rounds = (a.N + gmax - 1) / gmax;
+  static const int minrounds = getenv("SELFC_FUSEDGH_MINROUNDS") ? atoi(getenv("SELFC_FUSEDGH_MINROUNDS")) : 2;
+  int rounds = (a.N + gmax - 1) / gmax;
+  if (rounds < minrounds) rounds = a.N < minrounds ? a.N : minrounds;
   const int gfr = (a.N + rounds - 1) / rounds;
   const int gx = gfr * a.ntiles;
 #ifdef SELFC_STAMPS
