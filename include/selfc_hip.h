@@ -100,9 +100,14 @@ typedef struct {
   const float* b3[4];    /* 32 fp32 biases each                                       */
   const void* w5;        /* packed conv5 fragments                                    */
   const float* b5;       /* conv5 bias, zero-padded to a multiple of 32 floats        */
-  const void* wfused;    /* optional (cin == 3 subnets): fused conv1..4 fragment stream of
-                            packing.py:pack_fused_gh; when G and H both carry one, their
-                            conv1..4 run as ONE persistent fused launch (csrc/fused_gh.hip) */
+  const void* wfused;    /* optional: fused conv1..4 fragment stream.  cin == 3 subnets (G, H):
+                            packing.py:pack_fused_gh - when G and H both carry one, their conv1..4 run as
+                            ONE persistent fused launch (csrc/fused_gh.hip).  cin == 48 (F of SelfC-large):
+                            packing.py:pack_fused_f - conv1+conv2 and conv3+conv4 run as two pairwise-fused
+                            launches (csrc/fused_f.hip) */
+  const void* w5p;       /* optional (F with wfused, temporal conv5): packing.py:pack_f5_partial - the fused F
+                            launches then also emit the conv5 partial products and a small kernel replaces the
+                            conv5 pass over the 176 dense channels (needs selfc_latent.pf) */
 } selfc_subnet_w;
 
 typedef struct {
@@ -122,6 +127,7 @@ typedef struct {
   void* gd;
   void* hd;
   float* s_out;          /* optional: InvBlockExp.s as fp32 [N][H][W][c2p], or NULL */
+  float* pf;             /* optional workspace: F conv5 partial products, fp32 [2 pairs][3 taps][N][H][W][4] (see w5p), or NULL */
 } selfc_latent;
 
 /* InvBlockExp.forward(x, rev): Inv_arch.py:21-33 on the latent layout.

@@ -44,7 +44,7 @@ SYMBOLS = [
 
 class SubnetW(C.Structure):
     _fields_ = [("w3", C.c_void_p * 4), ("b3", C.c_void_p * 4), ("w5", C.c_void_p), ("b5", C.c_void_p),
-                ("wfused", C.c_void_p)]
+                ("wfused", C.c_void_p), ("w5p", C.c_void_p)]
 
 
 class SubnetBW(C.Structure):
@@ -59,7 +59,7 @@ class Latent(C.Structure):
     _fields_ = [("kind", C.c_int), ("N", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("c1", C.c_int), ("c2", C.c_int),
                 ("x1", C.c_void_p), ("x2", C.c_void_p), ("fd", C.c_void_p), ("gd", C.c_void_p),
-                ("hd", C.c_void_p), ("s_out", C.c_void_p)]
+                ("hd", C.c_void_p), ("s_out", C.c_void_p), ("pf", C.c_void_p)]
 
 
 _lib = None

@@ -40,6 +40,8 @@ struct FFArgs {
   int N, H, W;
   int tiles_x, tiles_y, ntiles;
   size_t plane;
+  const f16* w5p;           // optional: conv5 partial-product fragments of this pair (pair 0: x2, f1, f2 = 7; pair 1: f3, f4 = 4)
+  float* pf;                // optional: partial products of this pair, fp32 [3 taps][N][H][W][4]
   unsigned long long* stamps;   // diagnostic build only (-DSELFC_STAMPS): per wave 7 phase sums + lifetime
 };
 
@@ -74,7 +76,12 @@ struct Geo {
   static constexpr int RD = 3;                             // operand ring depth (fragments fetched RD-1 steps ahead)
   static constexpr int W_BYTES = RES ? NFRAG * 1024 : 3 * 12 * 1024;   // resident stream | three 12-fragment chunk buffers
   static constexpr int OFF_IMG = 0, OFF_FM = IMG_BYTES, OFF_W = OFF_FM + FM_BYTES, OFF_B = OFF_W + W_BYTES;
-  static constexpr int LDS = OFF_B + 256;
+  // conv5 partial-product A fragments (rows 4 tap + oc, 11 used): pair 0 keeps its 7 whole, pair 1 (LDS-bound) its 4
+  // compacted to 12 rows x 32 B (rows >= 11 of a fragment are zero: those lanes read the shared zero row)
+  static constexpr int NP = PAIR ? 4 : 7;
+  static constexpr int OFF_P = OFF_B + 256;
+  static constexpr int P_BYTES = PAIR ? NP * 384 : NP * 1024;
+  static constexpr int LDS = OFF_P + P_BYTES;
   static constexpr int NITEM = IS * IS * NCHK;             // 16-byte pieces of one input halo
   static constexpr int NPLANE_IN = PAIR ? 4 : 2;
   static constexpr int OUT1 = PAIR ? 4 : 2, OUT2 = OUT1 + 1;   // planes the two convs append
@@ -300,22 +307,23 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
   const unsigned char* const fb = smem + G::OFF_FM + c.py * G::FROW + c.px * PS + c.half * 16;
   const float* const lb = reinterpret_cast<const float*>(smem + G::OFF_B);
 
-  // epilogue of the pair's first conv: FM image (zero outside the frame) + centre crop to HBM
-  auto epilogue1 = [&](const f32x16& acc1c, const f32x16& acc1r, const int n, const int ty0, const int tx0) __attribute__((always_inline)) {
+  // epilogue of the pair's first conv: FM image (zero outside the frame) + centre crop to HBM; vc = the centre
+  // pixels' 32 features as two MFMA B fragments (k-step gp = channels 16 gp + 8 half ..) for the conv5 partial products
+  auto epilogue1 = [&](const f32x16& acc1c, const f32x16& acc1r, const int n, u32x4 (&vc)[2]) __attribute__((always_inline)) {
     f16* __restrict__ dplane = a.dense + (size_t)G::OUT1 * a.plane;
-    u32x4 v[2];
     const int y = ty0 + c.py, x = tx0 + c.px;
     const bool in = (y < a.H) & (x < a.W);
-    lrelu_pack(acc1c, in, v);
+    lrelu_pack(acc1c, in, vc);
     unsigned char* fdst = smem + G::OFF_FM + (c.py + 1) * G::FROW + (c.px + 1) * PS + 16 * c.half;
-    *reinterpret_cast<u32x4*>(fdst) = v[0];
-    *reinterpret_cast<u32x4*>(fdst + 32) = v[1];
+    *reinterpret_cast<u32x4*>(fdst) = vc[0];
+    *reinterpret_cast<u32x4*>(fdst + 32) = vc[1];
     if (in) {
       f16* d = dplane + ((size_t)(n * a.H + y) * a.W + x) * 32 + 8 * c.half;
-      *reinterpret_cast<u32x4*>(d) = v[0];
-      *reinterpret_cast<u32x4*>(d + 16) = v[1];
+      *reinterpret_cast<u32x4*>(d) = vc[0];
+      *reinterpret_cast<u32x4*>(d + 16) = vc[1];
     }
     if (ring) {
+      u32x4 v[2];
       const int ry = ty0 + c.rr - 1, rx = tx0 + c.rc - 1;
       const bool rin = (ry >= 0) & (ry < a.H) & (rx >= 0) & (rx < a.W);
       lrelu_pack(acc1r, rin, v);
@@ -326,9 +334,8 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
       }
     }
   };
-  auto epilogue2 = [&](const f32x16& acc2, const int n, const int ty0, const int tx0) __attribute__((always_inline)) {
+  auto epilogue2 = [&](const f32x16& acc2, const int n, u32x4 (&v)[2]) __attribute__((always_inline)) {
     const int y = ty0 + c.py, x = tx0 + c.px;
-    u32x4 v[2];
     lrelu_pack(acc2, true, v);
     if ((y < a.H) & (x < a.W)) {
       f16* d = a.dense + (size_t)G::OUT2 * a.plane + ((size_t)(n * a.H + y) * a.W + x) * 32 + 8 * c.half;
@@ -336,6 +343,37 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
       *reinterpret_cast<u32x4*>(d + 16) = v[1];
     }
   };
+  // ---- conv5 partial products (F's temporal conv5 has 3 outputs x 3 taps = 9 rows): P[row][px] += W5[row][16 ch] d[16 ch][px]
+  // on the features while they are in registers / LDS, instead of a later pass over all 176 dense channels.
+  const bool do_p = a.w5p != nullptr && a.pf != nullptr;
+  const unsigned char* const pfr = smem + G::OFF_P + (PAIR ? min(c.lane & 31, 11) * 32 + c.half * 16 : c.lane * 16);
+  auto p_frag = [&](const int j) __attribute__((always_inline)) {
+    return *reinterpret_cast<const f16x8*>(pfr + j * (PAIR ? 384 : 1024));
+  };
+  auto p_feat = [&](f32x16& accp, const int j0, const u32x4 (&v)[2]) __attribute__((always_inline)) {
+    accp = mfma_32x32x16(p_frag(j0), __builtin_bit_cast(f16x8, v[0]), accp);
+    accp = mfma_32x32x16(p_frag(j0 + 1), __builtin_bit_cast(f16x8, v[1]), accp);
+  };
+  auto p_store = [&](const f32x16& accp, const int n) __attribute__((always_inline)) {
+    const int y = ty0 + c.py, x = tx0 + c.px;
+    if ((y < a.H) & (x < a.W)) {
+      // accumulator rows (e & 3) + 8 (e >> 2) + 4 half, fragment rows 4 tap + oc: half 0 owns taps 0 (e 0-3) and 2
+      // (e 4-7), half 1 tap 1 (e 0-3); one float4 (3 outputs + a zero) per pixel and tap: pf[tap][N][H][W][4]
+      const size_t pix = (size_t)(n * a.H + y) * a.W + x, tapsz = (size_t)a.N * a.H * a.W * 4;
+      *reinterpret_cast<float4*>(a.pf + (c.half ? tapsz : 0) + pix * 4) = make_float4(accp[0], accp[1], accp[2], accp[3]);
+      if (c.half == 0) *reinterpret_cast<float4*>(a.pf + 2 * tapsz + pix * 4) = make_float4(accp[4], accp[5], accp[6], accp[7]);
+    }
+  };
+  if (do_p) {
+    const u32x4* __restrict__ psrc = reinterpret_cast<const u32x4*>(a.w5p);
+    if (PAIR == 0) {
+      if (c.tid < G::NP * 64) *reinterpret_cast<u32x4*>(smem + G::OFF_P + c.tid * 16) = psrc[c.tid];
+    } else if (c.tid < G::NP * 24) {       // item = (fragment j, row r of 12, half h): 16 bytes
+      const int j = c.tid / 24, r = (c.tid % 24) >> 1, h = c.tid & 1;
+      const u32x4 val = r < 11 ? psrc[j * 64 + h * 32 + r] : u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(smem + G::OFF_P + j * 384 + r * 32 + h * 16) = val;
+    }
+  }
 
   if (c.tid < 64) reinterpret_cast<float*>(smem + G::OFF_B)[c.tid] = (c.tid < 32 ? a.bias[0] : a.bias[1])[c.tid & 31];
 
@@ -402,7 +440,17 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
       }
       STAMP(ts2);
       STAMP_ADD(1, ts1, ts2);
-      epilogue1(acc1c, acc1r, n, ty0, tx0);
+      u32x4 vc[2];
+      epilogue1(acc1c, acc1r, n, vc);
+      f32x16& accp = acc1c;     // the first conv's accumulator is dead: its registers take the conv5 partial products
+      if (do_p) {        // x2 (centre tap of the image, still intact before the barrier) and f1
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accp[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+          accp = mfma_32x32x16(p_frag(ks), *reinterpret_cast<const f16x8*>(bc + G::ROWP + G::PITCH + ks * 32), accp);
+        p_feat(accp, 3, vc);
+      }
       STAMP(ts3);
       STAMP_ADD(2, ts2, ts3);
       __syncthreads();                                // FM complete; every wave is done with the input image
@@ -411,7 +459,11 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
       fm_steps<PAIR>(wl + 2 * G::S1 * 1024, fb, acc2, post_f);
       STAMP(ts5);
       STAMP_ADD(4, ts4, ts5);
-      epilogue2(acc2, n, ty0, tx0);
+      epilogue2(acc2, n, vc);
+      if (do_p) {
+        p_feat(accp, 5, vc);                          // f2
+        p_store(accp, n);
+      }
       STAMP(ts6);
       STAMP_ADD(5, ts5, ts6);
       __syncthreads();                                // image of the next tile visible; FM free again
@@ -466,6 +518,8 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
       STAMP(ts1);
       STAMP_ADD(0, ts0, ts1);
 
+      u32x4 vc[2];
+      f32x16& accp = acc1c;     // dead after epilogue 1: its registers take the conv5 partial products
       auto wfrag = [&](const int f) __attribute__((always_inline)) { return wb + ((f / CH3) % 3) * CH3 * 1024 + (f % CH3) * 1024; };
       // Behind barrier cidx (merged step 6 cidx + 2): steps +1, +2 commit chunk cidx+2, steps +3, +4 prefetch chunk cidx+4.
       auto chunk_task = [&](const int cidx, const int j) __attribute__((always_inline)) {
@@ -478,7 +532,14 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
       auto post_m = [&](auto gi) __attribute__((always_inline)) {
         constexpr int g = decltype(gi)::value;
         if constexpr (g % 6 == 2) {
-          if constexpr (g / 6 == 10) epilogue1(acc1c, acc1r, n, ty0, tx0);
+          if constexpr (g / 6 == 10) {
+            epilogue1(acc1c, acc1r, n, vc);
+            if (do_p) {                                          // f3 (acc1c is dead from here on)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) accp[e] = 0.f;
+              p_feat(accp, 0, vc);
+            }
+          }
 #ifdef SELFC_EXP_NOBAR      // timing experiment only (results are wrong): what do the mid-chunk barriers cost?
           if constexpr (g / 6 == 10) __syncthreads();
 #else
@@ -560,7 +621,11 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
       }
       STAMP(ts5);
       STAMP_ADD(4, ts2, ts5);
-      epilogue2(acc2, n, ty0, tx0);
+      epilogue2(acc2, n, vc);
+      if (do_p) {
+        p_feat(accp, 2, vc);                          // f4
+        p_store(accp, n);
+      }
       STAMP(ts6);
       STAMP_ADD(5, ts5, ts6);
     }
@@ -574,6 +639,33 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
     o[7] = tk1 - tk0;
   }
 #endif
+}
+
+// y1 = x1 +- (b5 + conv5 of F) from the partial products of the two pairs: out[t] = sum over pairs of
+// P[t-1][tap 0] + P[t][tap 1] + P[t+1][tap 2], zero outside the clip (Subnet_constructor.py:130, Inv_arch.py:25,31).
+__global__ __launch_bounds__(256) void f_couple_kernel(const float* __restrict__ pf, const float* __restrict__ bias, float* __restrict__ x1,
+                                                       const int N, const int T, const int HW, const float sgn) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, npx = (size_t)N * HW;
+  if (i >= npx) return;
+  const int t = (int)(i / HW) % T;
+  float4 o = make_float4(bias[0], bias[1], bias[2], 0.f);
+#pragma unroll
+  for (int pair = 0; pair < 2; ++pair) {          // pf[pair][tap][N][H][W][4]
+    const float4* p = reinterpret_cast<const float4*>(pf) + (size_t)pair * 3 * npx + i;
+    const float4 q1 = p[npx];
+    o.x += q1.x; o.y += q1.y; o.z += q1.z;
+    if (t > 0) {
+      const float4 q = p[-(ptrdiff_t)HW];
+      o.x += q.x; o.y += q.y; o.z += q.z;
+    }
+    if (t + 1 < T) {
+      const float4 q = p[2 * npx + HW];
+      o.x += q.x; o.y += q.y; o.z += q.z;
+    }
+  }
+  float4 v = *reinterpret_cast<float4*>(x1 + i * 4);
+  v.x += sgn * o.x; v.y += sgn * o.y; v.z += sgn * o.z;
+  *reinterpret_cast<float4*>(x1 + i * 4) = v;
 }
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 1000; }
@@ -624,8 +716,13 @@ int launch_pair(FFArgs& a, int maxwg, hipStream_t s) {
 }  // namespace
 
 // conv1..conv4 of F (cin = 48) on its dense buffer: two launches.  w = [pair 0: 72 fragments][pair 1: 144 fragments].
-int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, int H, int W, hipStream_t s) {
+// With w5p (11 partial-product fragments), pf and x1 the temporal conv5 + coupling y1 = x1 +- F is done here as well:
+// the two launches emit the conv5 partial products and f_couple_kernel sums them (returns 1: conv5 handled).
+int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, int H, int W, hipStream_t s,
+                   const void* w5p, float* pf, const float* b5, float* x1, int T, int rev) {
   static const int maxwg = getenv("SELFC_FUSEDF_MAXWG") ? atoi(getenv("SELFC_FUSEDF_MAXWG")) : 256;
+  static const bool no_p = getenv("SELFC_NO_F5P") != nullptr;     // developer A/B switch
+  const bool with_p = w5p && pf && b5 && x1 && T > 0 && !no_p;
   FFArgs a{};
   a.dense = (f16*)dense;
   a.N = N; a.H = H; a.W = W;
@@ -633,14 +730,26 @@ int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, 
   a.tiles_y = (H + TS - 1) / TS;
   a.ntiles = a.tiles_x * a.tiles_y;
   a.plane = (size_t)N * H * W * 32;
-  ProfScope prof(PROF_CONV3X3, s);
-  a.w = (const f16*)w;
-  a.bias[0] = bias[0]; a.bias[1] = bias[1];
-  int rc = launch_pair<0>(a, maxwg > 0 ? maxwg : 256, s);
-  if (rc) return rc;
-  a.w = (const f16*)w + (size_t)Geo<0>::NFRAG * 512;
-  a.bias[0] = bias[2]; a.bias[1] = bias[3];
-  return launch_pair<1>(a, maxwg > 0 ? maxwg : 256, s);
+  {
+    ProfScope prof(PROF_CONV3X3, s);
+    a.w = (const f16*)w;
+    a.bias[0] = bias[0]; a.bias[1] = bias[1];
+    a.w5p = with_p ? (const f16*)w5p : nullptr;
+    a.pf = with_p ? pf : nullptr;
+    int rc = launch_pair<0>(a, maxwg > 0 ? maxwg : 256, s);
+    if (rc) return rc;
+    a.w = (const f16*)w + (size_t)Geo<0>::NFRAG * 512;
+    a.bias[0] = bias[2]; a.bias[1] = bias[3];
+    a.w5p = with_p ? (const f16*)w5p + (size_t)Geo<0>::NP * 512 : nullptr;
+    a.pf = with_p ? pf + (size_t)N * H * W * 12 : nullptr;
+    rc = launch_pair<1>(a, maxwg > 0 ? maxwg : 256, s);
+    if (rc || !with_p) return rc;
+  }
+  ProfScope prof(PROF_CONV5_F, s);
+  const size_t npx = (size_t)N * H * W;
+  hipLaunchKernelGGL(f_couple_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, pf, b5, x1, N, T, H * W, rev ? -1.f : 1.f);
+  const int rc = hip_rc(hipGetLastError());
+  return rc ? rc : 1;
 }
 
 }  // namespace selfc

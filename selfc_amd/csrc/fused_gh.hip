@@ -68,7 +68,6 @@ template <> struct FeatGeom<3> { static constexpr int off = OFF_F3, pitch = P3; 
 
 // fragment offsets of the fused stream: per conv [im2col48: 3][feature j: 18 each]
 constexpr int LAYER_OFF[5] = {0, 0, 3, 24, 63};
-constexpr int STREAM_FRAGS = 120;
 
 #ifdef SELFC_STAMPS
 #define STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")

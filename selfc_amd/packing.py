@@ -224,6 +224,20 @@ def pack_fused_f(weights: Sequence[torch.Tensor], cin: int = 48) -> torch.Tensor
     return _operand(res)
 
 
+def pack_f5_partial(w5: torch.Tensor, cin: int = 48) -> torch.Tensor:
+    """Temporal conv5 of F (cout, cin + 128, 3, 1, 1), cout <= 3, as the A fragments of the conv5 partial products the
+    fused F launches emit (csrc/fused_f.hip): row = 4 tap + oc (rows 0-2, 4-6, 8-10 of 32 used), one 32x32x16 fragment per 16 input
+    channels in the reference's concat order [x2 | f1 | f2 | f3 | f4] -> f16 [(cin + 128) / 16, 64, 8]."""
+    w = w5.detach().float()
+    cout, ctot = w.shape[0], w.shape[1]
+    assert w.shape[2:] == (3, 1, 1) and cout <= 3 and ctot == cin + 128 and ctot % 16 == 0, tuple(w.shape)
+    wk = torch.zeros(32, ctot, dtype=torch.float32, device=w.device)
+    for tap in range(3):
+        wk[tap * 4: tap * 4 + cout] = w[:, :, tap, 0, 0]
+    nfrag = ctot // 16
+    return _operand(wk.reshape(32, nfrag, 2, 8).permute(1, 2, 0, 3).reshape(nfrag, 64, 8))
+
+
 def pack_conv_planes(weight: torch.Tensor, cin: int) -> torch.Tensor:
     """Conv3d weight (cout, cin + 128*j, kt, 3, 3), kt in {1, 3}, of a FeatureCalapseBlock-style dense block
     (inputs first, then 128-channel features) -> f16 [cout/32, nstages*18, 64, 8] for selfc_conv_planes_run.
@@ -408,6 +422,8 @@ def subnet_pack_entries(prefix: str, weights: Sequence[torch.Tensor], biases: Se
         e[f"{prefix}wfused"] = (pack_fused_gh(list(weights[:4]), 3), "w")
     if cin == 48:
         e[f"{prefix}wfused"] = (pack_fused_f(list(weights[:4]), 48), "w")
+        if temporal and cout <= 3:
+            e[f"{prefix}w5p"] = (pack_f5_partial(weights[4], 48), "w")
     if with_bwd and cout <= 96:
         wt5, wtd, wtx = pack_subnet_bwd(weights, cin, cout, temporal)
         e[f"{prefix}wt5"] = (wt5, "w")

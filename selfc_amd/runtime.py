@@ -49,6 +49,8 @@ class Workspace:
         self.fd = torch.zeros((self.FC // 32, N, H, W, 32), dtype=f16, device=device)
         self.gd = mk((4, N, H, W, 32), dtype=f16, device=device)
         self.hd = mk((4, N, H, W, 32), dtype=f16, device=device)
+        # F conv5 partial products of the pairwise-fused F launches (every in-frame element is rewritten by each block call)
+        self.pf = torch.empty((2, N, H, W, 12), dtype=f32, device=device) if c2 == 48 else None
         self.s: Optional[torch.Tensor] = None
         self.device = device
 
@@ -57,10 +59,10 @@ class Workspace:
             self.s = torch.empty((self.N, self.H, self.W, self.c2p), dtype=torch.float32, device=self.device)
         return _lib.Latent(self.kind, self.N, self.T, self.H, self.W, self.c1, self.c2,
                            _ptr(self.x1), _ptr(self.x2), _ptr(self.fd), _ptr(self.gd), _ptr(self.hd),
-                           _ptr(self.s) if want_s else None)
+                           _ptr(self.s) if want_s else None, _ptr(self.pf))
 
     def nbytes(self) -> int:
-        ts = [self.x1, self.x2, self.fd, self.gd, self.hd] + ([self.s] if self.s is not None else [])
+        ts = [self.x1, self.x2, self.fd, self.gd, self.hd] + [t for t in (self.s, self.pf) if t is not None]
         return sum(t.numel() * t.element_size() for t in ts)
 
 
@@ -99,6 +101,7 @@ class PackedSubnet:
         self.b3 = [d[f"{prefix}b3_{i}"] for i in range(4)]
         self.w5, self.b5 = d[f"{prefix}w5"], d[f"{prefix}b5"]
         self.wfused = d.get(f"{prefix}wfused")
+        self.w5p = d.get(f"{prefix}w5p")
         self.wt5 = d.get(f"{prefix}wt5")
         self.wtd = [d.get(f"{prefix}wtd_{i}") for i in range(3)]
         self.wtx = d.get(f"{prefix}wtx")
@@ -113,6 +116,7 @@ class PackedSubnet:
             s.w5 = _ptr(self.w5)
             s.b5 = _ptr(self.b5)
             s.wfused = _ptr(self.wfused)
+            s.w5p = _ptr(self.w5p)
             self._struct = s
         return s
 

@@ -226,6 +226,28 @@ def test_pack_fused_f_stream(pair):
     assert torch.allclose(out_b, ref_b, atol=1e-4, rtol=1e-4)
 
 
+def test_pack_f5_partial():
+    """conv5 partial products of the fused F launches: rows 4 tap + oc, one fragment per 16 channels of [x2 | f1..f4];
+    summing P[t-1][tap 0] + P[t][tap 1] + P[t+1][tap 2] reproduces the temporal conv5 (Subnet_constructor.py:106,130)."""
+    g = torch.Generator().manual_seed(91)
+    w5 = torch.randn(3, 176, 3, 1, 1, generator=g) * 0.1
+    fr = P.pack_f5_partial(w5, 48)
+    assert fr.shape == (11, 64, 8)
+    wk = unpack_a32(fr)                                        # (32, 176)
+    assert torch.count_nonzero(wk[11:]) == 0 and torch.count_nonzero(wk[3::4]) == 0
+    d = torch.randn(1, 176, 5, 4, 3, generator=g)              # (b, C, T, h, w)
+    ref = F.conv3d(d, w5.half().float(), None, 1, (1, 0, 0))   # (1, 3, 5, 4, 3)
+    pp = torch.einsum("rc,bcthw->brthw", wk[:12], d)           # (1, 12, T, h, w)
+    out = torch.zeros_like(ref)
+    for t in range(5):
+        out[:, :, t] += pp[:, 4:7, t]
+        if t > 0:
+            out[:, :, t] += pp[:, 0:3, t - 1]
+        if t + 1 < 5:
+            out[:, :, t] += pp[:, 8:11, t + 1]
+    assert torch.allclose(out, ref, atol=1e-4, rtol=1e-4)
+
+
 @pytest.mark.parametrize("cin,nfeat,kt,cout", [(48, 0, 3, 128), (48, 2, 1, 128), (192, 4, 3, 64)])
 def test_pack_conv_planes(cin, nfeat, kt, cout):
     """generic plane-list conv (FeatureCalapseBlock): K order = temporal tap, plane, spatial tap, 32 channels."""
