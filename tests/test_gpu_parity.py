@@ -213,6 +213,49 @@ def test_large_vs_oracle_ragged_sizes(dev, b, h, w):
     assert rel_err(xr.cpu(), O.large_inv_from_latent(g, z_ref, T)) < TOL
 
 
+_CHILD = """
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/tests')
+from conftest import load_golden
+from selfc_amd import GlobalVar
+GlobalVar.set_Temporal_LEN(7)
+from test_gpu_parity import _large_net
+dev = torch.device('cuda:0')
+g = load_golden('g8_large_stack')
+net = _large_net(dev, g)
+x = torch.rand(14, 3, 72, 100, generator=torch.Generator().manual_seed(77))
+with torch.no_grad():
+    z, _ = net(x=x.to(dev), rev=False)
+    xr = net.inverse_from_latent(z)
+np.savez(sys.argv[2], z=z.cpu().numpy(), xr=xr.cpu().numpy())
+"""
+
+
+@pytest.mark.parametrize("switch", ["SELFC_NO_FUSE_F", "SELFC_NO_F5P"])
+def test_fused_f_paths_agree_with_layerwise_path(dev, tmp_path, switch):
+    """F's conv1-4 as two pairwise-fused launches (csrc/fused_f.hip) and its conv5 as partial products, against the
+    layer-wise conv3x3 / temporal-conv5 kernels run in a child process with the developer switch set: same f16 operands,
+    different fp32 summation order (which flips some f16 roundings of the features): the two paths are each within
+    ~3.5e-4 of the fp32 oracle and must agree with each other inside the parity tolerance.  Ragged size (18 x 25 latent)."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "child.npz")
+    env = dict(os.environ, **{switch: "1"})
+    subprocess.run([sys.executable, "-c", _CHILD, root, out], check=True, env=env, timeout=300)
+    g = load_golden("g8_large_stack")
+    net = _large_net(dev, g)
+    x = torch.rand(14, 3, 72, 100, generator=torch.Generator().manual_seed(77))
+    with torch.no_grad():
+        z, _ = net(x=x.to(dev), rev=False)
+        xr = net.inverse_from_latent(z)
+    with np.load(out) as c:
+        assert rel_err(z.cpu(), torch.from_numpy(c["z"])) < 6e-4
+        assert rel_err(xr.cpu(), torch.from_numpy(c["xr"])) < TOL
+
+
 def test_temporal_len_one_and_clip_isolation(dev):
     """T=1 (every frame its own clip: temporal taps see only zero padding) and clip isolation."""
     from selfc_amd import GlobalVar
