@@ -685,14 +685,19 @@ __global__ __launch_bounds__(t5_waves<EPI>() * 64) void tconv5_kernel(const T5Ar
           const float4 xv = xrow[o];
           const float xin[4] = {xv.x, xv.y, xv.z, xv.w};
           const float gb[4] = {bg.x, bg.y, bg.z, bg.w}, hb[4] = {bh.x, bh.y, bh.z, bh.w};
+          // s = clamp (2 sigmoid(h) - 1); y2 = x2 e^s + g  /  (x2 - g) e^-s  (Inv_arch.py:26-27,29-30) on the hardware
+          // exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp; the libm expf + IEEE divisions were ~45 VALU instructions
+          // per element and a third of this kernel's time); rev is folded into the exponent's sign, no division.
           float yo[4], so[4];
+          const float esgn = a.rev ? -1.44269504f : 1.44269504f;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float gv = acc[0][o][j] + gb[j];
             const float hv = acc[NETS - 1][o][j] + hb[j];
-            const float s = a.clamp * (2.f / (1.f + expf(-hv)) - 1.f);
+            const float s = a.clamp * (2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504f * hv)) - 1.f);
             so[j] = s;
-            yo[j] = a.rev ? (xin[j] - gv) / expf(s) : xin[j] * expf(s) + gv;
+            const float es = __builtin_amdgcn_exp2f(esgn * s);
+            yo[j] = a.rev ? (xin[j] - gv) * es : xin[j] * es + gv;
           }
           *reinterpret_cast<float4*>(a.x2io + pix * a.c2p + oc) = make_float4(yo[0], yo[1], yo[2], yo[3]);
           if (a.s_out) *reinterpret_cast<float4*>(a.s_out + pix * a.c2p + oc) = make_float4(so[0], so[1], so[2], so[3]);
@@ -709,8 +714,12 @@ __global__ __launch_bounds__(t5_waves<EPI>() * 64) void tconv5_kernel(const T5Ar
 
   load_frame(bcur, xcur, 0);
   for (int t = 0; t < a.T; ++t) {
-    if (t + 1 < a.T) load_frame(bnxt, xnxt, t + 1);
+    // x2 rows of the epilogue first: the VM counter retires loads in issue order, so waiting for these (at the
+    // epilogue) must not mean waiting for the younger loads of frame t+1 as well - those stay in flight through
+    // the epilogue and into the next iteration
     if (t >= 1) prefetch_x2(t - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < a.T) load_frame(bnxt, xnxt, t + 1);
 #pragma unroll
     for (int q = 0; q < NETS; ++q) {
 #pragma unroll

@@ -48,7 +48,7 @@ constexpr int TS = 16;
 constexpr int XS = TS + 8;                 // X halo side (24)
 constexpr int XPITCH = XS * 8;             // bytes
 constexpr int X_BYTES = XS * XPITCH;       // 4608
-constexpr int P1 = 1792, P2 = 1792, P3 = 1536;                       // LDS row pitch of F1..F3 (bytes, multiples of 256)
+constexpr int P1 = 1856, P2 = 1696, P3 = 1536;                       // LDS row pitch of F1..F3 (bytes): pitch/16 = 5 R (mod 16) for the region width R of the image's busiest reader (conv2: 20, conv3: 18, conv4: 16), so a linearly enumerated M-tile stays on distinct 16-byte slots across a row wrap
 constexpr int F1_BYTES = 22 * P1, F2_BYTES = 20 * P2, F3_BYTES = 18 * P3;
 constexpr int WCH = 21;                    // fragments per weight chunk buffer
 constexpr int W_BYTES = WCH * 1024;
