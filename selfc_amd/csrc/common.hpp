@@ -30,8 +30,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // different slots.
 constexpr int PS = 80;
 
-// LeakyReLU(0.2) = max(v, 0.2 v): two VALU ops (0.2f*v rounds exactly as in v >= 0 ? v : 0.2f*v)
-__device__ __forceinline__ float lrelu02(float v) { return fmaxf(v, 0.2f * v); }
+// LeakyReLU(0.2) = max(v, 0.2 v): two VALU ops (0.2f*v rounds exactly as in v >= 0 ? v : 0.2f*v).  The max is emitted
+// directly: fmaxf() first canonicalises its operand (a second v_max_f32 v, v, v per element - a third of the epilogue's
+// arithmetic); accumulators of finite f16 products are never signalling NaNs.
+__device__ __forceinline__ float lrelu02(float v) {
+  const float m = 0.2f * v;
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(m));
+  return r;
+}
 
 // MI355X deals consecutive workgroup ids round-robin over its 8 XCDs (private
 // L2 each).  Remap so that each XCD receives a CONTIGUOUS range of logical tile

@@ -237,19 +237,19 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
           rr[g][0] = pack2(lrelu02(acc[m][4 * g + 0]), lrelu02(acc[m][4 * g + 1]));
           rr[g][1] = pack2(lrelu02(acc[m][4 * g + 2]), lrelu02(acc[m][4 * g + 3]));
         }
-        if (border) {   // features outside the image are the next conv's zero padding
-          const uint32_t keep = inimg ? 0xffffffffu : 0u;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) { rr[g][0] &= keep; rr[g][1] &= keep; }
-        }
+        // features outside the image are the next conv's zero padding: one AND per packed dword, applied after the
+        // half swap (lanes l and l + 32 hold the same pixel); laundered so that it stays an AND on the 8 packed
+        // dwords instead of 16 selects on the floats in front of the conversion
+        uint32_t keep = (border && !inimg) ? 0u : 0xffffffffu;
+        asm volatile("" : "+v"(keep));
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) {
           u32x4 v;
 #pragma unroll
           for (int d = 0; d < 2; ++d) {
             const auto sw = __builtin_amdgcn_permlane32_swap(rr[2 * gp][d], rr[2 * gp + 1][d], false, false);
-            v[d] = sw[0];
-            v[2 + d] = sw[1];
+            v[d] = sw[0] & keep;
+            v[2 + d] = sw[1] & keep;
           }
           if (valid[m]) {
             if (K < 4) {
