@@ -175,9 +175,11 @@ def main():
                       "frac": round(tf / PEAK_F16_TFLOPS, 4), "traffic": None, "avg_launch_us": round(avg_ms * 1e3, 2),
                       "launches": cls_n[name], "flops_per_launch": fl, "ms_per_step": round(cls_ms[name] / args.steps, 3)}
     # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/README.md)
+    traffic_all = {}
     try:
         with open(os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")) as fh:
             traffic = json.load(fh)
+        traffic_all = traffic
         if f_scopes == 1 and "fused_f" in traffic:
             traffic["conv3x3"] = traffic["fused_f"]
         for k in kern:
@@ -186,6 +188,18 @@ def main():
                 kern[k]["traffic_source"] = "profiles/r1/pmc_traffic.json (rocprofv3 --pmc passes of this workload, not re-measured in this run)"
     except (OSError, ValueError):
         pass
+    # HBM-bound kernel of the path: temporal conv5 of G+H with the affine coupling fused (tconv5_kernel<2,3,4,1,3>):
+    # algorithmic bytes per LR pixel-frame = 2 x 128 f16 features + 12 B y1 + 192 B x2 in, 192 B y2 + 96 B f16 copy out
+    if cls_n.get("conv5_GH", 0):
+        by = 1004.0 * npx
+        avg_ms = cls_ms["conv5_GH"] / cls_n["conv5_GH"]
+        gbs = by / (avg_ms * 1e-3) / 1e9
+        kern["conv5_GH"] = {"bound": "hbm", "kernel": "tconv5_kernel<2,3,4,1,3> (temporal conv5 of G+H + affine coupling)", "achieved": round(gbs, 1),
+                            "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": None, "avg_launch_us": round(avg_ms * 1e3, 2),
+                            "launches": cls_n["conv5_GH"], "bytes_per_launch": by, "ms_per_step": round(cls_ms["conv5_GH"] / args.steps, 3)}
+        if "conv5_GH" in traffic_all:
+            kern["conv5_GH"]["traffic"] = traffic_all["conv5_GH"]["hbm_bytes_per_launch"]
+            kern["conv5_GH"]["traffic_source"] = "profiles/r1/pmc_traffic.json"
     dominant = max(kern, key=lambda k: kern[k]["ms_per_step"])
     roofline = kern[dominant]
     sept = B_PER_GPU * world * args.steps
@@ -208,6 +222,8 @@ def main():
         "stack_roofline": {"mfma_frac": round(whole_flops * args.steps / dt / 1e12 / PEAK_F16_TFLOPS, 4),
                            "hbm_frac_layer_granular": round(2 * 8 * 1815 * 2 * npx * args.steps / dt / 8.0e12, 4),
                            "hbm_peak_GBps": 8000, "bytes_model": "2*8*1815 f16 elements per LR pixel-frame (SURVEY 8d)"},
+        # eager, one stream, HIP events around every launch: conv3x3 = conv1-4 of F, conv5_F = conv5 of F + coupling
+        # (f_couple_kernel on the fused path), fused_gh = conv1-4 of G+H, conv5_GH = conv5 of G+H + coupling
         "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in cls_ms.items()},
     }
     if not args.no_full_path and world == 1:
