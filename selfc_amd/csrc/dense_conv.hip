@@ -714,6 +714,9 @@ __global__ __launch_bounds__(t5_waves<EPI>() * 64) void tconv5_kernel(const T5Ar
 
   load_frame(bcur, xcur, 0);
   for (int t = 0; t < a.T; ++t) {
+    // (Measured and dropped: a THREE-frame register ring - biases in LDS, A fragments three at a time, SGPR-base
+    // addressing to make room - i.e. two frames of loads in flight per wave: 0.65 -> 0.72 ms per step.  At ~5 TB/s the
+    // kernel is no longer short of bytes in flight.)
     // x2 rows of the epilogue first: the VM counter retires loads in issue order, so waiting for these (at the
     // epilogue) must not mean waiting for the younger loads of frame t+1 as well - those stay in flight through
     // the epilogue and into the next iteration
