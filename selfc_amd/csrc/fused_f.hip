@@ -48,6 +48,7 @@ struct FFArgs {
 namespace {
 
 constexpr int TS = 16, IS = 20, FS = 18;
+static_assert(IS == 20, "x_store_item_from divides by IS with a 16-bit reciprocal");
 constexpr int NWAVE = 8, NTHR = NWAVE * 64;
 constexpr int NRING = FS * FS - TS * TS;          // 68 ring pixels
 constexpr int CHF = 18;                           // fragments per streamed weight chunk
@@ -279,10 +280,15 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
     int tidl = c.tid;
     asm volatile("" : "+v"(tidl));
     const bool mb = part == 0 && it >= 4;
-    const int i = tidl + (mb ? it - 4 : it) * NTHR;
-    const int p = mb ? i >> 1 : i >> 2, piece = mb ? i & 1 : i & 3;
-    const int hy = p / IS, hx = p - hy * IS;
-    const int loff = hy * G::ROWP + hx * G::PITCH + piece * 16 + (mb ? 64 : part == 0 ? 0 : part == 1 ? 96 : 160);
+    // 24-bit multiplies only (full rate; v_mul_lo / v_mul_hi / 64-bit mads are quarter rate and made these steps
+    // VALU-bound): p / 20 = (p * 3277) >> 16 for p < 16384
+    const unsigned i = (unsigned)tidl + (unsigned)((mb ? it - 4 : it) * NTHR);
+    const unsigned p = mb ? i >> 1 : i >> 2, piece = mb ? i & 1u : i & 3u;
+    const unsigned hy = __umul24(p, 3277u) >> 16;
+    unsigned hx;      // p - 20 hy as ONE full-rate v_mad_i32_i24 (hipcc turns every C spelling of it into a quarter-rate 64-bit mad)
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(hx) : "v"(hy), "s"(-IS), "v"(p));
+    const unsigned loff = __umul24(hy, (unsigned)G::ROWP) + __umul24(hx, (unsigned)G::PITCH) + piece * 16u +
+                          (mb ? 64u : part == 0 ? 0u : part == 1 ? 96u : 160u);
     if (((mb ? okB >> (it - 4) : okA >> it) & 1u)) *reinterpret_cast<u32x4*>(smem + G::OFF_IMG + loff) = v[it];
   };
   auto x_load_item = [&](const int part, const int it) __attribute__((always_inline)) { x_load_item_to(part, it, xv); };
@@ -511,7 +517,11 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
     constexpr int NCHUNK = G::NFRAG / CH3;   // 12
 
     for (int n = f0; n < a.N; n += gf) {
+#ifdef SELFC_EXP_NOX        // timing experiment only (results are wrong): what do the halo loads / stores cost?
+      const bool more = false;
+#else
       const bool more = n + gf < a.N;
+#endif
       STAMP(ts0);
       if (more) x_target(n + gf);
       f32x16 acc1c = bias_init(lb, c.half), acc1r = acc1c, acc2 = bias_init(lb + 32, c.half);
