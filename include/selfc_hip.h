@@ -242,6 +242,13 @@ int selfc_pwconv_run(const void* in, int in_is_f32, void* out, int out_is_f32, c
  * reference's (hf_dim, K, 3) order, eps fp32 [npix][hf_dim*K]; v fp32 [npix][hf_dim] (= the x2 latent
  * layout).  pi = softmax over the hf_dim axis, log-sigma clamped to [-7,7].  hf_dim = 48, K in {1,3,5}. */
 int selfc_gmm_sample(const float* raw, const float* eps, float* v, size_t npix, int hf_dim, int K, void* stream);
+/* The last head layer (Conv3d 1x1x1, cin = 256 -> hf_dim*K*3) and the GMM sample in one kernel (sampling path of
+ * SelfC_GMM_arch_inv.py:371-394: the 720-channel head output is never written).  `in`: f16 rows [npix][cin];
+ * w / bias: that conv packed by packing.py:pack_pointwise after the channel permutation of packing.py:gmm_head_perm
+ * (new channel (3 k + j) * hf_dim + c = reference channel (c*K + k)*3 + j); eps: fp32 rows [npix][k * hf_dim + c];
+ * v: fp32 rows of stride v_stride.  hf_dim = 48, K = 5, cin = 256. */
+int selfc_pwconv_gmm(const void* in, const void* w, const float* bias, const float* eps, float* v, size_t npix, int cin,
+                     int hf_dim, int K, int v_stride, void* stream);
 
 /* ---- live kernel timing (bench.py roofline leg) ------------------------------
  * HIP events are recorded on the launch stream around every kernel launch while

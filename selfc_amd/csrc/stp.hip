@@ -245,6 +245,130 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const void* __restrict__ in
   }
 }
 
+// ---- last head layer + GMM sample in one kernel (SelfC_GMM_arch_inv.py:371-394, eval / sampling path) -----------------
+// The unfused pair writes and re-reads the 720-channel head output (578 MB fp32 at 4 x 7 x 64 x 112 pixels).  Here the
+// last 1x1x1 conv's output channels are PERMUTED at packing time to [k][pi | log-sigma | mu][c] (group g = 3 k + j of
+// 48 channels = 3 MFMA tiles), so that for each mixture component k the softmax over the hf axis c, the clamp / exp of
+// log-sigma and the weighted sum all happen on the accumulators: lane (pixel = lane & 15, kq = lane >> 4) owns
+// c = 16 i + 4 kq + e of tile i; the softmax's max / sum cross the four kq lane groups by two xor shuffles.
+// eps rows are [px][k * 48 + c] (k-major, unlike selfc_gmm_sample's c-major rows); v rows have stride vstride.
+template <int KS, int K>
+__global__ __launch_bounds__(256) void pwconv_gmm_kernel(const f16* __restrict__ in, const f16* __restrict__ w, const float* __restrict__ bias,
+                                                         const float* __restrict__ eps, float* __restrict__ v, size_t npix, int cin, int vstride) {
+  constexpr int MT = 2, HF = 48, TI = HF / 16;
+  constexpr int OTB = 64 / KS;                       // output tiles per 64-KiB LDS block of fragments
+  constexpr int NT = 3 * K * TI;                     // 45 output tiles
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = lane >> 4;
+  const size_t p0 = ((size_t)blockIdx.x * 4 + wave) * (16 * MT);
+  f16x8 bf[MT][KS];
+  size_t pl[MT];
+  bool pv[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    pl[m] = p0 + m * 16 + (lane & 15);
+    pv[m] = pl[m] < npix;
+    const size_t pc = pv[m] ? pl[m] : npix - 1;
+    pl[m] = pc;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bf[m][ks] = *reinterpret_cast<const f16x8*>(in + pc * cin + ks * 32 + kq * 8);
+  }
+  f32x4 out[MT][TI], pi[MT][TI], sg[MT][TI];
+  float4 ep[MT][TI];
+  float mx[MT], inv[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < TI; ++i) out[m][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto tile = [&](const int gt, f32x4 (&acc)[MT]) __attribute__((always_inline)) {
+    if (gt % OTB == 0) {                             // next block of fragments (compile-time positions)
+      const int nt = (NT - gt) < OTB ? (NT - gt) : OTB;
+      __syncthreads();
+      const u32x4* src = reinterpret_cast<const u32x4*>(w) + (size_t)gt * KS * 64;
+      for (int i = tid; i < nt * KS * 64; i += 256) *reinterpret_cast<u32x4*>(smem + (size_t)i * 16) = src[i];
+      __syncthreads();
+    }
+    const int o = gt % OTB;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const f16x8 af = *reinterpret_cast<const f16x8*>(smem + ((size_t)(o * KS + ks) * 64 + lane) * 16);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = mfma_16x16x32(af, bf[m][ks], acc[m]);
+    }
+    const float4 bb = *reinterpret_cast<const float4*>(bias + gt * 16 + kq * 4);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { acc[m][0] += bb.x; acc[m][1] += bb.y; acc[m][2] += bb.z; acc[m][3] += bb.w; }
+  };
+
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < TI; ++i) ep[m][i] = *reinterpret_cast<const float4*>(eps + pl[m] * (HF * K) + k * HF + i * 16 + kq * 4);
+    // pi logits: softmax over the 48 values of c (per pixel)
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      f32x4 acc[MT];
+      tile((3 * k + 0) * TI + i, acc);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) pi[m][i] = acc[m];
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float a = pi[m][0][0];
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a = fmaxf(a, pi[m][i][e]);
+      a = fmaxf(a, __shfl_xor(a, 16, 64));
+      a = fmaxf(a, __shfl_xor(a, 32, 64));
+      mx[m] = a;
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pi[m][i][e] = __builtin_amdgcn_exp2f(1.44269504f * (pi[m][i][e] - a)); sum += pi[m][i][e]; }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      inv[m] = __builtin_amdgcn_rcpf(sum);
+    }
+    // log-sigma: clamp(-7, 7), exp
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      f32x4 acc[MT];
+      tile((3 * k + 1) * TI + i, acc);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sg[m][i][e] = __builtin_amdgcn_exp2f(1.44269504f * fminf(fmaxf(acc[m][e], -7.f), 7.f));
+    }
+    // mu: v[c] += pi (eps sigma + mu)
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      f32x4 acc[MT];
+      tile((3 * k + 2) * TI + i, acc);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float e4[4] = {ep[m][i].x, ep[m][i].y, ep[m][i].z, ep[m][i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[m][i][e] += (pi[m][i][e] * inv[m]) * (e4[e] * sg[m][i][e] + acc[m][e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    if (!pv[m]) continue;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+      *reinterpret_cast<float4*>(v + pl[m] * vstride + i * 16 + kq * 4) = make_float4(out[m][i][0], out[m][i][1], out[m][i][2], out[m][i][3]);
+  }
+}
+
 // ---- GMM sample (SelfC_GMM_arch_inv.py:382-394): raw[px][c*K*3 + k*3 + {pi-logit, log-sigma, mu}],
 // pi = softmax over the hf_dim axis c (per k), v[c] = sum_k pi (eps * exp(clamp(ls,-7,7)) + mu).
 // 16 lanes per pixel, lane j owns c in {j, j+16, j+32}.
@@ -698,6 +822,23 @@ int selfc_pwconv_run(const void* in, int in_is_f32, void* out, int out_is_f32, c
   SELFC_PW(1) SELFC_PW(2) SELFC_PW(4) SELFC_PW(8)
 #undef SELFC_PW
   return SELFC_EINVAL;
+}
+
+int selfc_pwconv_gmm(const void* in, const void* w, const float* bias, const float* eps, float* v, size_t npix, int cin,
+                     int hf_dim, int K, int v_stride, void* stream) {
+  if (!in || !w || !bias || !eps || !v || npix == 0 || hf_dim != 48 || K != 5 || cin != 256 || v_stride < hf_dim || (v_stride & 3)) return SELFC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int lds = 64 * 1024;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_gmm_kernel<8, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return hip_rc(e);
+    attr_done = true;
+  }
+  ProfScope prof(PROF_STP, s);
+  hipLaunchKernelGGL((pwconv_gmm_kernel<8, 5>), dim3((unsigned)((npix + 127) / 128)), dim3(256), lds, s, (const f16*)in, (const f16*)w, bias,
+                     eps, v, npix, cin, v_stride);
+  return hip_rc(hipGetLastError());
 }
 
 int selfc_gmm_sample(const float* raw, const float* eps, float* v, size_t npix, int hf_dim, int K, void* stream) {

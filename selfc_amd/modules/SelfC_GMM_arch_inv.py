@@ -185,6 +185,13 @@ class STPNet(nn.Module):
             from ..packing import pack_pointwise, pad_bias, roundup
             self._tail = [(pack_pointwise(m.weight), pad_bias(m.bias, roundup(m.out_channels, 16)), m.in_channels, m.out_channels)
                           for m in convs]
+            self._tail_fused = None
+            if self.fh_loss == "gmm" and len(convs) == 3 and self.hf_dim == 48 and self.K == 5 and convs[2].in_channels == 256:
+                # last layer with its output channels permuted to [k][pi | log-sigma | mu][c] for the fused head + sampler kernel
+                from ..packing import gmm_head_perm
+                perm = gmm_head_perm(self.hf_dim, self.K, convs[2].weight.device)
+                wl = convs[2].weight.detach().reshape(convs[2].out_channels, -1)[perm]
+                self._tail_fused = (pack_pointwise(wl), pad_bias(convs[2].bias.detach()[perm], roundup(convs[2].out_channels, 16)))
             self._tail_key = key
         return self._tail
 
@@ -229,20 +236,30 @@ class STPNet(nn.Module):
         if "h1" not in sc:
             sc["h1"] = torch.empty((npix, tail[0][3]), dtype=_lib.operand_dtype(), device=dev)
             sc["h2"] = torch.empty((npix, tail[1][3]), dtype=_lib.operand_dtype(), device=dev)
-            sc["raw"] = torch.empty((npix, tail[2][3]), dtype=torch.float32, device=dev)
         (w0, b0, ci0, co0), (w1_, b1_, ci1, co1), (w2_, b2_, ci2, co2) = tail
         # tail_gmm = [lrelu, conv, lrelu, conv, lrelu, conv]: each LeakyReLU is fused into the producer's epilogue
         rt.call("selfc_pwconv_run", feat.data_ptr(), 1, sc["h1"].data_ptr(), 0, w0.data_ptr(), b0.data_ptr(), npix, ci0, co0, co0, 1, 1, sp)
         rt.call("selfc_pwconv_run", sc["h1"].data_ptr(), 0, sc["h2"].data_ptr(), 0, w1_.data_ptr(), b1_.data_ptr(), npix, ci1, co1, co1, 0, 1, sp)
-        rt.call("selfc_pwconv_run", sc["h2"].data_ptr(), 0, sc["raw"].data_ptr(), 1, w2_.data_ptr(), b2_.data_ptr(), npix, ci2, co2, co2, 0, 0, sp)
+        fused = self._tail_fused is not None and not keep_raw       # sampling path: the 720-channel head output is never written
+        if not fused:
+            if "raw" not in sc:      # 720 fp32 channels per pixel-frame (578 MB at 4 x 7 x 64 x 112): only when somebody wants it
+                sc["raw"] = torch.empty((npix, tail[2][3]), dtype=torch.float32, device=dev)
+            rt.call("selfc_pwconv_run", sc["h2"].data_ptr(), 0, sc["raw"].data_ptr(), 1, w2_.data_ptr(), b2_.data_ptr(), npix, ci2, co2, co2, 0, 0, sp)
+        # noise rows: [npix][c*K + k] for selfc_gmm_sample, [npix][k*hf_dim + c] for the fused kernel
         if self.eps is not None:
             b = n // t
-            eps = self.eps.reshape(b, self.hf_dim, self.K, t, h, w).permute(0, 3, 4, 5, 1, 2).reshape(npix, self.hf_dim * self.K)
+            e6 = self.eps.reshape(b, self.hf_dim, self.K, t, h, w)
+            eps = (e6.permute(0, 3, 4, 5, 2, 1) if fused else e6.permute(0, 3, 4, 5, 1, 2)).reshape(npix, self.hf_dim * self.K)
             eps = eps.to(device=dev, dtype=torch.float32).contiguous()
         elif eps is not None:
             eps.normal_()
         else:
             eps = torch.randn((npix, self.hf_dim * self.K), dtype=torch.float32, device=dev)
+        if fused:
+            wf, bfz = self._tail_fused
+            rt.call("selfc_pwconv_gmm", sc["h2"].data_ptr(), wf.data_ptr(), bfz.data_ptr(), eps.data_ptr(), hf_out.data_ptr(),
+                    npix, ci2, self.hf_dim, self.K, hf_out.shape[-1], sp)
+            return None
         rt.call("selfc_gmm_sample", sc["raw"].data_ptr(), eps.data_ptr(), hf_out.data_ptr(), npix, self.hf_dim, self.K, sp)
         return sc["raw"] if keep_raw else None
 

@@ -132,6 +132,14 @@ def pack_pointwise(weight: torch.Tensor) -> torch.Tensor:
     return _operand(frag)
 
 
+def gmm_head_perm(hf_dim: int, K: int, device=None) -> torch.Tensor:
+    """Output-channel permutation of the GMM head's last conv for the fused head + sampler kernel (stp.hip:
+    pwconv_gmm_kernel): new channel (3 k + j) * hf_dim + c  <-  reference channel (c * K + k) * 3 + j
+    (SelfC_GMM_arch_inv.py:382-386: parameters viewed as (hf_dim, K, 3))."""
+    k, j, c = torch.meshgrid(torch.arange(K), torch.arange(3), torch.arange(hf_dim), indexing="ij")
+    return ((c * K + k) * 3 + j).reshape(-1).to(device)
+
+
 def pool_weight_map(fc_weight: torch.Tensor, h: int, w: int) -> torch.Tensor:
     """Fold ``fc(adaptive_avg_pool2d(x, (32,32)).flatten())`` (SelfC_GMM_arch_inv.py:269-271) into one
     (h*w,) map: g = sum_px x[px] * wmap[px] + fc.bias.  adaptive_avg_pool2d bin i covers

@@ -169,6 +169,26 @@ def test_stp_gmm_injected_eps(dev):
     assert rel_err(v.cpu(), g["v"]) < 2e-3
 
 
+def test_stp_gmm_fused_head_and_sampler(dev):
+    """sampling path of SelfCModel.test(): the last head layer and the GMM sample run as ONE kernel (selfc_pwconv_gmm,
+    output channels permuted to [k][pi | log-sigma | mu][c]) - same golden sample as the unfused pair."""
+    from selfc_amd.modules.SelfC_GMM_arch_inv import STPNet
+    g = load_golden("g7_stp_gmm")
+    stp = STPNet(dict(OPT, fh_loss="gmm"))
+    stp.load_state_dict({k: v for k, v in g.items() if k.split(".")[0] in
+                         ("local_m1", "local_m2", "global_m1", "global_m2", "other_stp_modules", "tail_gmm")}, strict=True)
+    stp.to(dev).eval()
+    stp.eps = g["eps"].permute(1, 2, 0, 3, 4).unsqueeze(0).to(dev)        # (1,48,5,T,h,w)
+    lr = g["lr"].to(dev).reshape(T, 3, 8, 12)
+    x1 = torch.zeros(T, 8, 12, 4, device=dev)
+    x1[..., :3] = lr.permute(0, 2, 3, 1)
+    hf = torch.zeros(T, 8, 12, 48, device=dev)
+    with torch.no_grad():
+        raw = stp.run_nhwc(x1, hf, T, T, 8, 12)
+    assert raw is None and stp._tail_fused is not None
+    assert rel_err(hf.permute(0, 3, 1, 2).cpu(), g["v"]) < 2e-3
+
+
 def test_globalagg(dev):
     from selfc_amd.modules.SelfC_GMM_arch_inv import GlobalAgg
     g = load_golden("g6_globalagg")
