@@ -252,8 +252,10 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const void* __restrict__ in
 // log-sigma and the weighted sum all happen on the accumulators: lane (pixel = lane & 15, kq = lane >> 4) owns
 // c = 16 i + 4 kq + e of tile i; the softmax's max / sum cross the four kq lane groups by two xor shuffles.
 // eps rows are [px][k * 48 + c] (k-major, unlike selfc_gmm_sample's c-major rows); v rows have stride vstride.
-template <int KS, int K>
-__global__ __launch_bounds__(256) void pwconv_gmm_kernel(const f16* __restrict__ in, const f16* __restrict__ w, const float* __restrict__ bias,
+// NW waves x 2 pixel tiles of 16 per workgroup: every workgroup streams all 360 KiB of weight fragments through LDS, so
+// the L2 -> LDS weight traffic is inversely proportional to the pixels per workgroup (4 waves: 564 MB per call, 421 us).
+template <int KS, int K, int NW>
+__global__ __launch_bounds__(NW * 64) void pwconv_gmm_kernel(const f16* __restrict__ in, const f16* __restrict__ w, const float* __restrict__ bias,
                                                          const float* __restrict__ eps, float* __restrict__ v, size_t npix, int cin, int vstride) {
   constexpr int MT = 2, HF = 48, TI = HF / 16;
   constexpr int OTB = 64 / KS;                       // output tiles per 64-KiB LDS block of fragments
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void pwconv_gmm_kernel(const f16* __restrict__
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kq = lane >> 4;
-  const size_t p0 = ((size_t)blockIdx.x * 4 + wave) * (16 * MT);
+  const size_t p0 = ((size_t)blockIdx.x * NW + wave) * (16 * MT);
   f16x8 bf[MT][KS];
   size_t pl[MT];
   bool pv[MT];
@@ -283,14 +285,15 @@ __global__ __launch_bounds__(256) void pwconv_gmm_kernel(const f16* __restrict__
     for (int i = 0; i < TI; ++i) out[m][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto tile = [&](const int gt, f32x4 (&acc)[MT]) __attribute__((always_inline)) {
-    if (gt % OTB == 0) {                             // next block of fragments (compile-time positions)
+    if (gt % OTB == 0) {                             // next block of fragments (workgroup-uniform)
       const int nt = (NT - gt) < OTB ? (NT - gt) : OTB;
       __syncthreads();
       const u32x4* src = reinterpret_cast<const u32x4*>(w) + (size_t)gt * KS * 64;
-      for (int i = tid; i < nt * KS * 64; i += 256) *reinterpret_cast<u32x4*>(smem + (size_t)i * 16) = src[i];
+      for (int i = tid; i < nt * KS * 64; i += NW * 64) *reinterpret_cast<u32x4*>(smem + (size_t)i * 16) = src[i];
       __syncthreads();
     }
     const int o = gt % OTB;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -302,9 +305,12 @@ __global__ __launch_bounds__(256) void pwconv_gmm_kernel(const f16* __restrict__
     const float4 bb = *reinterpret_cast<const float4*>(bias + gt * 16 + kq * 4);
 #pragma unroll
     for (int m = 0; m < MT; ++m) { acc[m][0] += bb.x; acc[m][1] += bb.y; acc[m][2] += bb.z; acc[m][3] += bb.w; }
+    __builtin_amdgcn_sched_barrier(0);               // one tile at a time: the unrolled 45 tiles' reads hoisted together spilled 366 registers
   };
 
-#pragma unroll
+  // a real loop over the mixture components (fully unrolled, the 45 tiles' bias / noise loads were hoisted to the top
+  // and the input fragments lived in scratch)
+#pragma unroll 1
   for (int k = 0; k < K; ++k) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -828,16 +834,16 @@ int selfc_pwconv_gmm(const void* in, const void* w, const float* bias, const flo
                      int hf_dim, int K, int v_stride, void* stream) {
   if (!in || !w || !bias || !eps || !v || npix == 0 || hf_dim != 48 || K != 5 || cin != 256 || v_stride < hf_dim || (v_stride & 3)) return SELFC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  constexpr int lds = 64 * 1024;
+  constexpr int lds = 64 * 1024, GMM_NW = 8;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_gmm_kernel<8, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_gmm_kernel<8, 5, GMM_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return hip_rc(e);
     attr_done = true;
   }
   ProfScope prof(PROF_STP, s);
-  hipLaunchKernelGGL((pwconv_gmm_kernel<8, 5>), dim3((unsigned)((npix + 127) / 128)), dim3(256), lds, s, (const f16*)in, (const f16*)w, bias,
-                     eps, v, npix, cin, v_stride);
+  hipLaunchKernelGGL((pwconv_gmm_kernel<8, 5, GMM_NW>), dim3((unsigned)((npix + GMM_NW * 32 - 1) / (GMM_NW * 32))), dim3(GMM_NW * 64), lds, s,
+                     (const f16*)in, (const f16*)w, bias, eps, v, npix, cin, v_stride);
   return hip_rc(hipGetLastError());
 }
 
