@@ -51,43 +51,52 @@ __global__ __launch_bounds__(256) void gagg_pool_kernel(const float* __restrict_
 }
 
 // ---- (2) per clip: g = sum(partials) + fc.bias; q = proj2(g), k = proj3(g); A = softmax(q k^T / 64, dim=-1)
-__global__ __launch_bounds__(64) void gagg_attn_kernel(const float* __restrict__ partial, int nchunk, const float* __restrict__ fcbp,
+// 256 threads per clip: the two 64x64 projection matrices go through LDS (coalesced loads, rows padded to 65 floats),
+// every (frame, channel) output has its own thread.  Summation orders are those of the first version (one 64-thread
+// workgroup walking its weight rows from global memory: 33 us per call for a few kFLOP).
+__global__ __launch_bounds__(256) void gagg_attn_kernel(const float* __restrict__ partial, int nchunk, const float* __restrict__ fcbp,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
                                                        const float* __restrict__ w3, const float* __restrict__ b3,
                                                        float* __restrict__ A, int T) {
-  __shared__ float g[TMAX][64], q[TMAX][64], k[TMAX][64], m[TMAX][TMAX];
-  const int b = blockIdx.x, c = threadIdx.x;
+  __shared__ float g[TMAX][64], q[TMAX][64], k[TMAX][64], m[TMAX][TMAX], w2s[64][65], w3s[64][65];
+  const int b = blockIdx.x, tid = threadIdx.x;
   const float fcb = *fcbp;
-  for (int t = 0; t < T; ++t) {
+  for (int i = tid; i < 64 * 64; i += 256) {
+    w2s[i >> 6][i & 63] = w2[i];
+    w3s[i >> 6][i & 63] = w3[i];
+  }
+  for (int i = tid; i < T * 64; i += 256) {
+    const int t = i >> 6, c = i & 63;
     float s = 0.f;
     const float* p = partial + (size_t)(b * T + t) * nchunk * 64 + c;
     for (int j = 0; j < nchunk; ++j) s += p[(size_t)j * 64];
     g[t][c] = s + fcb;
   }
   __syncthreads();
-  for (int t = 0; t < T; ++t) {
+  for (int i = tid; i < T * 64; i += 256) {
+    const int t = i >> 6, c = i & 63;
     float sq = b2[c], sk = b3[c];
     for (int j = 0; j < 64; ++j) {
-      sq += g[t][j] * w2[c * 64 + j];
-      sk += g[t][j] * w3[c * 64 + j];
+      sq += g[t][j] * w2s[c][j];
+      sk += g[t][j] * w3s[c][j];
     }
     q[t][c] = sq;
     k[t][c] = sk;
   }
   __syncthreads();
-  if (c < T * T) {
-    const int t1 = c / T, t2 = c % T;
+  if (tid < T * T) {
+    const int t1 = tid / T, t2 = tid % T;
     float s = 0.f;
     for (int j = 0; j < 64; ++j) s += q[t1][j] * k[t2][j];
     m[t1][t2] = s / 64.0f;
   }
   __syncthreads();
-  if (c < T) {            // softmax over the last axis of row c
-    float mx = m[c][0];
-    for (int j = 1; j < T; ++j) mx = fmaxf(mx, m[c][j]);
+  if (tid < T) {            // softmax over the last axis of row tid
+    float mx = m[tid][0];
+    for (int j = 1; j < T; ++j) mx = fmaxf(mx, m[tid][j]);
     float e[TMAX], s = 0.f;
-    for (int j = 0; j < T; ++j) { e[j] = expf(m[c][j] - mx); s += e[j]; }
-    for (int j = 0; j < T; ++j) A[((size_t)b * T + c) * T + j] = e[j] / s;
+    for (int j = 0; j < T; ++j) { e[j] = expf(m[tid][j] - mx); s += e[j]; }
+    for (int j = 0; j < T; ++j) A[((size_t)b * T + tid) * T + j] = e[j] / s;
   }
 }
 
@@ -796,7 +805,7 @@ int selfc_globalagg_run(const float* x, float* y, const float* wmap, const float
   if (rc) return rc;
   {
     ProfScope prof(PROF_STP, s);
-    hipLaunchKernelGGL(gagg_attn_kernel, dim3(B), dim3(64), 0, s, partial, nchunk, fc_bias, w2, b2, w3, b3, attn, T);
+    hipLaunchKernelGGL(gagg_attn_kernel, dim3(B), dim3(256), 0, s, partial, nchunk, fc_bias, w2, b2, w3, b3, attn, T);
   }
   rc = hip_rc(hipGetLastError());
   if (rc) return rc;
