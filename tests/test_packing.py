@@ -185,6 +185,17 @@ def test_pack_fused_gh_stream(layer):
     assert torch.allclose(out, ref, atol=1e-4, rtol=1e-4)
 
 
+def test_gmm_head_perm():
+    """output-channel permutation of the GMM head for the fused head + sampler kernel: new channel (3k + j)*48 + c holds the
+    reference's channel (c*K + k)*3 + j, i.e. `parameters.reshape(b, hf_dim, K, 3, ...)` (SelfC_GMM_arch_inv.py:382-386)."""
+    perm = P.gmm_head_perm(48, 5)
+    assert perm.shape == (720,) and sorted(perm.tolist()) == list(range(720))
+    raw = torch.arange(720.0)
+    p3 = raw.reshape(48, 5, 3)                       # [c][k][pi | log-sigma | mu]
+    new = raw[perm].reshape(5, 3, 48)                # [k][j][c]
+    assert torch.equal(new, p3.permute(1, 2, 0))
+
+
 @pytest.mark.parametrize("pair", [0, 1])
 def test_pack_fused_f_stream(pair):
     """pairwise-fused F stream of csrc/fused_f.hip: per pair [merged steps: (conv a, conv b) fragment pairs, source
