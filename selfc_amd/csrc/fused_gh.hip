@@ -58,6 +58,13 @@ constexpr int OFF_W = OFF_X + 2 * X_BYTES; // 2 buffers
 constexpr int OFF_B = OFF_W + 2 * W_BYTES; // biases of the four convs: 4 x 32 floats
 constexpr int FG_LDS = OFF_B + 512;
 static_assert(FG_LDS <= 160 * 1024, "LDS budget");
+#ifndef SELFC_RD1
+#define SELFC_RD1 3
+#endif
+#ifndef SELFC_RD2
+#define SELFC_RD2 3
+#endif
+constexpr int RD1 = SELFC_RD1, RD2 = SELFC_RD2;   // operand ring depths (one / two M-tiles per wave)
 constexpr int NWAVE = 8, NTHR = NWAVE * 64;   // 2 waves per SIMD: one wave's epilogue / LDS latency hides under the other's MFMAs
 constexpr int WITER = (WCH * 64 + NTHR - 1) / NTHR;   // 3
 
@@ -90,6 +97,9 @@ struct Ctx {
 
 template <int OFF, int NFR>
 __device__ __forceinline__ void w_prefetch(Ctx& c) {
+#ifdef SELFC_EXP_NOW        // timing experiment: no weight streaming
+  return;
+#endif
 #pragma unroll
   for (int it = 0; it < WITER; ++it) {
     const int i = min(c.tid + it * NTHR, NFR * 64 - 1);
@@ -98,6 +108,9 @@ __device__ __forceinline__ void w_prefetch(Ctx& c) {
 }
 template <int NFR>
 __device__ __forceinline__ void w_commit(Ctx& c) {
+#ifdef SELFC_EXP_NOW
+  return;
+#endif
   unsigned char* dst = c.smem + OFF_W + (c.par ^ 1) * W_BYTES;
 #pragma unroll
   for (int it = 0; it < WITER; ++it) {
@@ -106,31 +119,100 @@ __device__ __forceinline__ void w_commit(Ctx& c) {
   }
 }
 
+// ---- epilogue of conv K: bias is already in the accumulator; LeakyReLU, zero outside the image, f16 -> LDS feature image
+// (+ centre crop to HBM).  Split in PIECES so that the epilogues of conv2 / conv3 can be hung, a few instructions at a
+// time, behind the MFMA steps of the NEXT conv's first chunk (which reads only older features): piece p < 4 MT packs
+// 4 channels of M-tile p / 4, piece 4 MT + m swaps / masks / stores M-tile m.
+template <int K> struct ConvGeom {
+  static constexpr int R = TS + 2 * (4 - K), NPX = R * R, NTL = (NPX + 31) / 32, MT = (NTL + NWAVE - 1) / NWAVE;
+};
+template <int K>
+__device__ __forceinline__ void mtile_geom(const Ctx& c, const int m, int& r, int& cc, bool& valid) {
+  using G = ConvGeom<K>;
+  const int mt = c.wave + NWAVE * m;
+  const int q = mt * 32 + (c.lane & 31);
+  valid = (mt < G::NTL) & (q < G::NPX);
+  const int qc = min(q, G::NPX - 1);
+  r = qc / G::R;
+  cc = qc - r * G::R;
+}
+template <int K, int MT>
+__device__ __forceinline__ void epi_piece(const Ctx& c, const FGArgs& a, const int net, const size_t fofs, const int ty0, const int tx0,
+                                          const f32x16 (&acc)[MT], uint32_t (&rr)[MT][4][2], const int p) {
+#ifdef SELFC_EXP_NOEPI      // timing experiment: no epilogue at all
+  if (acc[0][0] == 123.456f) c.smem[0] = 1;
+  return;
+#endif
+  if (p < 4 * MT) {
+    const int m = p >> 2, g = p & 3;
+    rr[m][g][0] = pack2(lrelu02(acc[m][4 * g + 0]), lrelu02(acc[m][4 * g + 1]));
+    rr[m][g][1] = pack2(lrelu02(acc[m][4 * g + 2]), lrelu02(acc[m][4 * g + 3]));
+    return;
+  }
+  const int m = p - 4 * MT;
+  int r, cc;
+  bool valid;
+  mtile_geom<K>(c, m, r, cc, valid);
+  f16* __restrict__ dplane = a.dense[net] + (size_t)(K - 1) * a.plane;
+  // the region leaves the image only for tiles on the frame border (wave-uniform test)
+  const bool border = (ty0 - (4 - K) < 0) | (tx0 - (4 - K) < 0) | (ty0 + TS + (4 - K) > a.H) | (tx0 + TS + (4 - K) > a.W);
+  const int ar = r - (4 - K), ac = cc - (4 - K);
+  const int y = ty0 + ar, x = tx0 + ac;
+  const bool inimg = (y >= 0) & (y < a.H) & (x >= 0) & (x < a.W);
+  // features outside the image are the next conv's zero padding: one AND per packed dword, applied after the
+  // half swap (lanes l and l + 32 hold the same pixel); laundered so that it stays an AND on the 8 packed
+  // dwords instead of 16 selects on the floats in front of the conversion
+  uint32_t keep = (border && !inimg) ? 0u : 0xffffffffu;
+  asm volatile("" : "+v"(keep));
+#pragma unroll
+  for (int gp = 0; gp < 2; ++gp) {
+    u32x4 v;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(rr[m][2 * gp][d], rr[m][2 * gp + 1][d], false, false);
+      v[d] = sw[0] & keep;
+      v[2 + d] = sw[1] & keep;
+    }
+    if (valid) {
+#ifndef SELFC_EXP_NOLST      // timing experiment: no feature stores to LDS
+      if (K < 4) {
+        constexpr int pitch = FeatGeom<(K < 4 ? K : 1)>::pitch;
+        *reinterpret_cast<u32x4*>(c.smem + FeatGeom<(K < 4 ? K : 1)>::off + r * pitch + cc * PS + (16 * gp + 8 * c.half) * 2) = v;
+      }
+#endif
+      const bool centre = (ar >= 0) & (ar < TS) & (ac >= 0) & (ac < TS);
+#ifndef SELFC_EXP_NOGST      // timing experiment: no feature stores to HBM
+      if (centre && inimg)
+        *reinterpret_cast<u32x4*>(dplane + fofs + (unsigned)((y * a.W + x) * 32 + 16 * gp + 8 * c.half)) = v;
+#endif
+    }
+  }
+}
+
+struct AccPair { f32x16 a[2]; };      // accumulators of conv2 / conv3 (2 M-tiles per wave) handed to the next conv
+
 // One 3x3 conv K (1..4) of the current tile.  NEXT_OFF/NEXT_N: the chunk that follows this conv's
 // last chunk in the stream (prefetched during that chunk).
+// prev: accumulators of conv K-1 whose epilogue is still pending (K = 3, 4): it runs, piece by piece, behind the MFMA
+// steps of this conv's first chunk (im2col + F1: neither reads what that epilogue writes).  out: K = 2, 3 leave their
+// accumulators there instead of running their epilogue.
 template <int K>
 __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int net, const int xbuf,
-                                           const size_t fofs, const int ty0, const int tx0) {
-  constexpr int R = TS + 2 * (4 - K);
-  constexpr int NPX = R * R;
-  constexpr int NTL = (NPX + 31) / 32;
-  constexpr int MT = (NTL + NWAVE - 1) / NWAVE;
+                                           const size_t fofs, const int ty0, const int tx0, AccPair* prev, AccPair* out) {
+  constexpr int MT = ConvGeom<K>::MT;
   constexpr int NCH = K == 1 ? 1 : K - 1;          // weight chunks of this conv: [im2col(+f1)], [f2], [f3]
+  constexpr bool DEFER = K == 2 || K == 3, PENDING = K == 3 || K == 4;
+  static_assert(!DEFER || MT == 2, "AccPair");
   unsigned char* const smem = c.smem;
 
   int r[MT], cc[MT];
   bool valid[MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int mt = c.wave + NWAVE * m;
-    const int q = mt * 32 + (c.lane & 31);
-    valid[m] = (mt < NTL) & (q < NPX);
-    const int qc = min(q, NPX - 1);
-    r[m] = qc / R;
-    cc[m] = qc - r[m] * R;
-  }
+  for (int m = 0; m < MT; ++m) mtile_geom<K>(c, m, r[m], cc[m], valid[m]);
   // accumulators start at the bias (row = outch (e&3) + 8*(e>>2) + 4*half), read from the LDS copy
-  f32x16 acc[MT];
+  f32x16 acc_local[DEFER ? 1 : MT];
+  f32x16 (&acc)[MT] = *reinterpret_cast<f32x16 (*)[MT]>(DEFER ? &out->a[0] : &acc_local[0]);
+  uint32_t prr[2][4][2];                            // packed halves of the pending epilogue (PENDING)
   {
     const float* bl = reinterpret_cast<const float*>(smem + OFF_B) + 32 * (K - 1) + 4 * c.half;
     f32x16 binit;
@@ -185,8 +267,11 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
       pb[m] = (r[m] + K - J - 1) * pitch + (cc[m] + K - J - 1) * PS + c.half * 16;
       xbase[m] = ((r[m] + K - 1) * XS + (cc[m] + K - 1)) * 8;
     }
-    f16x8 ringA[3];
-    f16x8 ringB[3][MT];
+    // ring depth: fragments are fetched RD-1 steps ahead.  A step is MT MFMAs = MT x 32 cycles of matrix pipe per wave, so
+    // conv4 (one M-tile per wave) needs a deeper ring than the others to cover the same LDS latency.
+    constexpr int RD = MT == 1 ? RD1 : RD2;
+    f16x8 ringA[RD];
+    f16x8 ringB[RD][MT];
     auto load_step = [&](const int st, f16x8& A, f16x8 (&B)[MT]) __attribute__((always_inline)) {
       A = *reinterpret_cast<const f16x8*>(wb + st * 1024);
       if (st < NIM) {
@@ -207,73 +292,55 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
     };
     STAMP(ts1);
     STAMP_ADD(0, ts0, ts1);
-    load_step(0, ringA[0], ringB[0]);
-    if (NS > 1) load_step(1, ringA[1], ringB[1]);
+#pragma unroll
+    for (int i = 0; i < RD - 1; ++i)
+      if (i < NS) load_step(i, ringA[i], ringB[i]);
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
-      if (st + 2 < NS) load_step(st + 2, ringA[(st + 2) % 3], ringB[(st + 2) % 3]);
+#ifndef SELFC_EXP_NOLDS
+      if (st + RD - 1 < NS) load_step(st + RD - 1, ringA[(st + RD - 1) % RD], ringB[(st + RD - 1) % RD]);
+#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
-        acc[m] = mfma_32x32x16(ringA[st % 3], ringB[st % 3][m], acc[m]);
+      for (int m = 0; m < MT; ++m) {
+#if defined(SELFC_EXP_NOMFMA)          // timing experiment: everything but the MFMAs
+        acc[m][0] += (float)ringA[st % RD][0] * (float)ringB[st % RD][m][0];
+#elif defined(SELFC_EXP_NOLDS)         // timing experiment: MFMAs on the first step's fragments only
+        acc[m] = mfma_32x32x16(ringA[0], ringB[0][m], acc[m]);
+#else
+        acc[m] = mfma_32x32x16(ringA[st % RD], ringB[st % RD][m], acc[m]);
+#endif
+      }
       __builtin_amdgcn_sched_barrier(0);
+      // the pending epilogue of conv K-1: one piece (ten-odd VALU instructions, or one M-tile's stores) per step
+      // (packs behind steps 1..8; then this chunk's weight hand-over, so that no wait on the VM counter follows the
+      // feature stores; then the two M-tiles' stores behind steps 9 and 10)
+      if (PENDING && ch == 0 && st >= 1 && st <= 10) epi_piece<(PENDING ? K - 1 : 1), 2>(c, a, net, fofs, ty0, tx0, prev->a, prr, st - 1);
+      if (PENDING && ch == 0 && st == 8) w_commit<18>(c);
     }
 
     STAMP(ts2);
     STAMP_ADD(1, ts1, ts2);
-    if (ch == NCH - 1) {
-      // ---- epilogue: bias + LeakyReLU, zero outside the image, f16 -> LDS feature image (+ HBM crop)
-      f16* __restrict__ dplane = a.dense[net] + (size_t)(K - 1) * a.plane;
-      // the region leaves the image only for tiles on the frame border (wave-uniform test)
-      const bool border = (ty0 - (4 - K) < 0) | (tx0 - (4 - K) < 0) | (ty0 + TS + (4 - K) > a.H) | (tx0 + TS + (4 - K) > a.W);
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int ar = r[m] - (4 - K), ac = cc[m] - (4 - K);
-        const int y = ty0 + ar, x = tx0 + ac;
-        const bool inimg = (y >= 0) & (y < a.H) & (x >= 0) & (x < a.W);
-        uint32_t rr[4][2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          rr[g][0] = pack2(lrelu02(acc[m][4 * g + 0]), lrelu02(acc[m][4 * g + 1]));
-          rr[g][1] = pack2(lrelu02(acc[m][4 * g + 2]), lrelu02(acc[m][4 * g + 3]));
-        }
-        // features outside the image are the next conv's zero padding: one AND per packed dword, applied after the
-        // half swap (lanes l and l + 32 hold the same pixel); laundered so that it stays an AND on the 8 packed
-        // dwords instead of 16 selects on the floats in front of the conversion
-        uint32_t keep = (border && !inimg) ? 0u : 0xffffffffu;
-        asm volatile("" : "+v"(keep));
-#pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-          u32x4 v;
-#pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(rr[2 * gp][d], rr[2 * gp + 1][d], false, false);
-            v[d] = sw[0] & keep;
-            v[2 + d] = sw[1] & keep;
-          }
-          if (valid[m]) {
-            if (K < 4) {
-              constexpr int pitch = FeatGeom<(K < 4 ? K : 1)>::pitch;
-              *reinterpret_cast<u32x4*>(smem + FeatGeom<(K < 4 ? K : 1)>::off + r[m] * pitch + cc[m] * PS + (16 * gp + 8 * c.half) * 2) = v;
-            }
-            const bool centre = (ar >= 0) & (ar < TS) & (ac >= 0) & (ac < TS);
-            if (centre && inimg)
-              *reinterpret_cast<u32x4*>(dplane + fofs + (unsigned)((y * a.W + x) * 32 + 16 * gp + 8 * c.half)) = v;
-          }
-        }
-      }
-    }
-    STAMP(ts3);
-    STAMP_ADD(2, ts2, ts3);
-    // ---- hand the weight buffers over: next chunk -> the other buffer, one barrier per chunk
-    if (ch + 1 < NCH) w_commit<18>(c);
+    // ---- hand the weight buffers over FIRST (next chunk -> the other buffer): global stores share the VM counter with
+    // loads on gfx9, so waiting for the prefetched fragments behind the epilogue's feature stores meant waiting for
+    // those stores to be acknowledged (~1-2 us at every conv boundary; measured: the stores cost 29 % of the kernel)
+    if (PENDING && ch == 0) { /* handed over behind step 8 */ }
+    else if (ch + 1 < NCH) w_commit<18>(c);
     else if (K == 4) w_commit<3>(c);
     else w_commit<21>(c);
-    if (K == 4 && ch == NCH - 1) return;   // the tile loop stores the next X halo before its barrier
+    STAMP(ts3);
+    STAMP_ADD(3, ts2, ts3);
+    if (ch == NCH - 1 && !DEFER) {
+      // ---- epilogue now (conv1: its output is read by conv2's very first feature step; conv4: end of the tile)
+      uint32_t rr[MT][4][2];
+#pragma unroll
+      for (int p = 0; p < 5 * MT; ++p) epi_piece<K, MT>(c, a, net, fofs, ty0, tx0, acc, rr, p);
+    }
+    if (K == 4 && ch == NCH - 1) return;   // the tile loop has the tile's last barrier
     __syncthreads();
     c.par ^= 1;
     STAMP(ts4);
-    STAMP_ADD(3, ts3, ts4);
+    STAMP_ADD(2, ts3, ts4);
   }
 }
 
@@ -351,12 +418,13 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
     const bool more = n + gf < a.N;
     if (more) x_load(n + gf);                     // lands while this tile computes
     const size_t fofs = (size_t)n * fpix * 32;
-    conv_fused<1>(c, a, net, xbuf, fofs, ty0, tx0);
-    conv_fused<2>(c, a, net, xbuf, fofs, ty0, tx0);
-    conv_fused<3>(c, a, net, xbuf, fofs, ty0, tx0);
-    conv_fused<4>(c, a, net, xbuf, fofs, ty0, tx0);
+    AccPair acc2, acc3;
+    conv_fused<1>(c, a, net, xbuf, fofs, ty0, tx0, nullptr, nullptr);
+    conv_fused<2>(c, a, net, xbuf, fofs, ty0, tx0, nullptr, &acc2);
+    conv_fused<3>(c, a, net, xbuf, fofs, ty0, tx0, &acc2, &acc3);
+    if (more) x_store(xbuf ^ 1);                  // before conv4's feature stores (see conv_fused: one VM counter)
+    conv_fused<4>(c, a, net, xbuf, fofs, ty0, tx0, &acc3, nullptr);
     STAMP(tt0);
-    if (more) x_store(xbuf ^ 1);
     __syncthreads();
     c.par ^= 1;
     xbuf ^= 1;
