@@ -44,12 +44,29 @@ struct FGArgs {
 
 namespace {
 
+// DEPTH convs are fused (4: conv1..4, the default build; 3: conv1..3 - built from this same source with
+// -DSELFC_GH_DEPTH=3 as launch_fused_gh3, conv4 then runs as its own launch)
+#ifndef SELFC_GH_DEPTH
+#define SELFC_GH_DEPTH 4
+#endif
+constexpr int DEPTH = SELFC_GH_DEPTH;
+static_assert(DEPTH == 3 || DEPTH == 4, "fused depth");
 constexpr int TS = 16;
-constexpr int XS = TS + 8;                 // X halo side (24)
+constexpr int XS = TS + 2 * DEPTH;         // X halo side (24 / 22)
 constexpr int XPITCH = XS * 8;             // bytes
 constexpr int X_BYTES = XS * XPITCH;       // 4608
-constexpr int P1 = 1856, P2 = 1696, P3 = 1536;                       // LDS row pitch of F1..F3 (bytes): pitch/16 = 5 R (mod 16) for the region width R of the image's busiest reader (conv2: 20, conv3: 18, conv4: 16), so a linearly enumerated M-tile stays on distinct 16-byte slots across a row wrap
-constexpr int F1_BYTES = 22 * P1, F2_BYTES = 20 * P2, F3_BYTES = 18 * P3;
+// LDS row pitch of F1..F3 (bytes): pitch/16 = 5 R (mod 16) for the region width R of the image's busiest reader (the next
+// conv), so a linearly enumerated M-tile stays on distinct 16-byte slots across a row wrap
+constexpr int feat_pitch(const int rows_img, const int r_reader) {
+  int s = 5 * rows_img;
+  while (s % 16 != (5 * r_reader) % 16) ++s;
+  return s * 16;
+}
+constexpr int P1 = feat_pitch(TS + 2 * (DEPTH - 1), TS + 2 * (DEPTH - 2));
+constexpr int P2 = feat_pitch(TS + 2 * (DEPTH - 2), TS + 2 * (DEPTH - 3));
+constexpr int P3 = DEPTH == 4 ? feat_pitch(TS + 2, TS) : 16;
+static_assert(DEPTH != 4 || (P1 == 1856 && P2 == 1696 && P3 == 1536), "depth-4 pitches");
+constexpr int F1_BYTES = (TS + 2 * (DEPTH - 1)) * P1, F2_BYTES = (TS + 2 * (DEPTH - 2)) * P2, F3_BYTES = DEPTH == 4 ? (TS + 2) * P3 : 0;
 constexpr int WCH = 21;                    // fragments per weight chunk buffer
 constexpr int W_BYTES = WCH * 1024;
 constexpr int OFF_F1 = 0, OFF_F2 = OFF_F1 + F1_BYTES, OFF_F3 = OFF_F2 + F2_BYTES;
@@ -124,7 +141,7 @@ __device__ __forceinline__ void w_commit(Ctx& c) {
 // time, behind the MFMA steps of the NEXT conv's first chunk (which reads only older features): piece p < 4 MT packs
 // 4 channels of M-tile p / 4, piece 4 MT + m swaps / masks / stores M-tile m.
 template <int K> struct ConvGeom {
-  static constexpr int R = TS + 2 * (4 - K), NPX = R * R, NTL = (NPX + 31) / 32, MT = (NTL + NWAVE - 1) / NWAVE;
+  static constexpr int R = TS + 2 * (DEPTH - K), NPX = R * R, NTL = (NPX + 31) / 32, MT = (NTL + NWAVE - 1) / NWAVE;
 };
 template <int K>
 __device__ __forceinline__ void mtile_geom(const Ctx& c, const int m, int& r, int& cc, bool& valid) {
@@ -155,8 +172,8 @@ __device__ __forceinline__ void epi_piece(const Ctx& c, const FGArgs& a, const i
   mtile_geom<K>(c, m, r, cc, valid);
   f16* __restrict__ dplane = a.dense[net] + (size_t)(K - 1) * a.plane;
   // the region leaves the image only for tiles on the frame border (wave-uniform test)
-  const bool border = (ty0 - (4 - K) < 0) | (tx0 - (4 - K) < 0) | (ty0 + TS + (4 - K) > a.H) | (tx0 + TS + (4 - K) > a.W);
-  const int ar = r - (4 - K), ac = cc - (4 - K);
+  const bool border = (ty0 - (DEPTH - K) < 0) | (tx0 - (DEPTH - K) < 0) | (ty0 + TS + (DEPTH - K) > a.H) | (tx0 + TS + (DEPTH - K) > a.W);
+  const int ar = r - (DEPTH - K), ac = cc - (DEPTH - K);
   const int y = ty0 + ar, x = tx0 + ac;
   const bool inimg = (y >= 0) & (y < a.H) & (x >= 0) & (x < a.W);
   // features outside the image are the next conv's zero padding: one AND per packed dword, applied after the
@@ -175,9 +192,9 @@ __device__ __forceinline__ void epi_piece(const Ctx& c, const FGArgs& a, const i
     }
     if (valid) {
 #ifndef SELFC_EXP_NOLST      // timing experiment: no feature stores to LDS
-      if (K < 4) {
-        constexpr int pitch = FeatGeom<(K < 4 ? K : 1)>::pitch;
-        *reinterpret_cast<u32x4*>(c.smem + FeatGeom<(K < 4 ? K : 1)>::off + r * pitch + cc * PS + (16 * gp + 8 * c.half) * 2) = v;
+      if (K < DEPTH) {
+        constexpr int pitch = FeatGeom<(K < DEPTH ? K : 1)>::pitch;
+        *reinterpret_cast<u32x4*>(c.smem + FeatGeom<(K < DEPTH ? K : 1)>::off + r * pitch + cc * PS + (16 * gp + 8 * c.half) * 2) = v;
       }
 #endif
       const bool centre = (ar >= 0) & (ar < TS) & (ac >= 0) & (ac < TS);
@@ -201,7 +218,7 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
                                            const size_t fofs, const int ty0, const int tx0, AccPair* prev, AccPair* out) {
   constexpr int MT = ConvGeom<K>::MT;
   constexpr int NCH = K == 1 ? 1 : K - 1;          // weight chunks of this conv: [im2col(+f1)], [f2], [f3]
-  constexpr bool DEFER = K == 2 || K == 3, PENDING = K == 3 || K == 4;
+  constexpr bool DEFER = K >= 2 && K < DEPTH, PENDING = K >= 3;
   static_assert(!DEFER || MT == 2, "AccPair");
   unsigned char* const smem = c.smem;
 
@@ -245,10 +262,10 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
       if (ch == 0) w_prefetch<LAYER_OFF[K] + 21, 18>(c);
       else w_prefetch<LAYER_OFF[K] + 39, 18>(c);
     } else {
-      if (K == 1) w_prefetch<LAYER_OFF[2], 21>(c);
+      if (K == DEPTH) w_prefetch<LAYER_OFF[1], 3>(c);            // wraps to the next tile's conv1
+      else if (K == 1) w_prefetch<LAYER_OFF[2], 21>(c);
       else if (K == 2) w_prefetch<LAYER_OFF[3], 21>(c);
-      else if (K == 3) w_prefetch<LAYER_OFF[4], 21>(c);
-      else w_prefetch<LAYER_OFF[1], 3>(c);                      // wraps to the next tile's conv1
+      else w_prefetch<LAYER_OFF[4], 21>(c);
     }
     const unsigned char* wb = smem + OFF_W + c.par * W_BYTES + c.lane * 16;
     const unsigned char* xb = smem + OFF_X + xbuf * X_BYTES;
@@ -326,7 +343,7 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
     // those stores to be acknowledged (~1-2 us at every conv boundary; measured: the stores cost 29 % of the kernel)
     if (PENDING && ch == 0) { /* handed over behind step 8 */ }
     else if (ch + 1 < NCH) w_commit<18>(c);
-    else if (K == 4) w_commit<3>(c);
+    else if (K == DEPTH) w_commit<3>(c);
     else w_commit<21>(c);
     STAMP(ts3);
     STAMP_ADD(3, ts2, ts3);
@@ -336,7 +353,7 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
 #pragma unroll
       for (int p = 0; p < 5 * MT; ++p) epi_piece<K, MT>(c, a, net, fofs, ty0, tx0, acc, rr, p);
     }
-    if (K == 4 && ch == NCH - 1) return;   // the tile loop has the tile's last barrier
+    if (K == DEPTH && ch == NCH - 1) return;   // the tile loop has the tile's last barrier
     __syncthreads();
     c.par ^= 1;
     STAMP(ts4);
@@ -375,7 +392,7 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
   for (int it = 0; it < XITER; ++it) {
     const int p = min(c.tid + it * NTHR, XS * XS - 1);
     const int hy = p / XS, hx = p - hy * XS;
-    const int y = ty0 + hy - 4, x = tx0 + hx - 4;
+    const int y = ty0 + hy - DEPTH, x = tx0 + hx - DEPTH;
     const bool ok = (y >= 0) & (y < a.H) & (x >= 0) & (x < a.W);
     const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
     xgo[it] = (unsigned)(yc * a.W + xc) * 4u;
@@ -421,9 +438,14 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
     AccPair acc2, acc3;
     conv_fused<1>(c, a, net, xbuf, fofs, ty0, tx0, nullptr, nullptr);
     conv_fused<2>(c, a, net, xbuf, fofs, ty0, tx0, nullptr, &acc2);
-    conv_fused<3>(c, a, net, xbuf, fofs, ty0, tx0, &acc2, &acc3);
-    if (more) x_store(xbuf ^ 1);                  // before conv4's feature stores (see conv_fused: one VM counter)
-    conv_fused<4>(c, a, net, xbuf, fofs, ty0, tx0, &acc3, nullptr);
+    if (DEPTH == 3) {
+      if (more) x_store(xbuf ^ 1);                // before the last conv's feature stores (see conv_fused: one VM counter)
+      conv_fused<3>(c, a, net, xbuf, fofs, ty0, tx0, &acc2, nullptr);
+    } else {
+      conv_fused<3>(c, a, net, xbuf, fofs, ty0, tx0, &acc2, &acc3);
+      if (more) x_store(xbuf ^ 1);
+      conv_fused<(DEPTH == 4 ? 4 : 3)>(c, a, net, xbuf, fofs, ty0, tx0, &acc3, nullptr);
+    }
     STAMP(tt0);
     __syncthreads();
     c.par ^= 1;
@@ -445,7 +467,11 @@ inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 
 }  // namespace
 
 // Called from dense_conv.hip (run_GH) when the block carries fused fragment streams.
+#if SELFC_GH_DEPTH == 3
+int launch_fused_gh3(FGArgs& a, hipStream_t s) {
+#else
 int launch_fused_gh(FGArgs& a, hipStream_t s) {
+#endif
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_gh_kernel),
