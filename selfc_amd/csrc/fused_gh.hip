@@ -69,10 +69,13 @@ static_assert(DEPTH != 4 || (P1 == 1856 && P2 == 1696 && P3 == 1536), "depth-4 p
 constexpr int F1_BYTES = (TS + 2 * (DEPTH - 1)) * P1, F2_BYTES = (TS + 2 * (DEPTH - 2)) * P2, F3_BYTES = DEPTH == 4 ? (TS + 2) * P3 : 0;
 constexpr int WCH = 21;                    // fragments per weight chunk buffer
 constexpr int W_BYTES = WCH * 1024;
+// depth 3: the whole 63-fragment stream of conv1..3 stays RESIDENT in LDS (no streaming, no hand-over waits)
+constexpr bool WRES = DEPTH == 3;
+constexpr int NFRAG_RES = 63;
 constexpr int OFF_F1 = 0, OFF_F2 = OFF_F1 + F1_BYTES, OFF_F3 = OFF_F2 + F2_BYTES;
 constexpr int OFF_X = OFF_F3 + F3_BYTES;   // 2 buffers
 constexpr int OFF_W = OFF_X + 2 * X_BYTES; // 2 buffers
-constexpr int OFF_B = OFF_W + 2 * W_BYTES; // biases of the four convs: 4 x 32 floats
+constexpr int OFF_B = OFF_W + (WRES ? NFRAG_RES * 1024 : 2 * W_BYTES); // biases of the four convs: 4 x 32 floats
 constexpr int FG_LDS = OFF_B + 512;
 static_assert(FG_LDS <= 160 * 1024, "LDS budget");
 #ifndef SELFC_RD1
@@ -109,11 +112,13 @@ struct Ctx {
   const u32x4* wsrc;
   int tid, lane, wave, half;
   int par;            // weight buffer that holds the CURRENT chunk
+  bool first;         // resident mode: the workgroup's first tile streams the fragments INTO their resident places
   u32x4 wreg[WITER];
 };
 
 template <int OFF, int NFR>
 __device__ __forceinline__ void w_prefetch(Ctx& c) {
+  if (WRES && !c.first) return;
 #ifdef SELFC_EXP_NOW        // timing experiment: no weight streaming
   return;
 #endif
@@ -123,12 +128,14 @@ __device__ __forceinline__ void w_prefetch(Ctx& c) {
     c.wreg[it] = c.wsrc[OFF * 64 + i];
   }
 }
-template <int NFR>
+template <int OFF, int NFR>
 __device__ __forceinline__ void w_commit(Ctx& c) {
+  if (WRES && !c.first) return;
 #ifdef SELFC_EXP_NOW
   return;
 #endif
-  unsigned char* dst = c.smem + OFF_W + (c.par ^ 1) * W_BYTES;
+  // streamed: the other half of the double buffer; resident (depth 3, first tile only): the chunk's own place
+  unsigned char* dst = c.smem + OFF_W + (WRES ? OFF * 1024 : (c.par ^ 1) * W_BYTES);
 #pragma unroll
   for (int it = 0; it < WITER; ++it) {
     const int i = c.tid + it * NTHR;
@@ -267,7 +274,7 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
       else if (K == 2) w_prefetch<LAYER_OFF[3], 21>(c);
       else w_prefetch<LAYER_OFF[4], 21>(c);
     }
-    const unsigned char* wb = smem + OFF_W + c.par * W_BYTES + c.lane * 16;
+    const unsigned char* wb = smem + OFF_W + (WRES ? (LAYER_OFF[K] + (ch == 0 ? 0 : ch == 1 ? 21 : 39)) * 1024 : c.par * W_BYTES) + c.lane * 16;
     const unsigned char* xb = smem + OFF_X + xbuf * X_BYTES;
     // The chunk is a flat list of MFMA steps: [3 im2col48 k-steps (chunk 0 only)] + [18 (tap, k-step)
     // steps of feature J = ch + 1 (K >= 2)].  One wave per SIMD has no other wave to hide LDS latency
@@ -333,7 +340,7 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
       // (packs behind steps 1..8; then this chunk's weight hand-over, so that no wait on the VM counter follows the
       // feature stores; then the two M-tiles' stores behind steps 9 and 10)
       if (PENDING && ch == 0 && st >= 1 && st <= 10) epi_piece<(PENDING ? K - 1 : 1), 2>(c, a, net, fofs, ty0, tx0, prev->a, prr, st - 1);
-      if (PENDING && ch == 0 && st == 8) w_commit<18>(c);
+      if (PENDING && ch == 0 && st == 8) w_commit<LAYER_OFF[K] + 21, 18>(c);
     }
 
     STAMP(ts2);
@@ -342,9 +349,9 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
     // loads on gfx9, so waiting for the prefetched fragments behind the epilogue's feature stores meant waiting for
     // those stores to be acknowledged (~1-2 us at every conv boundary; measured: the stores cost 29 % of the kernel)
     if (PENDING && ch == 0) { /* handed over behind step 8 */ }
-    else if (ch + 1 < NCH) w_commit<18>(c);
-    else if (K == DEPTH) w_commit<3>(c);
-    else w_commit<21>(c);
+    else if (ch + 1 < NCH) { if (ch == 0) w_commit<LAYER_OFF[K] + 21, 18>(c); else w_commit<LAYER_OFF[K] + 39, 18>(c); }
+    else if (K == DEPTH) w_commit<LAYER_OFF[1], 3>(c);
+    else w_commit<LAYER_OFF[K < 4 ? K + 1 : 1], 21>(c);
     STAMP(ts3);
     STAMP_ADD(3, ts2, ts3);
     if (ch == NCH - 1 && !DEFER) {
@@ -370,6 +377,7 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
   c.wave = c.tid >> 6;
   c.half = c.lane >> 5;
   c.par = 0;
+  c.first = true;
 #ifdef SELFC_STAMPS
   c.phase[0] = c.phase[1] = c.phase[2] = c.phase[3] = 0;
   STAMP(tk0);
@@ -426,7 +434,8 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
   w_prefetch<LAYER_OFF[1], 3>(c);
   x_store(0);
   c.par = 1;            // w_commit writes buffer par^1 = 0
-  w_commit<3>(c);
+  c.first = true;
+  w_commit<LAYER_OFF[1], 3>(c);
   __syncthreads();
   c.par = 0;
 
@@ -449,6 +458,7 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
     STAMP(tt0);
     __syncthreads();
     c.par ^= 1;
+    c.first = false;
     xbuf ^= 1;
     STAMP(tt1);
     STAMP_ADD(3, tt0, tt1);
