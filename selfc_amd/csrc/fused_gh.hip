@@ -91,7 +91,7 @@ constexpr int WITER = (WCH * 64 + NTHR - 1) / NTHR;   // 3
 template <int J> struct FeatGeom;
 template <> struct FeatGeom<1> { static constexpr int off = OFF_F1, pitch = P1; };
 template <> struct FeatGeom<2> { static constexpr int off = OFF_F2, pitch = P2; };
-template <> struct FeatGeom<3> { static constexpr int off = OFF_F3, pitch = P3; };
+template <> struct FeatGeom<3> { [[maybe_unused]] static constexpr int off = OFF_F3, pitch = P3; };
 
 // fragment offsets of the fused stream: per conv [im2col48: 3][feature j: 18 each]
 constexpr int LAYER_OFF[5] = {0, 0, 3, 24, 63};
