@@ -251,10 +251,11 @@ np.savez(sys.argv[2], z=z.cpu().numpy(), xr=xr.cpu().numpy())
 """
 
 
-@pytest.mark.parametrize("switch", ["SELFC_NO_FUSE_F", "SELFC_NO_F5P"])
-def test_fused_f_paths_agree_with_layerwise_path(dev, tmp_path, switch):
-    """F's conv1-4 as two pairwise-fused launches (csrc/fused_f.hip) and its conv5 as partial products, against the
-    layer-wise conv3x3 / temporal-conv5 kernels run in a child process with the developer switch set: same f16 operands,
+@pytest.mark.parametrize("switch", ["SELFC_NO_FUSE_F=1", "SELFC_NO_F5P=1", "SELFC_NO_FUSE=1", "SELFC_GH_SPLIT=2"])
+def test_fused_paths_agree_with_alternative_paths(dev, tmp_path, switch):
+    """The default kernels (F's conv1-4 as two pairwise-fused launches with conv5 as partial products, G/H's conv1-4 as one
+    depth-4 fused launch) against the alternative paths of the library - layer-wise conv3x3 / temporal-conv5 kernels, the
+    depth-3 + conv4 split of G/H - run in a child process with the developer switch set: same f16 operands,
     different fp32 summation order (which flips some f16 roundings of the features): the two paths are each within
     ~3.5e-4 of the fp32 oracle and must agree with each other inside the parity tolerance.  Ragged size (18 x 25 latent)."""
     import os
@@ -263,7 +264,7 @@ def test_fused_f_paths_agree_with_layerwise_path(dev, tmp_path, switch):
     import numpy as np
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "child.npz")
-    env = dict(os.environ, **{switch: "1"})
+    env = dict(os.environ, **dict([switch.split("=")]))
     subprocess.run([sys.executable, "-c", _CHILD, root, out], check=True, env=env, timeout=300)
     g = load_golden("g8_large_stack")
     net = _large_net(dev, g)
