@@ -5,7 +5,7 @@ max|a-b| / max|b| (conftest.rel_err).  Run with `-m gpu` on the MI355X box."""
 import pytest
 import torch
 
-from conftest import load_golden, rel_err, seeded_fill, subdict
+from conftest import group_err, load_golden, rel_err, rel_l2, seeded_fill, subdict
 from oracle import selfc_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -138,8 +138,11 @@ def test_large_stack_golden(dev):
         assert float(loss_c) == 0.0
         assert rel_err(z.cpu(), g["z"]) < TOL
         assert rel_err(z[:, :3].cpu(), g["z"][:, :3]) < TOL          # the LR video itself
+        # LR (0:3) and HF (3:51) channel groups each against their OWN magnitude, max-norm and relative L2
+        assert group_err(z.cpu(), g["z"]) < TOL
         xr = net.inverse_from_latent(g["z"].to(dev))
         assert rel_err(xr.cpu(), g["x_rev"]) < TOL
+        assert rel_l2(xr.cpu(), g["x_rev"]) < TOL
 
 
 def test_large_full_reverse_with_stp_l2(dev):
@@ -149,7 +152,9 @@ def test_large_full_reverse_with_stp_l2(dev):
     with torch.no_grad():
         xr, hf = net(x=s["lr"].to(dev), rev=True)
     assert rel_err(hf.cpu(), s["hf"]) < 2e-3
+    assert rel_l2(hf.cpu(), s["hf"]) < 2e-3
     assert rel_err(xr.cpu(), s["x_rev"]) < 2e-3
+    assert rel_l2(xr.cpu(), s["x_rev"]) < 2e-3
 
 
 def test_stp_gmm_injected_eps(dev):
@@ -229,6 +234,7 @@ def test_large_vs_oracle_ragged_sizes(dev, b, h, w):
     with torch.no_grad():
         z, _ = net(x=x.to(dev), rev=False)
         assert rel_err(z.cpu(), z_ref) < TOL
+        assert group_err(z.cpu(), z_ref) < TOL
         xr = net.inverse_from_latent(z_ref.to(dev))
     assert rel_err(xr.cpu(), O.large_inv_from_latent(g, z_ref, T)) < TOL
 
