@@ -2,7 +2,10 @@
 """Headline benchmark: septuplets/s (7x3x256x448), forward + inverse InvBlock stack.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+    (N > 1: one rank per GPU over RCCL.  Without WORLD_SIZE in the environment bench.py starts its own N ranks -
+     a child `python -m torch.distributed.run --nproc-per-node N bench.py ...`, before this process touches the
+     GPU - and relays rank 0's JSON line and exit code; under an existing torch.distributed.run it simply is a rank.
+     --dry-run rehearses launch / sharding / timing protocol on CPU over gloo without any HIP call.)
 
 One step = the hot path over one batch of 4 synthetic septuplets per GPU, already
 resident in HBM: FrequencyAnalyzer.fwd -> 8 x InvBlockExp.fwd -> Quantization ->
@@ -91,34 +94,33 @@ def main():
     ap.add_argument("--no-full-path", action="store_true", help="skip the extra netG(x) + Quantization + netG(LR, rev=True) timing (incl. STP sampler)")
     ap.add_argument("--streams", type=int, default=4, help="split the septuplets of a step over this many HIP streams")
     ap.add_argument("--no-train-step", action="store_true", help="skip the extra training-step timing (config 3: 8 x 7x3x144x144)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo rehearsal of launch, sharding and the timing protocol: no HIP call, value is null")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    from selfc_amd import launch
+    rc = launch.self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:])     # before anything touches the GPU
+    if rc is not None:
+        sys.exit(rc)
+    if args.dry_run:
+        return dry_run(args)
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if local >= torch.cuda.device_count():       # device_count() does not initialise HIP
+        raise SystemExit(f"rank with LOCAL_RANK={local} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    ranks = launch.Ranks(args.gpus, "nccl", dev)
+    world, rank = ranks.world, ranks.rank
 
     from selfc_amd import _lib
     from selfc_amd.pipeline import MultiStreamRoundTrip, RescaleRoundTrip
     L = _lib.lib()
     net = build_net(dev)
     n_frames = B_PER_GPU * T
-    g = torch.Generator().manual_seed(1234 + rank)
+    g = torch.Generator().manual_seed(launch.rank_seed(1234, rank))
     x_cpu = torch.rand(n_frames, 3, H, W, generator=g)
     x = x_cpu.to(dev)
     rt = RescaleRoundTrip(net, n_frames, H, W, dev)
     runner = rt if args.streams <= 1 else MultiStreamRoundTrip(net, n_frames, H, W, dev, args.streams)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
 
     with torch.no_grad():
         use_graph = not args.no_graph
@@ -127,20 +129,8 @@ def main():
             step = runner.replay
         else:
             step = lambda: runner.run(x)      # noqa: E731
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        barrier()
-        dt = time.perf_counter() - t0
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = launch.timed_region(step, args.steps, args.warmup, ranks, torch.cuda.synchronize)
+        rccl_ranks = ranks.count()
 
         # ---- roofline leg: same K steps, eager, HIP events around every launch on its stream
         L.selfc_profile_reset()
@@ -202,8 +192,7 @@ def main():
             kern["conv5_GH"]["traffic_source"] = "profiles/r1/pmc_traffic.json"
     dominant = max(kern, key=lambda k: kern[k]["ms_per_step"])
     roofline = kern[dominant]
-    sept = B_PER_GPU * world * args.steps
-    value = sept / dt
+    value = launch.whole_job_rate(B_PER_GPU, world, args.steps, dt)
     whole_flops = 2.0 * MAC_BLOCK_PX * npx * 16
     out = {
         "metric": "septuplets/sec (7x3x256x448) fwd+inv InvBlock stack", "value": round(value, 2), "unit": "septuplets/s",
@@ -213,6 +202,7 @@ def main():
                                "FrequencyAnalyzer rev; 4 septuplets 7x3x256x448 per GPU, inputs resident in HBM, seeded default-init weights",
                    "septuplets_per_gpu": B_PER_GPU, "launch": "hipGraph replay" if use_graph else "eager", "streams": args.streams,
                    "sharding": f"{world} rank(s) x {B_PER_GPU} independent septuplets, no data-path collective"},
+        "rccl_ranks": rccl_ranks,
         "roofline": roofline,
         "roofline_other": {k: v for k, v in kern.items() if k != dominant},
         "stack_tflops": round(whole_flops * world * args.steps / dt / 1e12, 1),
@@ -296,9 +286,32 @@ def main():
                          "inv_rel_err": float((xr - xr_ref).abs().max() / xr_ref.abs().max()),
                          "tolerance": 1e-3, "metric": "max|a-b|/max|b|", "against": "CPU oracle, septuplet 0"}
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
+    ranks.close()
+
+
+def dry_run(args):
+    """Launch / shard / timing protocol on CPU over gloo (tests, and a rehearsal of --gpus N where there is no GPU): the
+    step is a placeholder, so the line says "dry_run": true and carries no throughput."""
+    from selfc_amd import launch
+    ranks = launch.Ranks(args.gpus, "gloo")
+    g = torch.Generator().manual_seed(launch.rank_seed(1234, ranks.rank))
+    x = torch.rand(B_PER_GPU * T, 3, 8, 8, generator=g)          # this rank's septuplets (tiny stand-ins)
+    sink = []
+    dt = launch.timed_region(lambda: sink.append(float(x.sum())), args.steps, args.warmup, ranks)
+    n = ranks.count()
+    sums = [None] * ranks.world
+    if ranks.dist is not None:
+        ranks.dist.all_gather_object(sums, sink[-1])
+    else:
+        sums = [sink[-1]]
+    if ranks.rank == 0:
+        print(json.dumps({"metric": "septuplets/sec (7x3x256x448) fwd+inv InvBlock stack", "value": None, "unit": "septuplets/s",
+                          "dry_run": True, "n_gpus": ranks.world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / max(1, args.steps) * 1e3, 6), "scaling": "weak", "rccl_ranks": n,
+                          "backend": "gloo", "septuplets_per_gpu": B_PER_GPU, "shards_distinct": len(set(sums)) == len(sums),
+                          "steps_counted": len(sink) - args.warmup}), flush=True)
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -329,6 +329,16 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
       for (int m = 0; m < MT; ++m) {
 #if defined(SELFC_EXP_NOMFMA)          // timing experiment: everything but the MFMAs
         acc[m][0] += (float)ringA[st % RD][0] * (float)ringB[st % RD][m][0];
+#elif defined(SELFC_EXP_MFMA16)        // timing experiment (results are garbage): the same MACs as two 16x16x32 MFMAs
+        {
+          const int q0 = (st & 1) * 2;   // compile-time after the unroll
+          f32x4 a0 = {acc[m][4 * q0], acc[m][4 * q0 + 1], acc[m][4 * q0 + 2], acc[m][4 * q0 + 3]};
+          f32x4 a1 = {acc[m][4 * q0 + 4], acc[m][4 * q0 + 5], acc[m][4 * q0 + 6], acc[m][4 * q0 + 7]};
+          a0 = mfma_16x16x32(ringA[st % RD], ringB[st % RD][m], a0);
+          a1 = mfma_16x16x32(ringA[st % RD], ringB[st % RD][m], a1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { acc[m][4 * q0 + e] = a0[e]; acc[m][4 * q0 + 4 + e] = a1[e]; }
+        }
 #elif defined(SELFC_EXP_NOLDS)         // timing experiment: MFMAs on the first step's fragments only
         acc[m] = mfma_32x32x16(ringA[0], ringB[0][m], acc[m]);
 #else

@@ -98,9 +98,12 @@ class GlobalAgg(nn.Module):
         pk = self._packed(h, w)
         L = _lib.lib()
         nfl = L.selfc_globalagg_partial_floats(n, h * w)
-        if "gagg_partial" not in scratch or scratch["gagg_partial"].numel() < nfl:
-            scratch["gagg_partial"] = torch.empty(nfl, dtype=torch.float32, device=x.device)
-            scratch["gagg_attn"] = torch.empty((n // t) * t * t, dtype=torch.float32, device=x.device)
+        # the two buffers grow independently (more clips of fewer pixels need a larger attn but a smaller partial) and
+        # never outlive a device change
+        for name, need in (("gagg_partial", nfl), ("gagg_attn", (n // t) * t * t)):
+            buf = scratch.get(name)
+            if buf is None or buf.numel() < need or buf.device != x.device:
+                scratch[name] = torch.empty(need, dtype=torch.float32, device=x.device)
         rt.call("selfc_globalagg_run", x.data_ptr(), y.data_ptr(), pk["wmap"].data_ptr(), pk["fcb"].data_ptr(),
                 pk["w1"].data_ptr(), pk["b1"].data_ptr(), pk["w2"].data_ptr(), pk["b2"].data_ptr(),
                 pk["w3"].data_ptr(), pk["b3"].data_ptr(), scratch["gagg_partial"].data_ptr(),

@@ -160,8 +160,23 @@ def plist(mod):
     return cached
 
 
+#: Bumped by invalidate_weights().  Packed-weight caches key on (data_ptr, tensor._version) of every parameter, which
+#: notices optimizer.step() / load_state_dict() / copy_() - but NOT writes that bypass the version counter: a replayed
+#: hipGraph of a captured optimisation step (RescaleTrainer.replay) and `p.data` writes (EMA, hand-written SGD).
+_WEIGHT_EPOCH = 0
+
+
+def invalidate_weights() -> int:
+    """Force every packed-weight cache (blocks, subnets, GlobalAgg, STP head, the nets' block arrays) to repack on its
+    next use.  Call after updating parameters in a way torch's version counter does not see (`p.data.copy_()`,
+    `p.data.mul_()`, a replayed graph that contains the optimizer step); RescaleTrainer.replay() does it itself."""
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+    return _WEIGHT_EPOCH
+
+
 def params_key(*mods) -> Tuple:
-    return tuple((p.data_ptr(), p._version) for m in mods for p in plist(m))
+    return (_WEIGHT_EPOCH,) + tuple((p.data_ptr(), p._version) for m in mods for p in plist(m))
 
 
 _FN: Dict[str, object] = {}

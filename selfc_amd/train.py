@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 from torch.optim.lr_scheduler import _LRScheduler
 
-from . import harness
+from . import harness, runtime as rt
 from .global_var import GlobalVar
 from .modules.Quantization import Quantization
 
@@ -196,6 +196,9 @@ class RescaleTrainer:
         self._static_h.copy_(real_H)
         self._static_l.copy_(ref_L)
         self.graph.replay()
+        # the replayed Adam step rewrote the parameters without touching torch's version counters: packed-weight caches
+        # keyed on (data_ptr, _version) would otherwise serve a later eager eval / validation pass stale weights
+        rt.invalidate_weights()
         return self._log(self._static_losses)
 
     def update_learning_rate(self):
