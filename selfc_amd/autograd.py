@@ -530,7 +530,7 @@ class STPSampleFn(torch.autograd.Function):
             rt.call("selfc_nhwc4_to_nchw", d.data_ptr(), dlr.data_ptr(), n, 3, h, w, sp)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
-        return (dlr, None, None, None, *[grads.get(id(p)) for p in stp.parameters()])
+        return (dlr, None, None, None, *[grads.get(id(p)) for p in rt.plist(stp)])
 
 
 class PointwiseHeadFn(torch.autograd.Function):

@@ -283,10 +283,10 @@ class STPNet(nn.Module):
         if ag.module_needs_grad(xf, self):
             # training: one differentiable op for chain + head + sample; `stp_parameters` (the raw head output) is only
             # exposed for the l2 head here - the reference's GMM likelihood path (neg_llh) is not used by its trainer
-            v = ag.STPSampleFn.apply(xf, self, t, self._eps_rows(b * t, t, h, w, xf.device), *self.parameters())
+            v = ag.STPSampleFn.apply(xf, self, t, self._eps_rows(b * t, t, h, w, xf.device), *rt.plist(self))
             v5 = v.reshape(b, t, -1, h, w).transpose(1, 2)
             if self.fh_loss == "l2":
-                self.stp_parameters = v5
+                self._publish(v5)
             else:
                 self.gmm_v = v5
             return
@@ -296,20 +296,39 @@ class STPNet(nn.Module):
         hf = torch.empty((n, h * w, self.hf_dim), dtype=torch.float32, device=xf.device)
         raw = self.run_nhwc(x1, hf, n, t, h, w, keep_raw=True)
         to5d = lambda a: a.reshape(b, t, h, w, -1).permute(0, 4, 1, 2, 3)  # noqa: E731
-        # the reference stores this as `self.parameters` (shadowing nn.Module.parameters, :377)
-        self.stp_parameters = to5d(raw)
+        self._publish(to5d(raw))
         if self.fh_loss != "l2":
             self.gmm_v = to5d(hf)
+
+    def _publish(self, raw5d):
+        """The raw head output (b,Cp,t,h,w) under both names: ``stp_parameters`` and - exactly as the reference does at
+        :377 - ``parameters``, which shadows nn.Module.parameters on this instance (callers such as the reference's
+        ``neg_llh`` read ``stp_net.parameters`` as a tensor; nothing in selfc_amd calls ``stp_net.parameters()``)."""
+        self.stp_parameters = raw5d
+        self.parameters = raw5d
+
+    @property
+    def gmm(self):
+        """torch.distributions mixture of the likelihood path (:396-411), built on demand from the raw head output; note
+        its index convention differs from sampling (:399-405): mean = idx1, log-sigma = idx2."""
+        p = self.stp_parameters
+        b, _, t, h, w = p.shape
+        p = p.reshape(b, self.hf_dim, self.K, 3, t, h, w).permute(0, 1, 4, 5, 6, 2, 3).reshape(-1, self.K, 3)
+        mix = torch.distributions.Categorical(F.softmax(p[:, :, 0], dim=1))
+        comp = torch.distributions.Normal(p[:, :, 1], torch.exp(torch.clamp(p[:, :, 2], -7, 7)))
+        return torch.distributions.MixtureSameFamily(mix, comp)
+
+    def reparametrize(self, mu, logvar):
+        """eps * exp(logvar) + mu with eps ~ N(0,1) drawn on mu's device (:410-417; the reference allocates it with
+        torch.cuda.FloatTensor, trap 5).  Host-side helper kept for the reference's signature - the sampling path of
+        forward() runs inside selfc_pwconv_gmm / selfc_gmm_sample."""
+        eps = self.eps.to(mu) if self.eps is not None and self.eps.shape == mu.shape else torch.randn_like(mu)
+        return eps.mul(torch.exp(logvar)).add_(mu)
 
     def neg_llh(self, hf):
         if self.fh_loss == "l2":
             return torch.mean((hf - self.stp_parameters) ** 2)
-        b, c, t, h, w = hf.size()
-        p = self.stp_parameters.reshape(b, self.hf_dim, self.K, 3, t, h, w).permute(0, 1, 4, 5, 6, 2, 3).reshape(-1, self.K, 3)
-        # index convention of the likelihood differs from sampling (:399-405): mean = idx1, log-sigma = idx2
-        mix = torch.distributions.Categorical(F.softmax(p[:, :, 0], dim=1))
-        comp = torch.distributions.Normal(p[:, :, 1], torch.exp(torch.clamp(p[:, :, 2], -7, 7)))
-        return -torch.distributions.MixtureSameFamily(mix, comp).log_prob(hf.reshape(-1))
+        return -self.gmm.log_prob(hf.reshape(-1))
 
     def sample(self):
         return self.stp_parameters if self.fh_loss == "l2" else self.gmm_v
@@ -397,7 +416,7 @@ class SelfCInvNet(nn.Module):
         n, c, h, w = x.shape
         lr = x[:, 0:3]
         stp = self.stp_net
-        recon_hf = ag.STPSampleFn.apply(lr, stp, t, stp._eps_rows(n, t, h, w, x.device), *stp.parameters())
+        recon_hf = ag.STPSampleFn.apply(lr, stp, t, stp._eps_rows(n, t, h, w, x.device), *rt.plist(stp))
         out = torch.cat((lr, recon_hf), dim=1)
         for op in reversed(self.operations):
             out = op.forward(out, True)

@@ -203,12 +203,15 @@ class FeatureCalapseBlock(nn.Module):
 
 
 def subnet(net_structure, init='xavier'):
-    """String-keyed factory, Subnet_constructor.py:719-788.  Live names of the
-    shipped configs: 'DBNet' and 'D2DTNet'; any other name returns None exactly
-    like the reference (it then fails at first use)."""
+    """String-keyed factory, Subnet_constructor.py:719-788.  Live names: 'DBNet', 'D2DTNet' and 'FeatureCalapseBlock'
+    (:731-735); any other name returns None exactly like the reference (it then fails at first use)."""
     def constructor(channel_in, channel_out, gc=32):
         if net_structure == 'DBNet':
             return DenseBlock(channel_in, channel_out, init) if init == 'xavier' else DenseBlock(channel_in, channel_out)
+        if net_structure == 'FeatureCalapseBlock':
+            # argument positions as in the reference (:732-735): with init == 'xavier' the string lands in the `scale`
+            # slot and the constructor raises TypeError there too; any other init builds the scale-4 block
+            return FeatureCalapseBlock(channel_in, channel_out, init) if init == 'xavier' else FeatureCalapseBlock(channel_in, channel_out)
         if net_structure == 'D2DTNet':
             if init == 'xavier':
                 return D2DTInput(channel_in, channel_out, init, gc=gc)

@@ -154,9 +154,9 @@ def plist(mod):
     - .to() / .cuda() - replaces tensors in place of the same Parameter objects, or re-registers them: the cache is keyed
     on the first parameter's identity to notice the latter)."""
     cached = mod.__dict__.get("_plist")
-    first = next(mod.parameters(), None)
+    first = next(torch.nn.Module.parameters(mod), None)     # unbound: STPNet shadows `parameters` with a tensor (as the reference does)
     if cached is None or (cached and cached[0] is not first):
-        cached = mod.__dict__["_plist"] = list(mod.parameters())
+        cached = mod.__dict__["_plist"] = list(torch.nn.Module.parameters(mod))
     return cached
 
 
