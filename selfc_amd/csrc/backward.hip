@@ -37,16 +37,26 @@ inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g, size_t n, unsigned* __restrict__ amax_bits) {
   float m = 0.f;
-  const size_t n4 = n >> 2;                  // fmaxf drops NaNs by itself
+  bool nan = false;                          // fmaxf drops NaNs: track them separately so that a diverged step stays visible
+  const size_t n4 = n >> 2;
   const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     const float4 v = g4[i];
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(g[(n4 << 2) + threadIdx.x]));
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float v = g[(n4 << 2) + threadIdx.x];
+    m = fmaxf(m, fabsf(v));
+    nan |= v != v;
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, __float_as_uint(m));   // non-negative floats order as uints
+  // non-negative floats order as uints, and a quiet NaN's bits (0x7fc00000) order above every finite value and infinity:
+  // a NaN anywhere makes *amax NaN, grad_scale(NaN) is NaN and every gradient of the call comes out NaN, as the
+  // reference's autograd would deliver it
+  if (__any(nan)) { if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, 0x7fc00000u); }
+  else if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, __float_as_uint(m));
 }
 
 // item = (pixel, 8-channel chunk of the padded planes): 16-byte stores

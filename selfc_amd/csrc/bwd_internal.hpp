@@ -8,6 +8,7 @@ namespace selfc {
 // Gradients travel through the MFMA as f16 scaled by a power of two S chosen from max|dOut| of the subnet call,
 // so that the largest element lands in (128, 256]: far from both the f16 overflow limit and its subnormals.
 __host__ __device__ inline float grad_scale(float amax) {
+  if (amax != amax) return amax;        // NaN in dOut: poison the whole call (see absmax_kernel)
   return (amax > 0.f && amax < 3.0e38f) ? exp2f(8.f - ceilf(log2f(amax))) : 1.f;
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace selfc {
 
@@ -63,6 +64,20 @@ __device__ __forceinline__ f32x4 mfma_16x16x32(const f16x8 a, const f16x8 b, con
 #else
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 #endif
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: opt a kernel in to > 64 KiB of LDS once per
+// (call site, device).  `done` is the call site's static bit mask (bit d = device d); atomic, so host threads driving
+// different GPUs race benignly (the attribute call is idempotent).
+inline hipError_t lds_optin(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+  int d = 0;
+  hipError_t e = hipGetDevice(&d);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (d & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
 }
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) {

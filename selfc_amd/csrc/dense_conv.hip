@@ -36,18 +36,6 @@ struct FGArgs {
   unsigned long long* stamps;
 };
 int launch_fused_gh(FGArgs& a, hipStream_t s);
-int launch_fused_gh3(FGArgs& a, hipStream_t s);      // the same source fused to depth 3 (conv1..3)
-// csrc/conv4_gh.hip
-struct G4Args {
-  const float* x1;
-  const f16* w[2];
-  const float* bias[2];
-  f16* dense[2];
-  int N, H, W;
-  int tiles_x, tiles_y, ntiles;
-  size_t plane;
-};
-int launch_conv4_gh(G4Args& a, hipStream_t s);
 // csrc/fused_f.hip
 int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, int H, int W, hipStream_t s,
                    const void* w5p, float* pf, const float* b5, float* x1, int T, int rev);
@@ -859,13 +847,9 @@ inline int dense_channels(int cin) { return cin <= 3 ? 128 : ((cin + 31) & ~31) 
 template <int NETS, int OT, int KD, int HASX, int EPI>
 int launch_t5(const T5Args& a, hipStream_t s) {
   constexpr int lds = 3 * NETS * (KD + HASX) * OT * 1024;
-  static bool attr_done = false;
-  if (lds > 64 * 1024 && !attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv5_kernel<NETS, OT, KD, HASX, EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return hip_rc(e);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> optin{0};
+  if (lds > 64 * 1024)
+    if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&tconv5_kernel<NETS, OT, KD, HASX, EPI>), lds, optin); e != hipSuccess) return hip_rc(e);
   constexpr int pxwg = t5_waves<EPI>() * 16;
   const int tiles = (a.HW + pxwg - 1) / pxwg;
   ProfScope prof(EPI == EPI_F ? PROF_CONV5_F : EPI == EPI_GH ? PROF_CONV5_GH : EPI == EPI_T5B ? -1 : PROF_CONV5_PLAIN, s);
@@ -961,34 +945,7 @@ int run_GH(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStrea
     for (int i = 0; i < 4; ++i) { fa.bias[0][i] = blk->G.b3[i]; fa.bias[1][i] = blk->H.b3[i]; }
     fa.dense[0] = (f16*)l->gd; fa.dense[1] = (f16*)l->hd;
     fa.N = l->N; fa.H = l->H; fa.W = l->W;
-    // conv1..3 fused (depth 3) + conv4 as its own persistent launch with resident weights, or all four fused (depth 4)
-    static const int split = getenv("SELFC_GH_SPLIT") ? atoi(getenv("SELFC_GH_SPLIT")) : 0;
-    if (split == 2) {
-      rc = launch_fused_gh3(fa, s);
-      if (rc) return rc;
-      G4Args g{};
-      g.x1 = l->x1;
-      g.w[0] = (const f16*)blk->G.wfused + (size_t)63 * 512; g.w[1] = (const f16*)blk->H.wfused + (size_t)63 * 512;
-      g.bias[0] = blk->G.b3[3]; g.bias[1] = blk->H.b3[3];
-      g.dense[0] = (f16*)l->gd; g.dense[1] = (f16*)l->hd;
-      g.N = l->N; g.H = l->H; g.W = l->W;
-      rc = launch_conv4_gh(g, s);
-    } else if (split == 1) {      // conv4 on the layer-wise kernel (reference point of the experiment)
-      rc = launch_fused_gh3(fa, s);
-      if (rc) return rc;
-      C3Args a{};
-      a.dense[0] = (const f16*)l->gd; a.out[0] = (f16*)l->gd;
-      a.w[0] = (const f16*)blk->G.w3[3]; a.bias[0] = blk->G.b3[3];
-      a.dense[1] = (const f16*)l->hd; a.out[1] = (f16*)l->hd;
-      a.w[1] = (const f16*)blk->H.w3[3]; a.bias[1] = blk->H.b3[3];
-      a.x1 = l->x1;
-      a.N = l->N; a.H = l->H; a.W = l->W; a.plane = (size_t)l->N * l->H * l->W * 32; a.c1 = l->c1;
-      build_stages(a, l->c1, 4);
-      a.out_coff = 32 * 3;
-      rc = launch_conv3x3<EPI_LRELU>(a, 2, s);
-    } else {
-      rc = launch_fused_gh(fa, s);
-    }
+    rc = launch_fused_gh(fa, s);
   } else {
     rc = run_conv1to4(&blk->G, &blk->H, l->gd, l->hd, l->x1, l->c1, l->N, l->H, l->W, s);
   }

@@ -207,6 +207,9 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
   c.tid = threadIdx.x;
   c.lane = c.tid & 63;
   c.wave = c.tid >> 6;
+#ifdef SELFC_EXP_PRIO      // experiment: static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH "Two waves per SIMD" item 4)
+  if (c.wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   c.half = c.lane >> 5;
   {
     const int i = c.lane & 15, row2 = (c.lane >> 4) & 1;
@@ -683,12 +686,8 @@ inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 
 template <int PAIR>
 int launch_pair(FFArgs& a, int maxwg, hipStream_t s) {
   using G = Geo<PAIR>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_f_kernel<PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-    if (e != hipSuccess) return hip_rc(e);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> optin{0};
+  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&fused_f_kernel<PAIR>), G::LDS, optin); e != hipSuccess) return hip_rc(e);
   // Frame walk (see the kernel): gf workgroups per spatial tile, workgroup b visits frames b / ntiles + k gf.  gf is
   // sized so that about maxwg workgroups exist, every one of them walks (nearly) the same number of frames, and -
   // when there are frames enough - at least three, which amortises the prologue (weights, first halo).

@@ -44,13 +44,9 @@ struct FGArgs {
 
 namespace {
 
-// DEPTH convs are fused (4: conv1..4, the default build; 3: conv1..3 - built from this same source with
-// -DSELFC_GH_DEPTH=3 as launch_fused_gh3, conv4 then runs as its own launch)
-#ifndef SELFC_GH_DEPTH
-#define SELFC_GH_DEPTH 4
-#endif
-constexpr int DEPTH = SELFC_GH_DEPTH;
-static_assert(DEPTH == 3 || DEPTH == 4, "fused depth");
+// DEPTH convs are fused.  The geometry below is written for DEPTH in {3, 4}; the product is depth 4 (conv1..4).  A depth-3
+// build + conv4 as its own persistent launch was measured in round 1 (-3 % ... +3 %) and removed.
+constexpr int DEPTH = 4;
 constexpr int TS = 16;
 constexpr int XS = TS + 2 * DEPTH;         // X halo side (24 / 22)
 constexpr int XPITCH = XS * 8;             // bytes
@@ -385,6 +381,9 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
   c.tid = threadIdx.x;
   c.lane = c.tid & 63;
   c.wave = c.tid >> 6;
+#ifdef SELFC_EXP_PRIO      // experiment: static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH "Two waves per SIMD" item 4)
+  if (c.wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   c.half = c.lane >> 5;
   c.par = 0;
   c.first = true;
@@ -487,18 +486,9 @@ inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 
 }  // namespace
 
 // Called from dense_conv.hip (run_GH) when the block carries fused fragment streams.
-#if SELFC_GH_DEPTH == 3
-int launch_fused_gh3(FGArgs& a, hipStream_t s) {
-#else
 int launch_fused_gh(FGArgs& a, hipStream_t s) {
-#endif
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_gh_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS);
-    if (e != hipSuccess) return hip_rc(e);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> optin{0};
+  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&fused_gh_kernel), FG_LDS, optin); e != hipSuccess) return hip_rc(e);
   a.tiles_x = (a.W + TS - 1) / TS;
   a.tiles_y = (a.H + TS - 1) / TS;
   a.ntiles = a.tiles_x * a.tiles_y;

@@ -771,13 +771,8 @@ template <int KS, bool IN_F32, bool OUT_F32>
 int launch_pw(const void* in, void* out, const void* w, const float* bias, size_t npix, int cin, int cout,
               int cout_stride, int lrelu_in, int lrelu_out, hipStream_t s) {
   constexpr int lds = 64 * 1024;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_kernel<KS, IN_F32, OUT_F32>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return hip_rc(e);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> optin{0};
+  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&pwconv_kernel<KS, IN_F32, OUT_F32>), lds, optin); e != hipSuccess) return hip_rc(e);
   ProfScope prof(PROF_STP, s);
   const unsigned grid = (unsigned)((npix + 127) / 128);
   hipLaunchKernelGGL((pwconv_kernel<KS, IN_F32, OUT_F32>), dim3(grid), dim3(256), lds, s, in, out, (const f16*)w, bias,
@@ -844,12 +839,8 @@ int selfc_pwconv_gmm(const void* in, const void* w, const float* bias, const flo
   if (!in || !w || !bias || !eps || !v || npix == 0 || hf_dim != 48 || K != 5 || cin != 256 || v_stride < hf_dim || (v_stride & 3)) return SELFC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   constexpr int lds = 64 * 1024, GMM_NW = 8;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_gmm_kernel<8, 5, GMM_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return hip_rc(e);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> optin{0};
+  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&pwconv_gmm_kernel<8, 5, GMM_NW>), lds, optin); e != hipSuccess) return hip_rc(e);
   ProfScope prof(PROF_STP, s);
   hipLaunchKernelGGL((pwconv_gmm_kernel<8, 5, GMM_NW>), dim3((unsigned)((npix + GMM_NW * 32 - 1) / (GMM_NW * 32))), dim3(GMM_NW * 64), lds, s,
                      (const f16*)in, (const f16*)w, bias, eps, v, npix, cin, v_stride);

@@ -247,7 +247,7 @@ __global__ void quantize_kernel(float* __restrict__ x, size_t n4) {
   float* f = reinterpret_cast<float*>(&v);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    float t = fminf(fmaxf(f[j], 0.f), 1.f);
+    const float t = f[j] != f[j] ? f[j] : fminf(fmaxf(f[j], 0.f), 1.f);   // fminf / fmaxf would turn a NaN into 0: torch.clamp keeps it
     f[j] = rintf(t * 255.0f) / 255.0f;
   }
   reinterpret_cast<float4*>(x)[i] = v;

@@ -29,14 +29,32 @@ class RescaleRoundTrip:
         self.h, self.w = H // self.k, W // self.k
         blk = net._blocks()[0]
         self.ws = rt.Workspace(device, blk.F.kind, n_frames, t, self.h, self.w, blk.split_len1, blk.split_len2)
-        self.arr, self.keep = rt.block_array(net._blocks())
-        self.nblk = len(self.keep)
+        self._params = [p for b in net._blocks() for p in rt.plist(b)] + self._extra_params()
+        self._bind()
         self.lat = self.ws.latent()
         self.out = torch.empty((n_frames, 3, H, W), dtype=torch.float32, device=device)
         self.graph = None
         self.static_x = None
 
+    def _extra_params(self):
+        return []
+
+    def _bind(self):
+        """(Re)pack the blocks' weights and remember which weights that was."""
+        self.arr, self.keep = rt.block_array(self.net._blocks())
+        self.nblk = len(self.keep)
+        self._stamp = rt.weights_stamp(self._params)
+
+    def _fresh(self, replaying: bool = False):
+        """Weights may have changed since __init__ / capture() (load_state_dict, an optimizer step): an eager run repacks
+        them; a captured graph has the OLD packed buffers baked in, so replaying it is refused."""
+        if rt.weights_stamp(self._params) != self._stamp:
+            if replaying:
+                raise RuntimeError("the net's weights changed after capture(): call capture() again (the graph holds the old packed weights)")
+            self._bind()
+
     def run(self, x: torch.Tensor) -> torch.Tensor:
+        self._fresh()
         ws, L, sp = self.ws, _lib.lib(), _lib.stream_ptr()
         chk = _lib.check
         chk(L.selfc_freq_fwd(x.data_ptr(), ws.x1.data_ptr(), ws.x2.data_ptr(), ws.fd.data_ptr(), ws.FC,
@@ -50,6 +68,7 @@ class RescaleRoundTrip:
 
     def forward_latent(self, x: torch.Tensor) -> torch.Tensor:
         """fwd half only; returns the (N,51,h,w) NCHW latent (for parity checks)."""
+        self._fresh()
         ws, L, sp = self.ws, _lib.lib(), _lib.stream_ptr()
         _lib.check(L.selfc_freq_fwd(x.data_ptr(), ws.x1.data_ptr(), ws.x2.data_ptr(), ws.fd.data_ptr(), ws.FC,
                                     self.N, self.H, self.W, self.k, sp), "selfc_freq_fwd")
@@ -58,6 +77,7 @@ class RescaleRoundTrip:
 
     def inverse_latent(self, z: torch.Tensor) -> torch.Tensor:
         """rev half only on a given (N,51,h,w) NCHW latent; returns the (N,3,H,W) reconstruction."""
+        self._fresh()
         ws, L, sp = self.ws, _lib.lib(), _lib.stream_ptr()
         rt.nchw_to_latent(z.contiguous(), ws, with_fd=False)
         _lib.check(L.selfc_invstack_run(self.arr, self.nblk, C.byref(self.lat), 1, sp), "selfc_invstack_run rev")
@@ -80,6 +100,7 @@ class RescaleRoundTrip:
         self.graph = g
 
     def replay(self):
+        self._fresh(replaying=True)
         self.graph.replay()
         return self.out
 
@@ -98,7 +119,11 @@ class FullTestPath(RescaleRoundTrip):
             self.eps = torch.empty((n_frames * self.h * self.w, stp.hf_dim * stp.K), dtype=torch.float32, device=device)
         self.lr = torch.empty((n_frames, 3, self.h, self.w), dtype=torch.float32, device=device)
 
+    def _extra_params(self):
+        return rt.plist(self.net.stp_net)      # the STP repacks itself per call (params_key); the stamp guards replay()
+
     def run(self, x: torch.Tensor) -> torch.Tensor:
+        self._fresh()
         ws, L, sp = self.ws, _lib.lib(), _lib.stream_ptr()
         chk = _lib.check
         chk(L.selfc_freq_fwd(x.data_ptr(), ws.x1.data_ptr(), ws.x2.data_ptr(), ws.fd.data_ptr(), ws.FC,
@@ -154,5 +179,6 @@ class MultiStreamRoundTrip:
         self.graph = g
 
     def replay(self):
+        self.parts[0]._fresh(replaying=True)
         self.graph.replay()
         return self.out

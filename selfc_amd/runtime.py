@@ -175,6 +175,12 @@ def invalidate_weights() -> int:
     return _WEIGHT_EPOCH
 
 
+def weights_stamp(params) -> Tuple:
+    """O(n) but cheap (no data_ptr calls) change detector over a fixed parameter list: weight epoch + sum of the version
+    counters (+ the first tensor's address, which moves on .to() / .cuda()).  pipeline.* compare it before every run."""
+    return (_WEIGHT_EPOCH, sum(p._version for p in params), params[0].data_ptr() if params else 0)
+
+
 def params_key(*mods) -> Tuple:
     return (_WEIGHT_EPOCH,) + tuple((p.data_ptr(), p._version) for m in mods for p in plist(m))
 

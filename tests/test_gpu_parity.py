@@ -257,7 +257,7 @@ np.savez(sys.argv[2], z=z.cpu().numpy(), xr=xr.cpu().numpy())
 """
 
 
-@pytest.mark.parametrize("switch", ["SELFC_NO_FUSE_F=1", "SELFC_NO_F5P=1", "SELFC_NO_FUSE=1", "SELFC_GH_SPLIT=2"])
+@pytest.mark.parametrize("switch", ["SELFC_NO_FUSE_F=1", "SELFC_NO_F5P=1", "SELFC_NO_FUSE=1"])
 def test_fused_paths_agree_with_alternative_paths(dev, tmp_path, switch):
     """The default kernels (F's conv1-4 as two pairwise-fused launches with conv5 as partial products, G/H's conv1-4 as one
     depth-4 fused launch) against the alternative paths of the library - layer-wise conv3x3 / temporal-conv5 kernels, the

@@ -23,9 +23,9 @@ def main():
         for r in csv.DictReader(open(f)):
             rows.append((float(r["Start_Timestamp"]), float(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "?")))
     rows.sort()
-    selfc = [r for r in rows if "selfc" in r[2]]
+    selfc = [r for r in rows if not any(k in r[2] for k in ("at::native", "__amd_rocclr", "elementwise_kernel", "rocprim"))]   # the library's kernels
     if not selfc:
-        print("no selfc kernels in the trace")
+        print("no library kernels in the trace")
         return
     t_lo = selfc[0][0] + skip * (selfc[-1][1] - selfc[0][0])     # drop capture / warm-up
     rows = [r for r in selfc if r[0] >= t_lo]
