@@ -229,6 +229,12 @@ int selfc_bwd_wgrad(const void* P, int Pn, const void* Q, int Qn, int taps, floa
 int selfc_globalagg_run(const float* x, float* y, const float* wmap, const float* fc_bias /* device, 1 float */, const void* w1, const float* b1,
                         const float* w2, const float* b2, const float* w3, const float* b3,
                         float* partial, float* attn, int N, int T, int HW, void* stream);
+/* The same for a GlobalAgg(c) with c < 64 (codec variant: c = stp_hidden_c = 24, SelfC_Codec_arch_inv.py:103-131): the
+ * caller zero-pads activations and parameters to 64 channels (exact: padded channels stay 0) and passes the module's
+ * real channel count, which is the softmax temperature of `/C` (:120). */
+int selfc_globalagg_run_c(const float* x, float* y, const float* wmap, const float* fc_bias, const void* w1, const float* b1,
+                          const float* w2, const float* b2, const float* w3, const float* b3,
+                          float* partial, float* attn, int N, int T, int HW, int c_real, void* stream);
 size_t selfc_globalagg_partial_floats(int N, int HW);
 
 /* Pointwise conv = the Conv3d(.,.,1) layers of STPNet.tail_gmm (SelfC_GMM_arch_inv.py:327-344):
@@ -242,6 +248,10 @@ int selfc_pwconv_run(const void* in, int in_is_f32, void* out, int out_is_f32, c
  * reference's (hf_dim, K, 3) order, eps fp32 [npix][hf_dim*K]; v fp32 [npix][hf_dim] (= the x2 latent
  * layout).  pi = softmax over the hf_dim axis, log-sigma clamped to [-7,7].  hf_dim = 48, K in {1,3,5}. */
 int selfc_gmm_sample(const float* raw, const float* eps, float* v, size_t npix, int hf_dim, int K, void* stream);
+/* Any (hf_dim, K): raw rows of stride raw_stride >= hf_dim*K*3, v rows of stride v_stride.  logsigma_scale = 1 gives the
+ * sampler above; 0.5 is STP v1's `std = exp(0.5 logvar)` (SelfC_arch_inv.py:151-162,179-186; hf_dim = 9 there). */
+int selfc_gmm_sample_generic(const float* raw, const float* eps, float* v, size_t npix, int hf_dim, int K, int raw_stride,
+                             int v_stride, float logsigma_scale, void* stream);
 /* The last head layer (Conv3d 1x1x1, cin = 256 -> hf_dim*K*3) and the GMM sample in one kernel (sampling path of
  * SelfC_GMM_arch_inv.py:371-394: the 720-channel head output is never written).  `in`: f16 rows [npix][cin];
  * w / bias: that conv packed by packing.py:pack_pointwise after the channel permutation of packing.py:gmm_head_perm

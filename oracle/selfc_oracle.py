@@ -216,23 +216,23 @@ def large_block_indices(params: Params) -> List[int]:
 
 
 def large_fwd(params: Params, x: torch.Tensor, t: int = 7, kind: str = "D2DTNet",
-              split1: int = 3) -> torch.Tensor:
+              split1: int = 3, k: int = 4) -> torch.Tensor:
     """FrequencyAnalyzer then every InvBlockExp in order: SelfC_GMM_arch_inv.py:454-469.
     Returns the (N,51,h,w) latent (``loss_c`` is identically 0 there, :466)."""
-    out = freq_fwd(x)
+    out = freq_fwd(x, k)
     for i in large_block_indices(params):
         out, _ = invblock(kind, _sub(params, f"operations.{i}"), out, split1, t, rev=False)
     return out
 
 
 def large_inv_from_latent(params: Params, z: torch.Tensor, t: int = 7, kind: str = "D2DTNet",
-                          split1: int = 3) -> torch.Tensor:
+                          split1: int = 3, k: int = 4) -> torch.Tensor:
     """Reversed InvBlockExp stack then FrequencyAnalyzer reverse on a full
     51-channel latent (the op loop of SelfC_GMM_arch_inv.py:486-489)."""
     out = z
     for i in reversed(large_block_indices(params)):
         out, _ = invblock(kind, _sub(params, f"operations.{i}"), out, split1, t, rev=True)
-    return freq_inv(out)
+    return freq_inv(out, k)
 
 
 def large_roundtrip(params: Params, x: torch.Tensor, t: int = 7) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -370,8 +370,33 @@ def stp_v1_parameters(params: Params, lr: torch.Tensor, t: int) -> torch.Tensor:
     else:
         x = feature_calapse_block(_sub(params, "blk1"), x, t)
         x = feature_calapse_block(_sub(params, "blk2"), x, t)
-    wgt = params["tail.1.weight"]
-    return F.conv2d(lrelu(x), wgt.reshape(wgt.shape[0], wgt.shape[1], 1, 1), params["tail.1.bias"])
+    if "tail.1.weight" in params:
+        wgt = params["tail.1.weight"]
+        return F.conv2d(lrelu(x), wgt.reshape(wgt.shape[0], wgt.shape[1], 1, 1), params["tail.1.bias"])
+    for j in (1, 3, 5):                              # fh_loss "gmm": tail_gmm = [lrelu, conv1x1x1] x 3 (:118-128) -> 9*K*3 channels
+        wgt = params[f"tail_gmm.{j}.weight"]
+        x = F.conv2d(lrelu(x), wgt.reshape(wgt.shape[0], wgt.shape[1], 1, 1), params[f"tail_gmm.{j}.bias"])
+    return x
+
+
+def stp_v1_gmm_sample(raw: torch.Tensor, eps: torch.Tensor, hf_dim: int = 9, k: int = 5) -> torch.Tensor:
+    """raw (N, 9*K*3, h, w), eps (K, 9, N, h, w) [one draw per mixture component] -> (N, 9, h, w).  :151-163: pi = softmax
+    over the hf_dim axis, log-scale = clamp(idx1,-7,7), mean = idx2, v = sum_i pi_i * reparametrize(mean_i, ls_i) with
+    std = exp(0.5 * ls) in THIS file's reparametrize (:179-186; v2 uses exp(ls))."""
+    n, _, h, w = raw.shape
+    r = raw.reshape(n, hf_dim, k, 3, h, w)
+    pi = torch.softmax(r[:, :, :, 0], dim=1)
+    ls = torch.clamp(r[:, :, :, 1], -7, 7)
+    mu = r[:, :, :, 2]
+    e = eps.permute(2, 1, 0, 3, 4)                   # (N, 9, K, h, w)
+    return (pi * (e * torch.exp(0.5 * ls) + mu)).sum(2)
+
+
+def irn_rev(params: Params, lr: torch.Tensor, hf: torch.Tensor, block_num: Sequence[int], t: int = 7) -> torch.Tensor:
+    """InvRescaleNet.forward(rev=True) (Inv_arch.py:115-123): cat(lr, 45 sampled channels), reversed op loop.  The
+    InvBlockExp's narrow() takes the channels it needs and silently drops the rest (:22)."""
+    need = 3 * 4 ** len(block_num)
+    return haar_net_inv(params, torch.cat((lr, hf), 1)[:, :need], block_num, t)
 
 
 def selfc_haar_fwd(params: Params, x: torch.Tensor, block_num: Sequence[int], t: int = 7,
@@ -520,3 +545,88 @@ def ssim_per_frame(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0) ->
     cs = (2 * s12 + c2) / (s1 + s2 + c2)
     m = ((2 * mu1 * mu2 + c1) / (mu1 * mu1 + mu2 * mu2 + c1)) * cs
     return [float(v) for v in m.mean(-1).mean(-1).mean(-1)]
+
+
+# ----------------------------------------------------------------------------
+# f4  codec variant (models/modules/SelfC_Codec_arch_inv.py): FrequencyAnalyzer(k=2) + 4 x InvBlockExp(15 | 3) + the
+#     narrow STP (hidden 24, growth 12, clips of TEMP_LEN = 3) + the segmenting / tiling of forward_test.  The H.265
+#     stream between the two halves is external and not restated.
+# ----------------------------------------------------------------------------
+
+def seg_add_pad(video: torch.Tensor, seg_len: int):
+    """(b,t,c,h,w) -> ((b,seg_num,seg_len,c,h,w), pad): utils/util.py:329-345; pads repeat out_video[:, -2:-1]."""
+    b, t, c, h, w = video.shape
+    pad = 0 if t % seg_len == 0 else seg_len - t % seg_len
+    for _ in range(pad):
+        video = torch.cat((video, video[:, -2:-1]), dim=1)
+    return video.reshape(b, -1, seg_len, c, h, w), pad
+
+
+def seg_remove_pad(video: torch.Tensor, pad: int, seg_len: int) -> torch.Tensor:
+    """utils/util.py:346-354"""
+    b, seg_num, seg_len, c, h, w = video.shape
+    if pad == 0:
+        return video.reshape(b, -1, c, h, w)
+    pre = video[:, :seg_num - 1].reshape(b, (seg_num - 1) * seg_len, c, h, w)
+    return torch.cat((pre, video[:, -1, :seg_len - pad]), dim=1)
+
+
+def codec_stp_parameters(params: Params, lr: torch.Tensor, t: int = 3, stp_blk_num: int = 4) -> torch.Tensor:
+    """STPNet.forward of the codec file (:292-312): the same chain as stp_v2_parameters on narrower modules (weights
+    carry the widths), GlobalAgg over clips of TEMP_LEN = 3 (:77,118), head = `tail` (:257-262).  lr (B*T,3,h,w)."""
+    x = d2dt(_sub(params, "local_m1"), lr, t)
+    x = global_agg(_sub(params, "global_m1"), x, 3)
+    x = d2dt(_sub(params, "local_m2"), x, t)
+    x = global_agg(_sub(params, "global_m2"), x, 3)
+    for i in range(stp_blk_num - 2):
+        x = d2dt(_sub(params, f"other_stp_modules.{2 * i}"), x, t)
+        x = global_agg(_sub(params, f"other_stp_modules.{2 * i + 1}"), x, 3)
+    for j in sorted({int(k.split(".")[1]) for k in params if k.startswith("tail.")}):
+        x = lrelu(x)
+        wgt = params[f"tail.{j}.weight"]
+        x = F.conv2d(x, wgt.reshape(wgt.shape[0], wgt.shape[1], 1, 1), params[f"tail.{j}.bias"])
+    return x
+
+
+def codec_decode(params: Params, lr: torch.Tensor, t: int = 3) -> torch.Tensor:
+    """forward_train(rev=True) (:480-498) with the l2 head: hf = STP(lr); reversed op loop on cat(lr, hf); k = 2."""
+    hf = codec_stp_parameters(_sub(params, "stp_net"), lr, t)
+    return large_inv_from_latent(params, torch.cat((lr, hf), 1), t, k=2)
+
+
+def codec_encode_tiled(params: Params, x: torch.Tensor, t_all: int, seg_len: int = 3, wdiv: int = 2) -> torch.Tensor:
+    """forward_test(rev=False) up to the H.265 writer (:510-552): 3-frame segments, each column strip through the whole op
+    loop on its own, LR channels concatenated along the width.  x (b*t,3,H,W) -> (b*t,3,H/2,W/2), unquantised."""
+    bt, c, h, w = x.shape
+    b = bt // t_all
+    video, pad = seg_add_pad(x.reshape(b, t_all, c, h, w), seg_len)
+    outs = []
+    for s in range(video.shape[1]):
+        seg = video[:, s].reshape(-1, c, h, w)
+        strips = [large_fwd(params, seg[:, :, :, i * (w // wdiv):(i + 1) * (w // wdiv)], seg_len, k=2)[:, 0:3] for i in range(wdiv)]
+        outs.append(torch.cat(strips, dim=-1))
+    lr = torch.stack(outs, 0)
+    hh, ww = lr.shape[-2:]
+    lr = lr.reshape(video.shape[1], b, seg_len, 3, hh, ww).permute(1, 0, 2, 3, 4, 5)
+    return seg_remove_pad(lr, pad, seg_len).reshape(-1, 3, hh, ww)
+
+
+def codec_decode_tiled(params: Params, lr: torch.Tensor, t_all: int, seg_len: int = 3, hdiv: int = 2, wdiv: int = 2) -> torch.Tensor:
+    """forward_test(rev=True) (:575-640): every 3-frame segment is cut into hdiv x wdiv tiles (no halo), each tile runs
+    STP + the reversed op loop on its own, the tiles are put back side by side.  lr (b*t,3,h,w) -> (b*t,3,2h,2w)."""
+    bt, c, h, w = lr.shape
+    b = bt // t_all
+    video, pad = seg_add_pad(lr.reshape(b, t_all, c, h, w), seg_len)
+    hd, wd = h // hdiv, w // wdiv
+    outs = []
+    for s in range(video.shape[1]):
+        seg = video[:, s].reshape(-1, c, h, w)[:, 0:3]
+        rows = []
+        for i in range(hdiv):
+            rows.append(torch.cat([codec_decode(params, seg[:, :, i * hd:(i + 1) * hd, j * wd:(j + 1) * wd], seg_len)
+                                   for j in range(wdiv)], dim=-1))
+        outs.append(torch.cat(rows, dim=-2))
+    hr = torch.stack(outs, 0)
+    H, W = hr.shape[-2:]
+    hr = hr.reshape(video.shape[1], b, seg_len, 3, H, W).permute(1, 0, 2, 3, 4, 5)
+    return seg_remove_pad(hr, pad, seg_len).reshape(-1, 3, H, W)

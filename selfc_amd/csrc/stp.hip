@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void gagg_pool_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void gagg_attn_kernel(const float* __restrict__ partial, int nchunk, const float* __restrict__ fcbp,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
                                                        const float* __restrict__ w3, const float* __restrict__ b3,
-                                                       float* __restrict__ A, int T) {
+                                                       float* __restrict__ A, int T, float creal) {
   __shared__ float g[TMAX][64], q[TMAX][64], k[TMAX][64], m[TMAX][TMAX], w2s[64][65], w3s[64][65];
   const int b = blockIdx.x, tid = threadIdx.x;
   const float fcb = *fcbp;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void gagg_attn_kernel(const float* __restrict_
     const int t1 = tid / T, t2 = tid % T;
     float s = 0.f;
     for (int j = 0; j < 64; ++j) s += q[t1][j] * k[t2][j];
-    m[t1][t2] = s / 64.0f;
+    m[t1][t2] = s / creal;          // the reference divides by the module's REAL channel count C (64; 24 in the codec variant)
   }
   __syncthreads();
   if (tid < T) {            // softmax over the last axis of row tid
@@ -430,6 +430,30 @@ __global__ __launch_bounds__(256) void gmm_sample_kernel(const float* __restrict
   if (ok) {
 #pragma unroll
     for (int i = 0; i < CP; ++i) v[px * HF + j + 16 * i] = out[i];
+  }
+}
+
+// ---- the same sampler for any (hf_dim, K) and either std convention: one thread per pixel (the Haar variant's head has
+// hf_dim = 9: SelfC_arch_inv.py:151-162, std = exp(0.5 logvar) there, :179-186).  raw rows have stride raw_stride.
+__global__ __launch_bounds__(256) void gmm_sample_generic_kernel(const float* __restrict__ raw, const float* __restrict__ eps,
+                                                                 float* __restrict__ v, size_t npix, int hf, int K, int raw_stride,
+                                                                 int v_stride, float ls_scale) {
+  const size_t px = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (px >= npix) return;
+  const float* r = raw + px * (size_t)raw_stride;
+  const float* e = eps + px * (size_t)(hf * K);
+  float* o = v + px * (size_t)v_stride;
+  for (int c = 0; c < hf; ++c) o[c] = 0.f;
+  for (int k = 0; k < K; ++k) {
+    float mx = r[k * 3];
+    for (int c = 1; c < hf; ++c) mx = fmaxf(mx, r[(c * K + k) * 3]);
+    float s = 0.f;
+    for (int c = 0; c < hf; ++c) s += expf(r[(c * K + k) * 3] - mx);
+    for (int c = 0; c < hf; ++c) {
+      const float* q = r + (c * K + k) * 3;
+      const float ls = fminf(fmaxf(q[1], -7.f), 7.f);
+      o[c] += (expf(q[0] - mx) / s) * (e[c * K + k] * expf(ls_scale * ls) + q[2]);
+    }
   }
 }
 
@@ -787,8 +811,14 @@ extern "C" {
 int selfc_globalagg_run(const float* x, float* y, const float* wmap, const float* fc_bias, const void* w1, const float* b1,
                         const float* w2, const float* b2, const float* w3, const float* b3,
                         float* partial, float* attn, int N, int T, int HW, void* stream) {
+  return selfc_globalagg_run_c(x, y, wmap, fc_bias, w1, b1, w2, b2, w3, b3, partial, attn, N, T, HW, 64, stream);
+}
+
+int selfc_globalagg_run_c(const float* x, float* y, const float* wmap, const float* fc_bias, const void* w1, const float* b1,
+                          const float* w2, const float* b2, const float* w3, const float* b3,
+                          float* partial, float* attn, int N, int T, int HW, int c_real, void* stream) {
   if (!x || !y || !wmap || !fc_bias || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !partial || !attn) return SELFC_EINVAL;
-  if (N <= 0 || T <= 0 || T > TMAX || N % T || HW <= 0 || x == y) return SELFC_EINVAL;
+  if (N <= 0 || T <= 0 || T > TMAX || N % T || HW <= 0 || x == y || c_real < 1 || c_real > 64) return SELFC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = (HW + POOL_CHUNK - 1) / POOL_CHUNK;
   const int B = N / T;
@@ -800,7 +830,7 @@ int selfc_globalagg_run(const float* x, float* y, const float* wmap, const float
   if (rc) return rc;
   {
     ProfScope prof(PROF_STP, s);
-    hipLaunchKernelGGL(gagg_attn_kernel, dim3(B), dim3(256), 0, s, partial, nchunk, fc_bias, w2, b2, w3, b3, attn, T);
+    hipLaunchKernelGGL(gagg_attn_kernel, dim3(B), dim3(256), 0, s, partial, nchunk, fc_bias, w2, b2, w3, b3, attn, T, (float)c_real);
   }
   rc = hip_rc(hipGetLastError());
   if (rc) return rc;
@@ -856,6 +886,16 @@ int selfc_gmm_sample(const float* raw, const float* eps, float* v, size_t npix, 
   else if (K == 3) hipLaunchKernelGGL(gmm_sample_kernel<3>, dim3(grid), dim3(256), 0, s, raw, eps, v, npix);
   else if (K == 1) hipLaunchKernelGGL(gmm_sample_kernel<1>, dim3(grid), dim3(256), 0, s, raw, eps, v, npix);
   else return SELFC_EINVAL;
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_gmm_sample_generic(const float* raw, const float* eps, float* v, size_t npix, int hf_dim, int K, int raw_stride,
+                             int v_stride, float logsigma_scale, void* stream) {
+  if (!raw || !eps || !v || npix == 0 || hf_dim < 1 || K < 1 || raw_stride < hf_dim * K * 3 || v_stride < hf_dim) return SELFC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(PROF_STP, s);
+  hipLaunchKernelGGL(gmm_sample_generic_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, raw, eps, v, npix, hf_dim, K,
+                     raw_stride, v_stride, logsigma_scale);
   return hip_rc(hipGetLastError());
 }
 

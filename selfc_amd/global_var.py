@@ -25,6 +25,9 @@ def _accessor(attr):
 
 
 class _GlobalVar:
+    def __init__(self):      # the reference declares an empty constructor (global_var.py:4-5); nothing is ever instantiated
+        pass
+
     get_Temporal_LEN, set_Temporal_LEN = _accessor("VIDEO_T_LEN")      # frames per clip (7 for septuplets)
     get_Istrain, set_Istrain = _accessor("Istrain")
 

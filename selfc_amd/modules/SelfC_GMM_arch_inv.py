@@ -72,10 +72,15 @@ class GlobalAgg(nn.Module):
     csrc/stp.hip: weighted pooling (fc folded through adaptive_avg_pool2d into one HxW map),
     a tiny per-clip attention kernel, and a fused temporal-mix + 1x1 projection + residual."""
 
+    #: frames per clip; None = GlobalVar.get_Temporal_LEN() (SelfC_GMM_arch_inv.py:276).  The codec variant's copy of this
+    #: class uses the module constant TEMP_LEN = 3 instead (SelfC_Codec_arch_inv.py:77,118).
+    TEMP_LEN = None
+
     def __init__(self, c):
         super().__init__()
-        if c != 64:
-            raise NotImplementedError("selfc_amd GlobalAgg kernels are built for c = 64 (the only value the reference uses)")
+        if not 1 <= c <= 64:
+            raise NotImplementedError("selfc_amd GlobalAgg kernels hold c <= 64 channels (64 in SelfC-large, 24 in the codec variant)")
+        self.c = c
         self.fc = nn.Linear(32 * 32, 1)
         self.proj1 = nn.Conv2d(c, c, 1, 1, 0)
         self.proj2 = nn.Linear(c, c)
@@ -85,11 +90,16 @@ class GlobalAgg(nn.Module):
         key = rt.params_key(self) + (h, w)
         if getattr(self, "_pk_key", None) != key:
             from ..packing import pack_pointwise, pad_bias, pool_weight_map
-            f32 = lambda t: t.detach().float().contiguous()  # noqa: E731
-            self._pk = dict(wmap=pool_weight_map(self.fc.weight, h, w), fcb=f32(self.fc.bias),
-                            w1=pack_pointwise(self.proj1.weight), b1=pad_bias(self.proj1.bias, 64),
-                            w2=f32(self.proj2.weight), b2=f32(self.proj2.bias),
-                            w3=f32(self.proj3.weight), b3=f32(self.proj3.bias))
+            c = self.c
+
+            def sq64(wt):        # (c,c[,1,1]) -> zero-padded (64,64): the kernels' rows are 64 channels wide, pads stay 0
+                out = torch.zeros(64, 64, dtype=torch.float32, device=wt.device)
+                out[:c, :c] = wt.detach().float().reshape(c, c)
+                return out
+            self._pk = dict(wmap=pool_weight_map(self.fc.weight, h, w), fcb=self.fc.bias.detach().float().contiguous(),
+                            w1=pack_pointwise(sq64(self.proj1.weight)), b1=pad_bias(self.proj1.bias, 64),
+                            w2=sq64(self.proj2.weight), b2=pad_bias(self.proj2.bias, 64),
+                            w3=sq64(self.proj3.weight), b3=pad_bias(self.proj3.bias, 64))
             self._pk_key = key
         return self._pk
 
@@ -104,21 +114,29 @@ class GlobalAgg(nn.Module):
             buf = scratch.get(name)
             if buf is None or buf.numel() < need or buf.device != x.device:
                 scratch[name] = torch.empty(need, dtype=torch.float32, device=x.device)
-        rt.call("selfc_globalagg_run", x.data_ptr(), y.data_ptr(), pk["wmap"].data_ptr(), pk["fcb"].data_ptr(),
+        rt.call("selfc_globalagg_run_c", x.data_ptr(), y.data_ptr(), pk["wmap"].data_ptr(), pk["fcb"].data_ptr(),
                 pk["w1"].data_ptr(), pk["b1"].data_ptr(), pk["w2"].data_ptr(), pk["b2"].data_ptr(),
                 pk["w3"].data_ptr(), pk["b3"].data_ptr(), scratch["gagg_partial"].data_ptr(),
-                scratch["gagg_attn"].data_ptr(), n, t, h * w, _lib.stream_ptr())
+                scratch["gagg_attn"].data_ptr(), n, t, h * w, self.c, _lib.stream_ptr())
 
     def forward(self, x):
         x = rt.as_input(x)
-        t = GlobalVar.get_Temporal_LEN()
+        t = self.TEMP_LEN or GlobalVar.get_Temporal_LEN()
         n, c, h, w = x.shape
-        if not t or n % t or c != 64:
-            raise RuntimeError(f"GlobalAgg expects (b*T,64,h,w) with T={t!r}, got {tuple(x.shape)}")
+        if not t or n % t or c != self.c:
+            raise RuntimeError(f"GlobalAgg expects (b*T,{self.c},h,w) with T={t!r}, got {tuple(x.shape)}")
         from .. import autograd as ag
         if ag.module_needs_grad(x, self):
-            return ag.GlobalAggFn.apply(x, self, t, *self.parameters())
+            if c != 64:
+                raise NotImplementedError("selfc_amd: GlobalAgg gradients are built for c = 64 (c < 64, the codec variant, runs in inference only)")
+            return ag.GlobalAggFn.apply(x, self, t, *rt.plist(self))
         sp = _lib.stream_ptr()
+        if c != 64:                    # zero-pad the rows to the kernels' 64 channels (host-side view ops, not a hot path)
+            xin = torch.zeros((n, h, w, 64), dtype=torch.float32, device=x.device)
+            xin[..., :c] = x.permute(0, 2, 3, 1)
+            yout = torch.empty_like(xin)
+            self.run_nhwc(xin, yout, n, t, h, w, self.__dict__.setdefault("_scratch", {}))
+            return yout[..., :c].permute(0, 3, 1, 2).contiguous()
         xin = torch.empty((n, h, w, 64), dtype=torch.float32, device=x.device)
         rt.call("selfc_nchw_to_nhwc4", x.data_ptr(), xin.data_ptr(), n, 64, h, w, sp)
         yout = torch.empty_like(xin)
@@ -142,7 +160,7 @@ class STPNet(nn.Module):
         self.scale = opt["scale"]
         self.K = opt["gmm_k"]
         self.stp_blk_num = opt["stp_blk_num"] - 2
-        c = 64
+        c = self.c = 64
         if self.global_module not in (None, 'nonlocal'):
             raise NotImplementedError("selfc_amd covers global_module: nonlocal (the shipped configs); "
                                       "the deform aggregators need torchvision.ops.deform_conv2d")
@@ -181,12 +199,28 @@ class STPNet(nn.Module):
             mods.append(self.global_m2)
         return mods + list(self.other_stp_modules)
 
+    def _tail_seq(self):
+        """the head's nn.Sequential (`tail_gmm` here, `tail` in the codec variant's STPNet)"""
+        return self.tail_gmm
+
+    def _virt(self, m):
+        """(cin, cout) the chain's kernels see for subnet m: features travel in 64-channel fp32 rows whatever c is"""
+        return (m.channel_in if m.channel_in <= 3 else 64, 64)
+
     def _tail_packed(self):
-        convs = [m for m in self.tail_gmm if isinstance(m, nn.Conv3d)]
+        convs = [m for m in self._tail_seq() if isinstance(m, nn.Conv3d)]
         key = rt.params_key(*convs)
         if getattr(self, "_tail_key", None) != key:
             from ..packing import pack_pointwise, pad_bias, roundup
-            self._tail = [(pack_pointwise(m.weight), pad_bias(m.bias, roundup(m.out_channels, 16)), m.in_channels, m.out_channels)
+            if self.c != 64 and len(convs) != 1:
+                raise NotImplementedError("selfc_amd: a GMM head on a hidden width other than 64 is not built (the codec variant ships fh_loss: l2)")
+
+            def wide(m):          # first layer of a c < 64 head: zero columns for the chain's padded channels
+                wt = m.weight.detach().float().reshape(m.out_channels, m.in_channels)
+                if m.in_channels % 32:
+                    wt = torch.cat((wt, wt.new_zeros(m.out_channels, roundup(m.in_channels, 64) - m.in_channels)), 1)
+                return wt
+            self._tail = [(pack_pointwise(wide(m)), pad_bias(m.bias, roundup(m.out_channels, 16)), roundup(m.in_channels, 32) if m.in_channels % 32 == 0 else roundup(m.in_channels, 64), m.out_channels)
                           for m in convs]
             self._tail_fused = None
             if self.fh_loss == "gmm" and len(convs) == 3 and self.hf_dim == 48 and self.K == 5 and convs[2].in_channels == 256:
@@ -205,8 +239,8 @@ class STPNet(nn.Module):
         eps: pre-allocated noise rows [n*h*w][hf_dim*K] to fill in place (hipGraph capture) instead of a fresh randn."""
         if self.fh_loss == "gmm_thin":
             raise NotImplementedError("fh_loss 'gmm_thin' (ReLU head) has no kernel; the shipped configs use 'gmm' / 'l2'")
-        if self.hf_dim != 48:
-            raise NotImplementedError("STP head kernels are built for hf_dim = 48 (scale 4)")
+        if self.hf_dim != 48 and self.fh_loss != "l2":
+            raise NotImplementedError("the GMM head kernels are built for hf_dim = 48 (scale 4); other scales run the l2 head")
         dev, sp = x1.device, _lib.stream_ptr()
         sc = scratch if scratch is not None else self.__dict__.setdefault("_scratch", {})
         shape_key = (n, h, w, str(dev))
@@ -222,9 +256,10 @@ class STPNet(nn.Module):
             if isinstance(m, D2DTInput):
                 src = x1 if cur is None else sc["feat"][cur]
                 dense = sc["dense4"] if m.channel_in <= 3 else sc["dense6"]
-                sw = m.packed().struct()
+                cin_v, cout_v = self._virt(m)
+                sw = rt.packed_subnet(m, (cin_v, cout_v)).struct()
                 rt.call("selfc_subnet_run", sw, m.kind, src.data_ptr(), dst.data_ptr(), dense.data_ptr(),
-                        n, t, h, w, m.channel_in, m.channel_out, sp)
+                        n, t, h, w, cin_v, cout_v, sp)
             else:
                 m.run_nhwc(sc["feat"][cur], dst, n, t, h, w, sc)
             cur, nxt = nxt, 1 - nxt
@@ -233,8 +268,16 @@ class STPNet(nn.Module):
         tail = self._tail_packed()
         if self.fh_loss == "l2":
             wp, bp, cin, cout = tail[0]
-            rt.call("selfc_pwconv_run", feat.data_ptr(), 1, hf_out.data_ptr(), 1, wp.data_ptr(), bp.data_ptr(),
-                    npix, cin, cout, cout, 1, 0, sp)
+            if cout % 16:             # whole 16-channel tiles are stored: go through a padded row, then narrow (scale 2: 12)
+                c16 = (cout + 15) // 16 * 16
+                if "hf16" not in sc:
+                    sc["hf16"] = torch.empty((npix, c16), dtype=torch.float32, device=dev)
+                rt.call("selfc_pwconv_run", feat.data_ptr(), 1, sc["hf16"].data_ptr(), 1, wp.data_ptr(), bp.data_ptr(),
+                        npix, cin, c16, c16, 1, 0, sp)
+                hf_out.view(npix, -1)[:, :cout].copy_(sc["hf16"][:, :cout])
+            else:
+                rt.call("selfc_pwconv_run", feat.data_ptr(), 1, hf_out.data_ptr(), 1, wp.data_ptr(), bp.data_ptr(),
+                        npix, cin, cout, cout, 1, 0, sp)
             return hf_out if keep_raw else None
         if "h1" not in sc:
             sc["h1"] = torch.empty((npix, tail[0][3]), dtype=_lib.operand_dtype(), device=dev)

@@ -20,8 +20,8 @@ class _DenseSubnet(nn.Module):
     kind = None  # SUBNET_DB2D / SUBNET_D2DT
 
     def _check(self):
-        if self.gc != 32:
-            raise NotImplementedError("selfc_amd dense-block kernels are built for growth channels gc=32")
+        if not 1 <= self.gc <= 32:
+            raise NotImplementedError("selfc_amd dense-block kernels cover growth channels gc <= 32 (gc < 32 is zero-padded to 32)")
         if self.channel_in > 96 or self.channel_out > (32 if self.kind == rt.SUBNET_DB2D else 64):
             raise NotImplementedError(f"subnet {self.channel_in}->{self.channel_out} is outside the compiled kernel set")
 
@@ -38,6 +38,8 @@ class _DenseSubnet(nn.Module):
             raise RuntimeError(f"{n} frames are not a multiple of the temporal length {T}")
         from .. import autograd as ag
         if ag.module_needs_grad(x, self):          # training: same kernels, buffers kept for the HIP backward
+            if self.gc != 32:
+                raise NotImplementedError("selfc_amd: the gradient kernels cover gc = 32 (gc < 32, the codec variant's STP, runs in inference only)")
             return ag.SubnetFn.apply(x, self, T, *ag.subnet_params(self))
         pk = self.packed()
         dev, sp = x.device, _lib.stream_ptr()

@@ -112,6 +112,34 @@ def pack_tconv5(weights: Sequence[torch.Tensor], cin: int) -> torch.Tensor:
     return _operand(frag)
 
 
+def widen_dense_params(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], cin: int, cout: int, gc: int,
+                       cin_v: int = None, cout_v: int = None):
+    """An EXACTLY equivalent dense block in the kernels' layout (growth 32, cin_v inputs, cout_v outputs) of a block with
+    growth gc <= 32 (codec variant: stp_denseblock_innerc = 12, SelfC_Codec_arch_inv.py:248-252), cin <= cin_v and
+    cout <= cout_v: real rows / columns keep their place in the reference's concat order [x | f1 | f2 | f3 | f4], every
+    added row, column and bias is zero - the padded features are LeakyReLU(0) = 0 and meet zero weights, so no rounding
+    differs.  Pure placement + zero fill (PackPlan-compatible).  Returns (weights, biases) of conv1..conv5."""
+    cin_v = cin if cin_v is None else cin_v
+    cout_v = cout if cout_v is None else cout_v
+    assert gc <= 32 and cin <= cin_v and cout <= cout_v
+    ws, bs = [], []
+    for k in range(1, 6):
+        w, b = weights[k - 1], biases[k - 1]
+        nfeat = k - 1
+        o_real = gc if k < 5 else cout
+        o_v = 32 if k < 5 else cout_v
+        assert w.shape[0] == o_real and w.shape[1] == cin + gc * nfeat, (tuple(w.shape), cin, gc, k)
+        wv = torch.zeros((o_v, cin_v + 32 * nfeat) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device)
+        wv[:o_real, :cin] = w[:, :cin]
+        for j in range(nfeat):
+            wv[:o_real, cin_v + 32 * j: cin_v + 32 * j + gc] = w[:, cin + gc * j: cin + gc * (j + 1)]
+        bv = torch.zeros(o_v, dtype=b.dtype, device=b.device)
+        bv[:o_real] = b
+        ws.append(wv)
+        bs.append(bv)
+    return ws, bs
+
+
 def pad_bias(bias, n: int = 64, device=None) -> torch.Tensor:
     out = torch.zeros(n, dtype=torch.float32, device=device if bias is None else bias.device)
     if bias is not None:

@@ -134,17 +134,28 @@ class PackedSubnet:
         return s
 
 
-def packed_subnet(mod) -> PackedSubnet:
-    """Stand-alone subnet (not inside an InvBlockExp): plan learnt once per module, re-run when the weights change."""
-    key = params_key(mod)
+def packed_subnet(mod, virt: Tuple[int, int] = None) -> PackedSubnet:
+    """Stand-alone subnet (not inside an InvBlockExp): plan learnt once per module, re-run when the weights change.
+    virt = (cin_v, cout_v): pack as the equivalent block with zero-padded inputs / outputs (packing.widen_dense_params) -
+    the STP chain of the codec variant keeps its 24-channel features in the kernels' 64-channel rows.  A growth gc < 32
+    is widened the same way."""
+    cin_v, cout_v = virt if virt is not None else (mod.channel_in, mod.channel_out)
+    key = params_key(mod) + (cin_v, cout_v)
     if getattr(mod, "_pk_key", None) != key:
         mod._check()
         params = _conv_params(mod)
         temporal = mod.kind == SUBNET_D2DT
-        if getattr(mod, "_plan", None) is None or mod._plan_dev != params[0].device:
-            mod._plan = PackPlan(params, lambda ps: subnet_pack_entries("", ps[0::2], ps[1::2], mod.channel_in, mod.channel_out, temporal))
-            mod._plan_dev = params[0].device
-        mod._pk = PackedSubnet(mod._plan.run(params), "", mod.channel_in, mod.channel_out, mod.kind)
+        widen = mod.gc != 32 or (cin_v, cout_v) != (mod.channel_in, mod.channel_out)
+        if getattr(mod, "_plan", None) is None or mod._plan_dev != params[0].device or mod._plan_virt != (cin_v, cout_v):
+            def build(ps):
+                ws, bs = ps[0::2], ps[1::2]
+                if widen:
+                    from .packing import widen_dense_params
+                    ws, bs = widen_dense_params(ws, bs, mod.channel_in, mod.channel_out, mod.gc, cin_v, cout_v)
+                return subnet_pack_entries("", ws, bs, cin_v, cout_v, temporal, with_bwd=not widen)
+            mod._plan = PackPlan(params, build)
+            mod._plan_dev, mod._plan_virt = params[0].device, (cin_v, cout_v)
+        mod._pk = PackedSubnet(mod._plan.run(params), "", cin_v, cout_v, mod.kind)
         mod._pk_key = key
     return mod._pk
 

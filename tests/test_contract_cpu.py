@@ -66,3 +66,30 @@ def test_no_cpu_fallback_anywhere():
         SelfC_GMM_arch_inv.FrequencyAnalyzer(3)(x)
     with pytest.raises(RuntimeError):
         Inv_arch.HaarDownsampling(3)(x)
+
+
+def test_public_api_matches_reference():
+    """Every mirrored class keeps the reference class's public methods and the parameter names / order / defaults of
+    __init__ and forward (tests/golden/api_contract.json, dumped from the reference classes by tools/make_golden.py r2).
+    Extra keyword parameters with defaults AFTER the reference's are allowed (e.g. FrequencyAnalyzer's k)."""
+    import inspect
+    from selfc_amd.modules import Quantization as Q, SelfC_Codec_arch_inv as CA
+    from selfc_amd import global_var
+    api = json.load(open(os.path.join(GOLDEN, "api_contract.json")))
+    mods = {"Inv_arch": Inv_arch, "Subnet_constructor": SC, "SelfC_GMM_arch_inv": SelfC_GMM_arch_inv, "SelfC_arch_inv": SelfC_arch_inv,
+            "SelfC_Codec_arch_inv": CA, "Quantization": Q, "global_var": global_var}
+
+    def sig(f):
+        return [[p.name, None if p.default is inspect._empty else repr(p.default)] for p in inspect.signature(f).parameters.values()]
+    for name, ref in api.items():
+        mod, cls_name = name.split(".")
+        cls = getattr(mods[mod], cls_name)
+        missing = [m for m in ref["methods"] if not hasattr(cls, m)]
+        assert not missing, (name, missing)
+        for what in ("init", "forward"):
+            if ref[what] is None:
+                continue
+            ours = sig(cls.__init__ if what == "init" else cls.forward)
+            want = [list(p) for p in ref[what]]
+            assert ours[:len(want)] == want, (name, what, ours, want)
+            assert all(d is not None for _, d in ours[len(want):]), (name, what, "extra parameters must have defaults")

@@ -202,3 +202,39 @@ def test_ssim_y():
     got = O.ssim_per_frame(O.rgb_to_y(g["a"]), O.rgb_to_y(g["b"]))
     assert rel_err(torch.tensor(got, dtype=torch.float64), g["ssim"]) < 1e-6
     assert abs(O.ssim_per_frame(O.rgb_to_y(g["a"]), O.rgb_to_y(g["a"]))[0] - 1.0) < 1e-6
+
+
+def test_irn_reverse_with_pinned_hf():
+    """InvRescaleNet.forward(rev=True) with the reference's torch.rand HF tensor pinned (fixture g14)."""
+    g = load_golden("g14_irn_rev")
+    out = O.irn_rev(g, g["lr"], g["hf45"], [1], T)
+    assert rel_err(out, g["x_rev"]) < 1e-5
+
+
+def test_codec_variant_pieces_and_tiling():
+    """f4: codec-variant shapes (SelfC_Codec_arch_inv.py) - InvBlockExp(15|3), narrow STP, GlobalAgg(24) over 3-frame clips,
+    and forward_test's segmenting / tiling, against vectors from the reference's own modules (fixture g15)."""
+    g = load_golden("g15_codec")
+    y, s = O.invblock("D2DTNet", subdict(g, "operations.1"), g["blk_x"], 3, 3)
+    assert rel_err(y, g["blk_y"]) < FTOL and rel_err(s, g["blk_s"]) < 5e-6
+    xr, _ = O.invblock("D2DTNet", subdict(g, "operations.1"), g["blk_x"], 3, 3, rev=True)
+    assert rel_err(xr, g["blk_xrev"]) < FTOL
+    assert rel_err(O.global_agg(subdict(g, "stp_net.global_m1"), g["ga_x"], 3), g["ga_y"]) < FTOL
+    assert rel_err(O.codec_stp_parameters(subdict(g, "stp_net"), g["stp_lr"], 3), g["stp_raw"]) < 2e-5
+    enc = O.codec_encode_tiled(g, g["x"], 5)
+    assert rel_err(enc, g["enc_lr"]) < 1e-5
+    assert torch.equal(O.quantize(g["enc_lr"]), g["lr_q"])
+    assert rel_err(O.codec_decode_tiled(g, g["lr_q"], 5), g["dec_hr"]) < 5e-5
+    # seg_add_pad repeats the SECOND-TO-LAST frame (utils/util.py:340), and remove undoes add
+    v = torch.arange(5.).reshape(1, 5, 1, 1, 1)
+    padded, pad = O.seg_add_pad(v, 3)
+    assert pad == 1 and padded.reshape(-1).tolist() == [0, 1, 2, 3, 4, 3]
+    assert torch.equal(O.seg_remove_pad(padded, pad, 3), v)
+
+
+def test_stp_v1_gmm_head():
+    """STP v1 GMM branch (SelfC_arch_inv.py:118-128,151-163; `.cuda()` at :161 neutralised when the fixture was made)."""
+    g = load_golden("g16_stp_v1_gmm")
+    raw = O.stp_v1_parameters(g, g["lr"], T)
+    assert rel_err(raw, g["raw"]) < 2e-5
+    assert rel_err(O.stp_v1_gmm_sample(g["raw"], g["eps"]), g["v"]) < 2e-6

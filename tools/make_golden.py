@@ -360,6 +360,170 @@ def dump_state_dict_contract():
     print("state_dict_contract.json:", {k: v.get("n_params") for k, v in out.items() if k != "init_facts"})
 
 
+def _stub_io_modules():
+    """cv2 / imageio / skvideo / lmdb / thop / torchvision.utils are imported at module level by utils/util.py and the codec
+    arch file only for image / video I/O: empty stand-ins let the pure-torch code import (none of their names is called)."""
+    class _Any(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return None
+    for name in ["torchvision.utils", "cv2", "imageio", "skvideo", "skvideo.io", "lmdb", "thop"]:
+        sys.modules.setdefault(name, _Any(name))
+    _tv.utils = sys.modules["torchvision.utils"]
+    _tv.__dict__["__getattr__"] = lambda k: None          # `from torchvision import transforms` etc. (PEP 562)
+    sys.modules["skvideo"].io = sys.modules["skvideo.io"]
+
+
+def main_r2():
+    """Round-2 fixtures (own generators: the round-1 files above keep their historical draws and are NOT rewritten).
+      g14_irn_rev      InvRescaleNet.forward(rev=True) (Inv_arch.py:115-123) with the torch.rand HF tensor pinned
+      g15_codec        codec variant (SelfC_Codec_arch_inv.py): FrequencyAnalyzer(k=2), InvBlockExp(15|3) x 4, narrow STP
+                       (hidden 24, growth 12, TEMP_LEN 3), and forward_test's segmenting / tiling restated around the
+                       reference's own modules (forward_test itself needs cuda(0) + an ffmpeg writer)
+      g16_stp_v1_gmm   STP v1 GMM head (SelfC_arch_inv.py:118-128,151-177) with injected eps
+      api_contract.json  public methods + __init__ / forward signatures of every mirrored class
+    """
+    import inspect
+    import json
+    _stub_io_modules()
+    import models.modules.SelfC_arch_inv as SA
+    import models.modules.SelfC_Codec_arch_inv as CA
+    import importlib.util as _ilu
+    spec = _ilu.spec_from_file_location("ref_utils_util_r2", os.path.join(REF, "utils/util.py"))
+    ref_util = _ilu.module_from_spec(spec)
+    spec.loader.exec_module(ref_util)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        # ---- G14
+        GlobalVar.set_Temporal_LEN(T)
+        g = torch.Generator().manual_seed(1400)
+        torch.manual_seed(14)
+        irn = IA.InvRescaleNet(3, 3, SC.subnet("DBNet", "xavier"), [1], 1)
+        for sub in (irn.operations[1].F, irn.operations[1].G, irn.operations[1].H):
+            rerandomise_conv5(sub, g)
+        lr = torch.rand(T, 3, 16, 24, generator=g)
+        hf45 = torch.rand(T, 45, 16, 24, generator=g)
+        real_rand = torch.rand
+        torch.rand = lambda *a, **k: hf45.clone()          # the reference draws torch.rand((b,45,h,w)) (:117)
+        try:
+            out, none = irn(lr, rev=True)
+        finally:
+            torch.rand = real_rand
+        assert none is None
+        save("g14_irn_rev", lr=lr.numpy(), hf45=hf45.numpy(), x_rev=out.numpy(), **sd_np(irn))
+
+        # ---- G15 codec variant
+        g = torch.Generator().manual_seed(1500)
+        torch.manual_seed(15)
+        SEG = 3
+        GlobalVar.set_Temporal_LEN(SEG)
+        fa = CA.FrequencyAnalyzer(3, 2)
+        blocks = [CA.InvBlockExp(SC.subnet("D2DTNet", "xavier"), 15, 3) for _ in range(4)]
+        ops = torch.nn.ModuleList([fa] + blocks)
+        opt = {"global_module": "nonlocal", "stp_blk_num": 4, "fh_loss": "l2", "scale": 2, "gmm_k": 5,
+               "stp_hidden_c": 24, "stp_denseblock_innerc": 12}
+        stp = CA.STPNet(opt).eval()
+        arrs = {f"operations.{k}": v for k, v in sd_np(ops).items()}
+        arrs.update({f"stp_net.{k}": v for k, v in sd_np(stp).items()})
+        # pieces
+        xb = torch.randn(2 * SEG, 15, 10, 12, generator=g) * 0.5
+        yb = blocks[0](xb)
+        s_f = blocks[0].s.clone()
+        xbr = blocks[0](xb, rev=True)
+        lr_t = torch.rand(2 * SEG, 3, 8, 12, generator=g)
+        stp(lr_t.reshape(2, SEG, 3, 8, 12).transpose(1, 2))
+        stp_raw = stp.parameters.transpose(1, 2).reshape(2 * SEG, -1, 8, 12)
+        ga = stp.global_m1
+        xg = torch.randn(2 * SEG, 24, 8, 12, generator=g)
+        yg = ga(xg)
+        # whole-path restatement of forward_test (:502-640) around the reference's modules, b = 1, 5 frames -> 2 segments
+        t_all = 5
+        x = torch.rand(t_all, 3, 32, 48, generator=g)
+
+        def enc(seg):
+            o = seg
+            for op in ops:
+                o = op.forward(o, False)
+            return o
+
+        def dec(lr_tile):
+            bt, _, hh, ww = lr_tile.shape
+            l5 = lr_tile.reshape(bt // SEG, SEG, 3, hh, ww).transpose(1, 2)
+            stp(l5)
+            o = torch.cat((l5, stp.sample()), 1).transpose(1, 2).reshape(bt, -1, hh, ww)
+            for op in reversed(ops):
+                o = op.forward(o, True)
+            return o
+        vid, pad = ref_util.seg_add_pad(x.reshape(1, t_all, 3, 32, 48), SEG)
+        outs = []
+        for si in range(vid.size(1)):
+            seg = vid[:, si].reshape(-1, 3, 32, 48)
+            outs.append(torch.cat([enc(seg[:, :, :, i * 24:(i + 1) * 24])[:, 0:3] for i in range(2)], dim=-1))
+        enc_lr = ref_util.seg_remove_pad(torch.cat(outs, dim=0).reshape(1, -1, SEG, 3, 16, 24), pad, SEG).reshape(-1, 3, 16, 24)   # :559-563
+        lrq = Quantization()(enc_lr)
+        vid, pad = ref_util.seg_add_pad(lrq.reshape(1, t_all, 3, 16, 24), SEG)
+        outs = []
+        for si in range(vid.size(1)):
+            seg = vid[:, si].reshape(-1, 3, 16, 24)
+            l5 = seg.reshape(1, SEG, 3, 16, 24).transpose(1, 2)                              # b c t h w
+            lt = l5.reshape(1, 3, SEG, 2, 8, 2, 12).permute(0, 3, 5, 1, 2, 4, 6).reshape(1, 4, 3, SEG, 8, 12)   # :590-592
+            here = []
+            for i in range(4):
+                tile = lt[:, i].transpose(1, 2).reshape(SEG, 3, 8, 12)
+                here.append(dec(tile))
+            o = torch.stack(here, dim=1)                                                     # bt p c h w (:608)
+            o = o.reshape(1, SEG, 2, 2, 3, 16, 24).permute(0, 4, 1, 2, 5, 3, 6).reshape(1, 3, SEG, 32, 48).transpose(1, 2)   # :612-616
+            outs.append(o)
+        dec_hr = ref_util.seg_remove_pad(torch.stack(outs, dim=1), pad, SEG).reshape(-1, 3, 32, 48)
+        GlobalVar.set_Temporal_LEN(T)
+        save("g15_codec", blk_x=xb.numpy(), blk_y=yb.numpy(), blk_s=s_f.numpy(), blk_xrev=xbr.numpy(),
+             stp_lr=lr_t.numpy(), stp_raw=stp_raw.numpy(), ga_x=xg.numpy(), ga_y=yg.numpy(),
+             x=x.numpy(), enc_lr=enc_lr.numpy(), lr_q=lrq.numpy(), dec_hr=dec_hr.numpy(), **arrs)
+
+        # ---- G16 STP v1 GMM head (CUDA-only in the reference: `.cuda(device)` at :161 - made a no-op for the capture)
+        g = torch.Generator().manual_seed(1600)
+        torch.manual_seed(16)
+        opt1 = {"stp_d2d_inner_c": 32, "stp_temporal_c": 32, "fh_loss": "gmm", "gmm_mixture_num": 5,
+                "stp_blk_num": 2, "condition_func": "D2DTNet"}
+        s1 = SA.STPNet(opt1).eval()
+        lr1 = torch.rand(T, 3, 8, 12, generator=g)
+        eps1 = torch.randn(5, 1, 9, T, 8, 12, generator=g)          # one draw per mixture component (:162-163)
+        it = iter(range(5))
+        s1.reparametrize = lambda mu, logvar: eps1[next(it)].mul(logvar.mul(0.5).exp()).add(mu)     # :179-186 with eps pinned
+        real_cuda = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        try:
+            s1(lr1.reshape(1, T, 3, 8, 12).transpose(1, 2))
+        finally:
+            torch.Tensor.cuda = real_cuda
+        save("g16_stp_v1_gmm", lr=lr1.numpy(), eps=eps1[:, 0].numpy(), raw=s1.parameters[0].transpose(0, 1).numpy(),
+             v=s1.gmm_v[0].transpose(0, 1).numpy(), **sd_np(s1))
+
+    # ---- public API contract
+    def api(cls):
+        pub = sorted(n for n, v in vars(cls).items() if callable(v) and not n.startswith("_"))
+        sig = lambda f: [(p.name, None if p.default is inspect._empty else repr(p.default)) for p in inspect.signature(f).parameters.values()]  # noqa: E731
+        return {"methods": pub, "init": sig(cls.__init__), "forward": sig(cls.forward) if hasattr(cls, "forward") else None}
+    classes = {
+        "Inv_arch.InvBlockExp": IA.InvBlockExp, "Inv_arch.HaarDownsampling": IA.HaarDownsampling, "Inv_arch.InvRescaleNet": IA.InvRescaleNet,
+        "Subnet_constructor.DenseBlock": SC.DenseBlock, "Subnet_constructor.D2DTInput": SC.D2DTInput,
+        "Subnet_constructor.FeatureCalapseBlock": SC.FeatureCalapseBlock, "Subnet_constructor.SpaceToDepth": SC.SpaceToDepth,
+        "SelfC_GMM_arch_inv.FrequencyAnalyzer": GA.FrequencyAnalyzer, "SelfC_GMM_arch_inv.PixelUnshuffle": GA.PixelUnshuffle,
+        "SelfC_GMM_arch_inv.GlobalAgg": GA.GlobalAgg, "SelfC_GMM_arch_inv.STPNet": GA.STPNet, "SelfC_GMM_arch_inv.SelfCInvNet": GA.SelfCInvNet,
+        "SelfC_arch_inv.STPNet": SA.STPNet, "SelfC_arch_inv.SelfCInvNet": SA.SelfCInvNet,
+        "SelfC_Codec_arch_inv.FrequencyAnalyzer": CA.FrequencyAnalyzer, "SelfC_Codec_arch_inv.GlobalAgg": CA.GlobalAgg,
+        "SelfC_Codec_arch_inv.STPNet": CA.STPNet,
+        "Quantization.Quantization": Quantization, "global_var.GlobalVar": GlobalVar,
+    }
+    with open(os.path.join(OUT, "api_contract.json"), "w") as fh:
+        json.dump({k: api(v) for k, v in classes.items()}, fh, indent=0, sort_keys=True)
+    print("api_contract.json:", len(classes), "classes")
+
+
 if __name__ == "__main__":
-    main()
-    dump_state_dict_contract()
+    if "r2" in sys.argv[1:]:
+        main_r2()
+    else:
+        main()
+        dump_state_dict_contract()
