@@ -172,3 +172,53 @@ def gaussian_downsample(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty((n, c, h // 4, w // 4), dtype=torch.float32, device=x.device)
     rt.call("selfc_gauss_down4", x.data_ptr(), y.data_ptr(), _GK[key].data_ptr(), n * c, h, w, _lib.stream_ptr())
     return y
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# config 4 of BASELINE.json: test_rescaling.py on folders of 7-frame groups (Vid4), pretrained weights
+# ----------------------------------------------------------------------------------------------------------------------
+
+def load_pretrained(net, path: str, strict: bool = True):
+    """BaseModel.load_network (base_model.py:87-107): torch.load on CPU, strip DistributedDataParallel's "module." prefix,
+    drop the codec-surrogate keys, load_state_dict(strict)."""
+    sd = torch.load(path, map_location="cpu")
+    clean = {}
+    for k, v in sd.items():
+        if "Quantization_H265_Suggrogate" in k:
+            continue
+        clean[k[7:] if k.startswith("module.") else k] = v
+    net.load_state_dict(clean, strict=strict)
+    return net
+
+
+def evaluate_folder(net, dataroot_GT: str, dataroot_list: str, device, max_groups: int = None, eps_seed: int = None) -> dict:
+    """cal_metric of test_rescaling.py:65-153 for one dataset entry of the yml (`dataroot_GT` + `dataroot_list`, one 7-frame
+    group per list line, batch size 1): frames come through selfc_amd.data (the reference's folder convention), every group
+    goes through rescale_metrics on the device.  eps_seed: fh_loss gmm samples its HF channels; a seed makes the draw a
+    fixed, device-independent tensor (``STPNet.eps``) so that another implementation can be fed the same noise.
+    Returns the averages of the four metrics over the groups and the per-group values (+ the noise used)."""
+    from .data import SeptupletDataset
+    ds = SeptupletDataset({"dataroot_GT": dataroot_GT, "dataroot_list": dataroot_list, "phase": "val", "video_len": GOP})
+    n = len(ds) if max_groups is None else min(len(ds), max_groups)
+    groups, stp = [], getattr(net, "stp_net", None)
+    for i in range(n):
+        gt = ds[i]["GT"]                                       # (C,T,H,W) RGB [0,1]
+        real_H = gt.transpose(0, 1).contiguous().to(device)    # feed_data: (T,C,H,W) frames (SelfC_model.py:117-124)
+        if real_H.shape[0] != GOP:
+            raise RuntimeError(f"{ds[i]['GT_path']}: {real_H.shape[0]} frames, expected groups of {GOP}")
+        eps = None
+        if eps_seed is not None and stp is not None and getattr(stp, "fh_loss", "l2") != "l2":
+            h, w = real_H.shape[2] // 4, real_H.shape[3] // 4
+            eps = torch.randn((1, stp.hf_dim, stp.K, GOP, h, w), generator=torch.Generator().manual_seed(eps_seed + i))
+            stp.eps = eps
+        try:
+            m = rescale_metrics(net, real_H)
+        finally:
+            if eps is not None:
+                stp.eps = None
+        m["path"], m["eps"] = ds[i]["GT_path"], eps
+        groups.append(m)
+    keys = ("psnr_y", "ssim_y", "lr_psnr_y", "lr_ssim_y")
+    out = {k: sum(g[k] for g in groups) / max(1, len(groups)) for k in keys}
+    out["groups"] = groups
+    return out
