@@ -159,6 +159,137 @@ class SubnetFn(torch.autograd.Function):
         return (dx, None, None, *grads)
 
 
+# ------------------------------------------------------------------------------------------------------------
+# FeatureCalapseBlock (Subnet_constructor.py:280-324): the dense block at 1/scale resolution with (3,3,3) conv1 / conv5
+# ------------------------------------------------------------------------------------------------------------
+
+def _fcb_seg(mod, j: int) -> Tuple[int, int, int]:
+    """(first plane, planes, channels) of input segment j of the block's plane buffer: j = 0 the cin inputs, j = 1..4 feature j"""
+    pin, gp = roundup(mod.cin, 32) // 32, mod.gc // 32
+    return (0, pin, mod.cin) if j == 0 else (pin + (j - 1) * gp, gp, mod.gc)
+
+
+def _fcb_bwd_pack(mod):
+    """{(k, j): generic plane-conv fragments of conv k's TRANSPOSE restricted to input segment j} for k = 1..5, j < k:
+    out channels = the segment's channels (zero padded to whole planes), in channels = conv k's outputs, temporal and
+    spatial taps reversed (y = sum W[o][c][t] x[c][. + t]  =>  dx[c] = sum W[o][c][T-1-t'] dy[o][. + t'])."""
+    key = rt.params_key(mod)
+    if getattr(mod, "_bwd_key", None) != key:
+        pk = {}
+        for k in range(1, 6):
+            wt = getattr(mod, f"conv{k}").weight.detach().float()                 # (O, C, kt, 3, 3)
+            o, _, kt = wt.shape[0], wt.shape[1], wt.shape[2]
+            wr = wt.reshape(o, wt.shape[1], kt, 9).flip(2).flip(3)
+            for j in range(k):
+                _, npl, ch = _fcb_seg(mod, j)
+                c0 = 0 if j == 0 else mod.cin + (j - 1) * mod.gc
+                t = torch.zeros(npl * 32, roundup(o, 32), kt, 9, dtype=torch.float32, device=wt.device)
+                t[:ch, :o] = wr[:, c0:c0 + ch].permute(1, 0, 2, 3)
+                pk[(k, j)] = pack_planes_generic(t)
+        mod._bwd_pk, mod._bwd_key = pk, key
+    return mod._bwd_pk
+
+
+def fcb_bwd(mod, dense: torch.Tensor, dout: torch.Tensor, n: int, t: int, h: int, w: int, want_dx: bool, want_params: bool):
+    """Backward of the five convs of a FeatureCalapseBlock on its saved plane buffer `dense` ([x planes | f1..f4], f16) given
+    dout fp32 NHWC (n,h,w,cout).  The dense recursion of DESIGN.md section 4b, segment by segment, on the generic plane conv
+    (selfc_bwd_conv_planes, temporal taps for conv1 / conv5); weight gradients per temporal tap on selfc_bwd_wgrad with the
+    activation planes shifted by one frame inside each clip.  Returns (dx fp32 NHWC (n,h,w,cin) | None, [dW1, db1, .., dW5, db5] | Nones)."""
+    dev, sp, L = dout.device, _lib.stream_ptr(), _lib.lib()
+    F16 = _lib.operand_dtype()
+    npix = n * h * w
+    pin, gp, cin, cout = roundup(mod.cin, 32) // 32, mod.gc // 32, mod.cin, mod.cout
+    pk = _fcb_bwd_pack(mod)
+    amax = torch.zeros(64, dtype=torch.float32, device=dev)
+    rt.call("selfc_bwd_scale", dout.data_ptr(), dout.numel(), amax.data_ptr(), sp)
+    g = {5: torch.empty((cout // 32, npix, 32), dtype=F16, device=dev)}          # gradient planes of each conv's output
+    rt.call("selfc_bwd_to_planes", dout.data_ptr(), g[5].data_ptr(), npix, cout, cout, 0, 1.0, amax.data_ptr(), sp)
+
+    def conv_t(k, j, out_planes=None, add=None, mask=None, plain=None, accumulate=0):
+        kt = 3 if k in (1, 5) else 1
+        _, npl, _ = _fcb_seg(mod, j)
+        rt.call("selfc_bwd_conv_planes", g[k].data_ptr(), g[k].shape[0], kt, 0, pk[(k, j)].data_ptr(), npl,
+                None if out_planes is None else out_planes.data_ptr(), None if add is None else add.data_ptr(),
+                None if mask is None else mask.data_ptr(), -2 if mask is not None else -1,
+                None if plain is None else plain.data_ptr(), cin if plain is not None else 0, accumulate,
+                amax.data_ptr(), n, t, h, w, sp)
+
+    # dpre_j = LeakyReLU'(f_j) * sum_{k > j} conv_k^T(dpre_k)[f_j], j = 4..1 (dpre_5 = dout); the sum is chained through `add`
+    for j in range(4, 0, -1):
+        p0, npl, _ = _fcb_seg(mod, j)
+        feat = dense[p0:p0 + npl]
+        bufs = [torch.empty((npl, npix, 32), dtype=F16, device=dev) for _ in range(2)]
+        ks = list(range(5, j, -1))
+        for i, k in enumerate(ks):
+            last = i == len(ks) - 1
+            conv_t(k, j, out_planes=bufs[i & 1], add=bufs[(i - 1) & 1] if i else None, mask=feat if last else None)
+        g[j] = bufs[(len(ks) - 1) & 1]
+    dx = None
+    if want_dx:
+        dx = torch.empty((n, h, w, cin), dtype=torch.float32, device=dev)
+        for i, k in enumerate(range(5, 0, -1)):
+            conv_t(k, 0, plain=dx, accumulate=1 if i else 0)
+    grads = [None] * 10
+    if want_params:
+        b = n // t
+        for k in range(1, 6):
+            conv = getattr(mod, f"conv{k}")
+            o, kt = conv.out_channels, conv.weight.shape[2]
+            qn = pin + (k - 1) * gp
+            q = dense[:qn]
+            gw = torch.empty((o, qn * 32, kt, 9), dtype=torch.float32, device=dev)
+            gb = torch.empty((o,), dtype=torch.float32, device=dev)
+            need = L.selfc_bwd_wgrad_scratch_bytes(n, h, w, g[k].shape[0], qn, 9)
+            sc = _buf(_STP_CACHE, "fcb_wgrad", need, dev)
+            for dt in range(kt):
+                sh = dt - (kt // 2)                              # input frame = output frame + sh
+                if sh == 0:
+                    qs = q
+                else:                                            # shift inside every clip, zero outside (the conv's zero padding)
+                    q5 = q.reshape(qn, b, t, h * w * 32)
+                    qs = torch.zeros_like(q5)
+                    if sh > 0:
+                        qs[:, :, : t - sh] = q5[:, :, sh:]
+                    else:
+                        qs[:, :, -sh:] = q5[:, :, : t + sh]
+                one = torch.empty((o, qn * 32, 9), dtype=torch.float32, device=dev)
+                rt.call("selfc_bwd_wgrad", g[k].data_ptr(), g[k].shape[0], qs.data_ptr(), qn, 9, one.data_ptr(), o, qn * 32,
+                        gb.data_ptr() if sh == 0 else None, 0.0, amax.data_ptr(), sc.data_ptr(), sc.numel(), n, t, h, w, sp)
+                gw[:, :, dt] = one
+            real = torch.cat((gw[:, :cin], gw[:, pin * 32:]), dim=1) if pin * 32 != cin else gw      # drop the input planes' pad channels
+            grads[2 * (k - 1)] = real.reshape(o, real.shape[1], kt, 3, 3).contiguous()
+            grads[2 * (k - 1) + 1] = gb
+    return dx, grads
+
+
+class FCBFn(torch.autograd.Function):
+    """The dense block of FeatureCalapseBlock.forward (Subnet_constructor.py:314-318) on space-to-depth'd frames
+    (n, scale^2 cin, h, w) -> (n, scale^2 cout, h, w); the two shuffles around it stay torch view ops."""
+
+    @staticmethod
+    def forward(ctx, xs, mod, t, *params):
+        xs = rt.as_input(xs)
+        n, c, h, w = xs.shape
+        y, dense = mod._run_planes(xs, t)
+        ctx.mod, ctx.t, ctx.shape, ctx.dense = mod, t, (n, c, h, w), dense
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        mod, t = ctx.mod, ctx.t
+        n, c, h, w = ctx.shape
+        gy = gy.contiguous().float()
+        dev, sp = gy.device, _lib.stream_ptr()
+        dout = torch.empty((n, h, w, mod.cout), dtype=torch.float32, device=dev)
+        rt.call("selfc_nchw_to_nhwc4", gy.data_ptr(), dout.data_ptr(), n, mod.cout, h, w, sp)
+        dxl, grads = fcb_bwd(mod, ctx.dense, dout, n, t, h, w, ctx.needs_input_grad[0], any(ctx.needs_input_grad[3:]))
+        dx = None
+        if dxl is not None:
+            dx = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
+            rt.call("selfc_nhwc4_to_nchw", dxl.data_ptr(), dx.data_ptr(), n, c, h, w, sp)
+        return (dx, None, None, *grads)
+
+
 class InvBlockFn(torch.autograd.Function):
     """InvBlockExp.forward(x, rev) (Inv_arch.py:21-33) with a HIP backward.
 

@@ -72,7 +72,12 @@ constexpr int OFF_F1 = 0, OFF_F2 = OFF_F1 + F1_BYTES, OFF_F3 = OFF_F2 + F2_BYTES
 constexpr int OFF_X = OFF_F3 + F3_BYTES;   // 2 buffers
 constexpr int OFF_W = OFF_X + 2 * X_BYTES; // 2 buffers
 constexpr int OFF_B = OFF_W + (WRES ? NFRAG_RES * 1024 : 2 * W_BYTES); // biases of the four convs: 4 x 32 floats
-constexpr int FG_LDS = OFF_B + 512;
+// conv1's three fragments stay RESIDENT: streamed like the rest, conv1's short phase (3 MFMA steps) had to wait for conv2's
+// first chunk right behind the previous tile's conv4 feature stores - loads and stores retire in order on one VM counter,
+// so that wait was the stores' full write latency, once per tile.  Now conv4's last chunk streams conv2's first chunk in
+// (committed BEFORE conv4's stores) and conv1 touches no global memory before its own epilogue.
+constexpr int OFF_W1 = OFF_B + 512;
+constexpr int FG_LDS = OFF_W1 + 3 * 1024;
 static_assert(FG_LDS <= 160 * 1024, "LDS budget");
 #ifndef SELFC_RD1
 #define SELFC_RD1 3
@@ -100,12 +105,16 @@ constexpr int LAYER_OFF[5] = {0, 0, 3, 24, 63};
 #define STAMP_ADD(k, a, b)
 #endif
 
+typedef __attribute__((address_space(1))) f16 gf16;                 // explicitly global: a laundered pointer would otherwise become flat
+typedef __attribute__((address_space(1))) u32x4 gu32x4;
+
 struct Ctx {
 #ifdef SELFC_STAMPS
   unsigned long long phase[4];   // 0 setup/prefetch, 1 MFMA loop, 2 epilogue, 3 commit + barrier
 #endif
   unsigned char* smem;
   const u32x4* wsrc;
+  gf16* dense;        // this net's dense buffer (kernel argument, kept opaque: see the kernel)
   int tid, lane, wave, half;
   int par;            // weight buffer that holds the CURRENT chunk
   bool first;         // resident mode: the workgroup's first tile streams the fragments INTO their resident places
@@ -135,7 +144,13 @@ __device__ __forceinline__ void w_commit(Ctx& c) {
 #pragma unroll
   for (int it = 0; it < WITER; ++it) {
     const int i = c.tid + it * NTHR;
-    if (i < NFR * 64) *reinterpret_cast<u32x4*>(dst + i * 16) = c.wreg[it];
+    // Wait for the prefetch load on EVERY path, not only inside the branch: a wave whose lanes all skip the store never
+    // executed the branch's s_waitcnt, so hipcc kept the load "pending" and, when it later reused the register in the
+    // middle of an epilogue, drained the whole VM queue there (vmcnt(0)) - i.e. waited for the feature stores just issued.
+    // (Removes those drains from the ISA; measured time unchanged)
+    u32x4 v = c.wreg[it];
+    asm volatile("" : "+v"(v));
+    if (i < NFR * 64) *reinterpret_cast<u32x4*>(dst + i * 16) = v;
   }
 }
 
@@ -173,7 +188,7 @@ __device__ __forceinline__ void epi_piece(const Ctx& c, const FGArgs& a, const i
   int r, cc;
   bool valid;
   mtile_geom<K>(c, m, r, cc, valid);
-  f16* __restrict__ dplane = a.dense[net] + (size_t)(K - 1) * a.plane;
+  gf16* __restrict__ dplane = c.dense + (size_t)(K - 1) * a.plane;
   // the region leaves the image only for tiles on the frame border (wave-uniform test)
   const bool border = (ty0 - (DEPTH - K) < 0) | (tx0 - (DEPTH - K) < 0) | (ty0 + TS + (DEPTH - K) > a.H) | (tx0 + TS + (DEPTH - K) > a.W);
   const int ar = r - (DEPTH - K), ac = cc - (DEPTH - K);
@@ -202,8 +217,14 @@ __device__ __forceinline__ void epi_piece(const Ctx& c, const FGArgs& a, const i
 #endif
       const bool centre = (ar >= 0) & (ar < TS) & (ac >= 0) & (ac < TS);
 #ifndef SELFC_EXP_NOGST      // timing experiment: no feature stores to HBM
-      if (centre && inimg)
-        *reinterpret_cast<u32x4*>(dplane + fofs + (unsigned)((y * a.W + x) * 32 + 16 * gp + 8 * c.half)) = v;
+      if (centre && inimg) {
+#ifdef SELFC_EXP_STL2       // timing experiment (results are wrong): every workgroup stores into the same 32 KiB (L2-resident)
+        gf16* const dst = dplane + (unsigned)(((ar * TS + ac) & 255) * 32 + 16 * gp + 8 * c.half) + (K - 1) * 8192;
+#else
+        gf16* const dst = dplane + fofs + (unsigned)((y * a.W + x) * 32 + 16 * gp + 8 * c.half);
+#endif
+        *(gu32x4*)dst = v;
+      }
 #endif
     }
   }
@@ -265,12 +286,13 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
       if (ch == 0) w_prefetch<LAYER_OFF[K] + 21, 18>(c);
       else w_prefetch<LAYER_OFF[K] + 39, 18>(c);
     } else {
-      if (K == DEPTH) w_prefetch<LAYER_OFF[1], 3>(c);            // wraps to the next tile's conv1
-      else if (K == 1) w_prefetch<LAYER_OFF[2], 21>(c);
+      if (K == DEPTH) w_prefetch<LAYER_OFF[2], 21>(c);           // wraps to the next tile's conv2 (conv1's fragments are resident)
+      else if (K == 1) { /* conv2's first chunk is already in place */ }
       else if (K == 2) w_prefetch<LAYER_OFF[3], 21>(c);
       else w_prefetch<LAYER_OFF[4], 21>(c);
     }
-    const unsigned char* wb = smem + OFF_W + (WRES ? (LAYER_OFF[K] + (ch == 0 ? 0 : ch == 1 ? 21 : 39)) * 1024 : c.par * W_BYTES) + c.lane * 16;
+    const unsigned char* wb = (K == 1 ? smem + OFF_W1
+                                      : smem + OFF_W + (WRES ? (LAYER_OFF[K] + (ch == 0 ? 0 : ch == 1 ? 21 : 39)) * 1024 : c.par * W_BYTES)) + c.lane * 16;
     const unsigned char* xb = smem + OFF_X + xbuf * X_BYTES;
     // The chunk is a flat list of MFMA steps: [3 im2col48 k-steps (chunk 0 only)] + [18 (tap, k-step)
     // steps of feature J = ch + 1 (K >= 2)].  One wave per SIMD has no other wave to hide LDS latency
@@ -356,8 +378,9 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
     // those stores to be acknowledged (~1-2 us at every conv boundary; measured: the stores cost 29 % of the kernel)
     if (PENDING && ch == 0) { /* handed over behind step 8 */ }
     else if (ch + 1 < NCH) { if (ch == 0) w_commit<LAYER_OFF[K] + 21, 18>(c); else w_commit<LAYER_OFF[K] + 39, 18>(c); }
-    else if (K == DEPTH) w_commit<LAYER_OFF[1], 3>(c);
-    else w_commit<LAYER_OFF[K < 4 ? K + 1 : 1], 21>(c);
+    else if (K == DEPTH) w_commit<LAYER_OFF[2], 21>(c);
+    else if (K == 1) { /* nothing streamed during conv1 */ }
+    else w_commit<LAYER_OFF[K < 4 ? K + 1 : 2], 21>(c);
     STAMP(ts3);
     STAMP_ADD(3, ts2, ts3);
     if (ch == NCH - 1 && !DEFER) {
@@ -368,7 +391,7 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
     }
     if (K == DEPTH && ch == NCH - 1) return;   // the tile loop has the tile's last barrier
     __syncthreads();
-    c.par ^= 1;
+    if (K != 1) c.par ^= 1;                    // conv1 consumed no streamed buffer
     STAMP(ts4);
     STAMP_ADD(2, ts3, ts4);
   }
@@ -393,6 +416,15 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
 #endif
   const int net = blockIdx.y;
   c.wsrc = reinterpret_cast<const u32x4*>(net ? a.w[1] : a.w[0]);
+  {
+    // Opaque to hipcc: under SGPR pressure it re-loaded a.dense[net] from the kernel-argument segment (s_load_dwordx2) in
+    // front of EVERY feature store, and a scalar load can only be awaited with lgkmcnt(0) - which also drains the wave's
+    // LDS operand ring (seven drains per tile).  Laundered, the pointer lives in SGPRs for the whole kernel.  (ISA clean-up;
+    // measured time unchanged)
+    unsigned long long d = reinterpret_cast<unsigned long long>(net ? a.dense[1] : a.dense[0]);
+    asm volatile("" : "+s"(d));
+    c.dense = (gf16*)d;
+  }
   // Frame walk: a workgroup owns ONE spatial tile (blockIdx.x % ntiles) and visits frames f0, f0 + gf, ...: everything
   // that depends on the tile position (halo offsets, border masks, output offsets) is a per-workgroup constant that the
   // compiler keeps in registers instead of re-deriving ~400 VALU instructions' worth of it per tile.
@@ -440,11 +472,12 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
     reinterpret_cast<float*>(smem + OFF_B)[c.tid] = bsrc[c.tid & 31];
   }
   x_load(f0);
-  w_prefetch<LAYER_OFF[1], 3>(c);
+  w_prefetch<LAYER_OFF[2], 21>(c);
+  if (c.tid < 3 * 64) *reinterpret_cast<u32x4*>(smem + OFF_W1 + c.tid * 16) = c.wsrc[LAYER_OFF[1] * 64 + c.tid];   // conv1: resident
   x_store(0);
   c.par = 1;            // w_commit writes buffer par^1 = 0
   c.first = true;
-  w_commit<LAYER_OFF[1], 3>(c);
+  w_commit<LAYER_OFF[2], 21>(c);
   __syncthreads();
   c.par = 0;
 
@@ -454,7 +487,9 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
     if (more) x_load(n + gf);                     // lands while this tile computes
     const size_t fofs = (size_t)n * fpix * 32;
     AccPair acc2, acc3;
+#ifndef SELFC_EXP_NOC1      // timing experiment (results are wrong): what does conv1's phase (MFMAs + immediate epilogue + barrier) cost?
     conv_fused<1>(c, a, net, xbuf, fofs, ty0, tx0, nullptr, nullptr);
+#endif
     conv_fused<2>(c, a, net, xbuf, fofs, ty0, tx0, nullptr, &acc2);
     if (DEPTH == 3) {
       if (more) x_store(xbuf ^ 1);                // before the last conv's feature stores (see conv_fused: one VM counter)

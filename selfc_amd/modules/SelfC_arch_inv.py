@@ -119,11 +119,9 @@ class STPNet(nn.Module):
         temp = x.transpose(1, 2).reshape(b * t, c, h, w)
         from .. import autograd as ag
         if ag.module_needs_grad(temp, self):
-            if self.condition_func != "D2DTNet":
-                rt.no_autograd_guard(temp, *rt.plist(self))          # FeatureCalapseBlock has no backward kernels yet
             if self.fh_loss != "l2":
                 raise NotImplementedError("selfc_amd: STP v1's GMM head runs in inference only (no shipped config trains it)")
-            feat = self.blk2(self.blk1(temp))                        # differentiable D2DTInput chain
+            feat = self.blk2(self.blk1(temp))                        # differentiable D2DTInput / FeatureCalapseBlock chain
             conv = self.tail[1]
             v = ag.PointwiseHeadFn.apply(feat, conv, self._tail_packed(), t, conv.weight, conv.bias)
             self._publish(v.reshape(b, t, self.hf_dim, h, w).transpose(1, 2))

@@ -170,18 +170,10 @@ class FeatureCalapseBlock(nn.Module):
             self._pk_key = key
         return self._pk
 
-    def forward(self, x, io_type="2d"):
-        if io_type != "2d":
-            raise NotImplementedError("FeatureCalapseBlock: only the io_type='2d' call of the reference's STPNet is built")
-        x = rt.as_input(x)
-        rt.no_autograd_guard(x, *self.parameters())
-        res = x
-        xs = self.ds(x) if self.scale > 1 else x
-        t = GlobalVar.get_Temporal_LEN() or 7
+    def _run_planes(self, xs, t):
+        """xs (n, cin, h, w) NCHW at 1/scale resolution -> (y (n, cout, h, w), the block's f16 plane buffer [x | f1..f4])"""
         n, c, h, w = xs.shape
-        if c != self.cin or n % t:
-            raise RuntimeError(f"FeatureCalapseBlock expects (b*{t},{self.cin // self.scale ** 2},H,W), got {tuple(x.shape)}")
-        dev, sp = x.device, _lib.stream_ptr()
+        dev, sp = xs.device, _lib.stream_ptr()
         pk = self._packed()
         pin = roundup(self.cin, 32) // 32
         gp = self.gc // 32
@@ -200,6 +192,23 @@ class FeatureCalapseBlock(nn.Module):
                 self.cout, -1, out.data_ptr(), n, t, h, w, sp)
         y = torch.empty((n, self.cout, h, w), dtype=torch.float32, device=dev)
         rt.call("selfc_nhwc4_to_nchw", out.data_ptr(), y.data_ptr(), n, self.cout, h, w, sp)
+        return y, dense
+
+    def forward(self, x, io_type="2d"):
+        if io_type != "2d":
+            raise NotImplementedError("FeatureCalapseBlock: only the io_type='2d' call of the reference's STPNet is built")
+        _lib.require_gpu(x)
+        res = x
+        xs = self.ds(x) if self.scale > 1 else x                     # SpaceToDepth / PixelShuffle: torch view ops (differentiable)
+        t = GlobalVar.get_Temporal_LEN() or 7
+        n, c, h, w = xs.shape
+        if c != self.cin or n % t:
+            raise RuntimeError(f"FeatureCalapseBlock expects (b*{t},{self.cin // self.scale ** 2},H,W), got {tuple(x.shape)}")
+        from .. import autograd as ag
+        if ag.module_needs_grad(xs, self):
+            y = ag.FCBFn.apply(xs, self, t, *ag.subnet_params(self))
+        else:
+            y, _ = self._run_planes(rt.as_input(xs), t)
         y = self.us(y) if self.scale > 1 else y
         return y + res if self.is_res else y
 
