@@ -416,11 +416,13 @@ def test_selfc_haar_variant_training_gradients(dev):
     errs = {n_: rel_l2(p_.grad.cpu(), p[n_].grad) for n_, p_ in net.named_parameters() if p_.requires_grad}
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     assert worst[0][1] < 5e-2, worst
-    # the default FeatureCalapseBlock conditioner still refuses loudly in training mode
+    # the default FeatureCalapseBlock conditioner trains too since round 2 (autograd.FCBFn; parity: test_feature_calapse_block_backward)
     opt2 = dict(opt1, condition_func="FeatureCalapseBlock")
     net2 = SelfCInvNet(opt2, 3, 3, "DBNet", [1], 1).to(dev)
-    with pytest.raises(NotImplementedError):
-        net2(x=x.to(dev), rev=False)
+    z2, nll2 = net2(x=x.to(dev), rev=False)
+    (z2[:, :3].mean() + nll2).backward()
+    missing = [n_ for n_, p_ in net2.named_parameters() if p_.requires_grad and p_.grad is None]
+    assert not missing, missing
 
 
 @pytest.mark.parametrize("t", [1, 3])
