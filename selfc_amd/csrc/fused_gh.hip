@@ -174,8 +174,11 @@ __device__ __forceinline__ void mtile_geom(const Ctx& c, const int m, int& r, in
 template <int K, int MT>
 __device__ __forceinline__ void epi_piece(const Ctx& c, const FGArgs& a, const int net, const size_t fofs, const int ty0, const int tx0,
                                           const f32x16 (&acc)[MT], uint32_t (&rr)[MT][4][2], const int p) {
-#ifdef SELFC_EXP_NOEPI      // timing experiment: no epilogue at all
-  if (acc[0][0] == 123.456f) c.smem[0] = 1;
+#ifdef SELFC_EXP_NOEPI      // timing experiment: no epilogue at all (every accumulator kept live: see SELFC_EXP_NOGST)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int m = 0; m < MT; ++m) asm volatile("" :: "v"(acc[m]));
+#endif
   return;
 #endif
   if (p < 4 * MT) {
@@ -216,7 +219,11 @@ __device__ __forceinline__ void epi_piece(const Ctx& c, const FGArgs& a, const i
       }
 #endif
       const bool centre = (ar >= 0) & (ar < TS) & (ac >= 0) & (ac < TS);
-#ifndef SELFC_EXP_NOGST      // timing experiment: no feature stores to HBM
+#ifdef SELFC_EXP_NOGST       // timing experiment: no feature stores to HBM.  The value and its address stay LIVE: dropping the
+      // store alone makes conv4 dead code (its only consumer) and hipcc deletes its 57 MFMA steps - that artefact, not the
+      // stores, was the "-31 %" first measured with this switch (cdna_hip_programming.md rule 17)
+      if (centre && inimg) asm volatile("" :: "v"(v), "v"(dplane + fofs + (unsigned)((y * a.W + x) * 32 + 16 * gp + 8 * c.half)));
+#else
       if (centre && inimg) {
 #ifdef SELFC_EXP_STL2       // timing experiment (results are wrong): every workgroup stores into the same 32 KiB (L2-resident)
         gf16* const dst = dplane + (unsigned)(((ar * TS + ac) & 255) * 32 + 16 * gp + 8 * c.half) + (K - 1) * 8192;
@@ -375,7 +382,7 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
     STAMP_ADD(1, ts1, ts2);
     // ---- hand the weight buffers over FIRST (next chunk -> the other buffer): global stores share the VM counter with
     // loads on gfx9, so waiting for the prefetched fragments behind the epilogue's feature stores meant waiting for
-    // those stores to be acknowledged (~1-2 us at every conv boundary; measured: the stores cost 29 % of the kernel)
+    // those stores to be acknowledged (~1-2 us at every conv boundary)
     if (PENDING && ch == 0) { /* handed over behind step 8 */ }
     else if (ch + 1 < NCH) { if (ch == 0) w_commit<LAYER_OFF[K] + 21, 18>(c); else w_commit<LAYER_OFF[K] + 39, 18>(c); }
     else if (K == DEPTH) w_commit<LAYER_OFF[2], 21>(c);
