@@ -185,8 +185,8 @@ __device__ __forceinline__ void lrelu_pack(const f32x16& acc, const bool keep, u
   uint32_t r[4][2];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    r[g][0] = pack2(lrelu02(acc[4 * g + 0]), lrelu02(acc[4 * g + 1]));
-    r[g][1] = pack2(lrelu02(acc[4 * g + 2]), lrelu02(acc[4 * g + 3]));
+    r[g][0] = lrelu_pack2(acc[4 * g + 0], acc[4 * g + 1]);
+    r[g][1] = lrelu_pack2(acc[4 * g + 2], acc[4 * g + 3]);
   }
   const uint32_t m = keep ? 0xffffffffu : 0u;
 #pragma unroll

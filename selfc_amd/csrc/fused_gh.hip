@@ -183,8 +183,8 @@ __device__ __forceinline__ void epi_piece(const Ctx& c, const FGArgs& a, const i
 #endif
   if (p < 4 * MT) {
     const int m = p >> 2, g = p & 3;
-    rr[m][g][0] = pack2(lrelu02(acc[m][4 * g + 0]), lrelu02(acc[m][4 * g + 1]));
-    rr[m][g][1] = pack2(lrelu02(acc[m][4 * g + 2]), lrelu02(acc[m][4 * g + 3]));
+    rr[m][g][0] = lrelu_pack2(acc[m][4 * g + 0], acc[m][4 * g + 1]);
+    rr[m][g][1] = lrelu_pack2(acc[m][4 * g + 2], acc[m][4 * g + 3]);
     return;
   }
   const int m = p - 4 * MT;

@@ -576,3 +576,41 @@ def test_rejects_bad_arguments(dev):
         D2DTInput(48, 3).to(dev)(torch.zeros(7, 3, 8, 8, device=dev))   # wrong channel count
     with pytest.raises(RuntimeError):
         D2DTInput(48, 3)(torch.zeros(7, 48, 8, 8))                      # CPU tensor: no fallback
+
+
+def test_globalagg_scratch_grows_per_buffer(dev):
+    """one GlobalAgg used first on few clips of many pixels, then on many clips of few pixels - the attention
+    buffer must grow although the pooling buffer does not (used to write past the end)."""
+    from selfc_amd.modules.SelfC_GMM_arch_inv import GlobalAgg
+    g = load_golden("g6_globalagg")
+    ga = GlobalAgg(64)
+    ga.load_state_dict({k: v for k, v in g.items() if k.split(".")[0] in ("fc", "proj1", "proj2", "proj3")}, strict=True)
+    ga.to(dev)
+    sd = {k: v for k, v in g.items() if k.split(".")[0] in ("fc", "proj1", "proj2", "proj3")}
+    gen = torch.Generator().manual_seed(3)
+    for n, h, w in ((T, 64, 112), (4 * T, 16, 28), (T, 20, 36)):
+        x = torch.randn(n, 64, h, w, generator=gen)
+        with torch.no_grad():
+            y = ga(x.to(dev))
+        assert rel_err(y.cpu(), O.global_agg(sd, x, T)) < TOL
+
+
+def test_pipeline_follows_weight_changes(dev):
+    """RescaleRoundTrip re-packs when the net's weights change (eager) and refuses to replay a graph that was
+    captured on the old weights."""
+    from selfc_amd.pipeline import RescaleRoundTrip
+    g = load_golden("g8_large_stack")
+    net = _large_net(dev, g)
+    x = torch.rand(T, 3, 32, 48, generator=torch.Generator().manual_seed(1)).to(dev)
+    with torch.no_grad():
+        rt_ = RescaleRoundTrip(net, T, 32, 48, dev)
+        a = rt_.run(x).clone()
+        rt_.capture(x)
+        assert torch.equal(rt_.replay(), a)
+        for p in net.operations[1].F.parameters():
+            p.mul_(1.5)
+        b = rt_.run(x).clone()                           # eager: repacked
+        assert not torch.equal(a, b)
+        assert torch.equal(b, RescaleRoundTrip(net, T, 32, 48, dev).run(x))
+        with pytest.raises(RuntimeError, match="capture"):
+            rt_.replay()

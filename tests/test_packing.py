@@ -321,3 +321,47 @@ def test_pack_plan_equals_direct_packing():
         params2 = [p * 0.5 for p in params]
         got2 = plan.run(params2)
         assert torch.equal(got2["s.w3_0"], P.pack_conv3x3(params2[0], cin, 1))
+
+
+def test_widen_dense_params_is_an_exact_equivalent():
+    """packing.widen_dense_params: a dense block with growth 12 and 24 channels (the codec variant's STP subnets) packed into the
+    kernels' growth-32 / 64-channel layout computes the same function (float64: the added terms are exact zeros)."""
+    import torch.nn.functional as F
+    from selfc_amd.packing import widen_dense_params
+    torch.manual_seed(0)
+    cin, cout, gc = 24, 24, 12
+    ws = [torch.randn(gc, cin + gc * k, 1, 3, 3, dtype=torch.float64) for k in range(4)] + [torch.randn(cout, cin + 4 * gc, 3, 1, 1, dtype=torch.float64)]
+    bs = [torch.randn(gc, dtype=torch.float64) for _ in range(4)] + [torch.randn(cout, dtype=torch.float64)]
+
+    def dense(x, ws, bs):
+        feats = [x]
+        for k in range(4):
+            feats.append(F.leaky_relu(F.conv3d(torch.cat(feats, 1), ws[k], bs[k], padding=(0, 1, 1)), 0.2))
+        return F.conv3d(torch.cat(feats, 1), ws[4], bs[4], padding=(1, 0, 0))
+    x = torch.randn(1, cin, 3, 6, 5, dtype=torch.float64)
+    wv, bv = widen_dense_params(ws, bs, cin, cout, gc, 64, 64)
+    assert [tuple(w.shape[:2]) for w in wv] == [(32, 64), (32, 96), (32, 128), (32, 160), (64, 192)]
+    xv = torch.zeros(1, 64, 3, 6, 5, dtype=torch.float64)
+    xv[:, :cin] = x
+    yv = dense(xv, wv, bv)
+    y = dense(x, ws, bs)
+    assert (yv[:, :cout] - y).abs().max() < 1e-13 * y.abs().max() and yv[:, cout:].abs().max() == 0.0
+
+
+def test_weight_epoch_invalidates_every_packed_cache_key():
+    """runtime.invalidate_weights: params_key / weights_stamp change although no tensor version did - what a
+    replayed optimiser step or a `.data` write needs."""
+    from selfc_amd import runtime as rt
+    m = torch.nn.Conv2d(3, 4, 3)
+    k0, s0 = rt.params_key(m), rt.weights_stamp(rt.plist(m))
+    assert rt.params_key(m) == k0
+    m.weight.data.mul_(2.0)                      # bypasses the version counter
+    assert rt.params_key(m) == k0
+    rt.invalidate_weights()
+    assert rt.params_key(m) != k0 and rt.weights_stamp(rt.plist(m)) != s0
+    with torch.no_grad():
+        m.weight.mul_(2.0)                       # a tracked in-place update changes the key by itself
+    k1 = rt.params_key(m)
+    with torch.no_grad():
+        m.weight.add_(1.0)
+    assert rt.params_key(m) != k1
