@@ -237,8 +237,8 @@ int selfc_globalagg_run_c(const float* x, float* y, const float* wmap, const flo
                           float* partial, float* attn, int N, int T, int HW, int c_real, void* stream);
 size_t selfc_globalagg_partial_floats(int N, int HW);
 
-/* Pointwise conv = the Conv3d(.,.,1) layers of STPNet.tail_gmm (SelfC_GMM_arch_inv.py:327-344):
- * out[px][o] = act_out(sum_k W[o][k] act_in(in[px][k]) + b[o]); act = LeakyReLU(0.2) when the flag is set.
+/* Pointwise conv = the Conv3d(.,.,1) layers of STPNet.tail_gmm (SelfC_GMM_arch_inv.py:327-354):
+ * out[px][o] = act_out(sum_k W[o][k] act_in(in[px][k]) + b[o]); act flag 0 = none, 1 = LeakyReLU(0.2), 2 = ReLU (gmm_thin head).
  * in: fp32 or f16 rows of cin (32 | cin <= 256) channels; out: fp32 or f16 rows of stride cout_stride;
  * cout a multiple of 16; `w` from pack_pointwise, bias zero-padded to cout. */
 int selfc_pwconv_run(const void* in, int in_is_f32, void* out, int out_is_f32, const void* w, const float* bias,

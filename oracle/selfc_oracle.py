@@ -304,7 +304,7 @@ def global_agg(p: Params, x: torch.Tensor, t: int) -> torch.Tensor:
 # a8  STPNet v2  (models/modules/SelfC_GMM_arch_inv.py:289-430)
 # ----------------------------------------------------------------------------
 
-def stp_v2_parameters(params: Params, lr: torch.Tensor, t: int, stp_blk_num: int = 6) -> torch.Tensor:
+def stp_v2_parameters(params: Params, lr: torch.Tensor, t: int, stp_blk_num: int = 6, thin: bool = False) -> torch.Tensor:
     """lr (B*T,3,h,w) -> raw head output (B*T, Cp, h, w) (``self.parameters`` of
     the reference, frame-major here instead of (b,Cp,t,h,w)); :358-376."""
     x = d2dt(_sub(params, "local_m1"), lr, t)
@@ -315,8 +315,8 @@ def stp_v2_parameters(params: Params, lr: torch.Tensor, t: int, stp_blk_num: int
         x = d2dt(_sub(params, f"other_stp_modules.{2 * i}"), x, t)
         x = global_agg(_sub(params, f"other_stp_modules.{2 * i + 1}"), x, t)
     tail = sorted({int(k.split(".")[1]) for k in params if k.startswith("tail_gmm.")})
-    for j in tail:                                   # tail_gmm = [lrelu, conv1x1x1]* : :327-344
-        x = lrelu(x)
+    for n_, j in enumerate(tail):                    # tail_gmm = [lrelu, conv1x1x1]* (:327-344); 'gmm_thin': ReLU after the first (:345-354)
+        x = torch.relu(x) if (thin and n_ > 0) else lrelu(x)
         wgt = params[f"tail_gmm.{j}.weight"]
         x = F.conv2d(x, wgt.reshape(wgt.shape[0], wgt.shape[1], 1, 1), params[f"tail_gmm.{j}.bias"])
     return x

@@ -568,6 +568,8 @@ class STPSampleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lr, stp, t, eps, *params):
         from .modules.Subnet_constructor import D2DTInput
+        if stp.fh_loss == "gmm_thin":
+            raise NotImplementedError("selfc_amd: the ReLU head of fh_loss 'gmm_thin' runs in inference only (no shipped config trains it)")
         lr = rt.as_input(lr)
         n, _, h, w = lr.shape
         dev, sp = lr.device, _lib.stream_ptr()

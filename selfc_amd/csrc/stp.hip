@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const void* __restrict__ in
         const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bf[m][ks][j] = (f16)(lrelu_in ? lrelu02(v[j]) : v[j]);
+        for (int j = 0; j < 8; ++j) bf[m][ks][j] = (f16)(lrelu_in == 1 ? lrelu02(v[j]) : lrelu_in == 2 ? fmaxf(v[j], 0.f) : v[j]);
       } else {
         bf[m][ks] = *reinterpret_cast<const f16x8*>(reinterpret_cast<const f16*>(in) + pc * cin + ks * 32 + kq * 8);
       }
@@ -237,9 +237,12 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const void* __restrict__ in
       for (int m = 0; m < MT; ++m) {
         if (!pv[m]) continue;
         float v[4] = {acc[m][0] + bb.x, acc[m][1] + bb.y, acc[m][2] + bb.z, acc[m][3] + bb.w};
-        if (lrelu_out) {
+        if (lrelu_out == 1) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = lrelu02(v[j]);
+        } else if (lrelu_out == 2) {          // ReLU (the gmm_thin head, SelfC_GMM_arch_inv.py:345-354)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
         if (OUT_F32) {
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + pl[m] * cout_stride + oc) = make_float4(v[0], v[1], v[2], v[3]);

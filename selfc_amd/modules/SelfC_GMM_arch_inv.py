@@ -237,8 +237,6 @@ class STPNet(nn.Module):
         buffer).  Returns the raw head output [n][h*w][Cp] when keep_raw (else None).
         scratch: a caller-owned dict for the intermediate buffers (one per stream when several calls overlap);
         eps: pre-allocated noise rows [n*h*w][hf_dim*K] to fill in place (hipGraph capture) instead of a fresh randn."""
-        if self.fh_loss == "gmm_thin":
-            raise NotImplementedError("fh_loss 'gmm_thin' (ReLU head) has no kernel; the shipped configs use 'gmm' / 'l2'")
         if self.hf_dim != 48 and self.fh_loss != "l2":
             raise NotImplementedError("the GMM head kernels are built for hf_dim = 48 (scale 4); other scales run the l2 head")
         dev, sp = x1.device, _lib.stream_ptr()
@@ -283,9 +281,11 @@ class STPNet(nn.Module):
             sc["h1"] = torch.empty((npix, tail[0][3]), dtype=_lib.operand_dtype(), device=dev)
             sc["h2"] = torch.empty((npix, tail[1][3]), dtype=_lib.operand_dtype(), device=dev)
         (w0, b0, ci0, co0), (w1_, b1_, ci1, co1), (w2_, b2_, ci2, co2) = tail
-        # tail_gmm = [lrelu, conv, lrelu, conv, lrelu, conv]: each LeakyReLU is fused into the producer's epilogue
-        rt.call("selfc_pwconv_run", feat.data_ptr(), 1, sc["h1"].data_ptr(), 0, w0.data_ptr(), b0.data_ptr(), npix, ci0, co0, co0, 1, 1, sp)
-        rt.call("selfc_pwconv_run", sc["h1"].data_ptr(), 0, sc["h2"].data_ptr(), 0, w1_.data_ptr(), b1_.data_ptr(), npix, ci1, co1, co1, 0, 1, sp)
+        # tail_gmm = [lrelu, conv, act, conv, act, conv]: each activation is fused into the producer's epilogue (act =
+        # LeakyReLU for 'gmm', ReLU for 'gmm_thin', :334-354; activation flag 1 / 2 of selfc_pwconv_run)
+        act = 2 if self.fh_loss == "gmm_thin" else 1
+        rt.call("selfc_pwconv_run", feat.data_ptr(), 1, sc["h1"].data_ptr(), 0, w0.data_ptr(), b0.data_ptr(), npix, ci0, co0, co0, 1, act, sp)
+        rt.call("selfc_pwconv_run", sc["h1"].data_ptr(), 0, sc["h2"].data_ptr(), 0, w1_.data_ptr(), b1_.data_ptr(), npix, ci1, co1, co1, 0, act, sp)
         fused = self._tail_fused is not None and not keep_raw       # sampling path: the 720-channel head output is never written
         if not fused:
             if "raw" not in sc:      # 720 fp32 channels per pixel-frame (578 MB at 4 x 7 x 64 x 112): only when somebody wants it

@@ -34,6 +34,7 @@ class RescaleRoundTrip:
         self.lat = self.ws.latent()
         self.out = torch.empty((n_frames, 3, H, W), dtype=torch.float32, device=device)
         self.graph = None
+        self._graph_stamp = None
         self.static_x = None
 
     def _extra_params(self):
@@ -48,9 +49,11 @@ class RescaleRoundTrip:
     def _fresh(self, replaying: bool = False):
         """Weights may have changed since __init__ / capture() (load_state_dict, an optimizer step): an eager run repacks
         them; a captured graph has the OLD packed buffers baked in, so replaying it is refused."""
-        if rt.weights_stamp(self._params) != self._stamp:
-            if replaying:
+        now = rt.weights_stamp(self._params)
+        if replaying:
+            if now != self._graph_stamp:
                 raise RuntimeError("the net's weights changed after capture(): call capture() again (the graph holds the old packed weights)")
+        elif now != self._stamp:
             self._bind()
 
     def run(self, x: torch.Tensor) -> torch.Tensor:
@@ -98,6 +101,7 @@ class RescaleRoundTrip:
         with torch.cuda.graph(g):
             self.run(x)
         self.graph = g
+        self._graph_stamp = self._stamp
 
     def replay(self):
         self._fresh(replaying=True)
@@ -177,6 +181,8 @@ class MultiStreamRoundTrip:
         with torch.cuda.graph(g):
             self.run(x)
         self.graph = g
+        for p in self.parts:
+            p._graph_stamp = p._stamp
 
     def replay(self):
         self.parts[0]._fresh(replaying=True)

@@ -139,3 +139,20 @@ def test_stp_v1_gmm_head(dev):
     v = stp.sample()[0].transpose(0, 1)
     assert rel_err(v.cpu(), g["v"]) < TOL
     assert torch.isfinite(stp.neg_llh(stp.sample())).all()
+
+
+def test_stp_v2_gmm_thin_head(dev):
+    """fh_loss 'gmm_thin' (SelfC_GMM_arch_inv.py:345-354): ReLU between the head's pointwise layers, then the same sampler"""
+    from selfc_amd.modules.SelfC_GMM_arch_inv import STPNet
+    g7, g = load_golden("g7_stp_gmm"), load_golden("g17_stp_gmm_thin")
+    stp = STPNet({"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": "gmm_thin", "scale": 4, "gmm_k": 5})
+    sd = {k: v for k, v in g7.items() if k.split(".")[0] in ("local_m1", "local_m2", "global_m1", "global_m2", "other_stp_modules")}
+    sd.update({k: v for k, v in g.items() if k.startswith("tail_gmm.")})
+    stp.load_state_dict(sd, strict=True)
+    stp.to(dev).eval()
+    stp.eps = g["eps"].permute(1, 2, 0, 3, 4).unsqueeze(0).to(dev)        # (1,48,5,T,h,w)
+    with torch.no_grad():
+        stp(g["lr"].to(dev).reshape(1, T, 3, 8, 12).transpose(1, 2))
+    raw = stp.parameters[0].transpose(0, 1)
+    assert rel_err(raw.cpu(), g["raw"]) < TOL and rel_l2(raw.cpu(), g["raw"]) < TOL
+    assert rel_err(stp.sample()[0].transpose(0, 1).cpu(), g["v"]) < TOL

@@ -238,3 +238,13 @@ def test_stp_v1_gmm_head():
     raw = O.stp_v1_parameters(g, g["lr"], T)
     assert rel_err(raw, g["raw"]) < 2e-5
     assert rel_err(O.stp_v1_gmm_sample(g["raw"], g["eps"]), g["v"]) < 2e-6
+
+
+def test_stp_v2_gmm_thin_head():
+    """fh_loss 'gmm_thin' (ReLU between the head's layers, SelfC_GMM_arch_inv.py:345-354); the chain's weights are G7's."""
+    g7, g = load_golden("g7_stp_gmm"), load_golden("g17_stp_gmm_thin")
+    params = {k: v for k, v in g7.items() if k.split(".")[0] in ("local_m1", "local_m2", "global_m1", "global_m2", "other_stp_modules")}
+    params.update({k: v for k, v in g.items() if k.startswith("tail_gmm.")})
+    raw = O.stp_v2_parameters(params, g["lr"], T, thin=True)
+    assert rel_err(raw, g["raw"]) < 2e-5
+    assert rel_err(O.stp_v2_gmm_sample(g["raw"], g["eps"]), g["v"]) < 2e-6

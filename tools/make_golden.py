@@ -500,6 +500,25 @@ def main_r2():
         save("g16_stp_v1_gmm", lr=lr1.numpy(), eps=eps1[:, 0].numpy(), raw=s1.parameters[0].transpose(0, 1).numpy(),
              v=s1.gmm_v[0].transpose(0, 1).numpy(), **sd_np(s1))
 
+    # ---- G17 STP v2 'gmm_thin' head (ReLU between the head's layers, SelfC_GMM_arch_inv.py:345-354), eps injected as in G7
+    with torch.no_grad():
+        GlobalVar.set_Temporal_LEN(T)
+        g = torch.Generator().manual_seed(1700)
+        torch.manual_seed(17)
+        st = GA.STPNet({"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": "gmm_thin", "scale": 4, "gmm_k": 5}).eval()
+        with np.load(os.path.join(OUT, "g7_stp_gmm.npz")) as z7:     # the chain in front of the head: G7's weights (not stored twice)
+            chain = {k: torch.from_numpy(np.asarray(z7[k])) for k in z7.files if k.split(".")[0] in
+                     ("local_m1", "local_m2", "global_m1", "global_m2", "other_stp_modules")}
+        missing, unexpected = st.load_state_dict(chain, strict=False)
+        assert not unexpected and all(k.startswith("tail_gmm.") for k in missing)
+        lr7 = torch.rand(T, 3, 8, 12, generator=g)
+        eps7 = torch.randn(1, 48, 5, T, 8, 12, generator=g)
+        st.reparametrize = lambda mu, logvar: eps7.mul(torch.exp(logvar)).add_(mu)
+        st(lr7.reshape(1, T, 3, 8, 12).transpose(1, 2))
+        head = {k: v for k, v in sd_np(st).items() if k.startswith("tail_gmm.")}
+        save("g17_stp_gmm_thin", lr=lr7.numpy(), raw=st.parameters[0].transpose(0, 1).numpy(),
+             eps=eps7[0].permute(2, 0, 1, 3, 4).numpy(), v=st.gmm_v[0].transpose(0, 1).numpy(), **head)
+
     # ---- public API contract
     def api(cls):
         pub = sorted(n for n, v in vars(cls).items() if callable(v) and not n.startswith("_"))
