@@ -47,6 +47,11 @@ def _record(metric, value):
     return value
 
 
+def record(metric, value):
+    """log any other measured figure (e.g. gradient-norm ratios) next to the parity values"""
+    return _record(metric, float(value))
+
+
 def rel_err(a, b):
     """max |a-b| / max |b|  (the "1e-3 relative fp32" metric of BASELINE.json, written down here)."""
     return _record("max|a-b|/max|b|", ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item())

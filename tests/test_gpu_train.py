@@ -57,9 +57,14 @@ def test_train_step_matches_reference_step(dev):
     names = g["names"]
     norms = torch.tensor([float(grads[n].norm()) for n in names], dtype=torch.float64)
     ref = g["grad_norms"]
-    rel = float((norms - ref).norm() / ref.norm())
-    assert rel < 3e-2, rel
-    assert abs(float(tr.grad_norm) - float(g["grad_norm"])) < 3e-2 * float(g["grad_norm"])
+    from conftest import record
+    rel = record("||grad norms - ref|| / ||ref|| over the 350 tensors", (norms - ref).norm() / ref.norm())
+    ratio = record("median per-tensor gradient-norm ratio", (norms / ref).median())
+    total = record("total gradient norm ratio", float(tr.grad_norm) / float(g["grad_norm"]))
+    # measured on the MI355X: 1.7e-4, 0.99991, 0.99989 (profiles/r2/parity_report_gpu.json); bars 10x above that - far
+    # below the 1 % a systematic scale error of the weight-gradient path (e.g. a wrong 1/S) would cause
+    assert rel < 2e-3, rel
+    assert abs(ratio - 1.0) < 2e-3 and abs(total - 1.0) < 2e-3, (ratio, total)
     # one clipped gradient tensor element-wise, and the Adam step itself: |delta| <= lr, direction = -sign(grad)
     clipped = net.operations[1].F.conv1.weight.grad.cpu()
     e = float((clipped - g["grad_F1_conv1_clipped"]).norm() / g["grad_F1_conv1_clipped"].norm())
