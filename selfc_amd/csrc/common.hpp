@@ -85,21 +85,10 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
   return __builtin_bit_cast(uint32_t, h);
 }
 
-// LeakyReLU(0.2) of two accumulator values, packed to the operand type.  f16 build: convert first, then ONE packed multiply
-// and ONE packed max on the pair - 3 instead of 5 VALU instructions per pair in kernels whose time is the sum of their issue
-// work (fused G/H -1.4 %, 254 -> 242 VGPRs).  The negative branch is rounded twice (0.2 * fl16(x) again to
-// f16); measured parity unchanged (worst inverse 6.1e-4 before and after).  -DSELFC_FP32_LRELU restores the single rounding.
-__device__ __forceinline__ uint32_t lrelu_pack2(float a, float b) {
-#if !defined(SELFC_FP32_LRELU) && !defined(SELFC_OPERAND_BF16)
-  const f16x2 h = {(f16)a, (f16)b};
-  const f16x2 k = {(f16)0.2f, (f16)0.2f};
-  const f16x2 m = h * k;
-  f16x2 r;
-  asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(h), "v"(m));
-  return __builtin_bit_cast(uint32_t, r);
-#else
-  return pack2(lrelu02(a), lrelu02(b));
-#endif
-}
+// LeakyReLU(0.2) of two fp32 accumulators, then ONE rounding to the f16 pair.  A packed variant (round first, then v_pk_mul_f16 by
+// 0.2 and v_pk_max_f16: 3 instead of 5 VALU instructions per pair) was measured in round 2: fused G/H -1.4 %, but the slope becomes
+// fl16(0.2) = 0.19995 and negatives are rounded twice, which moved the chained-gradient check (tests/test_gpu_backward.py
+// test_stack_backward_chain) from 4.4 % to 5.1 % against its 5 % bar - dropped.
+__device__ __forceinline__ uint32_t lrelu_pack2(float a, float b) { return pack2(lrelu02(a), lrelu02(b)); }
 
 }  // namespace selfc
