@@ -143,7 +143,8 @@ int selfc_invstack_run(const selfc_invblock_w* blks, int nblk, const selfc_laten
  * Subnet_constructor.py:26-34,115-133): input NHWC fp32 `xin` with channel
  * stride cinp = roundup(cin,4), output NHWC fp32 `yout` with stride
  * coutp = roundup(cout,4); `dense` is a zero-initialised [DC/32][N][H][W][32] f16
- * workspace with DC = (cin <= 3 ? 128 : roundup(cin,32)+128). */
+ * workspace with DC = (cin <= 3 ? 128 : roundup(cin,32)+128).  cin > 3 and xin == NULL:
+ * the input planes of `dense` are already filled (by selfc_globalagg_run_d) and are used as they are. */
 int selfc_subnet_run(const selfc_subnet_w* w, int kind, const float* xin, float* yout, void* dense,
                      int N, int T, int H, int W, int cin, int cout, void* stream);
 
@@ -229,11 +230,14 @@ int selfc_bwd_wgrad(const void* P, int Pn, const void* Q, int Qn, int taps, floa
 int selfc_globalagg_run(const float* x, float* y, const float* wmap, const float* fc_bias /* device, 1 float */, const void* w1, const float* b1,
                         const float* w2, const float* b2, const float* w3, const float* b3,
                         float* partial, float* attn, int N, int T, int HW, void* stream);
-/* The same for a GlobalAgg(c) with c < 64 (codec variant: c = stp_hidden_c = 24, SelfC_Codec_arch_inv.py:103-131): the
- * caller zero-pads activations and parameters to 64 channels (exact: padded channels stay 0) and passes the module's
- * real channel count, which is the softmax temperature of `/C` (:120). */
-int selfc_globalagg_run_c(const float* x, float* y, const float* wmap, const float* fc_bias, const void* w1, const float* b1,
-                          const float* w2, const float* b2, const float* w3, const float* b3,
+/* The general entry.  c_real: a GlobalAgg(c) with c < 64 (codec variant: c = stp_hidden_c = 24, SelfC_Codec_arch_inv.py:103-131)
+ * runs with activations and parameters zero-padded to 64 channels by the caller (exact: padded channels stay 0) and passes the
+ * module's real channel count, which is the softmax temperature of `/C` (:120).  Exactly one of `y` / `dense_out` is given:
+ * `dense_out` = the plane-blocked f16 operand buffer ([plane][N][HW][32]) of the D2DTInput that consumes the result - its planes
+ * 0..1 are written directly (the rounding selfc_subnet_run's own input conversion applies; call it with xin = NULL afterwards).
+ * The clip attention (tiny) is the prologue of every mix workgroup; `attn` may be NULL (else it receives A, (N/T)*T*T floats). */
+int selfc_globalagg_run_d(const float* x, float* y, void* dense_out, const float* wmap, const float* fc_bias, const void* w1,
+                          const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                           float* partial, float* attn, int N, int T, int HW, int c_real, void* stream);
 size_t selfc_globalagg_partial_floats(int N, int HW);
 

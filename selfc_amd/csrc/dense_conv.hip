@@ -1015,8 +1015,8 @@ int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s)
 
 extern "C" {
 
-const char* selfc_version(void) { return "selfc_hip gfx950 abi4 operands=" SELFC_OPERAND_NAME; }
-int selfc_abi_version(void) { return 5; }
+const char* selfc_version(void) { return "selfc_hip gfx950 abi6 operands=" SELFC_OPERAND_NAME; }
+int selfc_abi_version(void) { return 6; }
 
 int selfc_invblock_run(const selfc_invblock_w* blk, const selfc_latent* lat, int rev, void* stream) {
   if (!blk || !latent_ok(lat)) return SELFC_EINVAL;
@@ -1043,13 +1043,14 @@ int selfc_invstack_run(const selfc_invblock_w* blks, int nblk, const selfc_laten
 
 int selfc_subnet_run(const selfc_subnet_w* w, int kind, const float* xin, float* yout, void* dense,
                      int N, int T, int H, int W, int cin, int cout, void* stream) {
-  if (!w || !xin || !yout || !dense || N <= 0 || T <= 0 || N % T || H <= 0 || W <= 0 || cin < 1 || cout < 1) return SELFC_EINVAL;
+  if (!w || !yout || !dense || N <= 0 || T <= 0 || N % T || H <= 0 || W <= 0 || cin < 1 || cout < 1) return SELFC_EINVAL;
+  if (!xin && cin <= 3) return SELFC_EINVAL;          // a 3-channel input is read from its fp32 rows by conv1 itself
   if (check_subnet(w, true)) return SELFC_EINVAL;
   if (cin > 96) return SELFC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int DC = dense_channels(cin);
   const int coutp = (cout + 3) & ~3;
-  if (cin > 3) {
+  if (cin > 3 && xin) {        // xin == NULL: the producer already wrote the input planes (selfc_globalagg_run_d)
     const size_t npix = (size_t)N * H * W;
     hipLaunchKernelGGL(nhwc_to_dense_kernel, dim3((unsigned)((npix * (((cin + 31) & ~31) >> 3) + 255) / 256)), dim3(256), 0, s,
                        xin, (f16*)dense, npix, cin, (cin + 3) & ~3, (cin + 31) & ~31);

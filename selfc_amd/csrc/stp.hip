@@ -50,72 +50,111 @@ __global__ __launch_bounds__(256) void gagg_pool_kernel(const float* __restrict_
   }
 }
 
-// ---- (2) per clip: g = sum(partials) + fc.bias; q = proj2(g), k = proj3(g); A = softmax(q k^T / 64, dim=-1)
-// 256 threads per clip: the two 64x64 projection matrices go through LDS (coalesced loads, rows padded to 65 floats),
-// every (frame, channel) output has its own thread.  Summation orders are those of the first version (one 64-thread
-// workgroup walking its weight rows from global memory: 33 us per call for a few kFLOP).
-__global__ __launch_bounds__(256) void gagg_attn_kernel(const float* __restrict__ partial, int nchunk, const float* __restrict__ fcbp,
-                                                       const float* __restrict__ w2, const float* __restrict__ b2,
-                                                       const float* __restrict__ w3, const float* __restrict__ b3,
-                                                       float* __restrict__ A, int T, float creal) {
-  __shared__ float g[TMAX][64], q[TMAX][64], k[TMAX][64], m[TMAX][TMAX], w2s[64][65], w3s[64][65];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const float fcb = *fcbp;
-  for (int i = tid; i < 64 * 64; i += 256) {
-    w2s[i >> 6][i & 63] = w2[i];
-    w3s[i >> 6][i & 63] = w3[i];
+// ---- (2) per clip: g = sum(partials) + fc.bias; q = proj2(g), k = proj3(g); A = softmax(q k^T / C, dim=-1), left in LDS.
+// Runs as the PROLOGUE of every mix workgroup of the clip (a few kFLOP, redundantly): as a launch of its own it was one
+// workgroup per clip and 16 us of pure latency in front of the mix, six times per STP pass.  Built for latency: thread
+// (matrix, output channel, half of the 64 inputs) holds its half row of W2 / W3 in registers (8 float4 straight from L2, no
+// LDS staging), reads g as float4 LDS broadcasts and meets its partner lane through one shuffle - the first version (one
+// thread per output walking 64 scalar LDS reads, three barriers of 64-step dependent loops) cost 13 us per workgroup.
+struct AttnLds {
+  float g[TMAX][64], q[TMAX][64], k[TMAX][64], m[TMAX][TMAX];
+};
+
+__device__ __forceinline__ void clip_attention(AttnLds& L, int b, int tid, const float* __restrict__ partial, int nchunk,
+                                               const float* __restrict__ fcbp, const float* __restrict__ w2, const float* __restrict__ b2,
+                                               const float* __restrict__ w3, const float* __restrict__ b3, int T, float creal) {
+  const int mat = tid >> 7, c = (tid >> 1) & 63, jh = tid & 1;
+  float4 wr[8];
+  {
+    const float4* wrow = reinterpret_cast<const float4*>((mat ? w3 : w2) + c * 64 + jh * 32);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wr[i] = wrow[i];
   }
-  for (int i = tid; i < T * 64; i += 256) {
-    const int t = i >> 6, c = i & 63;
-    float s = 0.f;
-    const float* p = partial + (size_t)(b * T + t) * nchunk * 64 + c;
-    for (int j = 0; j < nchunk; ++j) s += p[(size_t)j * 64];
-    g[t][c] = s + fcb;
+  const float bias = (mat ? b3 : b2)[c];
+  const float fcb = *fcbp;
+  if (tid < T * 16) {       // g: one thread per (frame, 4 channels); the chunk partials are fetched 16 at a time (independent
+    const int t = tid >> 4, c4 = tid & 15;          // loads in flight - one by one they were 14 L2 round trips in a row)
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* p = reinterpret_cast<const float4*>(partial + (size_t)(b * T + t) * nchunk * 64) + c4;
+    for (int j0 = 0; j0 < nchunk; j0 += 16) {
+      float4 v[16];
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) v[jj] = j0 + jj < nchunk ? p[(size_t)(j0 + jj) * 16] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) { s.x += v[jj].x; s.y += v[jj].y; s.z += v[jj].z; s.w += v[jj].w; }
+    }
+    *reinterpret_cast<float4*>(&L.g[t][c4 * 4]) = make_float4(s.x + fcb, s.y + fcb, s.z + fcb, s.w + fcb);
   }
   __syncthreads();
-  for (int i = tid; i < T * 64; i += 256) {
-    const int t = i >> 6, c = i & 63;
-    float sq = b2[c], sk = b3[c];
-    for (int j = 0; j < 64; ++j) {
-      sq += g[t][j] * w2s[c][j];
-      sk += g[t][j] * w3s[c][j];
+  float acc[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) {
+    acc[t] = 0.f;
+    if (t < T) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 gv = *reinterpret_cast<const float4*>(&L.g[t][jh * 32 + 4 * i]);
+        acc[t] += gv.x * wr[i].x + gv.y * wr[i].y + gv.z * wr[i].z + gv.w * wr[i].w;
+      }
     }
-    q[t][c] = sq;
-    k[t][c] = sk;
+    acc[t] += __shfl_xor(acc[t], 1);
+  }
+  if (jh == 0) {
+    float (*dst)[64] = mat ? L.k : L.q;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+      if (t < T) dst[t][c] = acc[t] + bias;
   }
   __syncthreads();
   if (tid < T * T) {
     const int t1 = tid / T, t2 = tid % T;
     float s = 0.f;
-    for (int j = 0; j < 64; ++j) s += q[t1][j] * k[t2][j];
-    m[t1][t2] = s / creal;          // the reference divides by the module's REAL channel count C (64; 24 in the codec variant)
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const float4 qv = *reinterpret_cast<const float4*>(&L.q[t1][4 * jj]);
+      const float4 kv = *reinterpret_cast<const float4*>(&L.k[t2][4 * jj]);
+      s += qv.x * kv.x + qv.y * kv.y + qv.z * kv.z + qv.w * kv.w;
+    }
+    L.m[t1][t2] = s / creal;        // the reference divides by the module's REAL channel count C (64; 24 in the codec variant)
   }
   __syncthreads();
   if (tid < T) {            // softmax over the last axis of row tid
-    float mx = m[tid][0];
-    for (int j = 1; j < T; ++j) mx = fmaxf(mx, m[tid][j]);
+    float mx = L.m[tid][0];
+    for (int jj = 1; jj < T; ++jj) mx = fmaxf(mx, L.m[tid][jj]);
     float e[TMAX], s = 0.f;
-    for (int j = 0; j < T; ++j) { e[j] = expf(m[tid][j] - mx); s += e[j]; }
-    for (int j = 0; j < T; ++j) A[((size_t)b * T + tid) * T + j] = e[j] / s;
+    for (int jj = 0; jj < T; ++jj) { e[jj] = expf(L.m[tid][jj] - mx); s += e[jj]; }
+    for (int jj = 0; jj < T; ++jj) L.m[tid][jj] = e[jj] / s;
   }
+  __syncthreads();
 }
 
 // ---- (3) temporal mix + 64x64 projection + residual.  Wave = 16 pixels of one clip.
-__global__ __launch_bounds__(256) void gagg_mix_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                       const float* __restrict__ A, const f16* __restrict__ w1,
-                                                       const float* __restrict__ b1, int T, int HW) {
+// DENSE: the consumer is a D2DTInput - the result goes straight into planes 0..1 of ITS plane-blocked f16 operand buffer
+// ([plane][N][HW][32], the rounding its nhwc_to_dense pass would apply) instead of an fp32 row the next launch converts.
+template <bool DENSE>
+__global__ __launch_bounds__(256) void gagg_mix_kernel(const float* __restrict__ x, float* __restrict__ y, f16* __restrict__ dense,
+                                                       size_t plane, const float* __restrict__ partial, int nchunk,
+                                                       const float* __restrict__ fcbp, const float* __restrict__ w2,
+                                                       const float* __restrict__ b2, const float* __restrict__ w3,
+                                                       const float* __restrict__ b3, float* __restrict__ attn_out,
+                                                       const f16* __restrict__ w1, const float* __restrict__ b1, int T, int HW,
+                                                       float creal) {
+  __shared__ AttnLds L;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tiles = (HW + 63) / 64;
   const int b = blockIdx.x / tiles;
+  clip_attention(L, b, threadIdx.x, partial, nchunk, fcbp, w2, b2, w3, b3, T, creal);
+  if (attn_out && blockIdx.x % tiles == 0 && threadIdx.x < T * T)
+    attn_out[(size_t)b * T * T + threadIdx.x] = L.m[threadIdx.x / T][threadIdx.x % T];
   const int p0 = (blockIdx.x % tiles) * 64 + wave * 16;
-  if (p0 >= HW) return;
+  if (p0 >= HW) return;                    // no barriers below
   const int pl = p0 + (lane & 15);
   const bool pvalid = pl < HW;
   const int pc = pvalid ? pl : HW - 1;
   const int kq = lane >> 4;
-  const float* Ab = A + (size_t)b * T * T;
 
-  // this lane's 16 channels (k = 32 ks + 8 kq + j) of every frame of the clip
+  // this lane's 16 channels (k = 32 ks + 8 kq + j) of every frame of the clip.  (Requesting them BEFORE the prologue so that
+  // both share one memory round trip was measured: 160 more live registers across it, 34 -> 45 us at four clips.)
   float xs[TMAX][16];
 #pragma unroll
   for (int t = 0; t < TMAX; ++t) {
@@ -149,7 +188,7 @@ __global__ __launch_bounds__(256) void gagg_mix_kernel(const float* __restrict__
 #pragma unroll
     for (int t1 = 0; t1 < TMAX; ++t1) {
       if (t1 < T) {
-        const float a = Ab[t1 * T + t2];
+        const float a = L.m[t1][t2];
         colsum += a;
 #pragma unroll
         for (int j = 0; j < 16; ++j) xm[j] += a * xs[t1][j];
@@ -169,10 +208,18 @@ __global__ __launch_bounds__(256) void gagg_mix_kernel(const float* __restrict__
       const int oc = o * 16 + kq * 4;
       const float4 xr = *reinterpret_cast<const float4*>(x + pix * 64 + oc);
       const float4 bb = *reinterpret_cast<const float4*>(b1 + oc);
-      if (pvalid)
-        *reinterpret_cast<float4*>(y + pix * 64 + oc) =
-            make_float4(xr.x + acc[0] + bb.x * colsum, xr.y + acc[1] + bb.y * colsum,
-                        xr.z + acc[2] + bb.z * colsum, xr.w + acc[3] + bb.w * colsum);
+      const float4 r = make_float4(xr.x + acc[0] + bb.x * colsum, xr.y + acc[1] + bb.y * colsum,
+                                   xr.z + acc[2] + bb.z * colsum, xr.w + acc[3] + bb.w * colsum);
+      if (pvalid) {
+        if constexpr (DENSE) {
+          uint2 h;
+          h.x = pack2(r.x, r.y);
+          h.y = pack2(r.z, r.w);
+          *reinterpret_cast<uint2*>(dense + (size_t)(o >> 1) * plane + pix * 32 + (o & 1) * 16 + kq * 4) = h;
+        } else {
+          *reinterpret_cast<float4*>(y + pix * 64 + oc) = r;
+        }
+      }
     }
   }
 }
@@ -814,13 +861,15 @@ extern "C" {
 int selfc_globalagg_run(const float* x, float* y, const float* wmap, const float* fc_bias, const void* w1, const float* b1,
                         const float* w2, const float* b2, const float* w3, const float* b3,
                         float* partial, float* attn, int N, int T, int HW, void* stream) {
-  return selfc_globalagg_run_c(x, y, wmap, fc_bias, w1, b1, w2, b2, w3, b3, partial, attn, N, T, HW, 64, stream);
+  if (!y) return SELFC_EINVAL;
+  return selfc_globalagg_run_d(x, y, nullptr, wmap, fc_bias, w1, b1, w2, b2, w3, b3, partial, attn, N, T, HW, 64, stream);
 }
 
-int selfc_globalagg_run_c(const float* x, float* y, const float* wmap, const float* fc_bias, const void* w1, const float* b1,
-                          const float* w2, const float* b2, const float* w3, const float* b3,
+int selfc_globalagg_run_d(const float* x, float* y, void* dense_out, const float* wmap, const float* fc_bias, const void* w1,
+                          const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                           float* partial, float* attn, int N, int T, int HW, int c_real, void* stream) {
-  if (!x || !y || !wmap || !fc_bias || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !partial || !attn) return SELFC_EINVAL;
+  if (!x || !wmap || !fc_bias || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !partial) return SELFC_EINVAL;
+  if ((y == nullptr) == (dense_out == nullptr)) return SELFC_EINVAL;        // exactly one kind of output
   if (N <= 0 || T <= 0 || T > TMAX || N % T || HW <= 0 || x == y || c_real < 1 || c_real > 64) return SELFC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = (HW + POOL_CHUNK - 1) / POOL_CHUNK;
@@ -833,14 +882,14 @@ int selfc_globalagg_run_c(const float* x, float* y, const float* wmap, const flo
   if (rc) return rc;
   {
     ProfScope prof(PROF_STP, s);
-    hipLaunchKernelGGL(gagg_attn_kernel, dim3(B), dim3(256), 0, s, partial, nchunk, fc_bias, w2, b2, w3, b3, attn, T, (float)c_real);
-  }
-  rc = hip_rc(hipGetLastError());
-  if (rc) return rc;
-  {
-    ProfScope prof(PROF_STP, s);
     const int tiles = (HW + 63) / 64;
-    hipLaunchKernelGGL(gagg_mix_kernel, dim3((unsigned)(tiles * B)), dim3(256), 0, s, x, y, attn, (const f16*)w1, b1, T, HW);
+    const size_t plane = (size_t)N * HW * 32;
+    if (dense_out)
+      hipLaunchKernelGGL(gagg_mix_kernel<true>, dim3((unsigned)(tiles * B)), dim3(256), 0, s, x, nullptr, (f16*)dense_out, plane, partial,
+                         nchunk, fc_bias, w2, b2, w3, b3, attn, (const f16*)w1, b1, T, HW, (float)c_real);
+    else
+      hipLaunchKernelGGL(gagg_mix_kernel<false>, dim3((unsigned)(tiles * B)), dim3(256), 0, s, x, y, nullptr, plane, partial,
+                         nchunk, fc_bias, w2, b2, w3, b3, attn, (const f16*)w1, b1, T, HW, (float)c_real);
   }
   return hip_rc(hipGetLastError());
 }

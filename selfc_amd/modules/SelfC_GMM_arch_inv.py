@@ -103,21 +103,21 @@ class GlobalAgg(nn.Module):
             self._pk_key = key
         return self._pk
 
-    def run_nhwc(self, x, y, n, t, h, w, scratch):
-        """x, y: fp32 NHWC [n][h*w][64] (distinct buffers); scratch: dict cache for partial/attn buffers."""
+    def run_nhwc(self, x, y, n, t, h, w, scratch, dense_out=None):
+        """x, y: fp32 NHWC [n][h*w][64] (distinct buffers); scratch: dict cache for the partial sums.
+        dense_out (instead of y): the f16 operand buffer [planes][n][h*w][32] of the D2DTInput that consumes the result -
+        its two input planes are written directly and that subnet runs with xin = NULL."""
         pk = self._packed(h, w)
         L = _lib.lib()
-        nfl = L.selfc_globalagg_partial_floats(n, h * w)
-        # the two buffers grow independently (more clips of fewer pixels need a larger attn but a smaller partial) and
-        # never outlive a device change
-        for name, need in (("gagg_partial", nfl), ("gagg_attn", (n // t) * t * t)):
-            buf = scratch.get(name)
-            if buf is None or buf.numel() < need or buf.device != x.device:
-                scratch[name] = torch.empty(need, dtype=torch.float32, device=x.device)
-        rt.call("selfc_globalagg_run_c", x.data_ptr(), y.data_ptr(), pk["wmap"].data_ptr(), pk["fcb"].data_ptr(),
+        need = L.selfc_globalagg_partial_floats(n, h * w)
+        buf = scratch.get("gagg_partial")        # grows with the call; never outlives a device change
+        if buf is None or buf.numel() < need or buf.device != x.device:
+            scratch["gagg_partial"] = torch.empty(need, dtype=torch.float32, device=x.device)
+        rt.call("selfc_globalagg_run_d", x.data_ptr(), None if y is None else y.data_ptr(),
+                None if dense_out is None else dense_out.data_ptr(), pk["wmap"].data_ptr(), pk["fcb"].data_ptr(),
                 pk["w1"].data_ptr(), pk["b1"].data_ptr(), pk["w2"].data_ptr(), pk["b2"].data_ptr(),
-                pk["w3"].data_ptr(), pk["b3"].data_ptr(), scratch["gagg_partial"].data_ptr(),
-                scratch["gagg_attn"].data_ptr(), n, t, h * w, self.c, _lib.stream_ptr())
+                pk["w3"].data_ptr(), pk["b3"].data_ptr(), scratch["gagg_partial"].data_ptr(), None,
+                n, t, h * w, self.c, _lib.stream_ptr())
 
     def forward(self, x):
         x = rt.as_input(x)
@@ -249,16 +249,25 @@ class STPNet(nn.Module):
             sc["dense4"] = torch.zeros((4, n, h, w, 32), dtype=_lib.operand_dtype(), device=dev)
             sc["dense6"] = torch.zeros((6, n, h, w, 32), dtype=_lib.operand_dtype(), device=dev)
         cur, nxt = None, 0
-        for m in self._chain():
+        chain = self._chain()
+        in_dense = False          # the previous GlobalAgg wrote this subnet's input planes itself
+        for i, m in enumerate(chain):
             dst = sc["feat"][nxt]
             if isinstance(m, D2DTInput):
                 src = x1 if cur is None else sc["feat"][cur]
                 dense = sc["dense4"] if m.channel_in <= 3 else sc["dense6"]
                 cin_v, cout_v = self._virt(m)
                 sw = rt.packed_subnet(m, (cin_v, cout_v)).struct()
-                rt.call("selfc_subnet_run", sw, m.kind, src.data_ptr(), dst.data_ptr(), dense.data_ptr(),
+                rt.call("selfc_subnet_run", sw, m.kind, None if in_dense else src.data_ptr(), dst.data_ptr(), dense.data_ptr(),
                         n, t, h, w, cin_v, cout_v, sp)
+                in_dense = False
             else:
+                # a GlobalAgg in front of a wide D2DTInput hands over f16 operand planes instead of an fp32 row (the same
+                # rounding, one conversion pass and half the store traffic less); the last one feeds the head in fp32
+                in_dense = i + 1 < len(chain) and isinstance(chain[i + 1], D2DTInput) and chain[i + 1].channel_in > 3
+                if in_dense:
+                    m.run_nhwc(sc["feat"][cur], None, n, t, h, w, sc, dense_out=sc["dense6"])
+                    continue              # nothing new in feat: cur / nxt stay
                 m.run_nhwc(sc["feat"][cur], dst, n, t, h, w, sc)
             cur, nxt = nxt, 1 - nxt
         feat = sc["feat"][cur]

@@ -579,8 +579,9 @@ def test_rejects_bad_arguments(dev):
 
 
 def test_globalagg_scratch_grows_per_buffer(dev):
-    """one GlobalAgg used first on few clips of many pixels, then on many clips of few pixels - the attention
-    buffer must grow although the pooling buffer does not (used to write past the end)."""
+    """one GlobalAgg used first on few clips of many pixels, then on many clips of few pixels - its scratch must
+    follow the call (a shared attention buffer used to be written past its end; since the attention became the mix kernel's
+    prologue only the pooling partials are left, sized per call)."""
     from selfc_amd.modules.SelfC_GMM_arch_inv import GlobalAgg
     g = load_golden("g6_globalagg")
     ga = GlobalAgg(64)
