@@ -256,13 +256,15 @@ int selfc_gmm_sample(const float* raw, const float* eps, float* v, size_t npix, 
  * sampler above; 0.5 is STP v1's `std = exp(0.5 logvar)` (SelfC_arch_inv.py:151-162,179-186; hf_dim = 9 there). */
 int selfc_gmm_sample_generic(const float* raw, const float* eps, float* v, size_t npix, int hf_dim, int K, int raw_stride,
                              int v_stride, float logsigma_scale, void* stream);
-/* The last head layer (Conv3d 1x1x1, cin = 256 -> hf_dim*K*3) and the GMM sample in one kernel (sampling path of
- * SelfC_GMM_arch_inv.py:371-394: the 720-channel head output is never written).  `in`: f16 rows [npix][cin];
- * w / bias: that conv packed by packing.py:pack_pointwise after the channel permutation of packing.py:gmm_head_perm
- * (new channel (3 k + j) * hf_dim + c = reference channel (c*K + k)*3 + j); eps: fp32 rows [npix][k * hf_dim + c];
- * v: fp32 rows of stride v_stride.  hf_dim = 48, K = 5, cin = 256. */
-int selfc_pwconv_gmm(const void* in, const void* w, const float* bias, const float* eps, float* v, size_t npix, int cin,
-                     int hf_dim, int K, int v_stride, void* stream);
+/* The whole GMM head and the GMM sample in one kernel (sampling path of SelfC_GMM_arch_inv.py:327-344,371-394):
+ * feat (fp32 rows [npix][64]) -LeakyReLU-> Conv3d 1x1x1 64->128 -act-> 128->256 -act-> 256->hf_dim*K*3 -> v; no activation
+ * of the head is written to memory.  act: 1 = LeakyReLU(0.2) ('gmm').  w: ONE fragment stream [W0 | W1 | W2], each layer
+ * packed by packing.py:pack_pointwise after a permutation of its OUTPUT channels - W0 / W1 by packing.py:head_row_perm (the
+ * MFMA result layout becomes the next layer's operand layout), W2 by packing.py:gmm_head_perm (new channel
+ * (3 k + j) * hf_dim + c = reference channel (c*K + k)*3 + j); bias: the three permuted biases back to back (128 + 256 + 720);
+ * eps: fp32 rows [npix][k * hf_dim + c]; v: fp32 rows of stride v_stride.  hf_dim = 48, K = 5. */
+int selfc_stp_head_gmm(const float* feat, const void* w, const float* bias, const float* eps, float* v, size_t npix,
+                       int hf_dim, int K, int v_stride, int act, void* stream);
 
 /* ---- live kernel timing (bench.py roofline leg) ------------------------------
  * HIP events are recorded on the launch stream around every kernel launch while

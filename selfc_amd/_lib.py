@@ -33,7 +33,7 @@ SYMBOLS = [
     "selfc_invblock_run", "selfc_invstack_run", "selfc_subnet_run",
     "selfc_nchw_to_nhwc4", "selfc_nhwc4_to_nchw",
     "selfc_profile_enable", "selfc_profile_read", "selfc_profile_reset",
-    "selfc_globalagg_run", "selfc_globalagg_run_d", "selfc_gmm_sample_generic", "selfc_globalagg_partial_floats", "selfc_pwconv_run", "selfc_gmm_sample", "selfc_pwconv_gmm",
+    "selfc_globalagg_run", "selfc_globalagg_run_d", "selfc_gmm_sample_generic", "selfc_globalagg_partial_floats", "selfc_pwconv_run", "selfc_gmm_sample", "selfc_stp_head_gmm",
     "selfc_conv_planes_run", "selfc_nhwc_to_planes", "selfc_y_sse", "selfc_y_sse_blocks", "selfc_y_ssim", "selfc_gauss_down4",
     "selfc_subnet_bwd_scratch_bytes", "selfc_subnet_bwd", "selfc_subnet_bwd_phase", "selfc_coupling_bwd", "selfc_freq_fwd_bwd", "selfc_freq_inv_bwd",
     "selfc_bwd_scale", "selfc_bwd_to_planes", "selfc_f16_rows_to_planes", "selfc_bwd_conv_planes",
@@ -104,7 +104,7 @@ def lib():
             "selfc_gmm_sample_generic": [vp, vp, vp, sz, i, i, i, i, f, vp],
             "selfc_pwconv_run": [vp, i, vp, i, vp, vp, sz, i, i, i, i, i, vp],
             "selfc_gmm_sample": [vp, vp, vp, sz, i, i, vp],
-            "selfc_pwconv_gmm": [vp, vp, vp, vp, vp, sz, i, i, i, i, vp],
+            "selfc_stp_head_gmm": [vp, vp, vp, vp, vp, sz, i, i, i, i, vp],
             "selfc_conv_planes_run": [vp, i, i, vp, vp, i, i, vp, i, i, i, i, vp],
             "selfc_nhwc_to_planes": [vp, vp, sz, i, vp],
             "selfc_y_sse": [vp, vp, vp, i, i, vp],

@@ -10,6 +10,7 @@
 //   (2) gagg_attn : per clip, q/k projections and the TxT softmax (tiny)
 //   (3) gagg_mix  : y[t2] = x[t2] + W1 (sum_t1 A[t1][t2] x[t1]) + b1 sum_t1 A[t1][t2]
 //                   temporal mix in fp32 registers, then ONE 64x64 MFMA contraction per frame.
+#include <type_traits>
 #include "common.hpp"
 #include "prof.hpp"
 #include "bwd_internal.hpp"
@@ -304,28 +305,45 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const void* __restrict__ in
   }
 }
 
-// ---- last head layer + GMM sample in one kernel (SelfC_GMM_arch_inv.py:371-394, eval / sampling path) -----------------
-// The unfused pair writes and re-reads the 720-channel head output (578 MB fp32 at 4 x 7 x 64 x 112 pixels).  Here the
-// last 1x1x1 conv's output channels are PERMUTED at packing time to [k][pi | log-sigma | mu][c] (group g = 3 k + j of
-// 48 channels = 3 MFMA tiles), so that for each mixture component k the softmax over the hf axis c, the clamp / exp of
-// log-sigma and the weighted sum all happen on the accumulators: lane (pixel = lane & 15, kq = lane >> 4) owns
-// c = 16 i + 4 kq + e of tile i; the softmax's max / sum cross the four kq lane groups by two xor shuffles.
+// ---- the whole GMM head + the GMM sample in one kernel (SelfC_GMM_arch_inv.py:327-344,371-394, eval / sampling path) -----
+//   feat (fp32, 64) -lrelu-> conv 64->128 -act-> conv 128->256 -act-> conv 256->720 -> sample v (48)
+// Layer by layer the head wrote and re-read its 128- and 256-channel activations (pixel-major f16 rows) and, before the
+// sampler was fused, the 720-channel output (578 MB fp32 at 4 x 7 x 64 x 112 pixels).  Here a wave keeps its 32 pixels in
+// registers from the input row to the sample:
+//  * layers 0 and 1: the OUTPUT ROWS of W0 / W1 are permuted at packing time (packing.py: head_row_perm) so that the MFMA
+//    result of tile pair (2 s, 2 s + 1) - lane (pixel, kq) holds rows 4 kq + e of each - IS the next layer's B fragment of
+//    k-step s (channels 32 s + 8 kq + 0..7): bias, activation, one pack, no cross-lane movement, no LDS round trip;
+//  * layer 2: output channels permuted to [k][pi | log-sigma | mu][c] (group g = 3 k + j of 48 channels = 3 MFMA tiles), so
+//    that for each mixture component k the softmax over the hf axis c, the clamp / exp of log-sigma and the weighted sum all
+//    happen on the accumulators: lane (pixel = lane & 15, kq = lane >> 4) owns c = 16 i + 4 kq + e of tile i; the softmax's
+//    max / sum cross the four kq lane groups by two xor shuffles.
 // eps rows are [px][k * 48 + c] (k-major, unlike selfc_gmm_sample's c-major rows); v rows have stride vstride.
-// NW waves x 2 pixel tiles of 16 per workgroup: every workgroup streams all 360 KiB of weight fragments through LDS, so
-// the L2 -> LDS weight traffic is inversely proportional to the pixels per workgroup (4 waves: 564 MB per call, 421 us).
-template <int KS, int K, int NW>
-__global__ __launch_bounds__(NW * 64) void pwconv_gmm_kernel(const f16* __restrict__ in, const f16* __restrict__ w, const float* __restrict__ bias,
-                                                         const float* __restrict__ eps, float* __restrict__ v, size_t npix, int cin, int vstride) {
-  constexpr int MT = 2, HF = 48, TI = HF / 16;
-  constexpr int OTB = 64 / KS;                       // output tiles per 64-KiB LDS block of fragments
-  constexpr int NT = 3 * K * TI;                     // 45 output tiles
+// Weights: ONE fragment stream [W0: 8 tiles x 2 | W1: 16 tiles x 4 | W2: 45 tiles x 8] = 440 KiB through an 80-KiB LDS buffer
+// (W0 and W1 together, then W2 ten tiles at a time).  NW waves x 2 pixel tiles of 16 per workgroup: every workgroup streams
+// the whole set, so the L2 -> LDS weight traffic is inversely proportional to the pixels per workgroup (4 waves: 421 us for
+// the last layer alone, 8 waves: 207 us).
+template <int K, int NW, int MT>
+__global__ __launch_bounds__(NW * 64) void stp_head_gmm_kernel(const float* __restrict__ feat, const f16* __restrict__ w, const float* __restrict__ bias,
+                                                           const float* __restrict__ eps, float* __restrict__ v, size_t npix, int vstride, int act) {
+  constexpr int HF = 48, TI = HF / 16;
+  constexpr int KS0 = 2, KS1 = 4, KS2 = 8;           // k-steps of 32 channels: 64 -> 128 -> 256 -> 720
+  constexpr int OT0 = 8, OT1 = 16;
+  constexpr int F01 = OT0 * KS0 + OT1 * KS1;        // 80 fragments: W0 | W1
+  constexpr int NT = 3 * K * TI;                     // 45 output tiles of layer 2
+  // The stream moves in CHUNKS of 40 fragments (40 KiB: 5 tiles of layer 2; W0 | W1 = chunks 0, 1) through a ring of three LDS
+  // buffers, copied by global_load_lds (no VGPRs - the kernel sits at 246): chunk c+2 is requested when chunk c starts, a
+  // counted vmcnt + one raw barrier per chunk (cdna_hip_programming.md, "Pipelining across barriers").  With one 80-KiB buffer
+  // filled through registers between two __syncthreads the only workgroup of the CU stood still for every refill.
+  constexpr int CH = 40, OTB = CH / KS2, NCH = (F01 + NT * KS2) / CH, GL = CH / NW;
+  static_assert(F01 == 2 * CH && (NT * KS2) % CH == 0 && CH % NW == 0, "chunking");
+  constexpr int NBIAS = (OT0 + OT1 + NT) * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kq = lane >> 4;
   const size_t p0 = ((size_t)blockIdx.x * NW + wave) * (16 * MT);
-  f16x8 bf[MT][KS];
   size_t pl[MT];
   bool pv[MT];
+  f16x8 b0[MT][KS0];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     pl[m] = p0 + m * 16 + (lane & 15);
@@ -333,8 +351,83 @@ __global__ __launch_bounds__(NW * 64) void pwconv_gmm_kernel(const f16* __restri
     const size_t pc = pv[m] ? pl[m] : npix - 1;
     pl[m] = pc;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) bf[m][ks] = *reinterpret_cast<const f16x8*>(in + pc * cin + ks * 32 + kq * 8);
+    for (int ks = 0; ks < KS0; ++ks) {
+      const float* p = feat + pc * 64 + ks * 32 + kq * 8;
+      const float4 v0 = *reinterpret_cast<const float4*>(p);
+      const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
+      const u32x4 u = {pack2(lrelu02(v0.x), lrelu02(v0.y)), pack2(lrelu02(v0.z), lrelu02(v0.w)),
+                       pack2(lrelu02(v1.x), lrelu02(v1.y)), pack2(lrelu02(v1.z), lrelu02(v1.w))};
+      b0[m][ks] = __builtin_bit_cast(f16x8, u);
+    }
   }
+  auto stage = [&](const int c) __attribute__((always_inline)) {        // chunk c -> buffer c % 3: GL requests per thread
+    const f16* src = w + (size_t)c * CH * 512 + lane * 8;
+    unsigned char* dst = smem + (c % 3) * (CH * 1024);
+#pragma unroll
+    for (int i = 0; i < GL; ++i) {
+      const int f = i * NW + wave;                                         // one fragment (1 KiB) per wave and request
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)f * 512),
+                                       (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+    }
+  };
+  // the 1,104 biases live in LDS behind the ring: an ordinary global load per tile would make hipcc drain the whole VM queue
+  // (vmcnt(0) at its first use while LDS-DMA requests are in flight) and with it the prefetched chunks
+  float* __restrict__ lbias = reinterpret_cast<float*>(smem + 3 * CH * 1024);
+  for (int i = tid; i < NBIAS / 4; i += NW * 64) reinterpret_cast<float4*>(lbias)[i] = reinterpret_cast<const float4*>(bias)[i];
+  stage(0);
+  stage(1);
+  stage(2);
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(GL) : "memory");               // chunks 0, 1 (W0 | W1) landed; chunk 2 in flight
+  __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  const float slope = act == 2 ? 0.f : 0.2f;
+  // one tile of layer L (KSL k-steps over the fragments at LDS offset fbase), bias, activation, packed to two dwords
+  auto dense_tile = [&](auto ksl, const int fbase, const int t, const float* __restrict__ bl, const f16x8 (&bin)[MT][decltype(ksl)::value],
+                        uint2 (&res)[MT]) __attribute__((always_inline)) {
+    constexpr int KSL = decltype(ksl)::value;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KSL; ++ks) {
+      const f16x8 af = *reinterpret_cast<const f16x8*>(smem + ((size_t)(fbase + t * KSL + ks) * 64 + lane) * 16);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = mfma_16x16x32(af, bin[m][ks], acc[m]);
+    }
+    const float4 bb = *reinterpret_cast<const float4*>(bl + t * 16 + kq * 4);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float r[4] = {acc[m][0] + bb.x, acc[m][1] + bb.y, acc[m][2] + bb.z, acc[m][3] + bb.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], r[e] * slope);        // LeakyReLU(0.2) | ReLU
+      res[m].x = pack2(r[0], r[1]);
+      res[m].y = pack2(r[2], r[3]);
+    }
+  };
+
+  f16x8 b1[MT][KS1];
+#pragma unroll
+  for (int s = 0; s < KS1; ++s) {
+    uint2 lo[MT], hi[MT];
+    dense_tile(std::integral_constant<int, KS0>{}, 0, 2 * s, lbias, b0, lo);
+    dense_tile(std::integral_constant<int, KS0>{}, 0, 2 * s + 1, lbias, b0, hi);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) b1[m][s] = __builtin_bit_cast(f16x8, u32x4{lo[m].x, lo[m].y, hi[m].x, hi[m].y});
+  }
+  f16x8 bf[MT][KS2];
+#pragma unroll
+  for (int s = 0; s < KS2; ++s) {
+    uint2 lo[MT], hi[MT];
+    dense_tile(std::integral_constant<int, KS1>{}, OT0 * KS0, 2 * s, lbias + OT0 * 16, b1, lo);
+    dense_tile(std::integral_constant<int, KS1>{}, OT0 * KS0, 2 * s + 1, lbias + OT0 * 16, b1, hi);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) bf[m][s] = __builtin_bit_cast(f16x8, u32x4{lo[m].x, lo[m].y, hi[m].x, hi[m].y});
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // LDS byte address of this lane's four biases of layer-2 tile 0
+  const unsigned bias2_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + 3 * CH * 1024 + ((OT0 + OT1) * 16 + kq * 4) * 4;
   f32x4 out[MT][TI], pi[MT][TI], sg[MT][TI];
   float4 ep[MT][TI];
   float mx[MT], inv[MT];
@@ -344,26 +437,36 @@ __global__ __launch_bounds__(NW * 64) void pwconv_gmm_kernel(const f16* __restri
     for (int i = 0; i < TI; ++i) out[m][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto tile = [&](const int gt, f32x4 (&acc)[MT]) __attribute__((always_inline)) {
-    if (gt % OTB == 0) {                             // next block of fragments (workgroup-uniform)
-      const int nt = (NT - gt) < OTB ? (NT - gt) : OTB;
-      __syncthreads();
-      const u32x4* src = reinterpret_cast<const u32x4*>(w) + (size_t)gt * KS * 64;
-      for (int i = tid; i < nt * KS * 64; i += NW * 64) *reinterpret_cast<u32x4*>(smem + (size_t)i * 16) = src[i];
-      __syncthreads();
+    const int c = 2 + gt / OTB;                      // chunk of this tile (workgroup-uniform)
+    if (gt % OTB == 0) {
+      // own requests of chunk c retired (those of chunk c+1 may stay in flight), then the barrier: everybody's part of
+      // chunk c is in LDS and everybody is done reading chunk c-1, whose buffer chunk c+2 takes over
+      if (c == 2 || c + 1 >= NCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(GL) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (c == 2) { stage(3); stage(4); }            // buffers 0, 1 held W0 | W1 until this barrier
+      else if (c + 2 < NCH) stage(c + 2);
     }
+    const unsigned char* buf = smem + (c % 3) * (CH * 1024);
     const int o = gt % OTB;
     __builtin_amdgcn_sched_barrier(0);
+    // The tile's bias row, read by hand: an LDS load hipcc can see gets an s_waitcnt vmcnt(0) in front of it whenever LDS-DMA
+    // requests are pending (it cannot tell the ring from the bias rows), which drained the chunk requested a few lines up
+    // right at every chunk boundary (the weight fragments' own reads carry no memory operand and escape that rule).
+    f32x4 bb;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(bb) : "v"(bias2_lds + (unsigned)(gt * 64)));
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const f16x8 af = *reinterpret_cast<const f16x8*>(smem + ((size_t)(o * KS + ks) * 64 + lane) * 16);
+    for (int ks = 0; ks < KS2; ++ks) {
+      const f16x8 af = *reinterpret_cast<const f16x8*>(buf + ((size_t)(o * KS2 + ks) * 64 + lane) * 16);
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[m] = mfma_16x16x32(af, bf[m][ks], acc[m]);
     }
-    const float4 bb = *reinterpret_cast<const float4*>(bias + gt * 16 + kq * 4);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb));
 #pragma unroll
-    for (int m = 0; m < MT; ++m) { acc[m][0] += bb.x; acc[m][1] += bb.y; acc[m][2] += bb.z; acc[m][3] += bb.w; }
+    for (int m = 0; m < MT; ++m) acc[m] += bb;
     __builtin_amdgcn_sched_barrier(0);               // one tile at a time: the unrolled 45 tiles' reads hoisted together spilled 366 registers
   };
 
@@ -916,16 +1019,18 @@ int selfc_pwconv_run(const void* in, int in_is_f32, void* out, int out_is_f32, c
   return SELFC_EINVAL;
 }
 
-int selfc_pwconv_gmm(const void* in, const void* w, const float* bias, const float* eps, float* v, size_t npix, int cin,
-                     int hf_dim, int K, int v_stride, void* stream) {
-  if (!in || !w || !bias || !eps || !v || npix == 0 || hf_dim != 48 || K != 5 || cin != 256 || v_stride < hf_dim || (v_stride & 3)) return SELFC_EINVAL;
+int selfc_stp_head_gmm(const float* feat, const void* w, const float* bias, const float* eps, float* v, size_t npix,
+                       int hf_dim, int K, int v_stride, int act, void* stream) {
+  if (!feat || !w || !bias || !eps || !v || npix == 0 || hf_dim != 48 || K != 5 || v_stride < hf_dim || (v_stride & 3)) return SELFC_EINVAL;
+  if (act != 1 && act != 2) return SELFC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  constexpr int lds = 64 * 1024, GMM_NW = 8;
+  constexpr int lds = 120 * 1024 + (8 + 16 + 45) * 64, GMM_NW = 8, GMM_MT = 2;    // measured: 4 waves x 4 pixel tiles (512 registers, 48 spilled) 245 us against 162
   static std::atomic<unsigned long long> optin{0};
-  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&pwconv_gmm_kernel<8, 5, GMM_NW>), lds, optin); e != hipSuccess) return hip_rc(e);
+  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&stp_head_gmm_kernel<5, GMM_NW, GMM_MT>), lds, optin); e != hipSuccess) return hip_rc(e);
   ProfScope prof(PROF_STP, s);
-  hipLaunchKernelGGL((pwconv_gmm_kernel<8, 5, GMM_NW>), dim3((unsigned)((npix + GMM_NW * 32 - 1) / (GMM_NW * 32))), dim3(GMM_NW * 64), lds, s,
-                     (const f16*)in, (const f16*)w, bias, eps, v, npix, cin, v_stride);
+  constexpr int pxwg = GMM_NW * 16 * GMM_MT;
+  hipLaunchKernelGGL((stp_head_gmm_kernel<5, GMM_NW, GMM_MT>), dim3((unsigned)((npix + pxwg - 1) / pxwg)), dim3(GMM_NW * 64), lds, s,
+                     feat, (const f16*)w, bias, eps, v, npix, v_stride, act);
   return hip_rc(hipGetLastError());
 }
 

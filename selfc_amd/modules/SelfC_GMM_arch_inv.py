@@ -223,12 +223,16 @@ class STPNet(nn.Module):
             self._tail = [(pack_pointwise(wide(m)), pad_bias(m.bias, roundup(m.out_channels, 16)), roundup(m.in_channels, 32) if m.in_channels % 32 == 0 else roundup(m.in_channels, 64), m.out_channels)
                           for m in convs]
             self._tail_fused = None
-            if self.fh_loss == "gmm" and len(convs) == 3 and self.hf_dim == 48 and self.K == 5 and convs[2].in_channels == 256:
-                # last layer with its output channels permuted to [k][pi | log-sigma | mu][c] for the fused head + sampler kernel
-                from ..packing import gmm_head_perm
-                perm = gmm_head_perm(self.hf_dim, self.K, convs[2].weight.device)
-                wl = convs[2].weight.detach().reshape(convs[2].out_channels, -1)[perm]
-                self._tail_fused = (pack_pointwise(wl), pad_bias(convs[2].bias.detach()[perm], roundup(convs[2].out_channels, 16)))
+            if (self.fh_loss == "gmm" and len(convs) == 3 and self.hf_dim == 48 and self.K == 5
+                    and [(m.in_channels, m.out_channels) for m in convs] == [(64, 128), (128, 256), (256, 720)]):
+                # the whole head + sampler as one kernel: hidden layers with their output rows in operand order, the last
+                # layer's output channels as [k][pi | log-sigma | mu][c]; one fragment stream, one bias vector
+                from ..packing import gmm_head_perm, head_row_perm
+                dev = convs[0].weight.device
+                perms = [head_row_perm(128, dev), head_row_perm(256, dev), gmm_head_perm(self.hf_dim, self.K, dev)]
+                ws = [pack_pointwise(m.weight.detach().reshape(m.out_channels, -1)[pm]).reshape(-1) for m, pm in zip(convs, perms)]
+                bs = [m.bias.detach().float()[pm] for m, pm in zip(convs, perms)]
+                self._tail_fused = (torch.cat(ws).contiguous(), torch.cat(bs).contiguous())
             self._tail_key = key
         return self._tail
 
@@ -286,19 +290,19 @@ class STPNet(nn.Module):
                 rt.call("selfc_pwconv_run", feat.data_ptr(), 1, hf_out.data_ptr(), 1, wp.data_ptr(), bp.data_ptr(),
                         npix, cin, cout, cout, 1, 0, sp)
             return hf_out if keep_raw else None
-        if "h1" not in sc:
-            sc["h1"] = torch.empty((npix, tail[0][3]), dtype=_lib.operand_dtype(), device=dev)
-            sc["h2"] = torch.empty((npix, tail[1][3]), dtype=_lib.operand_dtype(), device=dev)
         (w0, b0, ci0, co0), (w1_, b1_, ci1, co1), (w2_, b2_, ci2, co2) = tail
-        # tail_gmm = [lrelu, conv, act, conv, act, conv]: each activation is fused into the producer's epilogue (act =
-        # LeakyReLU for 'gmm', ReLU for 'gmm_thin', :334-354; activation flag 1 / 2 of selfc_pwconv_run)
-        act = 2 if self.fh_loss == "gmm_thin" else 1
-        rt.call("selfc_pwconv_run", feat.data_ptr(), 1, sc["h1"].data_ptr(), 0, w0.data_ptr(), b0.data_ptr(), npix, ci0, co0, co0, 1, act, sp)
-        rt.call("selfc_pwconv_run", sc["h1"].data_ptr(), 0, sc["h2"].data_ptr(), 0, w1_.data_ptr(), b1_.data_ptr(), npix, ci1, co1, co1, 0, act, sp)
-        fused = self._tail_fused is not None and not keep_raw       # sampling path: the 720-channel head output is never written
+        fused = self._tail_fused is not None and not keep_raw       # sampling path: no activation of the head is ever written
         if not fused:
-            if "raw" not in sc:      # 720 fp32 channels per pixel-frame (578 MB at 4 x 7 x 64 x 112): only when somebody wants it
+            if "h1" not in sc:
+                sc["h1"] = torch.empty((npix, tail[0][3]), dtype=_lib.operand_dtype(), device=dev)
+                sc["h2"] = torch.empty((npix, tail[1][3]), dtype=_lib.operand_dtype(), device=dev)
+                # 720 fp32 channels per pixel-frame (578 MB at 4 x 7 x 64 x 112): only when somebody wants it
                 sc["raw"] = torch.empty((npix, tail[2][3]), dtype=torch.float32, device=dev)
+            # tail_gmm = [lrelu, conv, act, conv, act, conv]: each activation is fused into the producer's epilogue (act =
+            # LeakyReLU for 'gmm', ReLU for 'gmm_thin', :334-354; activation flag 1 / 2 of selfc_pwconv_run)
+            act = 2 if self.fh_loss == "gmm_thin" else 1
+            rt.call("selfc_pwconv_run", feat.data_ptr(), 1, sc["h1"].data_ptr(), 0, w0.data_ptr(), b0.data_ptr(), npix, ci0, co0, co0, 1, act, sp)
+            rt.call("selfc_pwconv_run", sc["h1"].data_ptr(), 0, sc["h2"].data_ptr(), 0, w1_.data_ptr(), b1_.data_ptr(), npix, ci1, co1, co1, 0, act, sp)
             rt.call("selfc_pwconv_run", sc["h2"].data_ptr(), 0, sc["raw"].data_ptr(), 1, w2_.data_ptr(), b2_.data_ptr(), npix, ci2, co2, co2, 0, 0, sp)
         # noise rows: [npix][c*K + k] for selfc_gmm_sample, [npix][k*hf_dim + c] for the fused kernel
         if self.eps is not None:
@@ -312,8 +316,8 @@ class STPNet(nn.Module):
             eps = torch.randn((npix, self.hf_dim * self.K), dtype=torch.float32, device=dev)
         if fused:
             wf, bfz = self._tail_fused
-            rt.call("selfc_pwconv_gmm", sc["h2"].data_ptr(), wf.data_ptr(), bfz.data_ptr(), eps.data_ptr(), hf_out.data_ptr(),
-                    npix, ci2, self.hf_dim, self.K, hf_out.shape[-1], sp)
+            rt.call("selfc_stp_head_gmm", feat.data_ptr(), wf.data_ptr(), bfz.data_ptr(), eps.data_ptr(), hf_out.data_ptr(),
+                    npix, self.hf_dim, self.K, hf_out.shape[-1], 1, sp)
             return None
         rt.call("selfc_gmm_sample", sc["raw"].data_ptr(), eps.data_ptr(), hf_out.data_ptr(), npix, self.hf_dim, self.K, sp)
         return sc["raw"] if keep_raw else None
@@ -373,7 +377,7 @@ class STPNet(nn.Module):
     def reparametrize(self, mu, logvar):
         """eps * exp(logvar) + mu with eps ~ N(0,1) drawn on mu's device (:410-417; the reference allocates it with
         torch.cuda.FloatTensor, trap 5).  Host-side helper kept for the reference's signature - the sampling path of
-        forward() runs inside selfc_pwconv_gmm / selfc_gmm_sample."""
+        forward() runs inside selfc_stp_head_gmm / selfc_gmm_sample."""
         eps = self.eps.to(mu) if self.eps is not None and self.eps.shape == mu.shape else torch.randn_like(mu)
         return eps.mul(torch.exp(logvar)).add_(mu)
 

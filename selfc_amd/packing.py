@@ -162,10 +162,20 @@ def pack_pointwise(weight: torch.Tensor) -> torch.Tensor:
 
 def gmm_head_perm(hf_dim: int, K: int, device=None) -> torch.Tensor:
     """Output-channel permutation of the GMM head's last conv for the fused head + sampler kernel (stp.hip:
-    pwconv_gmm_kernel): new channel (3 k + j) * hf_dim + c  <-  reference channel (c * K + k) * 3 + j
+    stp_head_gmm_kernel): new channel (3 k + j) * hf_dim + c  <-  reference channel (c * K + k) * 3 + j
     (SelfC_GMM_arch_inv.py:382-386: parameters viewed as (hf_dim, K, 3))."""
     k, j, c = torch.meshgrid(torch.arange(K), torch.arange(3), torch.arange(hf_dim), indexing="ij")
     return ((c * K + k) * 3 + j).reshape(-1).to(device)
+
+
+def head_row_perm(cout: int, device=None) -> torch.Tensor:
+    """Output-channel permutation of a hidden layer of the GMM head for the whole-head kernel (stp.hip: stp_head_gmm_kernel):
+    the 16x16x32 MFMA leaves rows 4 kq + e of an output tile in lane (pixel, kq) and wants k-channels 8 kq + 0..7 of a
+    32-channel k-step there as the next layer's operand, so tile 2 s + h, row 4 kq + e computes channel 32 s + 8 kq + 4 h + e:
+    two consecutive tiles ARE one operand fragment, without any cross-lane movement."""
+    assert cout % 32 == 0, cout
+    t, kq, e = torch.meshgrid(torch.arange(cout // 16), torch.arange(4), torch.arange(4), indexing="ij")
+    return ((t // 2) * 32 + 8 * kq + 4 * (t % 2) + e).reshape(-1).to(device)
 
 
 def pool_weight_map(fc_weight: torch.Tensor, h: int, w: int) -> torch.Tensor:

@@ -175,7 +175,7 @@ def test_stp_gmm_injected_eps(dev):
 
 
 def test_stp_gmm_fused_head_and_sampler(dev):
-    """sampling path of SelfCModel.test(): the last head layer and the GMM sample run as ONE kernel (selfc_pwconv_gmm,
+    """sampling path of SelfCModel.test(): the whole GMM head and the GMM sample run as ONE kernel (selfc_stp_head_gmm,
     output channels permuted to [k][pi | log-sigma | mu][c]) - same golden sample as the unfused pair."""
     from selfc_amd.modules.SelfC_GMM_arch_inv import STPNet
     g = load_golden("g7_stp_gmm")
