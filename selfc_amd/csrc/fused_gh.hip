@@ -119,6 +119,10 @@ struct Ctx {
   int par;            // weight buffer that holds the CURRENT chunk
   bool first;         // resident mode: the workgroup's first tile streams the fragments INTO their resident places
   u32x4 wreg[WITER];
+#ifdef SELFC_WBUF
+  __amdgpu_buffer_rsrc_t wrs;   // the net's fragment stream as a raw buffer: SGPR base + one 32-bit VGPR offset per load
+  unsigned wvo;                 // tid * 16
+#endif
 };
 
 template <int OFF, int NFR>
@@ -127,10 +131,22 @@ __device__ __forceinline__ void w_prefetch(Ctx& c) {
 #ifdef SELFC_EXP_NOW        // timing experiment: no weight streaming
   return;
 #endif
+#ifdef SELFC_EXP_NOW2       // timing experiment (results are wrong): no weight streaming after the prologue, which leaves REAL fragments
+  if (!c.first) return;     // in both buffers - finite, ordinary-looking data (an MFMA on garbage / zeros clocks differently)
+#endif
 #pragma unroll
   for (int it = 0; it < WITER; ++it) {
     const int i = min(c.tid + it * NTHR, NFR * 64 - 1);
+#ifdef SELFC_EXP_NOLOAD      // timing experiment (results are wrong): the LDS commits of stale registers, no loads
+    (void)i;
+#elif defined(SELFC_EXP_WL1)        // timing experiment (results are wrong): every fragment load hits the same 8 KiB (L1-resident) - same instructions, no L2 traffic
+    c.wreg[it] = c.wsrc[i & 511];
+#elif defined(SELFC_WBUF)
+    (void)i;
+    c.wreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(c.wrs, c.wvo + it * (NTHR * 16), OFF * 1024, 0));
+#else
     c.wreg[it] = c.wsrc[OFF * 64 + i];
+#endif
   }
 }
 template <int OFF, int NFR>
@@ -138,6 +154,9 @@ __device__ __forceinline__ void w_commit(Ctx& c) {
   if (WRES && !c.first) return;
 #ifdef SELFC_EXP_NOW
   return;
+#endif
+#ifdef SELFC_EXP_NOW2
+  if (!c.first) return;
 #endif
   // streamed: the other half of the double buffer; resident (depth 3, first tile only): the chunk's own place
   unsigned char* dst = c.smem + OFF_W + (WRES ? OFF * 1024 : (c.par ^ 1) * W_BYTES);
@@ -150,7 +169,11 @@ __device__ __forceinline__ void w_commit(Ctx& c) {
     // (Removes those drains from the ISA; measured time unchanged)
     u32x4 v = c.wreg[it];
     asm volatile("" : "+v"(v));
+#ifdef SELFC_EXP_NOCOMMIT   // timing experiment (results are wrong): fragments loaded and awaited, never written to LDS
+    (void)dst; (void)i;
+#else
     if (i < NFR * 64) *reinterpret_cast<u32x4*>(dst + i * 16) = v;
+#endif
   }
 }
 
@@ -423,6 +446,10 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
 #endif
   const int net = blockIdx.y;
   c.wsrc = reinterpret_cast<const u32x4*>(net ? a.w[1] : a.w[0]);
+#ifdef SELFC_WBUF
+  c.wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(net ? a.w[1] : a.w[0]), 0, 120 * 1024, 0x00020000);
+  c.wvo = (unsigned)c.tid * 16u;
+#endif
   {
     // Opaque to hipcc: under SGPR pressure it re-loaded a.dense[net] from the kernel-argument segment (s_load_dwordx2) in
     // front of EVERY feature store, and a scalar load can only be awaited with lgkmcnt(0) - which also drains the wave's
@@ -485,6 +512,11 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
   c.par = 1;            // w_commit writes buffer par^1 = 0
   c.first = true;
   w_commit<LAYER_OFF[2], 21>(c);
+#ifdef SELFC_EXP_NOW2
+  c.par = 0;
+  w_commit<LAYER_OFF[2], 21>(c);          // the same fragments into the other buffer as well
+  c.first = false;
+#endif
   __syncthreads();
   c.par = 0;
 
