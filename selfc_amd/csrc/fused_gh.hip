@@ -119,10 +119,6 @@ struct Ctx {
   int par;            // weight buffer that holds the CURRENT chunk
   bool first;         // resident mode: the workgroup's first tile streams the fragments INTO their resident places
   u32x4 wreg[WITER];
-#ifdef SELFC_WBUF
-  __amdgpu_buffer_rsrc_t wrs;   // the net's fragment stream as a raw buffer: SGPR base + one 32-bit VGPR offset per load
-  unsigned wvo;                 // tid * 16
-#endif
 };
 
 template <int OFF, int NFR>
@@ -137,16 +133,7 @@ __device__ __forceinline__ void w_prefetch(Ctx& c) {
 #pragma unroll
   for (int it = 0; it < WITER; ++it) {
     const int i = min(c.tid + it * NTHR, NFR * 64 - 1);
-#ifdef SELFC_EXP_NOLOAD      // timing experiment (results are wrong): the LDS commits of stale registers, no loads
-    (void)i;
-#elif defined(SELFC_EXP_WL1)        // timing experiment (results are wrong): every fragment load hits the same 8 KiB (L1-resident) - same instructions, no L2 traffic
-    c.wreg[it] = c.wsrc[i & 511];
-#elif defined(SELFC_WBUF)
-    (void)i;
-    c.wreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(c.wrs, c.wvo + it * (NTHR * 16), OFF * 1024, 0));
-#else
     c.wreg[it] = c.wsrc[OFF * 64 + i];
-#endif
   }
 }
 template <int OFF, int NFR>
@@ -169,11 +156,7 @@ __device__ __forceinline__ void w_commit(Ctx& c) {
     // (Removes those drains from the ISA; measured time unchanged)
     u32x4 v = c.wreg[it];
     asm volatile("" : "+v"(v));
-#ifdef SELFC_EXP_NOCOMMIT   // timing experiment (results are wrong): fragments loaded and awaited, never written to LDS
-    (void)dst; (void)i;
-#else
     if (i < NFR * 64) *reinterpret_cast<u32x4*>(dst + i * 16) = v;
-#endif
   }
 }
 
@@ -446,10 +429,6 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
 #endif
   const int net = blockIdx.y;
   c.wsrc = reinterpret_cast<const u32x4*>(net ? a.w[1] : a.w[0]);
-#ifdef SELFC_WBUF
-  c.wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(net ? a.w[1] : a.w[0]), 0, 120 * 1024, 0x00020000);
-  c.wvo = (unsigned)c.tid * 16u;
-#endif
   {
     // Opaque to hipcc: under SGPR pressure it re-loaded a.dense[net] from the kernel-argument segment (s_load_dwordx2) in
     // front of EVERY feature store, and a scalar load can only be awaited with lgkmcnt(0) - which also drains the wave's
