@@ -225,12 +225,9 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
   // (global offsets inside a frame, LDS offsets, which pixels fall outside the frame) is then a per-workgroup constant,
   // computed once, and a tile's 14 halo loads cost one instruction each (the per-tile address arithmetic - ~55 VALU
   // instructions per 16-byte piece - used to outweigh the MFMAs of the steps it was hung behind).
-#ifdef SELFC_F_XCD          // experiment: consecutive (tile, frame) pairs on ONE XCD - neighbouring tiles' halos then meet in one L2
-  const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
-#else
-  const int bid = blockIdx.x;
-#endif
-  const int stile = bid % a.ntiles, f0 = bid / a.ntiles, gf = gridDim.x / a.ntiles;
+  // (Measured and dropped: xcd_swizzle(blockIdx.x) here, so that neighbouring tiles' halos meet in one XCD's L2 - fused F
+  // -0.5 %, headline -1.5 %.)
+  const int stile = blockIdx.x % a.ntiles, f0 = blockIdx.x / a.ntiles, gf = gridDim.x / a.ntiles;
   if (f0 >= a.N) return;
   const int ty0 = (stile / a.tiles_x) * TS, tx0 = (stile % a.tiles_x) * TS;
 #ifdef SELFC_STAMPS
