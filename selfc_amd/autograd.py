@@ -48,6 +48,63 @@ def side_stream(device, which: int = 0):
     return _SIDE[key]
 
 
+# ------------------------------------------------------------------------------------------------------------
+# Flat gradient buffer.  Stock autograd hands every parameter gradient to an AccumulateGrad node: a copy or an add
+# launch per tensor and call - ~400 launches of 3 us per training step for the 350 tensors of SelfC-large, every block
+# being called twice per step (forward and reverse).  The weight-gradient kernels can accumulate into a caller's buffer
+# themselves (`beta` of selfc_subnet_bwd), so a trainer may own ONE flat buffer with a view per parameter as its
+# `.grad`, zero it once per step and let the subnet backward add into the views; those gradients are then reported to
+# autograd as None.  Opt-in (RescaleTrainer does it when the net is not wrapped in DistributedDataParallel, whose
+# hooks need the gradients to pass through autograd).
+# ------------------------------------------------------------------------------------------------------------
+class GradSink:
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        offs, total = [], 0
+        for p_ in self.params:
+            offs.append(total)
+            total += (p_.numel() + 63) & ~63            # 256-byte aligned slices, pads stay zero
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.views = [self.flat[o:o + p_.numel()].view(p_.shape) for o, p_ in zip(offs, self.params)]
+        self.index = {id(p_): v for p_, v in zip(self.params, self.views)}
+        self.attach()
+
+    def attach(self):
+        for p_, v in zip(self.params, self.views):
+            if p_.grad is not v:
+                p_.grad = v
+
+    def zero(self):
+        """Once per step, instead of optimizer.zero_grad(): one memset; re-attaches views somebody replaced."""
+        self.flat.zero_()
+        self.attach()
+
+    def view_of(self, p_) -> Optional[torch.Tensor]:
+        v = self.index.get(id(p_))
+        return v if v is not None and p_.grad is v else None
+
+
+_SINK: Optional[GradSink] = None
+
+
+class grad_sink:
+    """Context manager: parameter gradients of the subnet backward go into `sink` while it is active."""
+
+    def __init__(self, sink: Optional[GradSink]):
+        self.sink, self.prev = sink, None
+
+    def __enter__(self):
+        global _SINK
+        self.prev, _SINK = _SINK, self.sink
+        return self.sink
+
+    def __exit__(self, *exc):
+        global _SINK
+        _SINK = self.prev
+        return False
+
+
 def subnet_params(mod) -> List[torch.Tensor]:
     """conv1.weight, conv1.bias, ..., conv5.weight, conv5.bias (the order the Functions take and return)."""
     cached = mod.__dict__.get("_conv_plist")
@@ -74,7 +131,18 @@ def subnet_bwd(mod, dense: torch.Tensor, xin: Optional[torch.Tensor], dout: torc
     grads: List[Optional[torch.Tensor]] = [None] * 10
     wg = (C.c_void_p * 5)()
     bg = (C.c_void_p * 5)()
-    if want_params:
+    beta = 0.0
+    sunk = None
+    if want_params and _SINK is not None:
+        sunk = [_SINK.view_of(p_) for p_ in subnet_params(mod)]
+        if any(v is None for v in sunk):
+            sunk = None
+    if sunk is not None:
+        # the kernels add into the trainer's flat buffer (beta = 1); autograd sees no gradient for these tensors
+        for i, v in enumerate(sunk):
+            (wg if i % 2 == 0 else bg)[i // 2] = v.data_ptr()
+        beta = 1.0
+    elif want_params:
         # one allocation for the ten gradients (each slice 64-float aligned), handed out as views
         prm = subnet_params(mod)
         offs, total = [], 0
@@ -90,7 +158,7 @@ def subnet_bwd(mod, dense: torch.Tensor, xin: Optional[torch.Tensor], dout: torc
     bw = pk.bwd_struct()
     args = (bw, mod.kind, dense.data_ptr(), None if xin is None else xin.data_ptr(), dout.data_ptr(),
             float(sign), None if dx is None else dx.data_ptr(), 1 if accumulate_dx else 0,
-            wg if want_params else None, bg if want_params else None, 0.0,
+            wg if want_params else None, bg if want_params else None, beta,
             scratch.data_ptr(), scratch.numel(), n, t, h, w, cin, cout)
     if (side is None or not want_params) and on_data_done is None:
         rt.call("selfc_subnet_bwd", *args, _lib.stream_ptr())

@@ -222,19 +222,31 @@ class STPNet(nn.Module):
                 return wt
             self._tail = [(pack_pointwise(wide(m)), pad_bias(m.bias, roundup(m.out_channels, 16)), roundup(m.in_channels, 32) if m.in_channels % 32 == 0 else roundup(m.in_channels, 64), m.out_channels)
                           for m in convs]
-            self._tail_fused = None
-            if (self.fh_loss == "gmm" and len(convs) == 3 and self.hf_dim == 48 and self.K == 5
-                    and [(m.in_channels, m.out_channels) for m in convs] == [(64, 128), (128, 256), (256, 720)]):
-                # the whole head + sampler as one kernel: hidden layers with their output rows in operand order, the last
-                # layer's output channels as [k][pi | log-sigma | mu][c]; one fragment stream, one bias vector
-                from ..packing import gmm_head_perm, head_row_perm
-                dev = convs[0].weight.device
-                perms = [head_row_perm(128, dev), head_row_perm(256, dev), gmm_head_perm(self.hf_dim, self.K, dev)]
-                ws = [pack_pointwise(m.weight.detach().reshape(m.out_channels, -1)[pm]).reshape(-1) for m, pm in zip(convs, perms)]
-                bs = [m.bias.detach().float()[pm] for m, pm in zip(convs, perms)]
-                self._tail_fused = (torch.cat(ws).contiguous(), torch.cat(bs).contiguous())
+            self._tail_fused = self._tail_fused_key = None
             self._tail_key = key
         return self._tail
+
+    def _head_fused(self):
+        """(fragment stream, bias vector) of the whole-head + sampler kernel, or None when the head is not the shipped
+        64 -> 128 -> 256 -> 720 GMM head.  Built on first use per set of weights (the training path never asks for it)."""
+        convs = [m for m in self._tail_seq() if isinstance(m, nn.Conv3d)]
+        if not (self.fh_loss == "gmm" and len(convs) == 3 and self.hf_dim == 48 and self.K == 5
+                and [(m.in_channels, m.out_channels) for m in convs] == [(64, 128), (128, 256), (256, 720)]):
+            return None
+        self._tail_packed()
+        if self._tail_fused_key != self._tail_key:
+            # hidden layers with their output rows in operand order, the last layer's output channels as
+            # [k][pi | log-sigma | mu][c]; one fragment stream, one bias vector
+            from ..packing import gmm_head_perm, head_row_perm, pack_pointwise
+            dev = convs[0].weight.device
+            perms = self.__dict__.setdefault("_head_perms", {}).get(str(dev))
+            if perms is None:            # index tensors: made once per device (a host -> device copy cannot be captured)
+                perms = self._head_perms[str(dev)] = [head_row_perm(128, dev), head_row_perm(256, dev), gmm_head_perm(self.hf_dim, self.K, dev)]
+            ws = [pack_pointwise(m.weight.detach().reshape(m.out_channels, -1)[pm]).reshape(-1) for m, pm in zip(convs, perms)]
+            bs = [m.bias.detach().float()[pm] for m, pm in zip(convs, perms)]
+            self._tail_fused = (torch.cat(ws).contiguous(), torch.cat(bs).contiguous())
+            self._tail_fused_key = self._tail_key
+        return self._tail_fused
 
     def run_nhwc(self, x1, hf_out, n, t, h, w, keep_raw=False, scratch=None, eps=None):
         """x1: fp32 NHWC4 [n][h*w][4] (LR frames); hf_out: fp32 [n][h*w][hf_dim] (e.g. the latent x2
@@ -291,7 +303,8 @@ class STPNet(nn.Module):
                         npix, cin, cout, cout, 1, 0, sp)
             return hf_out if keep_raw else None
         (w0, b0, ci0, co0), (w1_, b1_, ci1, co1), (w2_, b2_, ci2, co2) = tail
-        fused = self._tail_fused is not None and not keep_raw       # sampling path: no activation of the head is ever written
+        head = None if keep_raw else self._head_fused()             # sampling path: no activation of the head is ever written
+        fused = head is not None
         if not fused:
             if "h1" not in sc:
                 sc["h1"] = torch.empty((npix, tail[0][3]), dtype=_lib.operand_dtype(), device=dev)
@@ -315,7 +328,7 @@ class STPNet(nn.Module):
         else:
             eps = torch.randn((npix, self.hf_dim * self.K), dtype=torch.float32, device=dev)
         if fused:
-            wf, bfz = self._tail_fused
+            wf, bfz = head
             rt.call("selfc_stp_head_gmm", feat.data_ptr(), wf.data_ptr(), bfz.data_ptr(), eps.data_ptr(), hf_out.data_ptr(),
                     npix, self.hf_dim, self.K, hf_out.shape[-1], 1, sp)
             return None

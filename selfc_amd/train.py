@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 from torch.optim.lr_scheduler import _LRScheduler
 
-from . import harness, runtime as rt
+from . import autograd as ag, harness, runtime as rt
 from .global_var import GlobalVar
 from .modules.Quantization import Quantization
 
@@ -104,8 +104,12 @@ class RescaleTrainer:
     pixel_criterion_forw/back, lambda_fit_forw, lambda_rec_back, lambda_cond_prob, gradient_clipping, lr_scheme,
     lr_steps, lr_gamma, restarts, restart_weights, clear_state."""
 
-    def __init__(self, netG: nn.Module, train_opt: dict, capturable: bool = False):
-        """capturable: prepare the optimizer for `capture()` (device-side step counter and learning rate)."""
+    def __init__(self, netG: nn.Module, train_opt: dict, capturable: bool = False, flat_grads: bool = None):
+        """capturable: prepare the optimizer for `capture()` (device-side step counter and learning rate).
+        flat_grads: the parameters' `.grad` are views of ONE buffer that the weight-gradient kernels accumulate into
+        directly (autograd.GradSink: no per-tensor accumulation launches, one memset instead of zero_grad, the clip on the
+        flat buffer).  Default: on, unless the net is wrapped in DistributedDataParallel (its hooks need the gradients to
+        pass through autograd)."""
         self.netG = netG
         self.capturable = capturable
         self.graph = None
@@ -131,6 +135,10 @@ class RescaleTrainer:
             raise NotImplementedError("MultiStepLR learning rate scheme is enough.")
         self.log_dict = OrderedDict()
         self.grad_norm = None
+        if flat_grads is None:
+            flat_grads = not isinstance(netG, nn.parallel.DistributedDataParallel) and optim_params[0].is_cuda
+        self.sink = ag.GradSink(optim_params) if flat_grads else None
+        self.before_clip = None          # optional callable(trainer): runs after backward, before clipping (tests, logging)
 
     def loss_forward(self, out, y):
         return self.train_opt["lambda_fit_forw"] * self.Reconstruction_forw(out, y)
@@ -148,9 +156,17 @@ class RescaleTrainer:
         LR = self.Quantization(lr_before_quant)
         l_back_rec = self.loss_backward(real_H, LR)
         loss = (l_forw_fit + l_back_rec + loss_c) * 144 * 144 * 3
-        loss.backward()
-        if self.train_opt.get("gradient_clipping"):
-            self.grad_norm = nn.utils.clip_grad_norm_(self.optim_params, self.train_opt["gradient_clipping"])
+        with ag.grad_sink(self.sink):
+            loss.backward()
+        if self.before_clip is not None:
+            self.before_clip(self)
+        max_norm = self.train_opt.get("gradient_clipping")
+        if max_norm and self.sink is not None:
+            # clip_grad_norm_ on the flat buffer (pads are zero): three launches instead of a foreach over 350 views
+            self.grad_norm = torch.linalg.vector_norm(self.sink.flat)
+            self.sink.flat.mul_(torch.clamp(max_norm / (self.grad_norm + 1e-6), max=1.0))
+        elif max_norm:
+            self.grad_norm = nn.utils.clip_grad_norm_(self.optim_params, max_norm)
         self.optimizer_G.step()
         return l_forw_fit.detach(), l_back_rec.detach(), loss_c.detach(), loss.detach()
 
@@ -165,8 +181,14 @@ class RescaleTrainer:
     def optimize_parameters(self, real_H: torch.Tensor, ref_L: torch.Tensor, step: int = 0):
         if self.graph is not None:
             return self.replay(real_H, ref_L)
-        self.optimizer_G.zero_grad()
+        self._zero_grad()
         return self._log(self._step(real_H, ref_L))
+
+    def _zero_grad(self):
+        if self.sink is not None:
+            self.sink.zero()
+        else:
+            self.optimizer_G.zero_grad(set_to_none=True)
 
     # -- whole-step hipGraph ----------------------------------------------------------------------------------------
     def capture(self, real_H: torch.Tensor, ref_L: torch.Tensor, warmup: int = 3):
@@ -181,13 +203,16 @@ class RescaleTrainer:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
-                self.optimizer_G.zero_grad(set_to_none=True)
+                self._zero_grad()
                 self._step(self._static_h, self._static_l)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        self.optimizer_G.zero_grad(set_to_none=True)
+        if self.sink is None:
+            self.optimizer_G.zero_grad(set_to_none=True)
         with torch.cuda.graph(g):
+            if self.sink is not None:
+                self.sink.zero()                 # part of the replayed step
             self._static_losses = self._step(self._static_h, self._static_l)
         self.graph = g
         return self

@@ -190,7 +190,7 @@ def test_stp_gmm_fused_head_and_sampler(dev):
     hf = torch.zeros(T, 8, 12, 48, device=dev)
     with torch.no_grad():
         raw = stp.run_nhwc(x1, hf, T, T, 8, 12)
-    assert raw is None and stp._tail_fused is not None
+    assert raw is None and stp._head_fused() is not None
     assert rel_err(hf.permute(0, 3, 1, 2).cpu(), g["v"]) < TOL
 
 

@@ -45,12 +45,12 @@ def test_train_step_matches_reference_step(dev):
     real_h, ref_l, clip_len = train.feed_data(gt, "sr_bd", 4)
     assert clip_len == T and torch.equal(real_h.cpu(), x)
     assert float((ref_l.cpu() - g["ref_l"]).abs().max()) < 1e-5
-    # keep the unclipped gradients: clip_grad_norm_ rescales .grad in place
+    # keep the unclipped gradients: the clip rescales .grad in place.  (The trainer's gradients live in one flat buffer
+    # the weight-gradient kernels add into - autograd.GradSink - so they are read there, not through tensor hooks.)
+    assert tr.sink is not None
     grads = {}
-    hooks = [p.register_hook(lambda gr, n=n: grads.__setitem__(n, gr.detach().clone())) for n, p in net.named_parameters()]
+    tr.before_clip = lambda t_: grads.update({n: p.grad.detach().clone() for n, p in net.named_parameters()})
     log = tr.optimize_parameters(real_h, ref_l)
-    for h_ in hooks:
-        h_.remove()
     assert abs(log["l_forw_fit"] - float(g["l_forw_fit"])) < 1e-3 * float(g["l_forw_fit"])
     assert abs(log["l_back_rec"] - float(g["l_back_rec"])) < 1e-3 * float(g["l_back_rec"])
     assert abs(log["loss"] - float(g["loss"])) < 1e-3 * float(g["loss"])
@@ -76,6 +76,34 @@ def test_train_step_matches_reference_step(dev):
     big = g["grad_F1_conv1_clipped"].abs() > 1e-3 * g["grad_F1_conv1_clipped"].abs().max()
     agree = (torch.sign(d[big]) == -torch.sign(g["grad_F1_conv1_clipped"][big])).float().mean()
     assert float(agree) > 0.98
+
+
+def test_flat_gradient_sink_equals_autograd_accumulation(dev):
+    """RescaleTrainer(flat_grads=True): gradients accumulated by the kernels into one buffer (beta = 1) and clipped there -
+    the same step as stock autograd accumulation + clip_grad_norm_ (two calls per block and step: the sums differ only in
+    the order of two fp32 additions)."""
+    from selfc_amd import train
+    x = load_golden("g8_large_stack")["x"]
+    gt = x.reshape(1, T, 3, 32, 48).transpose(1, 2).to(dev)
+    real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
+    out = {}
+    for flat in (False, True):
+        net = _net(dev)
+        tr = train.RescaleTrainer(net, dict(train.TRAIN_OPT_LARGE), flat_grads=flat)
+        assert (tr.sink is not None) == flat
+        got = {}
+        tr.before_clip = lambda t_, net=net, got=got: got.update({n: p.grad.detach().clone() for n, p in net.named_parameters()})
+        logs = [tr.optimize_parameters(real_h, ref_l)["loss"] for _ in range(2)]      # the second step checks the re-zeroing
+        out[flat] = (got, float(tr.grad_norm), logs, {n: p.detach().clone() for n, p in net.named_parameters()})
+    ga, na, la, pa = out[False]
+    gb, nb, lb, pb = out[True]
+    assert set(ga) == set(gb) and all(v is not None for v in gb.values())
+    worst = max(float((ga[n] - gb[n]).norm() / (ga[n].norm() + 1e-12)) for n in ga)
+    from conftest import record
+    record("flat gradient sink vs autograd accumulation, worst per-tensor relative L2 (second step)", worst)
+    assert worst < 1e-4, worst                    # second-step gradients: also covers the first step's identical update
+    assert abs(na - nb) < 1e-4 * na and abs(la[1] - lb[1]) < 1e-5 * abs(la[1])
+    assert max(float((pa[n] - pb[n]).abs().max()) for n in pa) < 2e-6
 
 
 def test_gmm_training_reduces_loss(dev):
