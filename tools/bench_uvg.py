@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--gpus", type=int, default=int(os.environ.get("WORLD_SIZE", "1")))
+    ap.add_argument("--streams", type=int, default=2, help="GOPs in flight per GPU: one HIP stream each inside one hipGraph "
+                    "(GOPs are independent; the HBM-bound temporal convs of one overlap the MFMA-bound fused convs of another)")
     a = ap.parse_args()
     from selfc_amd import launch
     rc = launch.self_launch(a.gpus, os.path.abspath(__file__), sys.argv[1:])      # before anything touches the GPU
@@ -38,7 +40,7 @@ def main():
     rank, world = ranks.rank, ranks.world
     from selfc_amd import GlobalVar, _lib, harness
     from selfc_amd.modules.SelfC_GMM_arch_inv import SelfCInvNet
-    from selfc_amd.pipeline import FullTestPath
+    from selfc_amd.pipeline import FullTestPath, MultiStreamRoundTrip
     GlobalVar.set_Temporal_LEN(7)
     torch.manual_seed(10)
     opt = {"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": "gmm", "scale": 4, "gmm_k": 5}
@@ -48,20 +50,24 @@ def main():
         raise SystemExit("frame size must be a multiple of 4 (the reference tiles / pads outside the network)")
     mine = launch.shard(range(a.clips), rank, world)
     gops = harness.gop_slices(a.frames)
-    path = FullTestPath(net, 7, H, W, dev)
+    S = max(1, a.streams)
+    path = MultiStreamRoundTrip(net, 7 * S, H, W, dev, S, part_cls=FullTestPath) if S > 1 else FullTestPath(net, 7, H, W, dev)
     gen = torch.Generator().manual_seed(launch.rank_seed(99, rank))
     clip = torch.rand(a.frames, 3, H, W, generator=gen).to(dev)                  # one resident clip, reused per owned clip
+    work = [g for _ in mine for g in gops]                                       # this rank's GOPs, S per replay
     with torch.no_grad():
-        # one GOP = one hipGraph replay: the GOP's frames are copied into the graph's static input first (0.17 GB, device
-        # to device); the last GOP of a clip is padded by repeating its final frame, so every GOP has 7 frames
-        xs = torch.empty(7, 3, H, W, device=dev)
-        xs.copy_(clip[gops[0]])
+        # S GOPs = one hipGraph replay: their frames are copied into the graph's static input first (0.17 GB each, device
+        # to device); the last GOP of a clip is padded by repeating its final frame, so every GOP has 7 frames; a last,
+        # incomplete group of GOPs re-runs the first ones in its free slots (not counted)
+        xs = torch.empty(7 * S, 3, H, W, device=dev)
+        for j in range(S):
+            xs[7 * j:7 * j + 7].copy_(clip[gops[0]])
         path.capture(xs)
         def all_my_clips():
-            for _ in mine:
-                for g in gops:
-                    xs.copy_(clip[g])
-                    path.replay()
+            for i in range(0, len(work), S):
+                for j in range(S):
+                    xs[7 * j:7 * j + 7].copy_(clip[work[i + j] if i + j < len(work) else work[j]])
+                path.replay()
         path.replay()                                                            # warm-up
         sec = launch.timed_region(all_my_clips, 1, 0, ranks, torch.cuda.synchronize)
     nranks = ranks.count()
@@ -74,7 +80,7 @@ def main():
                           "frames_per_clip": a.frames, "gops_per_clip": len(gops), "seconds": round(sec, 3), "dtype": _lib.OPERAND,
                           "stack_roofline_per_gpu": {"mfma_frac": round(flops * ngop / world / sec / 1e12 / 2500.0, 4),
                                                      "hbm_frac_layer_granular": round(2 * 8 * 1815 * 2 * npx * ngop / world / sec / 8.0e12, 4)},
-                          "sharding": f"{world} rank(s), clips round-robin, no data-path collective", "rccl_ranks": nranks, "data": "synthetic"}))
+                          "streams_per_gpu": S, "sharding": f"{world} rank(s), clips round-robin, no data-path collective", "rccl_ranks": nranks, "data": "synthetic"}))
     ranks.close()
 
 
