@@ -167,12 +167,18 @@ __device__ __forceinline__ void w_commit(Ctx& c) {
 template <int K> struct ConvGeom {
   static constexpr int R = TS + 2 * (DEPTH - K), NPX = R * R, NTL = (NPX + 31) / 32, MT = (NTL + NWAVE - 1) / NWAVE;
 };
+// Which waves own a SECOND M-tile: conv3's three (tiles 8..10) go to waves 0..2, conv2's five (tiles 8..12) to waves 3..7 -
+// so that no SIMD (waves w and w + 4) carries more than one of each, and a wave is in one of only TWO classes:
+// X (waves 0..2: one tile in conv2, two in conv3) and Y (waves 3..7: two in conv2, one in conv3).
+template <int K> constexpr int second_tile_first_wave() { return (DEPTH == 4 && K == 2) ? 3 : 0; }
 template <int K>
 __device__ __forceinline__ void mtile_geom(const Ctx& c, const int m, int& r, int& cc, bool& valid) {
   using G = ConvGeom<K>;
-  const int mt = c.wave + NWAVE * m;
+  constexpr int W0 = second_tile_first_wave<K>();
+  static_assert(G::NTL - NWAVE <= NWAVE - W0, "second tiles fit the waves from W0 on");
+  const int mt = m == 0 ? c.wave : NWAVE + c.wave - W0;
   const int q = mt * 32 + (c.lane & 31);
-  valid = (mt < G::NTL) & (q < G::NPX);
+  valid = (m == 0 || c.wave >= W0) & (mt < G::NTL) & (q < G::NPX);
   const int qc = min(q, G::NPX - 1);
   r = qc / G::R;
   cc = qc - r * G::R;
@@ -250,10 +256,16 @@ struct AccPair { f32x16 a[2]; };      // accumulators of conv2 / conv3 (2 M-tile
 // prev: accumulators of conv K-1 whose epilogue is still pending (K = 3, 4): it runs, piece by piece, behind the MFMA
 // steps of this conv's first chunk (im2col + F1: neither reads what that epilogue writes).  out: K = 2, 3 leave their
 // accumulators there instead of running their epilogue.
-template <int K>
+// HAS2 / PREV2: does this wave own a SECOND M-tile of conv K / of conv K-1?  conv2's 20x20 and conv3's 18x18 regions are 13 and
+// 11 tiles of 32 pixels for 8 waves: three (conv2) / five (conv3) waves have no second tile.  They used to run its MFMAs, operand
+// reads and epilogue pieces on clamped addresses with the stores masked - a quarter of conv3's and a fifth of conv2's issue
+// slots; the kernel's time is the sum of what the two waves of a SIMD issue.  Two wave classes (see
+// mtile_geom) run their own straight-line instance of the whole tile loop (dispatch once, in the kernel; identical barriers).
+template <int K, bool HAS2 = true, bool PREV2 = true>
 __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int net, const int xbuf,
                                            const size_t fofs, const int ty0, const int tx0, AccPair* prev, AccPair* out) {
   constexpr int MT = ConvGeom<K>::MT;
+  constexpr int MTE = (MT == 2 && !HAS2) ? 1 : MT;        // M-tiles this wave really computes
   constexpr int NCH = K == 1 ? 1 : K - 1;          // weight chunks of this conv: [im2col(+f1)], [f2], [f3]
   constexpr bool DEFER = K >= 2 && K < DEPTH, PENDING = K >= 3;
   static_assert(!DEFER || MT == 2, "AccPair");
@@ -331,7 +343,7 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
       A = *reinterpret_cast<const f16x8*>(wb + st * 1024);
       if (st < NIM) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+        for (int m = 0; m < MTE; ++m) {
           uint2 p0 = make_uint2(0u, 0u), p1 = make_uint2(0u, 0u);
           if (xo[st][0] >= 0) p0 = *reinterpret_cast<const uint2*>(xb + xbase[m] + xo[st][0]);
           if (xo[st][1] >= 0) p1 = *reinterpret_cast<const uint2*>(xb + xbase[m] + xo[st][1]);
@@ -341,7 +353,7 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
       } else {
         const int fs = st - NIM, tap = fs >> 1, ks = fs & 1;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MTE; ++m)
           B[m] = *reinterpret_cast<const f16x8*>(fb + pb[m] + (tap / 3) * pitch + (tap % 3) * PS + ks * 32);
       }
     };
@@ -357,7 +369,7 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
 #endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
+      for (int m = 0; m < MTE; ++m) {
 #if defined(SELFC_EXP_NOMFMA)          // timing experiment: everything but the MFMAs
         acc[m][0] += (float)ringA[st % RD][0] * (float)ringB[st % RD][m][0];
 #elif defined(SELFC_EXP_MFMA16)        // timing experiment (results are garbage): the same MACs as two 16x16x32 MFMAs
@@ -380,7 +392,9 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
       // the pending epilogue of conv K-1: one piece (ten-odd VALU instructions, or one M-tile's stores) per step
       // (packs behind steps 1..8; then this chunk's weight hand-over, so that no wait on the VM counter follows the
       // feature stores; then the two M-tiles' stores behind steps 9 and 10)
-      if (PENDING && ch == 0 && st >= 1 && st <= 10) epi_piece<(PENDING ? K - 1 : 1), 2>(c, a, net, fofs, ty0, tx0, prev->a, prr, st - 1);
+      // (a wave without a second tile in conv K-1 skips that tile's four pack pieces and its store piece)
+      if (PENDING && ch == 0 && st >= 1 && st <= 10 && (PREV2 || st <= 4 || st == 9))
+        epi_piece<(PENDING ? K - 1 : 1), 2>(c, a, net, fofs, ty0, tx0, prev->a, prr, st - 1);
       if (PENDING && ch == 0 && st == 8) w_commit<LAYER_OFF[K] + 21, 18>(c);
     }
 
@@ -499,6 +513,8 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
   __syncthreads();
   c.par = 0;
 
+  auto tile_loop = [&](auto two2c, auto two3c) __attribute__((always_inline)) {
+  constexpr bool TWO2 = decltype(two2c)::value, TWO3 = decltype(two3c)::value;
   int xbuf = 0;
   for (int n = f0; n < a.N; n += gf) {
     const bool more = n + gf < a.N;
@@ -508,14 +524,14 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
 #ifndef SELFC_EXP_NOC1      // timing experiment (results are wrong): what does conv1's phase (MFMAs + immediate epilogue + barrier) cost?
     conv_fused<1>(c, a, net, xbuf, fofs, ty0, tx0, nullptr, nullptr);
 #endif
-    conv_fused<2>(c, a, net, xbuf, fofs, ty0, tx0, nullptr, &acc2);
+    conv_fused<2, TWO2>(c, a, net, xbuf, fofs, ty0, tx0, nullptr, &acc2);
     if (DEPTH == 3) {
       if (more) x_store(xbuf ^ 1);                // before the last conv's feature stores (see conv_fused: one VM counter)
       conv_fused<3>(c, a, net, xbuf, fofs, ty0, tx0, &acc2, nullptr);
     } else {
-      conv_fused<3>(c, a, net, xbuf, fofs, ty0, tx0, &acc2, &acc3);
+      conv_fused<3, TWO3, TWO2>(c, a, net, xbuf, fofs, ty0, tx0, &acc2, &acc3);
       if (more) x_store(xbuf ^ 1);
-      conv_fused<(DEPTH == 4 ? 4 : 3)>(c, a, net, xbuf, fofs, ty0, tx0, &acc3, nullptr);
+      conv_fused<(DEPTH == 4 ? 4 : 3), true, TWO3>(c, a, net, xbuf, fofs, ty0, tx0, &acc3, nullptr);
     }
     STAMP(tt0);
     __syncthreads();
@@ -525,6 +541,12 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
     STAMP(tt1);
     STAMP_ADD(3, tt0, tt1);
   }
+  };
+  // second M-tile owners (mtile_geom): conv3 waves 0..2, conv2 waves 3..7
+  static_assert(DEPTH != 4 || (ConvGeom<3>::NTL - NWAVE == 3 && ConvGeom<2>::NTL - NWAVE == 5 && second_tile_first_wave<2>() == 3),
+                "the two wave classes below");
+  if (c.wave < 3) tile_loop(std::false_type{}, std::true_type{});
+  else tile_loop(std::true_type{}, std::false_type{});
 #ifdef SELFC_STAMPS
   STAMP(tk1);
   if (a.stamps && c.lane == 0) {
