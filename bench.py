@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-path", action="store_true", help="skip the extra netG(x) + Quantization + netG(LR, rev=True) timing (incl. STP sampler)")
-    ap.add_argument("--streams", type=int, default=4, help="split the septuplets of a step over this many HIP streams")
+    ap.add_argument("--streams", type=int, default=2, help="split the septuplets of a step over this many HIP streams (2 x 2 clips: measured best since the round-2 G/H kernel; 4 x 1 clip before)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the extra training-step timing (config 3: 8 x 7x3x144x144)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo rehearsal of launch, sharding and the timing protocol: no HIP call, value is null")
     args = ap.parse_args()

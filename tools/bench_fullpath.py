@@ -18,6 +18,7 @@ from selfc_amd.pipeline import FullTestPath, MultiStreamRoundTrip            # n
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+nstreams = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 T, H, W, B = 7, 256, 448, 4
 GlobalVar.set_Temporal_LEN(T)
 dev = torch.device("cuda:0")
@@ -26,7 +27,7 @@ opt = {"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": "gmm", "scale":
 net = SelfCInvNet(opt, 3, 3, "D2DTNet", [4, 4], 2).to(dev).eval()
 x = torch.rand((B * T, 3, H, W), generator=torch.Generator().manual_seed(1234)).to(dev)
 with torch.no_grad():
-    ftp = MultiStreamRoundTrip(net, B * T, H, W, dev, 4, part_cls=FullTestPath)
+    ftp = MultiStreamRoundTrip(net, B * T, H, W, dev, nstreams, part_cls=FullTestPath)
     ftp.capture(x)
     for _ in range(10):
         ftp.replay()
