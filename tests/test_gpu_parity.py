@@ -194,6 +194,36 @@ def test_stp_gmm_fused_head_and_sampler(dev):
     assert rel_err(hf.permute(0, 3, 1, 2).cpu(), g["v"]) < TOL
 
 
+def test_stp_two_clips_ragged_against_oracle(dev):
+    """Two clips of 7 frames at 20x36 (not a multiple of the kernels' 64 / 128 / 256-pixel workgroups) through the whole STP
+    sampling path with injected noise, against the oracle: the per-clip attention inside the mix kernel (clip index, clip-local
+    softmax), the f16 hand-over into the next D2DTInput's operand planes with N = 14 and the partial last workgroup of the
+    one-kernel GMM head."""
+    from selfc_amd.modules.SelfC_GMM_arch_inv import STPNet
+    g = load_golden("g7_stp_gmm")
+    keys = ("local_m1", "local_m2", "global_m1", "global_m2", "other_stp_modules", "tail_gmm")
+    sd = {k: v for k, v in g.items() if k.split(".")[0] in keys}
+    stp = STPNet(dict(OPT, fh_loss="gmm"))
+    stp.load_state_dict(sd, strict=True)
+    stp.to(dev).eval()
+    gen = torch.Generator().manual_seed(21)
+    n, h, w = 2 * T, 20, 36
+    lr = torch.rand(n, 3, h, w, generator=gen)
+    eps = torch.randn(n, 48, 5, h, w, generator=gen)
+    raw_ref = O.stp_v2_parameters(sd, lr, T)
+    v_ref = O.stp_v2_gmm_sample(raw_ref, eps)
+    stp.eps = eps.reshape(2, T, 48, 5, h, w).permute(0, 2, 3, 1, 4, 5).to(dev)       # (b, 48, 5, T, h, w)
+    x1 = torch.zeros(n, h, w, 4, device=dev)
+    x1[..., :3] = lr.to(dev).permute(0, 2, 3, 1)
+    hf = torch.zeros(n, h, w, 48, device=dev)
+    with torch.no_grad():
+        assert stp.run_nhwc(x1, hf, n, T, h, w) is None                    # fused head: nothing but the sample is written
+        assert rel_err(hf.permute(0, 3, 1, 2).cpu(), v_ref) < TOL
+        assert rel_l2(hf.permute(0, 3, 1, 2).cpu(), v_ref) < TOL
+        raw = stp.run_nhwc(x1, torch.zeros_like(hf), n, T, h, w, keep_raw=True)   # layer-wise head, raw output kept
+    assert rel_err(raw.reshape(n, h, w, -1).permute(0, 3, 1, 2).cpu(), raw_ref) < TOL
+
+
 def test_globalagg(dev):
     from selfc_amd.modules.SelfC_GMM_arch_inv import GlobalAgg
     g = load_golden("g6_globalagg")
