@@ -137,9 +137,13 @@ __device__ __forceinline__ void merged_steps(const unsigned char* __restrict__ w
   if (RD > 2 && NS > 1) load_step(1);
   static_for<0, NS>([&](auto si) __attribute__((always_inline)) {
     constexpr int st = decltype(si)::value;
+#ifdef SELFC_EXP_NOLDS      // timing experiment (results are wrong, data stays ordinary): every step multiplies the FIRST step's fragments
+    constexpr int s = 0;
+#else
     if constexpr (st + RD - 1 < NS) load_step(st + RD - 1);
     __builtin_amdgcn_sched_barrier(0);
     constexpr int s = st % RD;
+#endif
     acc1c = mfma_32x32x16(rA1[s], rBc[s], acc1c);
     acc2 = mfma_32x32x16(rA2[s], rBc[s], acc2);
     if (RING) acc1r = mfma_32x32x16(rA1[s], rBr[s], acc1r);
@@ -162,9 +166,13 @@ __device__ __forceinline__ void fm_steps(const unsigned char* __restrict__ wl, c
   load_step(1);
   static_for<0, 18>([&](auto si) __attribute__((always_inline)) {
     constexpr int st = decltype(si)::value;
+#ifdef SELFC_EXP_NOLDS
+    acc2 = mfma_32x32x16(rA[0], rB[0], acc2);
+#else
     if constexpr (st + 2 < 18) load_step(st + 2);
     __builtin_amdgcn_sched_barrier(0);
     acc2 = mfma_32x32x16(rA[st % 3], rB[st % 3], acc2);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     post(si);
   });
