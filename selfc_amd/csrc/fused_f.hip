@@ -549,6 +549,9 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
 #ifdef SELFC_EXP_NOW        // timing experiment only (results are wrong): what does the weight streaming cost?
         return;
 #endif
+#ifdef SELFC_EXP_NOW2       // the same with ORDINARY data: the first tile streams (all three buffers hold real fragments), later tiles do not
+        if (n != f0) return;
+#endif
         if (j == 1 || j == 2) w_commit_item((cidx + 2) % 3, cidx & 1, j - 1);
         if (j == 3 || j == 4) w_prefetch_item((cidx + 4) % NCHUNK, cidx & 1, j - 3);
       };
