@@ -253,7 +253,7 @@ def test_haar_net(dev):
         assert rel_err(out.cpu(), g["x_rev"]) < TOL
 
 
-@pytest.mark.parametrize("b,h,w", [(1, 36, 52), (2, 20, 44), (3, 64, 64)])
+@pytest.mark.parametrize("b,h,w", [(1, 36, 52), (2, 20, 44), (3, 64, 64), (1, 136, 200), (2, 68, 132)])
 def test_large_vs_oracle_ragged_sizes(dev, b, h, w):
     """latent sizes that are not multiples of the 16x16 tile / 128-pixel strip; several clips."""
     g = load_golden("g8_large_stack")
