@@ -87,8 +87,8 @@ def cpu_baseline(net, x_cpu, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (2.8 ms each: the rate keeps rising until ~100 steps - clocks, caches - so short runs under-report the steady state by ~4 %%)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-path", action="store_true", help="skip the extra netG(x) + Quantization + netG(LR, rev=True) timing (incl. STP sampler)")
@@ -258,14 +258,14 @@ def main():
             with torch.no_grad():
                 ftp = MultiStreamRoundTrip(net, n_frames, H, W, dev, args.streams if args.streams > 1 else 1, part_cls=FullTestPath)
                 ftp.capture(x)
-                for _ in range(3):
-                    ftp.replay()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
                 for _ in range(10):
                     ftp.replay()
                 torch.cuda.synchronize()
-                tg = (time.perf_counter() - t0) / 10
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    ftp.replay()
+                torch.cuda.synchronize()
+                tg = (time.perf_counter() - t0) / 100
             out["full_test_path"]["pipeline"] = {"septuplets_per_s": round(B_PER_GPU / tg, 1), "ms_per_batch": round(tg * 1e3, 3),
                                                   "launch": f"hipGraph replay, {ftp.nstreams} streams"}
         except Exception as e:  # noqa: BLE001
@@ -275,7 +275,7 @@ def main():
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
         try:                                          # a secondary leg must never cost the headline line
             import bench_train
-            tr = bench_train.run(batch=8, size=144, steps=5, warmup=2, fh_loss="gmm", profile=False)
+            tr = bench_train.run(batch=8, size=144, steps=20, warmup=3, fh_loss="gmm", profile=False)
             out["train_step"] = {"septuplets_per_s": round(tr["value"], 1), "ms_per_step": round(tr["ms_per_step"], 2),
                                  "config": "8 x 7x3x144x144 crops, fh_loss gmm, l2 + l1 losses, clip 10, Adam; eager, 3 streams",
                                  "note": "every forward / reverse / gradient kernel is HIP (selfc_amd/autograd.py); losses, clip and Adam are torch"}
