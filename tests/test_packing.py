@@ -365,3 +365,24 @@ def test_weight_epoch_invalidates_every_packed_cache_key():
     with torch.no_grad():
         m.weight.add_(1.0)
     assert rt.params_key(m) != k1
+
+
+def test_grad_sink_views_and_zero():
+    """autograd.GradSink (host logic only): one flat buffer, a 256-byte aligned view per parameter as its `.grad`, zero()
+    is one fill and re-attaches views somebody replaced, view_of() only vouches for views that are still attached."""
+    from selfc_amd import autograd as ag
+    ps = [torch.nn.Parameter(torch.randn(3, 5)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2), requires_grad=False)]
+    sink = ag.GradSink(ps)
+    assert len(sink.params) == 2 and sink.flat.numel() == 128              # 15 -> 64, 7 -> 64 floats
+    assert ps[0].grad.shape == (3, 5) and ps[1].grad.shape == (7,) and ps[2].grad is None
+    assert ps[0].grad.data_ptr() == sink.flat.data_ptr() and ps[1].grad.data_ptr() == sink.flat.data_ptr() + 64 * 4
+    ps[0].grad.add_(1.0)
+    assert float(sink.flat.sum()) == 15.0                                   # the pads stay zero
+    assert sink.view_of(ps[0]) is ps[0].grad and sink.view_of(ps[2]) is None
+    ps[1].grad = None                                                       # e.g. optimizer.zero_grad(set_to_none=True)
+    assert sink.view_of(ps[1]) is None
+    sink.zero()
+    assert float(sink.flat.abs().sum()) == 0.0 and sink.view_of(ps[1]) is ps[1].grad
+    with ag.grad_sink(sink) as s_:
+        assert ag._SINK is sink and s_ is sink
+    assert ag._SINK is None
