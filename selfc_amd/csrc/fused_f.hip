@@ -614,11 +614,22 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
           if constexpr (g + 2 < G::S1) load_m(g + 2);
           __builtin_amdgcn_sched_barrier(0);
           constexpr int s = g % 3;
+#if defined(SELFC_STAMPS) && defined(SELFC_STEP_STAMPS)     // diagnostic: the step split into its MFMA group (bucket 2) and its hook (bucket 3)
+          STAMP(tsa);
+#endif
           acc1c = mfma_32x32x16(rA1[s], rBc[s], acc1c);
           acc2 = mfma_32x32x16(rA2[s], rBc[s], acc2);
           if (RING) acc1r = mfma_32x32x16(rA1[s], rBr[s], acc1r);
           __builtin_amdgcn_sched_barrier(0);
+#if defined(SELFC_STAMPS) && defined(SELFC_STEP_STAMPS)
+          STAMP(tsb);
+          STAMP_ADD(2, tsa, tsb);
+#endif
           post_m(gi);
+#if defined(SELFC_STAMPS) && defined(SELFC_STEP_STAMPS)
+          STAMP(tsc);
+          STAMP_ADD(3, tsb, tsc);
+#endif
         });
       };
       if (ring) body(std::true_type{});
