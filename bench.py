@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed steps (2.8 ms each: the rate keeps rising until ~100 steps - clocks, caches - so short runs under-report the steady state by ~4 %%)")
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--prewarm-s", type=float, default=1.0, help="untimed pre-warm (seconds of steps) before the W warm-up steps and the timed region; reported in config.prewarm")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-path", action="store_true", help="skip the extra netG(x) + Quantization + netG(LR, rev=True) timing (incl. STP sampler)")
@@ -129,10 +130,9 @@ def main():
             step = runner.replay
         else:
             step = lambda: runner.run(x)      # noqa: E731
-        dt = launch.timed_region(step, args.steps, args.warmup, ranks, torch.cuda.synchronize)
-        rccl_ranks = ranks.count()
-
-        # ---- roofline leg: same K steps, eager, HIP events around every launch on its stream
+        # ---- roofline leg FIRST: K steps, eager, one stream, HIP events around every launch on its stream.  Running it (and
+        # the stated pre-warm below) ahead of the timed region means the timed region is not the first GPU work of the
+        # process: a 20-step run then measures the same steady state as a 200-step one (clocks and caches settled).
         L.selfc_profile_reset()
         L.selfc_profile_enable(1)
         for _ in range(args.steps):
@@ -145,6 +145,16 @@ def main():
             L.selfc_profile_read(cls, C.byref(ms), C.byref(n))
             cls_ms[name], cls_n[name] = ms.value, n.value
         L.selfc_profile_reset()
+        # ---- stated pre-warm: untimed steps for --prewarm-s seconds of wall time (in addition to the W warm-up steps)
+        t_pw, n_pw = time.perf_counter(), 0
+        while time.perf_counter() - t_pw < args.prewarm_s:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            n_pw += 10
+        # ---- the timed region: W untimed warm-up steps, barrier + sync, EXACTLY K steps, barrier + sync, MAX over ranks
+        dt = launch.timed_region(step, args.steps, args.warmup, ranks, torch.cuda.synchronize)
+        rccl_ranks = ranks.count()
 
     npx = n_frames * (H // 4) * (W // 4)
     # per-kernel rooflines: algorithmic FLOPs per launch / live HIP-event duration of that launch
@@ -210,6 +220,7 @@ def main():
         "config": {"workload": "SelfC-large FrequencyAnalyzer + 8 InvBlockExp(D2DTNet) fwd, Quantization, 8 InvBlockExp rev, "
                                "FrequencyAnalyzer rev; 4 septuplets 7x3x256x448 per GPU, inputs resident in HBM, seeded default-init weights",
                    "septuplets_per_gpu": B_PER_GPU, "launch": "hipGraph replay" if use_graph else "eager", "streams": args.streams,
+                   "prewarm": f"untimed, before the W warm-up steps: the eager roofline leg ({args.steps} steps) + {n_pw} steps over {args.prewarm_s} s of wall time",
                    "sharding": f"{world} rank(s) x {B_PER_GPU} independent septuplets, no data-path collective"},
         "rccl_ranks": rccl_ranks,
         "roofline": roofline,

@@ -128,7 +128,13 @@ typedef struct {
   void* hd;
   float* s_out;          /* optional: InvBlockExp.s as fp32 [N][H][W][c2p], or NULL */
   float* pf;             /* optional workspace: F conv5 partial products, fp32 [2 pairs][3 taps][N][H][W][4] (see w5p), or NULL */
+  int flags;             /* SELFC_LAT_* (abi 7) */
 } selfc_latent;
+
+/* The caller reads the dense feature buffers (fd / gd / hd planes f1..f4) after the call - the training forward, whose
+ * backward consumes them (selfc_subnet_bwd).  Without it (inference) a kernel may keep features that nothing else reads
+ * on chip: the pairwise-fused F launches then do not store f3 / f4 (128 B per pixel-frame per block and direction). */
+#define SELFC_LAT_KEEP_FEATURES 1
 
 /* InvBlockExp.forward(x, rev): Inv_arch.py:21-33 on the latent layout.
  * Precondition: channels [0,c2) of `fd` hold x2 as f16 when rev == 0 (every

@@ -24,6 +24,8 @@ def operand_dtype():
 
 SUBNET_D2DT = 0
 SUBNET_DB2D = 1
+LAT_KEEP_FEATURES = 1      # selfc_latent.flags (SELFC_LAT_KEEP_FEATURES)
+ABI_VERSION = 7
 
 #: every symbol include/selfc_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -59,7 +61,7 @@ class Latent(C.Structure):
     _fields_ = [("kind", C.c_int), ("N", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("c1", C.c_int), ("c2", C.c_int),
                 ("x1", C.c_void_p), ("x2", C.c_void_p), ("fd", C.c_void_p), ("gd", C.c_void_p),
-                ("hd", C.c_void_p), ("s_out", C.c_void_p), ("pf", C.c_void_p)]
+                ("hd", C.c_void_p), ("s_out", C.c_void_p), ("pf", C.c_void_p), ("flags", C.c_int)]
 
 
 _lib = None
@@ -140,6 +142,8 @@ def lib():
         L.selfc_subnet_bwd_scratch_bytes.argtypes = [i, i, i, i, i]
         L.selfc_globalagg_partial_floats.restype = sz
         L.selfc_globalagg_partial_floats.argtypes = [i, i]
+        if L.selfc_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI {L.selfc_abi_version()}, this binding needs {ABI_VERSION}: rebuild it (make -C selfc_amd/csrc)")
         if ("operands=" + OPERAND).encode() not in L.selfc_version():
             raise RuntimeError(f"{LIB_PATH} was not built for {OPERAND} operands: {L.selfc_version()!r}")
         _lib = L

@@ -38,7 +38,7 @@ struct FGArgs {
 int launch_fused_gh(FGArgs& a, hipStream_t s);
 // csrc/fused_f.hip
 int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, int H, int W, hipStream_t s,
-                   const void* w5p, float* pf, const float* b5, float* x1, int T, int rev);
+                   const void* w5p, float* pf, const float* b5, float* x1, int T, int rev, int keep_features);
 }  // namespace selfc
 #include "bwd_internal.hpp"
 
@@ -914,7 +914,7 @@ int run_F(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStream
     // two pairwise-fused launches; with the partial-product fragments they also cover the temporal conv5 (rc 1)
     const bool t5 = l->kind == SELFC_SUBNET_D2DT && l->c1 <= 3;
     rc = launch_fused_f(l->fd, blk->F.wfused, blk->F.b3, l->N, l->H, l->W, s, t5 ? blk->F.w5p : nullptr, t5 ? l->pf : nullptr,
-                        blk->F.b5, l->x1, l->T, rev);
+                        blk->F.b5, l->x1, l->T, rev, (l->flags & SELFC_LAT_KEEP_FEATURES) != 0);
     if (rc == 1) return SELFC_OK;
   } else
     rc = run_conv1to4(&blk->F, nullptr, l->fd, nullptr, nullptr, l->c2, l->N, l->H, l->W, s);
@@ -1015,8 +1015,8 @@ int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s)
 
 extern "C" {
 
-const char* selfc_version(void) { return "selfc_hip gfx950 abi6 operands=" SELFC_OPERAND_NAME; }
-int selfc_abi_version(void) { return 6; }
+const char* selfc_version(void) { return "selfc_hip gfx950 abi7 operands=" SELFC_OPERAND_NAME; }
+int selfc_abi_version(void) { return 7; }
 
 int selfc_invblock_run(const selfc_invblock_w* blk, const selfc_latent* lat, int rev, void* stream) {
   if (!blk || !latent_ok(lat)) return SELFC_EINVAL;

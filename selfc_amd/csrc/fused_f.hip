@@ -42,6 +42,8 @@ struct FFArgs {
   size_t plane;
   const f16* w5p;           // optional: conv5 partial-product fragments of this pair (pair 0: x2, f1, f2 = 7; pair 1: f3, f4 = 4)
   float* pf;                // optional: partial products of this pair, fp32 [3 taps][N][H][W][4]
+  int store_feat;           // 1: the pair's two feature planes go to HBM; 0 (pair 1 on the inference path with partial
+                            //    products): nothing reads f3 / f4 afterwards - they stay in registers / the FM image
   unsigned long long* stamps;   // diagnostic build only (-DSELFC_STAMPS): per wave 7 phase sums + lifetime
 };
 
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
     unsigned char* fdst = smem + G::OFF_FM + (c.py + 1) * G::FROW + (c.px + 1) * PS + 16 * c.half;
     *reinterpret_cast<u32x4*>(fdst) = vc[0];
     *reinterpret_cast<u32x4*>(fdst + 32) = vc[1];
-    if (in) {
+    if (in & (a.store_feat != 0)) {
       f16* d = dplane + ((size_t)(n * a.H + y) * a.W + x) * 32 + 8 * c.half;
       *reinterpret_cast<u32x4*>(d) = vc[0];
       *reinterpret_cast<u32x4*>(d + 16) = vc[1];
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
   auto epilogue2 = [&](const f32x16& acc2, const int n, u32x4 (&v)[2]) __attribute__((always_inline)) {
     const int y = ty0 + c.py, x = tx0 + c.px;
     lrelu_pack(acc2, true, v);
-    if ((y < a.H) & (x < a.W)) {
+    if ((y < a.H) & (x < a.W) & (a.store_feat != 0)) {
       f16* d = a.dense + (size_t)G::OUT2 * a.plane + ((size_t)(n * a.H + y) * a.W + x) * 32 + 8 * c.half;
       *reinterpret_cast<u32x4*>(d) = v[0];
       *reinterpret_cast<u32x4*>(d + 16) = v[1];
@@ -752,7 +754,7 @@ int launch_pair(FFArgs& a, int maxwg, hipStream_t s) {
 // With w5p (11 partial-product fragments), pf and x1 the temporal conv5 + coupling y1 = x1 +- F is done here as well:
 // the two launches emit the conv5 partial products and f_couple_kernel sums them (returns 1: conv5 handled).
 int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, int H, int W, hipStream_t s,
-                   const void* w5p, float* pf, const float* b5, float* x1, int T, int rev) {
+                   const void* w5p, float* pf, const float* b5, float* x1, int T, int rev, int keep_features) {
   static const int maxwg = getenv("SELFC_FUSEDF_MAXWG") ? atoi(getenv("SELFC_FUSEDF_MAXWG")) : 256;
   static const bool no_p = getenv("SELFC_NO_F5P") != nullptr;     // developer A/B switch
   const bool with_p = w5p && pf && b5 && x1 && T > 0 && !no_p;
@@ -769,12 +771,17 @@ int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, 
     a.bias[0] = bias[0]; a.bias[1] = bias[1];
     a.w5p = with_p ? (const f16*)w5p : nullptr;
     a.pf = with_p ? pf : nullptr;
+    a.store_feat = 1;                                  // f1, f2: pair 1 reads them
     int rc = launch_pair<0>(a, maxwg > 0 ? maxwg : 256, s);
     if (rc) return rc;
     a.w = (const f16*)w + (size_t)Geo<0>::NFRAG * 512;
     a.bias[0] = bias[2]; a.bias[1] = bias[3];
     a.w5p = with_p ? (const f16*)w5p + (size_t)Geo<0>::NP * 512 : nullptr;
     a.pf = with_p ? pf + (size_t)N * H * W * 12 : nullptr;
+    // f3, f4 feed only conv5: with the partial products taken here nothing reads them again unless the caller keeps the
+    // dense buffer for a backward pass (selfc_latent.flags & SELFC_LAT_KEEP_FEATURES) - 128 B per pixel-frame of dead stores
+    static const bool force_keep = getenv("SELFC_F_KEEP_FEATURES") != nullptr;     // developer A/B switch
+    a.store_feat = (keep_features || !with_p || force_keep) ? 1 : 0;
     rc = launch_pair<1>(a, maxwg > 0 ? maxwg : 256, s);
     if (rc || !with_p) return rc;
   }

@@ -54,12 +54,16 @@ class Workspace:
         self.s: Optional[torch.Tensor] = None
         self.device = device
 
-    def latent(self, want_s: bool = False) -> _lib.Latent:
+    def latent(self, want_s: bool = False, keep_features: Optional[bool] = None) -> _lib.Latent:
+        """selfc_latent view of the buffers.  want_s: also produce InvBlockExp.s; keep_features (default: want_s, i.e. the
+        callers that may run a backward): the dense feature planes are read after the call (SELFC_LAT_KEEP_FEATURES)."""
+        if keep_features is None:
+            keep_features = want_s
         if want_s and self.s is None:      # every element (incl. pads) is written by the coupling epilogue
             self.s = torch.empty((self.N, self.H, self.W, self.c2p), dtype=torch.float32, device=self.device)
         return _lib.Latent(self.kind, self.N, self.T, self.H, self.W, self.c1, self.c2,
                            _ptr(self.x1), _ptr(self.x2), _ptr(self.fd), _ptr(self.gd), _ptr(self.hd),
-                           _ptr(self.s) if want_s else None, _ptr(self.pf))
+                           _ptr(self.s) if want_s else None, _ptr(self.pf), _lib.LAT_KEEP_FEATURES if keep_features else 0)
 
     def nbytes(self) -> int:
         ts = [self.x1, self.x2, self.fd, self.gd, self.hd] + [t for t in (self.s, self.pf) if t is not None]
