@@ -58,6 +58,17 @@ def side_stream(device, which: int = 0):
 # hooks need the gradients to pass through autograd).
 # ------------------------------------------------------------------------------------------------------------
 class GradSink:
+    """ONE flat fp32 buffer with a view per parameter as its ``.grad`` (see above).
+
+    Data parallelism: ``all_reduce()`` is the step's ONE collective - a SUM over the ranks of the flat buffer
+    (3,365,038 floats + pads = 13.5 MB for SelfC-large), divided by the world size, i.e. what DistributedDataParallel's
+    bucketed hooks compute (SelfC_model.py:41-44), without its per-tensor hooks: the kernels keep accumulating straight
+    into the buffer and the step stays capturable.
+
+    Parameters the backward did not reach in a step (a frozen path, an unused head) are tracked: their views stay zero,
+    and ``detach_untouched()`` sets their ``.grad`` to None before the optimizer step, so Adam skips them exactly as it does
+    with stock autograd (no moment decay, no weight decay on tensors without a gradient)."""
+
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         offs, total = [], 0
@@ -68,7 +79,14 @@ class GradSink:
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.views = [self.flat[o:o + p_.numel()].view(p_.shape) for o, p_ in zip(offs, self.params)]
         self.index = {id(p_): v for p_, v in zip(self.params, self.views)}
+        self.pos = {id(p_): i for i, p_ in enumerate(self.params)}
+        self.touched = set()
+        # gradients that still arrive through autograd (AccumulateGrad adds them into the view in place) count as touched
+        self._hooks = [p_.register_post_accumulate_grad_hook(self._mark) for p_ in self.params]
         self.attach()
+
+    def _mark(self, p_):
+        self.touched.add(self.pos[id(p_)])
 
     def attach(self):
         for p_, v in zip(self.params, self.views):
@@ -76,13 +94,45 @@ class GradSink:
                 p_.grad = v
 
     def zero(self):
-        """Once per step, instead of optimizer.zero_grad(): one memset; re-attaches views somebody replaced."""
+        """Once per step, instead of optimizer.zero_grad(): one memset; re-attaches views somebody replaced (or that
+        detach_untouched() took away) and forgets which views were written."""
         self.flat.zero_()
+        self.touched.clear()
         self.attach()
 
     def view_of(self, p_) -> Optional[torch.Tensor]:
+        """The view a kernel may accumulate into (marks the parameter as having received a gradient this step)."""
         v = self.index.get(id(p_))
-        return v if v is not None and p_.grad is v else None
+        if v is not None and p_.grad is v:
+            self.touched.add(self.pos[id(p_)])
+            return v
+        return None
+
+    def untouched(self) -> List[torch.Tensor]:
+        return [p_ for i, p_ in enumerate(self.params) if i not in self.touched]
+
+    def detach_untouched(self) -> int:
+        """After backward, before clip / optimizer.step(): parameters without a gradient this step get ``.grad = None``
+        (their slice of the flat buffer is zero, so norms and the all-reduce are unaffected).  Returns how many."""
+        n = 0
+        for i, p_ in enumerate(self.params):
+            if i not in self.touched and p_.grad is not None:
+                p_.grad = None
+                n += 1
+        return n
+
+    def all_reduce(self, group=None, average: bool = True) -> int:
+        """The data-parallel step's single collective: SUM of the flat buffer over the ranks of `group` (RCCL on GPUs, gloo
+        on CPU), then / world.  Call between backward and clip.  Returns the world size (1: nothing was sent)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1
+        world = dist.get_world_size(group)
+        if world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            if average:
+                self.flat.mul_(1.0 / world)
+        return world
 
 
 _SINK: Optional[GradSink] = None

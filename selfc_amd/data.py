@@ -8,13 +8,22 @@ iteration-oriented distributed sampler and its dataloader factory, without cv2 /
   create_dataloader   codes/data/__init__.py:7-27
 
 PNG decoding uses PIL (cv2.imread + the BGR->RGB swap of the reference yield the same RGB values); a clip directory may
-instead hold one ``clip.npy`` (N,H,W,3) uint8 file, which avoids the PNG decode that starves 8 GPUs at 2 workers each."""
+instead hold one ``clip.npy`` (N,H,W,3) uint8 file, which avoids the PNG decode that starves 8 GPUs at 2 workers each.
+
+Feeding the GPU (the reference: worker processes, codes/data/__init__.py:20-26, and a blocking ``.to(device)`` in feed_data,
+SelfC_model.py:114-115):
+
+  DevicePrefetcher    wraps any batch iterable: a background thread pulls batch k+1 (worker processes keep decoding), pins
+                      it and issues its host-to-device copy on a side stream while step k computes; order is preserved
+  SyntheticSeptuplets the synthetic leg: uniform [0,1) clips drawn ON the device (no host work, no PCIe) from a per-rank seed"""
 from __future__ import annotations
 
 import math
 import os
+import queue
 import random
-from typing import List, Optional
+import threading
+from typing import Iterable, Iterator, List, Optional
 
 import numpy as np
 import torch
@@ -120,7 +129,8 @@ class SeptupletDataset(tud.Dataset):
 
 
 def create_dataloader(dataset, dataset_opt: dict, opt: Optional[dict] = None, sampler=None):
-    """data/__init__.py:7-27: training batch = batch_size // world when distributed, drop_last; test: batch as given."""
+    """data/__init__.py:7-27: training batch = batch_size // world when distributed, drop_last; test: batch as given.
+    (pin_memory stays False as in the reference: DevicePrefetcher pins in its own thread.)"""
     phase = dataset_opt["phase"]
     if phase == "train":
         if opt and opt.get("dist"):
@@ -137,3 +147,98 @@ def create_dataloader(dataset, dataset_opt: dict, opt: Optional[dict] = None, sa
                               drop_last=True, pin_memory=False)
     return tud.DataLoader(dataset, batch_size=dataset_opt["batch_size"], shuffle=False, num_workers=dataset_opt.get("n_workers", 0),
                           drop_last=False, pin_memory=False)
+
+
+def _map_tensors(obj, fn):
+    if torch.is_tensor(obj):
+        return fn(obj)
+    if isinstance(obj, dict):
+        return {k: _map_tensors(v, fn) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_map_tensors(v, fn) for v in obj)
+    return obj
+
+
+class DevicePrefetcher:
+    """Iterate `loader` with batch k+1 already on its way to `device` while step k runs.
+
+    A daemon thread pulls the next batch from the loader (so DataLoader workers never wait for the training step), pins
+    its tensors and enqueues the host-to-device copies on a side stream; ``__next__`` makes the consumer's current stream
+    wait for that copy's event.  At most `depth` batches are in flight.  Batches come out in exactly the loader's order
+    (one producer, one FIFO) - the DistIterSampler index streams are unchanged.  `device` "cpu": tensors pass through
+    untouched (tests, dry runs); exceptions raised by the loader are re-raised in the consumer."""
+
+    _END = object()
+
+    def __init__(self, loader: Iterable, device, depth: int = 2):
+        self.loader, self.device, self.depth = loader, torch.device(device), max(1, int(depth))
+        self.cuda = self.device.type == "cuda"
+        self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _producer(self, it: Iterator, q: "queue.Queue", stop: threading.Event):
+        try:
+            if self.cuda:
+                torch.cuda.set_device(self.device)
+            for batch in it:
+                if self.cuda:
+                    with torch.cuda.stream(self.stream):
+                        moved = _map_tensors(batch, lambda t: t.pin_memory().to(self.device, non_blocking=True))
+                        ev = self.stream.record_event()
+                    item = (moved, ev)
+                else:
+                    item = (batch, None)
+                while not stop.is_set():
+                    try:
+                        q.put(item, timeout=0.1)
+                        break
+                    except queue.Full:
+                        continue
+                if stop.is_set():
+                    return
+            q.put((self._END, None))
+        except BaseException as e:  # noqa: BLE001 - handed to the consumer
+            q.put((e, None))
+
+    def __iter__(self):
+        q: "queue.Queue" = queue.Queue(maxsize=self.depth)
+        stop = threading.Event()
+        th = threading.Thread(target=self._producer, args=(iter(self.loader), q, stop), daemon=True)
+        th.start()
+        try:
+            while True:
+                item, ev = q.get()
+                if item is self._END:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                if ev is not None:
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ev)
+                    _map_tensors(item, lambda t: t.record_stream(cur) if t.is_cuda else None)
+                yield item
+        finally:
+            stop.set()
+            while th.is_alive():           # unblock a producer waiting on a full queue
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    th.join(timeout=0.05)
+
+
+class SyntheticSeptuplets:
+    """Endless stream of data['GT'] batches (B,C,T,H,W), uniform [0,1), drawn on `device` from its own generator
+    (seed: per rank).  What tools/train_synthetic.py and bench_train.py feed - Vimeo-shaped crops without a dataset."""
+
+    def __init__(self, batch: int, t_len: int, size: int, device, seed: int):
+        self.shape = (batch, 3, t_len, size, size)
+        self.device = torch.device(device)
+        self.gen = torch.Generator(device=self.device).manual_seed(seed)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return {"GT": torch.rand(self.shape, device=self.device, generator=self.gen)}

@@ -104,9 +104,10 @@ def rank_seed(base: int, rank: int) -> int:
 
 
 def timed_region(step: Callable[[], None], steps: int, warmup: int, ranks: Ranks,
-                 sync: Callable[[], None] = lambda: None) -> float:
+                 sync: Callable[[], None] = lambda: None, info: Optional[dict] = None) -> float:
     """The benchmark contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + device sync on
-    both sides; returns the MAX over ranks of the elapsed seconds."""
+    both sides; returns the MAX over ranks of the elapsed seconds.  `info` (optional) receives this rank's own time up to
+    its device sync, before the closing barrier ("local_seconds")."""
     for _ in range(warmup):
         step()
     ranks.barrier()
@@ -115,7 +116,10 @@ def timed_region(step: Callable[[], None], steps: int, warmup: int, ranks: Ranks
     for _ in range(steps):
         step()
     sync()
+    local = time.perf_counter() - t0
     ranks.barrier()
+    if info is not None:
+        info["local_seconds"] = local
     return ranks.max(time.perf_counter() - t0)
 
 

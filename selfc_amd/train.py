@@ -10,8 +10,16 @@ same names and option keys, around the HIP-backed ``SelfCInvNet``:
                        clip, Adam step)
 
 Forward, reverse and every gradient run on the HIP kernels (selfc_amd/autograd.py); the loss reductions, the clip and
-Adam are the reference's own torch calls.  Multi-GPU: wrap ``net`` in DistributedDataParallel exactly as the reference
-does (SelfC_model.py:42) - parameter gradients are ordinary ``.grad`` tensors, one 13.46 MB all-reduce per step.
+Adam are the reference's own torch calls.
+
+Multi-GPU (SelfC_model.py:41-44, data/__init__.py:13-14: DistributedDataParallel around netG, global batch split over the
+ranks).  Default here: pass the PLAIN net while torch.distributed is initialised with more than one rank - the trainer
+then keeps the flat gradient buffer, broadcasts rank 0's parameters once, and between backward and clip issues ONE
+all-reduce (SUM, / world) of that 13.5 MB buffer over RCCL (``GradSink.all_reduce``): the same averaged gradients DDP's
+hooks produce, with the kernels still accumulating in place and the step still capturable (``capture()`` records
+[zero, forward, backward] and [clip, Adam] as two hipGraphs with the collective between them).  Fallback: wrap the net in
+DistributedDataParallel exactly as the reference does - parameter gradients are then ordinary ``.grad`` tensors that pass
+through autograd and DDP's buckets (no flat buffer, no capture).
 """
 from __future__ import annotations
 
@@ -104,15 +112,20 @@ class RescaleTrainer:
     pixel_criterion_forw/back, lambda_fit_forw, lambda_rec_back, lambda_cond_prob, gradient_clipping, lr_scheme,
     lr_steps, lr_gamma, restarts, restart_weights, clear_state."""
 
-    def __init__(self, netG: nn.Module, train_opt: dict, capturable: bool = False, flat_grads: bool = None):
+    def __init__(self, netG: nn.Module, train_opt: dict, capturable: bool = False, flat_grads: bool = None,
+                 data_parallel: bool = None, process_group=None):
         """capturable: prepare the optimizer for `capture()` (device-side step counter and learning rate).
         flat_grads: the parameters' `.grad` are views of ONE buffer that the weight-gradient kernels accumulate into
         directly (autograd.GradSink: no per-tensor accumulation launches, one memset instead of zero_grad, the clip on the
         flat buffer).  Default: on, unless the net is wrapped in DistributedDataParallel (its hooks need the gradients to
-        pass through autograd)."""
+        pass through autograd).
+        data_parallel: average the flat gradient buffer over the ranks of `process_group` once per step (module
+        docstring).  Default: on when torch.distributed is initialised with more than one rank and the net is not
+        wrapped in DistributedDataParallel; needs flat_grads."""
         self.netG = netG
         self.capturable = capturable
         self.graph = None
+        self.graph_tail = None
         self.train_opt = train_opt
         self.Quantization = Quantization()
         self.netG.train()
@@ -135,9 +148,32 @@ class RescaleTrainer:
             raise NotImplementedError("MultiStepLR learning rate scheme is enough.")
         self.log_dict = OrderedDict()
         self.grad_norm = None
+        is_ddp = isinstance(netG, nn.parallel.DistributedDataParallel)
         if flat_grads is None:
-            flat_grads = not isinstance(netG, nn.parallel.DistributedDataParallel) and optim_params[0].is_cuda
+            flat_grads = not is_ddp and optim_params[0].is_cuda
         self.sink = ag.GradSink(optim_params) if flat_grads else None
+        self.process_group = process_group
+        self.world = 1
+        if data_parallel is None:
+            import torch.distributed as dist
+            data_parallel = (not is_ddp and self.sink is not None and dist.is_available() and dist.is_initialized()
+                             and dist.get_world_size(process_group) > 1)
+        self.data_parallel = bool(data_parallel)
+        if self.data_parallel:
+            import torch.distributed as dist
+            if is_ddp:
+                raise RuntimeError("data_parallel=True averages the flat gradient buffer itself: pass the plain net, not a DistributedDataParallel wrapper")
+            if self.sink is None:
+                raise RuntimeError("data_parallel=True needs flat_grads (the collective runs on the flat gradient buffer)")
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("data_parallel=True needs an initialised torch.distributed process group")
+            self.world = dist.get_world_size(process_group)
+            # what DistributedDataParallel does at construction: every rank starts from rank 0's parameters and buffers
+            src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+            with torch.no_grad():
+                for t_ in list(nn.Module.parameters(netG)) + list(netG.buffers()):
+                    dist.broadcast(t_.data, src, group=process_group)
+            rt.invalidate_weights()
         self.before_clip = None          # optional callable(trainer): runs after backward, before clipping (tests, logging)
 
     def loss_forward(self, out, y):
@@ -147,8 +183,8 @@ class RescaleTrainer:
         x_samples, _ = self.netG(x=y, rev=True)
         return self.train_opt["lambda_rec_back"] * self.Reconstruction_back(x, x_samples[:, :3, :, :])
 
-    def _step(self, real_H: torch.Tensor, ref_L: torch.Tensor):
-        """optimize_parameters (SelfC_model.py:153-176) up to and including optimizer.step(); returns the loss tensors."""
+    def _forward_backward(self, real_H: torch.Tensor, ref_L: torch.Tensor):
+        """optimize_parameters (SelfC_model.py:153-170) up to and including loss.backward(); returns the loss tensors."""
         output, loss_c = self.netG(x=real_H, rev=False)
         loss_c = loss_c.mean() * self.train_opt.get("lambda_cond_prob", 0)
         lr_before_quant = output[:, :3, :, :]
@@ -158,6 +194,17 @@ class RescaleTrainer:
         loss = (l_forw_fit + l_back_rec + loss_c) * 144 * 144 * 3
         with ag.grad_sink(self.sink):
             loss.backward()
+        if self.sink is not None:
+            self.sink.detach_untouched()       # tensors the backward did not reach: .grad None, as with stock autograd
+        return l_forw_fit.detach(), l_back_rec.detach(), loss_c.detach(), loss.detach()
+
+    def _sync_grads(self):
+        """The data-parallel step's one collective: all-reduce (SUM, / world) of the flat gradient buffer."""
+        if self.data_parallel:
+            self.sink.all_reduce(self.process_group, average=True)
+
+    def _clip_and_step(self):
+        """gradient clipping + optimizer step (SelfC_model.py:172-176)."""
         if self.before_clip is not None:
             self.before_clip(self)
         max_norm = self.train_opt.get("gradient_clipping")
@@ -168,7 +215,13 @@ class RescaleTrainer:
         elif max_norm:
             self.grad_norm = nn.utils.clip_grad_norm_(self.optim_params, max_norm)
         self.optimizer_G.step()
-        return l_forw_fit.detach(), l_back_rec.detach(), loss_c.detach(), loss.detach()
+
+    def _step(self, real_H: torch.Tensor, ref_L: torch.Tensor):
+        """optimize_parameters (SelfC_model.py:153-176) up to and including optimizer.step(); returns the loss tensors."""
+        losses = self._forward_backward(real_H, ref_L)
+        self._sync_grads()
+        self._clip_and_step()
+        return losses
 
     def _log(self, losses):
         l_forw_fit, l_back_rec, loss_c, loss = losses
@@ -207,20 +260,35 @@ class RescaleTrainer:
                 self._step(self._static_h, self._static_l)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
         if self.sink is None:
             self.optimizer_G.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        if not self.data_parallel:
+            with torch.cuda.graph(g):
+                if self.sink is not None:
+                    self.sink.zero()                 # part of the replayed step
+                self._static_losses = self._step(self._static_h, self._static_l)
+            self.graph, self.graph_tail = g, None
+            return self
+        # data parallel: the collective stays OUTSIDE the captured regions (an RCCL call inside a hipGraph is not something
+        # this stack promises): graph 1 = zero + forward + backward, eager all-reduce of the flat buffer, graph 2 = clip + Adam
         with torch.cuda.graph(g):
-            if self.sink is not None:
-                self.sink.zero()                 # part of the replayed step
-            self._static_losses = self._step(self._static_h, self._static_l)
-        self.graph = g
+            self.sink.zero()
+            self._static_losses = self._forward_backward(self._static_h, self._static_l)
+        self._sync_grads()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, pool=g.pool()):
+            self._clip_and_step()
+        self.graph, self.graph_tail = g, g2
         return self
 
     def replay(self, real_H: torch.Tensor, ref_L: torch.Tensor):
         self._static_h.copy_(real_H)
         self._static_l.copy_(ref_L)
         self.graph.replay()
+        if self.graph_tail is not None:
+            self._sync_grads()
+            self.graph_tail.replay()
         # the replayed Adam step rewrote the parameters without touching torch's version counters: packed-weight caches
         # keyed on (data_ptr, _version) would otherwise serve a later eager eval / validation pass stale weights
         rt.invalidate_weights()

@@ -121,3 +121,53 @@ def test_multistep_lr_restart_product_class_matches_reference_trace():
         sch2.step()
         lrs.append(opt2.param_groups[0]["lr"])
     assert abs(lrs[1] - 0.01) < 1e-12 and abs(lrs[3] - 1.0) < 1e-12 and len(opt2.state) == 0
+
+
+def test_prefetcher_preserves_sampler_order_and_batches():
+    """DevicePrefetcher (the loader side of SURVEY 8f3) must hand out exactly the batches of the loader it wraps, in order: the
+    DistIterSampler index stream pinned by G13 is unchanged by the background thread, with worker processes and at any depth."""
+    import torch.utils.data as tud
+    from selfc_amd.data import DevicePrefetcher, DistIterSampler
+
+    class Idx(tud.Dataset):
+        def __len__(self):
+            return 11
+
+        def __getitem__(self, i):
+            return {"GT": torch.full((3, 2, 4, 4), float(i)), "index": i}
+
+    g = load_golden("g13_sampler")
+    n, world, rank, epoch, ratio = g["cfgs"].tolist()[0]
+    ds = list(range(n))
+    s = DistIterSampler(ds, num_replicas=world, rank=rank, ratio=ratio)
+    s.set_epoch(epoch)
+
+    class Plain(tud.Dataset):
+        def __len__(self):
+            return n
+
+        def __getitem__(self, i):
+            return {"GT": torch.full((2, 2), float(i)), "index": i}
+    for workers, depth in ((0, 1), (2, 2), (2, 4)):
+        loader = tud.DataLoader(Plain(), batch_size=2, sampler=s, num_workers=workers, drop_last=True)
+        got = [b["index"].tolist() for b in DevicePrefetcher(loader, "cpu", depth=depth)]
+        want = g["idx0"].tolist()
+        want = [want[i:i + 2] for i in range(0, len(want) - len(want) % 2, 2)]
+        assert got == want, (workers, depth)
+    loader = tud.DataLoader(Idx(), batch_size=3, shuffle=False)
+    pf = DevicePrefetcher(loader, "cpu")
+    assert len(pf) == len(loader)
+    vals = [float(b["GT"][0, 0, 0, 0, 0]) for b in pf]
+    assert vals == [0.0, 3.0, 6.0, 9.0]
+    it = iter(pf)                      # abandoning an iterator half way must not hang (producer blocked on a full queue)
+    next(it)
+    del it
+
+    def broken():
+        yield {"GT": torch.zeros(1)}
+        raise ValueError("decode failed")
+    try:
+        list(DevicePrefetcher(broken(), "cpu"))
+        raise AssertionError("loader exception was swallowed")
+    except ValueError as e:
+        assert "decode failed" in str(e)

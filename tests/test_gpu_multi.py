@@ -39,13 +39,26 @@ def test_bench_two_gpus_self_launched():
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["value"] > 0
 
 
-def test_ddp_two_ranks_keep_equal_parameters():
-    """config 3 (train.py under torch.distributed.launch, README.md:85): after optimisation steps on DIFFERENT data the
-    ranks' parameters must be identical - DDP's gradient all-reduce over RCCL is the only thing that makes them so."""
-    _need_two()
+def _train2(*extra):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_synthetic.py"), "--gpus", "2", "--steps", "2",
-                        "--warmup", "1", "--global-batch", "2", "--size", "64"],
+                        "--warmup", "1", "--global-batch", "2", "--size", "64", *extra],
                        env=_clean_env(), capture_output=True, text=True, timeout=900)
     d = _json_line(p)
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["global_batch"] == 2
-    assert d["param_spread_over_ranks"] == 0.0
+    assert d["param_spread_over_ranks"] == 0.0       # ranks started from DIFFERENT seeds and saw different data
+    return d
+
+
+def test_ddp_two_ranks_keep_equal_parameters():
+    """config 3 (train.py under torch.distributed.launch, README.md:85): after optimisation steps on DIFFERENT data the
+    ranks' parameters must be identical - the gradient all-reduce over RCCL is the only thing that makes them so.  Three
+    legs: the default (flat gradient buffer, one all-reduce, step replayed as two hipGraphs around it), the same eager, and
+    the reference's DistributedDataParallel wrapper; the flat path must land where DDP lands."""
+    _need_two()
+    graphs = _train2()
+    assert "ONE all-reduce" in graphs["gradient_sync"] and graphs["launch"] == "hipGraph replay" and len(graphs["ms_per_step_per_rank"]) == 2
+    flat = _train2("--eager")
+    ddp = _train2("--ddp")
+    assert "DistributedDataParallel" in ddp["gradient_sync"]
+    assert abs(flat["param_sq_sum"] - ddp["param_sq_sum"]) < 1e-6 * ddp["param_sq_sum"]
+    assert abs(graphs["param_sq_sum"] - ddp["param_sq_sum"]) < 1e-5 * ddp["param_sq_sum"]

@@ -156,6 +156,51 @@ def test_train_synthetic_script_one_rank(dev):
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["loss"] == line["loss"]
 
 
+def test_train_synthetic_data_parallel_path_one_rank(dev):
+    """The data-parallel code path on ONE GPU: a one-rank RCCL group, RescaleTrainer(data_parallel=True) - rank-0 broadcast,
+    flat gradient buffer, the all-reduce between the two captured hipGraphs - fed by host batches through DevicePrefetcher
+    (pinned, H2D on a side stream).  Must land on the same parameters as the plain single-GPU captured step on the same data."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "tools", "train_synthetic.py"), "--steps", "3", "--warmup", "1", "--global-batch", "2", "--size", "64"]
+    lines = []
+    for extra in (["--dist-1"], ["--dist-1", "--eager", "--host-loader"], []):
+        out = subprocess.run(base + extra, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    dp, dp_host, plain = lines
+    assert "ONE all-reduce" in dp["gradient_sync"] and "two hipGraphs" in dp["gradient_sync"] and dp["launch"] == "hipGraph replay"
+    assert "DevicePrefetcher" in dp_host["data"] and dp_host["launch"] == "eager"
+    assert plain["gradient_sync"] == "single GPU"
+    assert all(d["loss"] == d["loss"] and d["value"] > 0 for d in lines)
+    assert abs(dp["param_sq_sum"] - plain["param_sq_sum"]) < 1e-6 * plain["param_sq_sum"]      # same seeds, same data, same graphed Adam
+
+
+def test_parameters_without_gradient_are_skipped_like_stock_autograd(dev):
+    """with the flat gradient buffer every parameter owns a zeroed .grad view; a parameter the backward does not
+    reach must still be skipped by Adam (no weight decay, no moment decay) exactly as with stock autograd accumulation."""
+    from selfc_amd import train
+    x = load_golden("g8_large_stack")["x"]
+    gt = x.reshape(1, T, 3, 32, 48).transpose(1, 2).to(dev)
+    real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
+    opt = dict(train.TRAIN_OPT_LARGE, weight_decay_G=0.1)
+    after = {}
+    for flat in (False, True):
+        net = _net(dev)
+        net.never_used = torch.nn.Parameter(torch.ones(17, device=dev))
+        tr = train.RescaleTrainer(net, opt, flat_grads=flat)
+        for _ in range(2):
+            tr.optimize_parameters(real_h, ref_l)
+        assert net.never_used.grad is None
+        after[flat] = net.never_used.detach().clone()
+        if flat:
+            assert len(tr.sink.untouched()) == 1 and float(tr.sink.flat.abs().max()) > 0
+    assert torch.equal(after[False], torch.ones(17, device=dev)) and torch.equal(after[True], after[False])
+
+
 def test_backward_argument_errors(dev):
     """The gradient entry points refuse bad arguments with SELFC_EINVAL -> RuntimeError, launching nothing."""
     from selfc_amd import _lib, runtime as rt
