@@ -857,15 +857,24 @@ int launch_t5(const T5Args& a, hipStream_t s) {
   return hip_rc(hipGetLastError());
 }
 
-// dispatch over the compiled (outch tiles, dense k-steps) combinations
+// dispatch over the compiled (outch tiles, dense k-steps) combinations.  Only what a caller can reach is instantiated: F's
+// conv5 (one net, no fp32 x input) has one outch tile and 5..7 dense k-steps (c2 <= 32 / 64 / 96); the G/H pair always has the
+// four feature planes and 1..4 outch tiles (c2 <= 64); stand-alone subnets (EPI_PLAIN) keep the full table.  (The unreachable
+// G/H combinations with 5 or 6 k-steps spilled.)
 template <int NETS, int HASX, int EPI>
 int dispatch_t5(const T5Args& a, int ot, int kd, hipStream_t s) {
 #define SELFC_T5_CASE(OT_, KD_) \
   if (ot == OT_ && kd == KD_) return launch_t5<NETS, OT_, KD_, HASX, EPI>(a, s);
-  SELFC_T5_CASE(1, 4) SELFC_T5_CASE(1, 5) SELFC_T5_CASE(1, 6) SELFC_T5_CASE(1, 7)
-  SELFC_T5_CASE(2, 4) SELFC_T5_CASE(2, 5) SELFC_T5_CASE(2, 6)
-  SELFC_T5_CASE(3, 4) SELFC_T5_CASE(3, 5) SELFC_T5_CASE(3, 6)
-  SELFC_T5_CASE(4, 4) SELFC_T5_CASE(4, 5) SELFC_T5_CASE(4, 6)
+  if constexpr (NETS == 1) {
+    SELFC_T5_CASE(1, 4) SELFC_T5_CASE(1, 5) SELFC_T5_CASE(1, 6) SELFC_T5_CASE(1, 7)
+    if constexpr (EPI != EPI_F) {          // stand-alone subnets (selfc_subnet_run): up to 128 output channels
+      SELFC_T5_CASE(2, 4) SELFC_T5_CASE(2, 5) SELFC_T5_CASE(2, 6)
+      SELFC_T5_CASE(3, 4) SELFC_T5_CASE(3, 5) SELFC_T5_CASE(3, 6)
+      SELFC_T5_CASE(4, 4) SELFC_T5_CASE(4, 5) SELFC_T5_CASE(4, 6)
+    }
+  } else {
+    SELFC_T5_CASE(1, 4) SELFC_T5_CASE(2, 4) SELFC_T5_CASE(3, 4) SELFC_T5_CASE(4, 4)
+  }
 #undef SELFC_T5_CASE
   return SELFC_EINVAL;
 }

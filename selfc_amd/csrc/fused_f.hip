@@ -139,13 +139,9 @@ __device__ __forceinline__ void merged_steps(const unsigned char* __restrict__ w
   if (RD > 2 && NS > 1) load_step(1);
   static_for<0, NS>([&](auto si) __attribute__((always_inline)) {
     constexpr int st = decltype(si)::value;
-#ifdef SELFC_EXP_NOLDS      // timing experiment (results are wrong, data stays ordinary): every step multiplies the FIRST step's fragments
-    constexpr int s = 0;
-#else
     if constexpr (st + RD - 1 < NS) load_step(st + RD - 1);
     __builtin_amdgcn_sched_barrier(0);
     constexpr int s = st % RD;
-#endif
     acc1c = mfma_32x32x16(rA1[s], rBc[s], acc1c);
     acc2 = mfma_32x32x16(rA2[s], rBc[s], acc2);
     if (RING) acc1r = mfma_32x32x16(rA1[s], rBr[s], acc1r);
@@ -168,13 +164,9 @@ __device__ __forceinline__ void fm_steps(const unsigned char* __restrict__ wl, c
   load_step(1);
   static_for<0, 18>([&](auto si) __attribute__((always_inline)) {
     constexpr int st = decltype(si)::value;
-#ifdef SELFC_EXP_NOLDS
-    acc2 = mfma_32x32x16(rA[0], rB[0], acc2);
-#else
     if constexpr (st + 2 < 18) load_step(st + 2);
     __builtin_amdgcn_sched_barrier(0);
     acc2 = mfma_32x32x16(rA[st % 3], rB[st % 3], acc2);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     post(si);
   });
@@ -217,9 +209,6 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
   c.tid = threadIdx.x;
   c.lane = c.tid & 63;
   c.wave = c.tid >> 6;
-#ifdef SELFC_EXP_PRIO      // experiment: static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH "Two waves per SIMD" item 4)
-  if (c.wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
   c.half = c.lane >> 5;
   {
     const int i = c.lane & 15, row2 = (c.lane >> 4) & 1;
@@ -532,11 +521,7 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
     constexpr int NCHUNK = G::NFRAG / CH3;   // 12
 
     for (int n = f0; n < a.N; n += gf) {
-#ifdef SELFC_EXP_NOX        // timing experiment only (results are wrong): what do the halo loads / stores cost?
-      const bool more = false;
-#else
       const bool more = n + gf < a.N;
-#endif
       STAMP(ts0);
       if (more) x_target(n + gf);
       f32x16 acc1c = bias_init(lb, c.half), acc1r = acc1c, acc2 = bias_init(lb + 32, c.half);
@@ -548,12 +533,6 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
       auto wfrag = [&](const int f) __attribute__((always_inline)) { return wb + ((f / CH3) % 3) * CH3 * 1024 + (f % CH3) * 1024; };
       // Behind barrier cidx (merged step 6 cidx + 2): steps +1, +2 commit chunk cidx+2, steps +3, +4 prefetch chunk cidx+4.
       auto chunk_task = [&](const int cidx, const int j) __attribute__((always_inline)) {
-#ifdef SELFC_EXP_NOW        // timing experiment only (results are wrong): what does the weight streaming cost?
-        return;
-#endif
-#ifdef SELFC_EXP_NOW2       // the same with ORDINARY data: the first tile streams (all three buffers hold real fragments), later tiles do not
-        if (n != f0) return;
-#endif
         if (j == 1 || j == 2) w_commit_item((cidx + 2) % 3, cidx & 1, j - 1);
         if (j == 3 || j == 4) w_prefetch_item((cidx + 4) % NCHUNK, cidx & 1, j - 3);
       };
@@ -568,11 +547,7 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
               p_feat(accp, 0, vc);
             }
           }
-#ifdef SELFC_EXP_NOBAR      // timing experiment only (results are wrong): what do the mid-chunk barriers cost?
-          if constexpr (g / 6 == 10) __syncthreads();
-#else
           __syncthreads();
-#endif
         } else if constexpr (g >= 3) {
           chunk_task((g - 3) / 6, g - (6 * ((g - 3) / 6) + 2));
         }

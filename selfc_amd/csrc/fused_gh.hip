@@ -124,12 +124,6 @@ struct Ctx {
 template <int OFF, int NFR>
 __device__ __forceinline__ void w_prefetch(Ctx& c) {
   if (WRES && !c.first) return;
-#ifdef SELFC_EXP_NOW        // timing experiment: no weight streaming
-  return;
-#endif
-#ifdef SELFC_EXP_NOW2       // timing experiment (results are wrong): no weight streaming after the prologue, which leaves REAL fragments
-  if (!c.first) return;     // in both buffers - finite, ordinary-looking data (an MFMA on garbage / zeros clocks differently)
-#endif
 #pragma unroll
   for (int it = 0; it < WITER; ++it) {
     const int i = min(c.tid + it * NTHR, NFR * 64 - 1);
@@ -139,12 +133,6 @@ __device__ __forceinline__ void w_prefetch(Ctx& c) {
 template <int OFF, int NFR>
 __device__ __forceinline__ void w_commit(Ctx& c) {
   if (WRES && !c.first) return;
-#ifdef SELFC_EXP_NOW
-  return;
-#endif
-#ifdef SELFC_EXP_NOW2
-  if (!c.first) return;
-#endif
   // streamed: the other half of the double buffer; resident (depth 3, first tile only): the chunk's own place
   unsigned char* dst = c.smem + OFF_W + (WRES ? OFF * 1024 : (c.par ^ 1) * W_BYTES);
 #pragma unroll
@@ -186,13 +174,6 @@ __device__ __forceinline__ void mtile_geom(const Ctx& c, const int m, int& r, in
 template <int K, int MT>
 __device__ __forceinline__ void epi_piece(const Ctx& c, const FGArgs& a, const int net, const size_t fofs, const int ty0, const int tx0,
                                           const f32x16 (&acc)[MT], uint32_t (&rr)[MT][4][2], const int p) {
-#ifdef SELFC_EXP_NOEPI      // timing experiment: no epilogue at all (every accumulator kept live: see SELFC_EXP_NOGST)
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-  for (int m = 0; m < MT; ++m) asm volatile("" :: "v"(acc[m]));
-#endif
-  return;
-#endif
   if (p < 4 * MT) {
     const int m = p >> 2, g = p & 3;
     rr[m][g][0] = lrelu_pack2(acc[m][4 * g + 0], acc[m][4 * g + 1]);
@@ -224,27 +205,15 @@ __device__ __forceinline__ void epi_piece(const Ctx& c, const FGArgs& a, const i
       v[2 + d] = sw[1] & keep;
     }
     if (valid) {
-#ifndef SELFC_EXP_NOLST      // timing experiment: no feature stores to LDS
       if (K < DEPTH) {
         constexpr int pitch = FeatGeom<(K < DEPTH ? K : 1)>::pitch;
         *reinterpret_cast<u32x4*>(c.smem + FeatGeom<(K < DEPTH ? K : 1)>::off + r * pitch + cc * PS + (16 * gp + 8 * c.half) * 2) = v;
       }
-#endif
       const bool centre = (ar >= 0) & (ar < TS) & (ac >= 0) & (ac < TS);
-#ifdef SELFC_EXP_NOGST       // timing experiment: no feature stores to HBM.  The value and its address stay LIVE: dropping the
-      // store alone makes conv4 dead code (its only consumer) and hipcc deletes its 57 MFMA steps - that artefact, not the
-      // stores, was the "-31 %" first measured with this switch (cdna_hip_programming.md rule 17)
-      if (centre && inimg) asm volatile("" :: "v"(v), "v"(dplane + fofs + (unsigned)((y * a.W + x) * 32 + 16 * gp + 8 * c.half)));
-#else
       if (centre && inimg) {
-#ifdef SELFC_EXP_STL2       // timing experiment (results are wrong): every workgroup stores into the same 32 KiB (L2-resident)
-        gf16* const dst = dplane + (unsigned)(((ar * TS + ac) & 255) * 32 + 16 * gp + 8 * c.half) + (K - 1) * 8192;
-#else
         gf16* const dst = dplane + fofs + (unsigned)((y * a.W + x) * 32 + 16 * gp + 8 * c.half);
-#endif
         *(gu32x4*)dst = v;
       }
-#endif
     }
   }
 }
@@ -364,29 +333,11 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
       if (i < NS) load_step(i, ringA[i], ringB[i]);
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
-#ifndef SELFC_EXP_NOLDS
       if (st + RD - 1 < NS) load_step(st + RD - 1, ringA[(st + RD - 1) % RD], ringB[(st + RD - 1) % RD]);
-#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < MTE; ++m) {
-#if defined(SELFC_EXP_NOMFMA)          // timing experiment: everything but the MFMAs
-        acc[m][0] += (float)ringA[st % RD][0] * (float)ringB[st % RD][m][0];
-#elif defined(SELFC_EXP_MFMA16)        // timing experiment (results are garbage): the same MACs as two 16x16x32 MFMAs
-        {
-          const int q0 = (st & 1) * 2;   // compile-time after the unroll
-          f32x4 a0 = {acc[m][4 * q0], acc[m][4 * q0 + 1], acc[m][4 * q0 + 2], acc[m][4 * q0 + 3]};
-          f32x4 a1 = {acc[m][4 * q0 + 4], acc[m][4 * q0 + 5], acc[m][4 * q0 + 6], acc[m][4 * q0 + 7]};
-          a0 = mfma_16x16x32(ringA[st % RD], ringB[st % RD][m], a0);
-          a1 = mfma_16x16x32(ringA[st % RD], ringB[st % RD][m], a1);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { acc[m][4 * q0 + e] = a0[e]; acc[m][4 * q0 + 4 + e] = a1[e]; }
-        }
-#elif defined(SELFC_EXP_NOLDS)         // timing experiment: MFMAs on the first step's fragments only
-        acc[m] = mfma_32x32x16(ringA[0], ringB[0][m], acc[m]);
-#else
         acc[m] = mfma_32x32x16(ringA[st % RD], ringB[st % RD][m], acc[m]);
-#endif
       }
       __builtin_amdgcn_sched_barrier(0);
       // the pending epilogue of conv K-1: one piece (ten-odd VALU instructions, or one M-tile's stores) per step
@@ -431,9 +382,6 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
   c.tid = threadIdx.x;
   c.lane = c.tid & 63;
   c.wave = c.tid >> 6;
-#ifdef SELFC_EXP_PRIO      // experiment: static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH "Two waves per SIMD" item 4)
-  if (c.wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
   c.half = c.lane >> 5;
   c.par = 0;
   c.first = true;
@@ -505,11 +453,6 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
   c.par = 1;            // w_commit writes buffer par^1 = 0
   c.first = true;
   w_commit<LAYER_OFF[2], 21>(c);
-#ifdef SELFC_EXP_NOW2
-  c.par = 0;
-  w_commit<LAYER_OFF[2], 21>(c);          // the same fragments into the other buffer as well
-  c.first = false;
-#endif
   __syncthreads();
   c.par = 0;
 
@@ -521,9 +464,7 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
     if (more) x_load(n + gf);                     // lands while this tile computes
     const size_t fofs = (size_t)n * fpix * 32;
     AccPair acc2, acc3;
-#ifndef SELFC_EXP_NOC1      // timing experiment (results are wrong): what does conv1's phase (MFMAs + immediate epilogue + barrier) cost?
     conv_fused<1>(c, a, net, xbuf, fofs, ty0, tx0, nullptr, nullptr);
-#endif
     conv_fused<2, TWO2>(c, a, net, xbuf, fofs, ty0, tx0, nullptr, &acc2);
     if (DEPTH == 3) {
       if (more) x_store(xbuf ^ 1);                // before the last conv's feature stores (see conv_fused: one VM counter)

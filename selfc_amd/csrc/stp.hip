@@ -377,9 +377,10 @@ __global__ __launch_bounds__(NW * 64) void stp_head_gmm_kernel(const float* __re
   stage(0);
   stage(1);
   stage(2);
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(GL) : "memory");               // chunks 0, 1 (W0 | W1) landed; chunk 2 in flight
+  // chunks 0, 1 (W0 | W1) landed, chunk 2 in flight; the lbias ds_writes above retired (lgkmcnt) BEFORE the raw barrier - a
+  // bare s_barrier waits for no counter, so without it a wave could pass with its bias rows still in flight
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(GL) : "memory");
   __builtin_amdgcn_s_barrier();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   const float slope = act == 2 ? 0.f : 0.2f;
   // one tile of layer L (KSL k-steps over the fragments at LDS offset fbase), bias, activation, packed to two dwords

@@ -11,6 +11,7 @@ import torch.nn.functional as F
 
 from .. import _lib, runtime as rt
 from ..global_var import GlobalVar
+from .module_util import HeadOutput
 from .Inv_arch import InvBlockExp  # noqa: F401  (same class, as in the reference's three copies)
 from .Subnet_constructor import D2DTInput, subnet
 
@@ -374,7 +375,7 @@ class STPNet(nn.Module):
         :377 - ``parameters``, which shadows nn.Module.parameters on this instance (callers such as the reference's
         ``neg_llh`` read ``stp_net.parameters`` as a tensor; nothing in selfc_amd calls ``stp_net.parameters()``)."""
         self.stp_parameters = raw5d
-        self.parameters = raw5d
+        self.parameters = HeadOutput.wrap(raw5d, self)     # a tensor, as in the reference - and still callable (module_util.HeadOutput)
 
     @property
     def gmm(self):

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 from .. import _lib, runtime as rt
 from ..global_var import GlobalVar
+from .module_util import HeadOutput
 from .Inv_arch import HaarDownsampling, InvBlockExp
 from .Subnet_constructor import D2DTInput, FeatureCalapseBlock, subnet
 
@@ -77,7 +78,7 @@ class STPNet(nn.Module):
         """as the reference: ``self.parameters`` = the head output (shadowing nn.Module.parameters, :149,153), plus
         ``stp_parameters``"""
         self.stp_parameters = raw5d
-        self.parameters = raw5d
+        self.parameters = HeadOutput.wrap(raw5d, self)     # a tensor, as in the reference - and still callable (module_util.HeadOutput)
 
     def _gmm_head(self, feat, b, t, h, w):
         """feat fp32 NHWC (n,h,w,c) -> publishes parameters (b,135,t,h,w) and gmm_v (b,9,t,h,w) (:151-163)"""

@@ -4,6 +4,7 @@ Only ``nn.Conv2d`` / ``nn.Linear`` / ``nn.BatchNorm2d`` are touched: ``nn.Conv3d
 layers keep PyTorch's default init (SURVEY trap 4), which is why D2DTInput's
 "INN_init" leaves conv5 non-zero while DenseBlock's conv5 starts at zero.
 """
+import torch
 import torch.nn as nn
 import torch.nn.init as init
 
@@ -28,3 +29,30 @@ def initialize_weights(net_l, scale=1):
 
 def initialize_weights_xavier(net_l, scale=1):
     _apply(net_l, init.xavier_normal_, scale)
+
+
+class HeadOutput(torch.Tensor):
+    """The tensor an STP net publishes as ``self.parameters`` (the reference assigns the raw head output to that name,
+    SelfC_GMM_arch_inv.py:377 / SelfC_arch_inv.py:149,153, shadowing ``nn.Module.parameters`` on the instance).  Reading it
+    behaves as the reference's tensor does (shape, indexing, arithmetic - results are plain tensors, autograd intact); CALLING
+    it still yields the module's parameters, so ``Adam(stp_net.parameters())``, ``stp_net.zero_grad()`` or wrapping the
+    sub-module in DistributedDataParallel keep working after the first forward, and ``copy.deepcopy(net)`` copies it detached
+    instead of failing on a non-leaf tensor."""
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @staticmethod
+    def wrap(t: torch.Tensor, owner: nn.Module) -> "HeadOutput":
+        import weakref
+        out = t.as_subclass(HeadOutput)
+        out._owner = weakref.ref(owner)
+        return out
+
+    def __call__(self, recurse: bool = True):
+        owner = self._owner() if getattr(self, "_owner", None) is not None else None
+        if owner is None:
+            raise TypeError("this head output is no longer attached to its STP module")
+        return nn.Module.parameters(owner, recurse)
+
+    def __deepcopy__(self, memo):
+        return self.detach().clone().as_subclass(torch.Tensor)

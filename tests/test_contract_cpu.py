@@ -93,3 +93,24 @@ def test_public_api_matches_reference():
             want = [list(p) for p in ref[what]]
             assert ours[:len(want)] == want, (name, what, ours, want)
             assert all(d is not None for _, d in ours[len(want):]), (name, what, "extra parameters must have defaults")
+
+
+def test_head_output_is_a_tensor_and_still_yields_module_parameters():
+    """the STP nets publish the head output as ``self.parameters`` exactly as the reference does (a tensor that
+    shadows nn.Module.parameters); here that tensor stays callable, so optimizers / zero_grad / deepcopy on the sub-module
+    keep working after the first forward."""
+    import copy
+    import torch.nn as nn
+    from selfc_amd.modules.module_util import HeadOutput
+    m = nn.Linear(3, 2)
+    y = m(torch.randn(4, 3))
+    m.parameters = HeadOutput.wrap(y, m)
+    assert torch.is_tensor(m.parameters) and m.parameters.shape == (4, 2)
+    assert type(m.parameters * 2) is torch.Tensor and (m.parameters * 2).requires_grad      # plain results, graph intact
+    assert [p.shape for p in m.parameters()] == [(2, 3), (2,)]
+    m.zero_grad()
+    torch.optim.Adam(m.parameters())
+    (m.parameters ** 2).sum().backward()
+    assert m.weight.grad is not None
+    c = copy.deepcopy(m)                                                                    # non-leaf attribute: copied detached
+    assert type(c.parameters) is torch.Tensor and not c.parameters.requires_grad

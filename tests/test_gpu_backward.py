@@ -207,6 +207,20 @@ def test_stack_backward_chain(dev):
     gref = {k: v.grad for k, v in p.items()}
     errs = {n_: rel_l2(p_.grad.cpu(), gref[n_]) for n_, p_ in blocks.named_parameters()}
     print("worst", sorted(errs.items(), key=lambda kv: -kv[1])[:5])
+    # Two bars.  (1) All 60 tensors together: ||g - g_ref|| / ||g_ref|| over the concatenated gradients - the quantity an
+    # optimizer step sees.  (2) Per tensor 5e-2: the worst single tensor sits at ~4.4e-2 on this 12x8 latent, and that figure is
+    # a kink lottery, not kernel error - the f16 forward puts a handful of pre-activations (|v| < ~1e-3) on the other side of
+    # LeakyReLU's kink than the fp32 oracle, each flip changes that pixel's contribution to a 32-channel gradient row by a factor
+    # 5, and a bias gradient of a late conv sums only 7 x 96 pixels.  With the masks frozen to the forward's own
+    # (test_subnet_backward, bar (1): <= 3e-3 max-norm) and against the reference's whole training
+    # step on 36x36 latents (G11, test_gpu_train: gradient norms 1.7e-4) the same kernels are two orders tighter.
+    from conftest import record
+    num = sum(float((p_.grad.cpu().double() - gref[n_].double()).pow(2).sum()) for n_, p_ in blocks.named_parameters())
+    den = sum(float(gref[n_].double().pow(2).sum()) for n_, _ in blocks.named_parameters())
+    total = (num / den) ** 0.5
+    record("stack backward chain (2 blocks fwd + rev), relative L2 over ALL parameter gradients", total)
+    record("stack backward chain, worst single tensor relative L2 (f16-forward LeakyReLU kink lottery)", max(errs.values()))
+    assert total < 1e-2, total          # measured 3.4e-3
     assert max(errs.values()) < 5e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
 
 
