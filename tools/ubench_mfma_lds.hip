@@ -1,0 +1,150 @@
+// Micro-benchmark: what one CU sustains on the fused kernels' inner-loop SHAPE - MFMA 32x32x16 f16 fed from LDS through a
+// 3-deep register ring, 4 or 8 waves per workgroup (1 or 2 per SIMD), with / without the per-chunk workgroup barrier and the
+// one-LDS-store-per-step hook.  Answers, on the device and on random operands (MI355X_MICROARCH.md "DVFS give-back"), what a
+// tile design can reach before it is written: cycles per MFMA per SIMD and the clock the chip holds.
+//
+//   hipcc -O3 --offload-arch=gfx950 tools/ubench_mfma_lds.hip -o tools/ubench_mfma_lds && tools/ubench_mfma_lds
+//
+// Per step a wave reads NA weight fragments (shared by all waves, like the A operands of the convs) and NB activation
+// fragments (its own pixels) and issues NA x NB MFMAs.  Product shapes: fused F non-ring wave = <8 waves, NA 2, NB 1>
+// (3 reads / 2 MFMAs), ring wave ~ <NA 2, NB 2> minus one; the "two M-tiles per wave on 4 waves" design = <4, 2, 2>.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <algorithm>
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int LDS_BYTES = 128 * 1024;
+constexpr int NFRAG_A = 48;                 // weight fragments cycled through (48 KiB)
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+// MODE bits: 1 = LDS reads in the loop, 2 = barrier every 6 steps, 4 = one ds_write_b128 per step (the hook)
+template <int WAVES, int NA, int NB, int MODE>
+__global__ __launch_bounds__(WAVES * 64) void loop_kernel(const u32x4* __restrict__ src, float* __restrict__ out, int outer,
+                                                          unsigned long long* __restrict__ stamps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < LDS_BYTES / 16; i += WAVES * 64) *reinterpret_cast<u32x4*>(smem + i * 16) = src[i];
+  __syncthreads();
+  const unsigned char* wa = smem + lane * 16;                                     // weight fragments: 1 KiB each, lane-linear
+  const unsigned char* wb = smem + NFRAG_A * 1024 + wave * (8 * 1024) + lane * 16;   // this wave's activation fragments (8 KiB window)
+  unsigned char* wdst = smem + NFRAG_A * 1024 + 8 * 8 * 1024 + tid * 16;         // hook store target (never read)
+  f32x16 acc[NA][NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  f16x8 rA[3][NA], rB[3][NB];
+  constexpr int STEPS = 48;                                 // unrolled steps per outer iteration (multiple of 6 and 3)
+  auto load_step = [&](const int st) __attribute__((always_inline)) {
+    const int s = st % 3;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) rA[s][i] = *reinterpret_cast<const f16x8*>(wa + ((st * NA + i) % NFRAG_A) * 1024);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rB[s][j] = *reinterpret_cast<const f16x8*>(wb + ((st * NB + j) % 8) * 1024);
+  };
+  load_step(0);
+  load_step(1);
+  load_step(2);
+  unsigned long long t0, t1, r0, r1;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
+  const u32x4 hookv = {1u, 2u, 3u, 4u};
+  for (int it = 0; it < outer; ++it) {
+    static_for<0, STEPS>([&](auto si) __attribute__((always_inline)) {
+      constexpr int st = decltype(si)::value;
+      if constexpr ((MODE & 1) != 0) load_step(st + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int s = (MODE & 1) ? st % 3 : 0;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rA[s][i], rB[s][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((MODE & 4) != 0) *reinterpret_cast<u32x4*>(wdst + (st % 2) * 8192) = hookv;
+      if constexpr ((MODE & 2) != 0 && st % 6 == 2) __syncthreads();
+    });
+  }
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
+  out[(size_t)blockIdx.x * WAVES * 64 + tid] = sum;
+  if (lane == 0) {
+    stamps[((size_t)blockIdx.x * WAVES + wave) * 2 + 0] = t1 - t0;
+    stamps[((size_t)blockIdx.x * WAVES + wave) * 2 + 1] = r1 - r0;
+  }
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int WAVES, int NA, int NB, int MODE>
+void run(const u32x4* src, float* out, unsigned long long* stamps, const char* label) {
+  constexpr int STEPS = 48;
+  const int grid = 256, outer = 400;
+  auto kern = loop_kernel<WAVES, NA, NB, MODE>;
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), LDS_BYTES, 0, src, out, outer, stamps);
+  CK(hipDeviceSynchronize());
+  const int reps = 10;
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), LDS_BYTES, 0, src, out, outer, stamps);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> h((size_t)grid * WAVES * 2);
+  CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<double> cyc, clk;
+  for (size_t i = 0; i < h.size(); i += 2) { cyc.push_back((double)h[i]); clk.push_back((double)h[i] / (double)h[i + 1] * 0.1); }
+  std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
+  const double med_cyc = cyc[cyc.size() / 2], med_clk = clk[clk.size() / 2];
+  const double mfma_per_simd = (double)outer * STEPS * NA * NB * (WAVES / 4);
+  const double tf = (double)grid * WAVES * outer * STEPS * NA * NB * 32768.0 * reps / (ms * 1e-3) / 1e12;
+  printf("%-58s waves %d NA %d NB %d reads/MFMA %.2f | %6.1f cyc/MFMA/SIMD  clock %.2f GHz  %7.1f TFLOP/s (chip, 256 WGs)  %.3f ms/launch\n",
+         label, WAVES, NA, NB, (MODE & 1) ? (double)(NA + NB) / (NA * NB) : 0.0, med_cyc / mfma_per_simd, med_clk, tf, ms / reps);
+  fflush(stdout);
+}
+
+int main() {
+  u32x4* src; float* out; unsigned long long* stamps;
+  CK(hipMalloc(&src, LDS_BYTES)); CK(hipMalloc(&out, 256 * 512 * 4)); CK(hipMalloc(&stamps, 256 * 8 * 2 * 8));
+  std::vector<f16> h(LDS_BYTES / 2);
+  srand(1);
+  for (auto& v : h) v = (f16)((rand() / (float)RAND_MAX) * 2.f - 1.f);
+  CK(hipMemcpy(src, h.data(), LDS_BYTES, hipMemcpyHostToDevice));
+  // MODE: 1 reads, 2 barrier / 6 steps, 4 hook store
+  run<8, 2, 1, 0>(src, out, stamps, "8 waves, bare MFMA (no LDS)");
+  run<8, 2, 1, 1>(src, out, stamps, "8 waves, F non-ring shape, reads");
+  run<8, 2, 1, 3>(src, out, stamps, "8 waves, F non-ring shape, reads + barrier");
+  run<8, 2, 1, 7>(src, out, stamps, "8 waves, F non-ring shape, reads + barrier + store");
+  run<8, 2, 2, 1>(src, out, stamps, "8 waves, 2 M-tiles, reads");
+  run<8, 2, 2, 7>(src, out, stamps, "8 waves, 2 M-tiles, reads + barrier + store");
+  run<8, 1, 1, 1>(src, out, stamps, "8 waves, 1 conv 1 tile (FM steps / G-H conv4), reads");
+  run<8, 1, 2, 1>(src, out, stamps, "8 waves, 1 conv 2 tiles (G-H), reads");
+  run<4, 2, 1, 0>(src, out, stamps, "4 waves, bare MFMA (no LDS)");
+  run<4, 2, 2, 1>(src, out, stamps, "4 waves, 2 M-tiles, reads");
+  run<4, 2, 2, 7>(src, out, stamps, "4 waves, 2 M-tiles, reads + barrier + store");
+  run<4, 2, 3, 1>(src, out, stamps, "4 waves, 3 M-tiles, reads");
+  run<4, 2, 3, 7>(src, out, stamps, "4 waves, 3 M-tiles, reads + barrier + store");
+  run<4, 2, 4, 1>(src, out, stamps, "4 waves, 4 M-tiles, reads");
+  run<4, 1, 2, 1>(src, out, stamps, "4 waves, 1 conv 2 tiles, reads");
+  run<4, 1, 4, 1>(src, out, stamps, "4 waves, 1 conv 4 tiles, reads");
+  return 0;
+}
