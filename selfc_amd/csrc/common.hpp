@@ -91,4 +91,26 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 // test_stack_backward_chain) from 4.4 % to 5.1 % against its 5 % bar - dropped.
 __device__ __forceinline__ uint32_t lrelu_pack2(float a, float b) { return pack2(lrelu02(a), lrelu02(b)); }
 
+
+// ---- diagnostic build only (make diag DIAG=-DSELFC_CLOCKS): the clock a kernel really runs at inside the benchmark's
+// hipGraph.  Thread 0 of workgroup 0 reads the shader-clock counter and the constant 100 MHz counter at kernel entry and exit
+// (MI355X_MICROARCH.md "DVFS give-back" item 6) and adds the differences to its slot; tools/clock_probe.py reads the sums.
+// Nothing of this exists in the shipped library.
+#ifdef SELFC_CLOCKS
+struct ClockProbe { unsigned long long t0, r0; };
+__device__ __forceinline__ void clock_probe_begin(ClockProbe& p) {
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(p.t0), "=s"(p.r0) :: "memory");
+}
+__device__ __forceinline__ void clock_probe_end(const ClockProbe& p, unsigned long long* slot, const bool leader) {
+  unsigned long long t1, r1;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+  if (leader && slot) {
+    atomicAdd(slot + 0, t1 - p.t0);
+    atomicAdd(slot + 1, r1 - p.r0);
+    atomicAdd(slot + 2, 1ull);
+  }
+}
+unsigned long long* clock_probe_slot(int which);      // prof.hip: device buffer of 3 counters per slot (0 F pair 0, 1 F pair 1, 2 G/H)
+#endif
+
 }  // namespace selfc

@@ -210,6 +210,10 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
   c.lane = c.tid & 63;
   c.wave = c.tid >> 6;
   c.half = c.lane >> 5;
+#ifdef SELFC_CLOCKS
+  ClockProbe ckp;
+  clock_probe_begin(ckp);
+#endif
   {
     const int i = c.lane & 15, row2 = (c.lane >> 4) & 1;
     c.py = 2 * c.wave + row2;
@@ -644,6 +648,9 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
       STAMP_ADD(5, ts5, ts6);
     }
   }
+#ifdef SELFC_CLOCKS
+  clock_probe_end(ckp, a.stamps, blockIdx.x == 0 && c.tid == 0);
+#endif
 #ifdef SELFC_STAMPS
   STAMP(tk1);
   if (a.stamps && c.lane == 0) {
@@ -718,6 +725,9 @@ int launch_pair(FFArgs& a, int maxwg, hipStream_t s) {
       fclose(f);
     }
   }
+#endif
+#ifdef SELFC_CLOCKS
+  a.stamps = clock_probe_slot(PAIR);
 #endif
   hipLaunchKernelGGL(fused_f_kernel<PAIR>, dim3((unsigned)gx), dim3(NTHR), G::LDS, s, a);
   return hip_rc(hipGetLastError());

@@ -383,6 +383,10 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
   c.lane = c.tid & 63;
   c.wave = c.tid >> 6;
   c.half = c.lane >> 5;
+#ifdef SELFC_CLOCKS
+  ClockProbe ckp;
+  clock_probe_begin(ckp);
+#endif
   c.par = 0;
   c.first = true;
 #ifdef SELFC_STAMPS
@@ -488,6 +492,9 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
                 "the two wave classes below");
   if (c.wave < 3) tile_loop(std::false_type{}, std::true_type{});
   else tile_loop(std::true_type{}, std::false_type{});
+#ifdef SELFC_CLOCKS
+  clock_probe_end(ckp, a.stamps, blockIdx.x == 0 && blockIdx.y == 0 && c.tid == 0);
+#endif
 #ifdef SELFC_STAMPS
   STAMP(tk1);
   if (a.stamps && c.lane == 0) {
@@ -534,6 +541,9 @@ int launch_fused_gh(FGArgs& a, hipStream_t s) {
       fclose(f);
     }
   }
+#endif
+#ifdef SELFC_CLOCKS
+  a.stamps = clock_probe_slot(2);
 #endif
   ProfScope prof(PROF_FUSED_GH, s);
   hipLaunchKernelGGL(fused_gh_kernel, dim3((unsigned)gx, 2), dim3(NTHR), FG_LDS, s, a);

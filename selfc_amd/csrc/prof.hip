@@ -67,3 +67,24 @@ int selfc_profile_reset(void) {
 }
 
 }  // extern "C"
+
+#ifdef SELFC_CLOCKS
+#include "common.hpp"
+namespace selfc {
+static unsigned long long* g_clock_buf = nullptr;
+unsigned long long* clock_probe_slot(int which) {
+  if (!g_clock_buf) {
+    if (hipMalloc(&g_clock_buf, 8 * 3 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+    (void)hipMemset(g_clock_buf, 0, 8 * 3 * sizeof(unsigned long long));
+  }
+  return g_clock_buf + 3 * which;
+}
+}  // namespace selfc
+extern "C" int selfc_debug_clocks(unsigned long long* out24, int reset) {      // diag library only: [slot][cycles, 100 MHz ticks, launches]
+  if (!selfc::g_clock_buf) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpy(out24, selfc::g_clock_buf, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -3;
+  if (reset) (void)hipMemset(selfc::g_clock_buf, 0, 24 * sizeof(unsigned long long));
+  return 0;
+}
+#endif
