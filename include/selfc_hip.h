@@ -215,7 +215,8 @@ int selfc_bwd_to_planes(const float* x, void* planes, size_t npix, int c, int cs
 int selfc_f16_rows_to_planes(const void* rows, void* planes, size_t npix, int C, void* stream);   /* f16 [npix][C] -> planes */
 /* Generic plane-list conv with the gradient epilogue: in = nplanes_in contiguous planes, (kt, sp1 ? 1x1 : 3x3) kernel
  * packed by packing.py:pack_planes_generic, ngroups 32-channel output groups.  v = acc + add[z] (optional planes);
- * v *= LeakyReLU'(mask) for group mask_z (mask = one plane) or for every group (mask_z == -2, mask = ngroups planes).
+ * v *= LeakyReLU'(mask) for group mask_z (mask = one plane) or for every group (mask_z == -2, mask = ngroups planes;
+ * mask_z == -3: the same with ReLU' - 0 instead of 0.2 where the saved activation is not positive: the 'gmm_thin' head).
  * Output: f16 planes out_planes[z], or (plain) fp32 rows of stride coutp holding v / S (+ old when accumulate). */
 int selfc_bwd_conv_planes(const void* in, int nplanes_in, int kt, int sp1, const void* w, int ngroups, void* out_planes,
                           const void* add, const void* mask, int mask_z, float* plain, int coutp, int accumulate,
@@ -286,6 +287,10 @@ int selfc_profile_reset(void);
 /* ---- STP gradients (csrc/stp.hip) ---- */
 /* d raw of selfc_gmm_sample given dv: raw/draw [npix][hf_dim*K*3], eps [npix][hf_dim*K], dv [npix][hf_dim]. */
 int selfc_gmm_sample_bwd(const float* raw, const float* eps, const float* dv, float* draw, size_t npix, int hf_dim, int K, void* stream);
+/* The same for selfc_gmm_sample_generic (any hf_dim / K / row strides / log-sigma scale: STP v1's head, SelfC_arch_inv.py:151-186);
+ * draw rows have raw's stride, columns beyond hf_dim*K*3 are set to 0. */
+int selfc_gmm_sample_generic_bwd(const float* raw, const float* eps, const float* dv, float* draw, size_t npix, int hf_dim, int K,
+                                 int raw_stride, int v_stride, float logsigma_scale, void* stream);
 int selfc_lrelu_bwd(float* dx, const float* x, size_t n, void* stream);       /* dx *= (x > 0 ? 1 : 0.2), n % 4 == 0 */
 size_t selfc_globalagg_bwd_scratch_bytes(int N, int T, int H, int W);
 /* Backward of selfc_globalagg_run (GlobalAgg.forward, SelfC_GMM_arch_inv.py:265-285): x, dy, dx fp32 [N][H*W][64];

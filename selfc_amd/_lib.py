@@ -39,7 +39,7 @@ SYMBOLS = [
     "selfc_conv_planes_run", "selfc_nhwc_to_planes", "selfc_y_sse", "selfc_y_sse_blocks", "selfc_y_ssim", "selfc_gauss_down4",
     "selfc_subnet_bwd_scratch_bytes", "selfc_subnet_bwd", "selfc_subnet_bwd_phase", "selfc_coupling_bwd", "selfc_freq_fwd_bwd", "selfc_freq_inv_bwd",
     "selfc_bwd_scale", "selfc_bwd_to_planes", "selfc_f16_rows_to_planes", "selfc_bwd_conv_planes",
-    "selfc_bwd_wgrad_scratch_bytes", "selfc_bwd_wgrad", "selfc_gmm_sample_bwd", "selfc_lrelu_bwd",
+    "selfc_bwd_wgrad_scratch_bytes", "selfc_bwd_wgrad", "selfc_gmm_sample_bwd", "selfc_gmm_sample_generic_bwd", "selfc_lrelu_bwd",
     "selfc_globalagg_bwd_scratch_bytes", "selfc_globalagg_bwd",
 ]
 
@@ -126,6 +126,7 @@ def lib():
             "selfc_bwd_conv_planes": [vp, i, i, i, vp, i, vp, vp, vp, i, vp, i, i, vp, i, i, i, i, vp],
             "selfc_bwd_wgrad": [vp, i, vp, i, i, vp, i, i, vp, f, vp, vp, sz, i, i, i, i, vp],
             "selfc_gmm_sample_bwd": [vp, vp, vp, vp, sz, i, i, vp],
+            "selfc_gmm_sample_generic_bwd": [vp, vp, vp, vp, sz, i, i, i, i, f, vp],
             "selfc_lrelu_bwd": [vp, vp, sz, vp],
             "selfc_globalagg_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, i, vp],
         }

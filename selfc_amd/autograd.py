@@ -631,10 +631,11 @@ def _head_convs(stp):
     return [m for m in stp.tail_gmm if isinstance(m, torch.nn.Conv3d)]
 
 
-def _head_bwd(convs, feat, acts, dlast, n, t, h, w) -> Tuple[torch.Tensor, Dict[int, Tuple[torch.Tensor, torch.Tensor]]]:
+def _head_bwd(convs, feat, acts, dlast, n, t, h, w, relu_hidden: bool = False) -> Tuple[torch.Tensor, Dict[int, Tuple[torch.Tensor, torch.Tensor]]]:
     """Backward of a [lrelu, conv1x1x1]* head given d(last conv output) `dlast` fp32 [npix][>= Cl].
-    feat: fp32 [npix][C0] (input of the head, C0 a multiple of 32), acts: the saved post-LeakyReLU f16 rows of the hidden
-    layers.  Returns (dfeat fp32 [npix][C0], {conv index: (dweight, dbias)})."""
+    feat: fp32 [npix][C0] (input of the head, C0 a multiple of 32), acts: the saved post-activation f16 rows of the hidden
+    layers (LeakyReLU; relu_hidden: ReLU, the 'gmm_thin' head of SelfC_GMM_arch_inv.py:345-354 - the activation in FRONT of
+    the first conv is LeakyReLU in every head).  Returns (dfeat fp32 [npix][C0], {conv index: (dweight, dbias)})."""
     dev, sp = feat.device, _lib.stream_ptr()
     npix = n * h * w
     c0 = feat.shape[-1]
@@ -670,7 +671,7 @@ def _head_bwd(convs, feat, acts, dlast, n, t, h, w) -> Tuple[torch.Tensor, Dict[
         if li > 0:
             nxt = torch.empty((cin // 32, npix, 32), dtype=F16, device=dev)
             rt.call("selfc_bwd_conv_planes", gp.data_ptr(), pn, 1, 1, wt.data_ptr(), cin // 32, nxt.data_ptr(), None,
-                    q.data_ptr(), -2, None, 0, 0, amax.data_ptr(), n, t, h, w, sp)
+                    q.data_ptr(), -3 if relu_hidden else -2, None, 0, 0, amax.data_ptr(), n, t, h, w, sp)
             gp = nxt
         else:
             rt.call("selfc_bwd_conv_planes", gp.data_ptr(), pn, 1, 1, wt.data_ptr(), c0 // 32, None, None, None, -1,
@@ -686,8 +687,6 @@ class STPSampleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lr, stp, t, eps, *params):
         from .modules.Subnet_constructor import D2DTInput
-        if stp.fh_loss == "gmm_thin":
-            raise NotImplementedError("selfc_amd: the ReLU head of fh_loss 'gmm_thin' runs in inference only (no shipped config trains it)")
         lr = rt.as_input(lr)
         n, _, h, w = lr.shape
         dev, sp = lr.device, _lib.stream_ptr()
@@ -721,8 +720,9 @@ class STPSampleFn(torch.autograd.Function):
             h1 = torch.empty((npix, co0), dtype=F16, device=dev)
             h2 = torch.empty((npix, co1), dtype=F16, device=dev)
             raw = torch.empty((npix, co2), dtype=torch.float32, device=dev)
-            rt.call("selfc_pwconv_run", feat.data_ptr(), 1, h1.data_ptr(), 0, w0.data_ptr(), b0.data_ptr(), npix, ci0, co0, co0, 1, 1, sp)
-            rt.call("selfc_pwconv_run", h1.data_ptr(), 0, h2.data_ptr(), 0, w1_.data_ptr(), b1_.data_ptr(), npix, ci1, co1, co1, 0, 1, sp)
+            act = 2 if stp.fh_loss == "gmm_thin" else 1          # hidden activations: ReLU ('gmm_thin', :345-354) | LeakyReLU
+            rt.call("selfc_pwconv_run", feat.data_ptr(), 1, h1.data_ptr(), 0, w0.data_ptr(), b0.data_ptr(), npix, ci0, co0, co0, 1, act, sp)
+            rt.call("selfc_pwconv_run", h1.data_ptr(), 0, h2.data_ptr(), 0, w1_.data_ptr(), b1_.data_ptr(), npix, ci1, co1, co1, 0, act, sp)
             rt.call("selfc_pwconv_run", h2.data_ptr(), 0, raw.data_ptr(), 1, w2_.data_ptr(), b2_.data_ptr(), npix, ci2, co2, co2, 0, 0, sp)
             if eps is None:
                 eps = torch.randn((npix, stp.hf_dim * stp.K), dtype=torch.float32, device=dev)
@@ -750,7 +750,7 @@ class STPSampleFn(torch.autograd.Function):
         else:
             dlast = torch.empty_like(ctx.raw)
             rt.call("selfc_gmm_sample_bwd", ctx.raw.data_ptr(), ctx.eps.data_ptr(), dv.data_ptr(), dlast.data_ptr(), npix, stp.hf_dim, stp.K, sp)
-        d, head_grads = _head_bwd(_head_convs(stp), ctx.feat, ctx.acts, dlast, n, t, h, w)
+        d, head_grads = _head_bwd(_head_convs(stp), ctx.feat, ctx.acts, dlast, n, t, h, w, relu_hidden=stp.fh_loss == "gmm_thin")
         grads: Dict[int, torch.Tensor] = {}
         for conv, (gw, gb) in zip(_head_convs(stp), [head_grads[i] for i in range(len(head_grads))]):
             grads[id(conv.weight)], grads[id(conv.bias)] = gw, gb
@@ -816,3 +816,78 @@ class PointwiseHeadFn(torch.autograd.Function):
         rt.call("selfc_nhwc4_to_nchw", dfeat.data_ptr(), dx.data_ptr(), n, cc, h, w, sp)
         gw, gb = grads[0]
         return dx, None, None, None, gw, gb
+
+
+class HeadFn(torch.autograd.Function):
+    """A whole [LeakyReLU, Conv3d 1x1x1]* head (STP v1's GMM head, SelfC_arch_inv.py:118-128,151-153): x (N,C,h,w) ->
+    the raw output of the last conv (N,cout,h,w).  `packed`: [(fragments, bias, cin, cout_padded)] per conv (the module's
+    _tail_packed()); params = w0, b0, w1, b1, ...  Hidden activations are kept as f16 rows for the backward."""
+
+    @staticmethod
+    def forward(ctx, x, convs, packed, t, *params):
+        x = rt.as_input(x)
+        n, cc, h, w = x.shape
+        dev, sp = x.device, _lib.stream_ptr()
+        npix = n * h * w
+        feat = torch.empty((n, h, w, cc), dtype=torch.float32, device=dev)
+        rt.call("selfc_nchw_to_nhwc4", x.data_ptr(), feat.data_ptr(), n, cc, h, w, sp)
+        cur, cur_f32, acts = feat, 1, []
+        for i, (wp, bp, ci, co) in enumerate(packed):
+            last = i == len(packed) - 1
+            out = torch.empty((npix, co), dtype=torch.float32 if last else _lib.operand_dtype(), device=dev)
+            rt.call("selfc_pwconv_run", cur.data_ptr(), cur_f32, out.data_ptr(), 1 if last else 0, wp.data_ptr(), bp.data_ptr(),
+                    npix, ci, co, co, 1 if i == 0 else 0, 0 if last else 1, sp)
+            if not last:
+                acts.append(out)
+            cur, cur_f32 = out, 0
+        cout = convs[-1].out_channels
+        ctx.convs, ctx.t, ctx.feat, ctx.acts, ctx.shape, ctx.cop = convs, t, feat, acts, (n, cc, h, w), cur.shape[-1]
+        return cur[:, :cout].reshape(n, h, w, cout).permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, gy):
+        convs, t, feat = ctx.convs, ctx.t, ctx.feat
+        n, cc, h, w = ctx.shape
+        dev, sp = gy.device, _lib.stream_ptr()
+        cout = convs[-1].out_channels
+        cs = roundup(cout, 4)
+        dlast = torch.empty((n, h, w, cs), dtype=torch.float32, device=dev)
+        rt.call("selfc_nchw_to_nhwc4", gy.contiguous().float().data_ptr(), dlast.data_ptr(), n, cout, h, w, sp)
+        dfeat, grads = _head_bwd(convs, feat.reshape(n * h * w, cc), ctx.acts, dlast.reshape(n * h * w, cs), n, t, h, w)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((n, cc, h, w), dtype=torch.float32, device=dev)
+            rt.call("selfc_nhwc4_to_nchw", dfeat.data_ptr(), dx.data_ptr(), n, cc, h, w, sp)
+        flat = []
+        for i in range(len(convs)):
+            flat += list(grads[i])
+        return (dx, None, None, None, *flat)
+
+
+class GmmSampleFn(torch.autograd.Function):
+    """v[c] = sum_k softmax_c(raw[c,k,0]) * (eps[c,k] * exp(ls_scale * clamp(raw[c,k,1], -7, 7)) + raw[c,k,2]) for any
+    (hf_dim, K): the reparameterised sample of STP v1's GMM head (SelfC_arch_inv.py:151-163,179-186: ls_scale = 0.5).
+    raw (N, hf*K*3, h, w) NCHW, eps fp32 rows [N*h*w][hf*K] (not differentiated) -> v (N, hf, h, w)."""
+
+    @staticmethod
+    def forward(ctx, raw, eps, hf, k, ls_scale):
+        raw = rt.as_input(raw)
+        n, c, h, w = raw.shape
+        dev, sp = raw.device, _lib.stream_ptr()
+        npix = n * h * w
+        rows = raw.permute(0, 2, 3, 1).contiguous()
+        v = torch.empty((npix, hf), dtype=torch.float32, device=dev)
+        rt.call("selfc_gmm_sample_generic", rows.data_ptr(), eps.data_ptr(), v.data_ptr(), npix, hf, k, c, hf, float(ls_scale), sp)
+        ctx.rows, ctx.eps, ctx.args, ctx.shape = rows, eps, (hf, k, float(ls_scale)), (n, c, h, w)
+        return v.reshape(n, h, w, hf).permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, gv):
+        hf, k, ls = ctx.args
+        n, c, h, w = ctx.shape
+        sp = _lib.stream_ptr()
+        dv = gv.permute(0, 2, 3, 1).contiguous().float()
+        draw = torch.empty_like(ctx.rows)
+        rt.call("selfc_gmm_sample_generic_bwd", ctx.rows.data_ptr(), ctx.eps.data_ptr(), dv.data_ptr(), draw.data_ptr(), n * h * w,
+                hf, k, c, hf, ls, sp)
+        return draw.reshape(n, h, w, c).permute(0, 3, 1, 2).contiguous(), None, None, None, None

@@ -91,7 +91,8 @@ struct C3Args {
   size_t wz_stride;
   int gen_sp1;           // generic mode: centre spatial tap only ((kt,1,1) kernels: 2 fragments per stage)
   // EPI_BWD (generic mode, csrc/backward.hip): v = acc + add[z] (f16 plane, optional); group z == bw_mask_z is
-  // multiplied by LeakyReLU'(bw_mask) (1 where the saved feature is > 0, else 0.2).  Output: f16 plane
+  // multiplied by LeakyReLU'(bw_mask) (1 where the saved feature is > 0, else 0.2; bw_mask_z -2: every group against its own
+  // mask plane, -3: the same with ReLU' = 0 where the feature is 0).  Output: f16 plane
   // out[0] + (out_coff/32 + z) planes (group bw_mask_z goes to bw_alt when that is set), or, with `plain`,
   // fp32 NHWC rows of stride coutp scaled by 1/grad_scale(*bw_amax), added to the old value when bw_acc.
   const f16* bw_add;
@@ -425,7 +426,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
         *reinterpret_cast<u32x4*>(dst + 16 * gp) = v;
       }
     } else if (EPI == EPI_BWD) {
-      const bool masked = a.bw_mask && (a.bw_mask_z == -2 || zg == a.bw_mask_z);     // -2: every group, mask planes z
+      const bool masked = a.bw_mask && (a.bw_mask_z <= -2 || zg == a.bw_mask_z);     // -2 / -3: every group, mask planes z
+      const float mslope = a.bw_mask_z == -3 ? 0.f : 0.2f;                           // -3: ReLU' instead of LeakyReLU'
       float v[4][4];
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -441,12 +443,12 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
         }
       }
       if (masked) {
-        const f16* __restrict__ mk = a.bw_mask + (a.bw_mask_z == -2 ? (size_t)zg * a.plane : 0) + pix * 32 + 4 * half;
+        const f16* __restrict__ mk = a.bw_mask + (a.bw_mask_z <= -2 ? (size_t)zg * a.plane : 0) + pix * 32 + 4 * half;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f16x4 t = *reinterpret_cast<const f16x4*>(mk + 8 * g);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[g][j] *= ((float)t[j] > 0.f) ? 1.f : 0.2f;
+          for (int j = 0; j < 4; ++j) v[g][j] *= ((float)t[j] > 0.f) ? 1.f : mslope;
         }
       }
       if (a.plain) {

@@ -611,6 +611,40 @@ __global__ __launch_bounds__(256) void gmm_sample_generic_kernel(const float* __
   }
 }
 
+// gradient of gmm_sample_generic_kernel w.r.t. raw (any hf_dim, K, raw / dv row strides, log-sigma scale): one thread per
+// pixel; pad columns of a raw row (beyond hf*K*3) receive 0
+__global__ __launch_bounds__(256) void gmm_sample_generic_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ eps,
+                                                                     const float* __restrict__ dv, float* __restrict__ draw, size_t npix,
+                                                                     int hf, int K, int raw_stride, int v_stride, float ls_scale) {
+  const size_t px = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (px >= npix) return;
+  const float* r = raw + px * (size_t)raw_stride;
+  const float* e = eps + px * (size_t)(hf * K);
+  const float* g = dv + px * (size_t)v_stride;
+  float* o = draw + px * (size_t)raw_stride;
+  for (int i = hf * K * 3; i < raw_stride; ++i) o[i] = 0.f;
+  for (int k = 0; k < K; ++k) {
+    float mx = r[k * 3];
+    for (int c = 1; c < hf; ++c) mx = fmaxf(mx, r[(c * K + k) * 3]);
+    float s = 0.f;
+    for (int c = 0; c < hf; ++c) s += expf(r[(c * K + k) * 3] - mx);
+    float dot = 0.f;
+    for (int c = 0; c < hf; ++c) {
+      const float* q = r + (c * K + k) * 3;
+      const float ls = fminf(fmaxf(q[1], -7.f), 7.f);
+      dot += (expf(q[0] - mx) / s) * g[c] * (e[c * K + k] * expf(ls_scale * ls) + q[2]);
+    }
+    for (int c = 0; c < hf; ++c) {
+      const float* q = r + (c * K + k) * 3;
+      const float ls = fminf(fmaxf(q[1], -7.f), 7.f), sg = expf(ls_scale * ls), pi = expf(q[0] - mx) / s;
+      float* d = o + (c * K + k) * 3;
+      d[0] = pi * (g[c] * (e[c * K + k] * sg + q[2]) - dot);
+      d[1] = (q[1] >= -7.f && q[1] <= 7.f) ? g[c] * pi * e[c * K + k] * sg * ls_scale : 0.f;
+      d[2] = g[c] * pi;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // gradients (training): GMM sampler, GlobalAgg, small elementwise helpers
 // ---------------------------------------------------------------------------------------------------------
@@ -1054,6 +1088,16 @@ int selfc_gmm_sample_generic(const float* raw, const float* eps, float* v, size_
   ProfScope prof(PROF_STP, s);
   hipLaunchKernelGGL(gmm_sample_generic_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, raw, eps, v, npix, hf_dim, K,
                      raw_stride, v_stride, logsigma_scale);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_gmm_sample_generic_bwd(const float* raw, const float* eps, const float* dv, float* draw, size_t npix, int hf_dim, int K,
+                                 int raw_stride, int v_stride, float logsigma_scale, void* stream) {
+  if (!raw || !eps || !dv || !draw || npix == 0 || hf_dim < 1 || K < 1 || raw_stride < hf_dim * K * 3 || v_stride < hf_dim) return SELFC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(PROF_BWD, s);
+  hipLaunchKernelGGL(gmm_sample_generic_bwd_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, raw, eps, dv, draw, npix,
+                     hf_dim, K, raw_stride, v_stride, logsigma_scale);
   return hip_rc(hipGetLastError());
 }
 

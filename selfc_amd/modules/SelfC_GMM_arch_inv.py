@@ -129,7 +129,11 @@ class GlobalAgg(nn.Module):
         from .. import autograd as ag
         if ag.module_needs_grad(x, self):
             if c != 64:
-                raise NotImplementedError("selfc_amd: GlobalAgg gradients are built for c = 64 (c < 64, the codec variant, runs in inference only)")
+                # c < 64 (the codec variant: 24): train the exactly equivalent 64-channel module on zero-padded rows (shadow.py)
+                from .. import shadow
+                sh = shadow.globalagg_shadow(self)
+                return shadow.shadow_apply(x, sh, lambda xw: ag.GlobalAggFn.apply(F.pad(xw, (0, 0, 0, 0, 0, 64 - c)), sh.wide, t,
+                                                                                  *rt.plist(sh.wide))[:, :c])
             return ag.GlobalAggFn.apply(x, self, t, *rt.plist(self))
         sp = _lib.stream_ptr()
         if c != 64:                    # zero-pad the rows to the kernels' 64 channels (host-side view ops, not a hot path)
@@ -203,6 +207,10 @@ class STPNet(nn.Module):
     def _tail_seq(self):
         """the head's nn.Sequential (`tail_gmm` here, `tail` in the codec variant's STPNet)"""
         return self.tail_gmm
+
+    def _needs_shadow(self) -> bool:
+        """narrower than the kernels' native widths (64-channel rows, growth 32)?"""
+        return self.c != 64 or any(isinstance(m, D2DTInput) and m.gc != 32 for m in self._chain())
 
     def _virt(self, m):
         """(cin, cout) the chain's kernels see for subnet m: features travel in 64-channel fp32 rows whatever c is"""
@@ -353,7 +361,13 @@ class STPNet(nn.Module):
         if ag.module_needs_grad(xf, self):
             # training: one differentiable op for chain + head + sample; `stp_parameters` (the raw head output) is only
             # exposed for the l2 head here - the reference's GMM likelihood path (neg_llh) is not used by its trainer
-            v = ag.STPSampleFn.apply(xf, self, t, self._eps_rows(b * t, t, h, w, xf.device), *rt.plist(self))
+            if self._needs_shadow():
+                # hidden width < 64 and / or dense growth < 32 (the codec variant): the native-width shadow net (shadow.py)
+                from .. import shadow
+                sh = shadow.stp_shadow(self)
+                v = shadow.shadow_apply(xf, sh, lambda xw: ag.STPSampleFn.apply(xw, sh.wide, t, None, *rt.plist(sh.wide))[:, :self.hf_dim])
+            else:
+                v = ag.STPSampleFn.apply(xf, self, t, self._eps_rows(b * t, t, h, w, xf.device), *rt.plist(self))
             v5 = v.reshape(b, t, -1, h, w).transpose(1, 2)
             if self.fh_loss == "l2":
                 self._publish(v5)

@@ -120,9 +120,22 @@ class STPNet(nn.Module):
         temp = x.transpose(1, 2).reshape(b * t, c, h, w)
         from .. import autograd as ag
         if ag.module_needs_grad(temp, self):
-            if self.fh_loss != "l2":
-                raise NotImplementedError("selfc_amd: STP v1's GMM head runs in inference only (no shipped config trains it)")
             feat = self.blk2(self.blk1(temp))                        # differentiable D2DTInput / FeatureCalapseBlock chain
+            if self.fh_loss == "gmm":
+                # the three-layer head and the reparameterised sample as differentiable HIP ops: `parameters` feeds neg_llh
+                # (torch.distributions, :165-177), `gmm_v` the reverse pass (:151-163)
+                convs = [m for m in self.tail_gmm if isinstance(m, nn.Conv3d)]
+                prm = [q for m in convs for q in (m.weight, m.bias)]
+                raw = ag.HeadFn.apply(feat, convs, self._tail_packed(), t, *prm)          # (b*t, 9*K*3, h, w)
+                hf, K, npix = self.hf_dim, self.K, b * t * h * w
+                if self.eps is not None:
+                    eps = self.eps.reshape(K, b, hf, t, h, w).permute(1, 3, 4, 5, 2, 0).reshape(npix, hf * K).to(device=raw.device, dtype=torch.float32).contiguous()
+                else:
+                    eps = torch.randn((npix, hf * K), dtype=torch.float32, device=raw.device)
+                v = ag.GmmSampleFn.apply(raw, eps, hf, K, 0.5)
+                self._publish(raw.reshape(b, t, hf * K * 3, h, w).transpose(1, 2))
+                self.gmm_v = v.reshape(b, t, hf, h, w).transpose(1, 2)
+                return
             conv = self.tail[1]
             v = ag.PointwiseHeadFn.apply(feat, conv, self._tail_packed(), t, conv.weight, conv.bias)
             self._publish(v.reshape(b, t, self.hf_dim, h, w).transpose(1, 2))

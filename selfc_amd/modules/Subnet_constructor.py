@@ -39,7 +39,10 @@ class _DenseSubnet(nn.Module):
         from .. import autograd as ag
         if ag.module_needs_grad(x, self):          # training: same kernels, buffers kept for the HIP backward
             if self.gc != 32:
-                raise NotImplementedError("selfc_amd: the gradient kernels cover gc = 32 (gc < 32, the codec variant's STP, runs in inference only)")
+                # growth < 32 (the codec variant's dense blocks): train the exactly equivalent growth-32 block (shadow.py)
+                from .. import shadow
+                sh = shadow.dense_shadow(self)
+                return shadow.shadow_apply(x, sh, lambda xw: ag.SubnetFn.apply(xw, sh.wide, T, *ag.subnet_params(sh.wide)))
             return ag.SubnetFn.apply(x, self, T, *ag.subnet_params(self))
         pk = self.packed()
         dev, sp = x.device, _lib.stream_ptr()

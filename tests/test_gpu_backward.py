@@ -546,3 +546,192 @@ def test_stp_v1_default_conditioner_trains(dev):
     for name, prm in nn.Module.named_parameters(stp):
         assert prm.grad is not None, name
         assert rel_l2(prm.grad.cpu(), p[name].grad) < 5e-2, name
+
+
+# ---- round 3: the shapes that were inference-only (narrow dense blocks / GlobalAgg / STP via zero-padded shadows, ReLU head, STP v1 GMM head)
+
+CODEC_OPT = {"global_module": "nonlocal", "stp_blk_num": 4, "fh_loss": "l2", "scale": 2, "gmm_k": 5,
+             "stp_hidden_c": 24, "stp_denseblock_innerc": 12}
+
+
+def _all_tensor_rel_l2(mod, g_ref):
+    """||g - g_ref|| / ||g_ref|| over the concatenation of every parameter gradient: what an optimizer step sees"""
+    num = sum(float((p_.grad.cpu().double() - g_ref[n_].double()).pow(2).sum()) for n_, p_ in mod.named_parameters())
+    den = sum(float(g_ref[n_].double().pow(2).sum()) for n_, _ in mod.named_parameters())
+    return (num / den) ** 0.5
+
+
+def _fc_merged_errs(mod, g_ref, skip=("proj3.bias",)):
+    """per-tensor relative L2 with fc.weight / fc.bias of a GlobalAgg judged as one vector (fc.bias is a single scalar obtained
+    by heavy cancellation) and proj3.bias skipped (exactly zero: the softmax is invariant to a key shift)"""
+    named = dict(mod.named_parameters())
+    errs = {}
+    for n_, p_ in named.items():
+        if n_.endswith(skip) or n_.endswith("fc.bias"):
+            continue
+        assert p_.grad is not None, n_
+        a, b_ = p_.grad.cpu().reshape(-1), g_ref[n_].reshape(-1)
+        if n_.endswith("fc.weight"):
+            nb = n_[:-len("weight")] + "bias"
+            a, b_ = torch.cat((a, named[nb].grad.cpu().reshape(-1))), torch.cat((b_, g_ref[nb].reshape(-1)))
+        errs[n_] = rel_l2(a, b_)
+    return errs
+
+
+@pytest.mark.parametrize("cls,ci,co,gc", [("D2DTInput", 24, 24, 12), ("D2DTInput", 3, 24, 12), ("DenseBlock", 9, 3, 16)])
+def test_narrow_growth_dense_block_backward(dev, cls, ci, co, gc):
+    """Dense blocks with growth < 32 (the codec variant's STP: stp_denseblock_innerc = 12, SelfC_Codec_arch_inv.py:248-252) train
+    through the exactly equivalent growth-32 block (selfc_amd/shadow.py): gradients against autograd through the oracle."""
+    from selfc_amd.modules import Subnet_constructor as SC
+    torch.manual_seed(11)
+    mod = getattr(SC, cls)(ci, co, gc=gc, INN_init=False)
+    sd = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+    x = torch.randn(T, ci, 12, 8) * 0.5
+    gy = torch.randn(T, co, 12, 8) * 0.02
+    fn = (lambda p, xx: O.d2dt(p, xx, T)) if cls == "D2DTInput" else (lambda p, xx: O.dense_block(p, xx))
+    y_ref, dx_ref, g_ref = _oracle_grads(fn, sd, x, gy)
+    mod.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    y = mod(xd)
+    assert rel_err(y.detach().cpu(), y_ref) < 1e-3
+    y.backward(gy.to(dev))
+    assert rel_l2(xd.grad.cpu(), dx_ref) < L2TOL
+    # per tensor 5e-2 (the end-to-end bar of the chained tests): a 12-element bias gradient on a 12x8 frame is the f16-forward
+    # LeakyReLU kink lottery at its noisiest (see test_stack_backward_chain); all tensors together stay far below
+    worst = _check_module_grads(mod, g_ref, tol=5e-2)
+    tot = (sum(float((p_.grad.cpu().double() - g_ref[n_].double()).pow(2).sum()) for n_, p_ in mod.named_parameters()) /
+           sum(float(g_ref[n_].double().pow(2).sum()) for n_, _ in mod.named_parameters())) ** 0.5
+    print(cls, ci, co, gc, "worst parameter-gradient rel L2", worst, "all tensors", tot)
+    assert tot < 1.5e-2, tot
+    # a second call accumulates into .grad, and the shadow follows an optimizer step (weights changed -> re-synced)
+    with torch.no_grad():
+        for p_ in mod.parameters():
+            p_.mul_(1.01)
+    mod.zero_grad()
+    mod(xd).backward(gy.to(dev))
+    _, _, g2 = _oracle_grads(fn, {k: v * 1.01 for k, v in sd.items()}, x, gy)
+    _check_module_grads(mod, g2, tol=5e-2)
+
+
+def test_narrow_globalagg_backward(dev):
+    """GlobalAgg(24) over 3-frame clips (codec variant, SelfC_Codec_arch_inv.py:103-131): the 64-channel shadow with the softmax
+    temperature 1/24 folded into proj2."""
+    from selfc_amd.modules.SelfC_Codec_arch_inv import GlobalAgg
+    g = load_golden("g15_codec")
+    sd = subdict(g, "stp_net.global_m1")
+    ga = GlobalAgg(24)
+    ga.load_state_dict(sd, strict=True)
+    x = g["ga_x"]
+    torch.manual_seed(4)
+    gy = torch.randn_like(x) * 0.01
+    y_ref, dx_ref, g_ref = _oracle_grads(lambda p, xx: O.global_agg(p, xx, 3), sd, x, gy)
+    ga.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    y = ga(xd)
+    assert rel_err(y.detach().cpu(), y_ref) < 1e-3 and rel_err(y.detach().cpu(), g["ga_y"]) < 1e-3
+    y.backward(gy.to(dev))
+    assert rel_err(xd.grad.cpu(), dx_ref) < 5e-3
+    errs = _fc_merged_errs(ga, g_ref)
+    print("GlobalAgg(24) worst", sorted(errs.items(), key=lambda kv: -kv[1])[:4])
+    assert max(errs.values()) < L2TOL, errs
+
+
+@pytest.mark.parametrize("hw", [(8, 12), (24, 32)])
+def test_codec_stp_trains(dev, hw):
+    """The codec variant's STP (hidden 24, growth 12, l2 head of 12 channels, 3-frame clips; SelfC_Codec_arch_inv.py:234-312,
+    which the reference trains through its H.265 surrogate) under autograd: every parameter gradient against the oracle.  Two
+    sizes: the fixture's 8x12 frames and 24x32 ones - the error of a correct backward is the f16-forward kink lottery and falls
+    with the number of pixels a gradient sums over; a wrong placement in the shadow would not."""
+    from selfc_amd.modules.SelfC_Codec_arch_inv import STPNet
+    g = load_golden("g15_codec")
+    sd = subdict(g, "stp_net")
+    stp = STPNet(CODEC_OPT)
+    stp.load_state_dict(sd, strict=True)
+    h, w = hw
+    lr = g["stp_lr"] if hw == (8, 12) else torch.rand(6, 3, h, w, generator=torch.Generator().manual_seed(21))      # 2 clips of 3 frames
+    torch.manual_seed(9)
+    gy = torch.randn(6, 12, h, w) * 0.01
+    y_ref, dx_ref, g_ref = _oracle_grads(lambda p, xx: O.codec_stp_parameters(p, xx, 3, 4), sd, lr, gy)
+    stp.to(dev)
+    xd = lr.to(dev).requires_grad_(True)
+    stp(xd.reshape(2, 3, 3, h, w).transpose(1, 2))
+    v = stp.sample().transpose(1, 2).reshape(6, 12, h, w)
+    assert rel_err(v.detach().cpu(), y_ref) < 1e-3
+    if hw == (8, 12):
+        assert rel_err(v.detach().cpu(), g["stp_raw"]) < 1e-3
+    v.backward(gy.to(dev))
+    assert rel_l2(xd.grad.cpu(), dx_ref) < 5e-2
+    errs = _fc_merged_errs(stp, g_ref)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    tot = _all_tensor_rel_l2(stp, g_ref)
+    print("codec STP", hw, "worst", worst, "all tensors", tot)
+    from conftest import record
+    record(f"codec STP (24 / 12) backward at {h}x{w}, relative L2 over all parameter gradients", tot)
+    # 24-channel rows / 12-channel growth on 2 clips of 3 frames: the per-tensor figures of the small vectors (a 12-element
+    # bias, the 1024-tap pooled map fc.weight whose gradient is a sum of cancelling terms) are the f16-forward kink lottery;
+    # the bar that binds is the one over all tensors
+    assert tot < (2.5e-2 if hw == (8, 12) else 1.2e-2), tot
+    assert worst[0][1] < 1.5e-1, worst
+    assert len(list(stp.parameters())) == len(sd)         # `parameters` (the head output) is still callable
+
+
+def test_stp_v2_gmm_thin_backward(dev):
+    """fh_loss 'gmm_thin' (SelfC_GMM_arch_inv.py:345-354): ReLU between the head's layers - its mask in the HIP backward."""
+    from selfc_amd.modules.SelfC_GMM_arch_inv import STPNet
+    g7, g = load_golden("g7_stp_gmm"), load_golden("g17_stp_gmm_thin")
+    sd = {k: v for k, v in g7.items() if k.split(".")[0] in ("local_m1", "local_m2", "global_m1", "global_m2", "other_stp_modules")}
+    sd.update({k: v for k, v in g.items() if k.startswith("tail_gmm.")})
+    stp = STPNet(dict(OPT, fh_loss="gmm_thin"))
+    stp.load_state_dict(sd, strict=True)
+    lr, eps = g["lr"], g["eps"]                           # (T,3,8,12), (T,48,5,8,12)
+    torch.manual_seed(5)
+    gy = torch.randn(T, 48, 8, 12) * 0.01
+    y_ref, dx_ref, g_ref = _oracle_grads(lambda p, xx: O.stp_v2_gmm_sample(O.stp_v2_parameters(p, xx, T, thin=True), eps), sd, lr, gy)
+    stp.to(dev)
+    stp.eps = eps.permute(1, 2, 0, 3, 4).unsqueeze(0).to(dev)
+    xd = lr.to(dev).requires_grad_(True)
+    stp(xd.reshape(1, T, 3, 8, 12).transpose(1, 2))
+    v = stp.sample()[0].transpose(0, 1)
+    assert rel_err(v.detach().cpu(), y_ref) < 3e-3
+    v.backward(gy.to(dev))
+    errs = _fc_merged_errs(stp, g_ref)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    tot = _all_tensor_rel_l2(stp, g_ref)
+    print("gmm_thin dx", rel_l2(xd.grad.cpu(), dx_ref), "worst", worst, "all tensors", tot)
+    # ReLU kinks are hard zeros: a hidden unit the f16 forward puts on the other side loses (or gains) its whole contribution,
+    # which shows in the ill-conditioned small vectors of the LAST GlobalAgg (fc.weight: a sum of cancelling terms); all tensors
+    # together and dx are what bind
+    assert rel_l2(xd.grad.cpu(), dx_ref) < 5e-2 and tot < 2e-2, (tot, worst)
+    assert worst[0][1] < 2e-1, worst
+
+
+def test_stp_v1_gmm_head_trains(dev):
+    """STP v1 with fh_loss gmm (SelfC_arch_inv.py:118-128,151-177): the three-layer head (HeadFn) and the reparameterised sample
+    (GmmSampleFn, std = exp(0.5 ls)) are differentiable; `parameters` feeds the likelihood, `gmm_v` the reverse pass."""
+    from selfc_amd.modules.SelfC_arch_inv import STPNet
+    g = load_golden("g16_stp_v1_gmm")
+    opt = {"stp_d2d_inner_c": 32, "stp_temporal_c": 32, "fh_loss": "gmm", "gmm_mixture_num": 5, "stp_blk_num": 2, "condition_func": "D2DTNet"}
+    sd = {k: v for k, v in g.items() if k.split(".")[0] in ("blk1", "blk2", "tail_gmm")}
+    stp = STPNet(opt)
+    stp.load_state_dict(sd, strict=True)
+    lr, eps = g["lr"], g["eps"]                           # (T,3,8,12), (K,9,T,8,12)
+    torch.manual_seed(6)
+    gv = torch.randn(T, 9, 8, 12) * 0.01
+    graw = torch.randn(T, 135, 8, 12) * 0.001
+
+    def fn(p, xx):                                        # both consumers of the head at once: sample + raw parameters
+        raw = O.stp_v1_parameters(p, xx, T)
+        return torch.cat((O.stp_v1_gmm_sample(raw, eps), raw), 1)
+    y_ref, dx_ref, g_ref = _oracle_grads(fn, sd, lr, torch.cat((gv, graw), 1))
+    stp.to(dev)
+    stp.eps = eps.unsqueeze(1).to(dev)                    # (K, b=1, 9, T, h, w)
+    xd = lr.to(dev).requires_grad_(True)
+    stp(xd.reshape(1, T, 3, 8, 12).transpose(1, 2))
+    v = stp.sample()[0].transpose(0, 1)
+    raw = stp.parameters[0].transpose(0, 1)
+    assert rel_err(v.detach().cpu(), g["v"]) < 1e-3 and rel_err(raw.detach().cpu(), g["raw"]) < 1e-3
+    ((v * gv.to(dev)).sum() + (raw * graw.to(dev)).sum()).backward()
+    assert rel_l2(xd.grad.cpu(), dx_ref) < 5e-2
+    worst = _check_module_grads(stp, g_ref, tol=5e-2)
+    print("STP v1 gmm worst parameter-gradient rel L2", worst)
+    assert torch.isfinite(stp.neg_llh(stp.sample().detach())).all()
