@@ -197,6 +197,11 @@ int selfc_subnet_bwd(const selfc_subnet_bw* bw, int kind, const void* dense, con
 int selfc_subnet_bwd_phase(int phases, const selfc_subnet_bw* bw, int kind, const void* dense, const float* xin, const float* dout,
                            float sign, float* dx, int accumulate_dx, float* const* wgrad, float* const* bgrad, float beta,
                            void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout, void* stream);
+/* The affine coupling of InvBlockExp (Inv_arch.py:26-27 / 29-30) as a stand-alone elementwise pass over n fp32 elements
+ * (n % 4 == 0; any layout, shared by all operands): s = clamp*(2*sigmoid(h)-1); rev == 0: y2 = x2*e^s + g; rev != 0:
+ * y2 = (x2-g)/e^s.  The fused conv5 epilogues do this for channel_split_num <= 3; a block with a wider split is composed from
+ * stand-alone subnets (selfc_subnet_run) and this pass. */
+int selfc_coupling_fwd(int rev, const float* x2, const float* g, const float* h, float* y2, float* s, float clamp, size_t n, void* stream);
 /* Gradient of the affine coupling of InvBlockExp (Inv_arch.py:24-32) w.r.t. its x2 path and H's output, n = npix*c2p
  * fp32 elements: rev == 0: v = x2 (input), dx2 = dy2*e^s, dh = dx2*x2*ds/dh (dG = dy2);
  * rev != 0: v = y2 (output), dx2 = dy2*e^-s, dh = -dy2*y2*ds/dh (dG = -dx2); ds/dh = clamp*(1-(s/clamp)^2)/2. */

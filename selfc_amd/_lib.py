@@ -37,7 +37,7 @@ SYMBOLS = [
     "selfc_profile_enable", "selfc_profile_read", "selfc_profile_reset",
     "selfc_globalagg_run", "selfc_globalagg_run_d", "selfc_gmm_sample_generic", "selfc_globalagg_partial_floats", "selfc_pwconv_run", "selfc_gmm_sample", "selfc_stp_head_gmm",
     "selfc_conv_planes_run", "selfc_nhwc_to_planes", "selfc_y_sse", "selfc_y_sse_blocks", "selfc_y_ssim", "selfc_gauss_down4",
-    "selfc_subnet_bwd_scratch_bytes", "selfc_subnet_bwd", "selfc_subnet_bwd_phase", "selfc_coupling_bwd", "selfc_freq_fwd_bwd", "selfc_freq_inv_bwd",
+    "selfc_subnet_bwd_scratch_bytes", "selfc_subnet_bwd", "selfc_subnet_bwd_phase", "selfc_coupling_fwd", "selfc_coupling_bwd", "selfc_freq_fwd_bwd", "selfc_freq_inv_bwd",
     "selfc_bwd_scale", "selfc_bwd_to_planes", "selfc_f16_rows_to_planes", "selfc_bwd_conv_planes",
     "selfc_bwd_wgrad_scratch_bytes", "selfc_bwd_wgrad", "selfc_gmm_sample_bwd", "selfc_gmm_sample_generic_bwd", "selfc_lrelu_bwd",
     "selfc_globalagg_bwd_scratch_bytes", "selfc_globalagg_bwd",
@@ -117,6 +117,7 @@ def lib():
                                  vp, sz, i, i, i, i, i, i, vp],
             "selfc_subnet_bwd_phase": [i, C.POINTER(SubnetBW), i, vp, vp, vp, f, vp, i, C.POINTER(vp), C.POINTER(vp), f,
                                        vp, sz, i, i, i, i, i, i, vp],
+            "selfc_coupling_fwd": [i, vp, vp, vp, vp, vp, f, sz, vp],
             "selfc_coupling_bwd": [i, vp, vp, vp, vp, vp, f, sz, vp],
             "selfc_freq_fwd_bwd": [vp, vp, vp, i, i, i, vp],
             "selfc_freq_inv_bwd": [vp, vp, vp, i, i, i, vp],

@@ -491,6 +491,46 @@ class InvBlockFn(torch.autograd.Function):
         return (dx, None, None, None, *gF, *gG, *gH)
 
 
+class CouplingFn(torch.autograd.Function):
+    """(y2, s) = affine coupling of InvBlockExp (Inv_arch.py:26-27,29-30) on NCHW tensors, as its own op: the composed path of
+    a block with channel_split_num > 3 (the fused conv5 epilogues cover splits <= 3).  s is returned for InvBlockExp.s /
+    jacobian and is not differentiated (as in the fused path)."""
+
+    @staticmethod
+    def forward(ctx, x2, g, h, clamp, rev):
+        x2, g, h = rt.as_input(x2), rt.as_input(g), rt.as_input(h)
+        n = x2.numel()
+        pad = (-n) % 4                                   # the kernel works on float4 groups
+        if pad:
+            x2f, gf, hf = (torch.cat((t.reshape(-1), t.new_zeros(pad))) for t in (x2, g, h))
+        else:
+            x2f, gf, hf = x2.reshape(-1), g.reshape(-1), h.reshape(-1)
+        y2 = torch.empty_like(x2f)
+        s = torch.empty_like(x2f)
+        rt.call("selfc_coupling_fwd", 1 if rev else 0, x2f.data_ptr(), gf.data_ptr(), hf.data_ptr(), y2.data_ptr(), s.data_ptr(),
+                float(clamp), x2f.numel(), _lib.stream_ptr())
+        ctx.rev, ctx.clamp, ctx.shape, ctx.n = bool(rev), float(clamp), x2.shape, n
+        ctx.save_for_backward(y2 if rev else x2f, s)
+        y2o, so = y2[:n].reshape(x2.shape), s[:n].reshape(x2.shape)
+        ctx.mark_non_differentiable(so)
+        return y2o, so
+
+    @staticmethod
+    def backward(ctx, dy2, _ds):
+        v, s = ctx.saved_tensors
+        n = ctx.n
+        d = dy2.contiguous().float().reshape(-1)
+        if v.numel() != n:
+            d = torch.cat((d, d.new_zeros(v.numel() - n)))
+        dx2 = torch.empty_like(v)
+        dh = torch.empty_like(v)
+        rt.call("selfc_coupling_bwd", 1 if ctx.rev else 0, v.data_ptr(), s.data_ptr(), d.data_ptr(), dx2.data_ptr(), dh.data_ptr(),
+                ctx.clamp, v.numel(), _lib.stream_ptr())
+        dx2, dh = dx2[:n].reshape(ctx.shape), dh[:n].reshape(ctx.shape)
+        dg = -dx2 if ctx.rev else dy2
+        return dx2, dg, dh, None, None
+
+
 def block_params(blk) -> List[torch.Tensor]:
     return subnet_params(blk.F) + subnet_params(blk.G) + subnet_params(blk.H)
 

@@ -450,6 +450,26 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const FinArgs a) {
 // coupling and FrequencyAnalyzer gradients (elementwise / index shuffles, fp32)
 // ---------------------------------------------------------------------------------------------------------
 // s = clamp*(2 sigmoid(h) - 1)  =>  ds/dh = clamp*(1 - (s/clamp)^2)/2.
+// The affine coupling itself as a stand-alone elementwise pass (Inv_arch.py:26-27,29-30): s = clamp (2 sigmoid(h) - 1),
+// rev == 0: y2 = x2 e^s + g;  rev != 0: y2 = (x2 - g) / e^s.  Used where the fused conv5 epilogues do not apply: an InvBlockExp
+// with channel_split_num > 3, composed from stand-alone subnets.  Any layout (all operands share it).
+__global__ __launch_bounds__(256) void coupling_fwd_kernel(int rev, const float4* __restrict__ x2, const float4* __restrict__ g,
+                                                           const float4* __restrict__ h, float4* __restrict__ y2, float4* __restrict__ s,
+                                                           float clamp, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 xv = x2[i], gv = g[i], hv = h[i];
+  const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w}, ha[4] = {hv.x, hv.y, hv.z, hv.w};
+  float oy[4], os[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    os[j] = clamp * (2.f / (1.f + expf(-ha[j])) - 1.f);
+    oy[j] = rev ? (xa[j] - ga[j]) / expf(os[j]) : xa[j] * expf(os[j]) + ga[j];
+  }
+  y2[i] = make_float4(oy[0], oy[1], oy[2], oy[3]);
+  s[i] = make_float4(os[0], os[1], os[2], os[3]);
+}
+
 // rev == 0 (y2 = x2*e^s + g, v = x2):   dx2 = dy2*e^s,   dh = dy2*x2*e^s * ds/dh,   dg = dy2
 // rev != 0 (y2 = (x2-g)*e^-s, v = y2):  dx2 = dy2*e^-s,  dh = -dy2*y2 * ds/dh,      dg = -dx2
 __global__ __launch_bounds__(256) void coupling_bwd_kernel(int rev, const float4* __restrict__ v, const float4* __restrict__ s,
@@ -748,6 +768,15 @@ weights:
     if ((rc = bwd_wgrad(j, amax, wgs, N, T, H, W, s))) return rc;
   }
   return SELFC_OK;
+}
+
+int selfc_coupling_fwd(int rev, const float* x2, const float* g, const float* h, float* y2, float* s, float clamp, size_t n, void* stream) {
+  if (!x2 || !g || !h || !y2 || !s || n == 0 || (n & 3)) return SELFC_EINVAL;
+  ProfScope prof(PROF_CONV5_GH, (hipStream_t)stream);
+  const size_t n4 = n / 4;
+  hipLaunchKernelGGL(coupling_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rev,
+                     (const float4*)x2, (const float4*)g, (const float4*)h, (float4*)y2, (float4*)s, clamp, n4);
+  return hip_rc(hipGetLastError());
 }
 
 int selfc_coupling_bwd(int rev, const float* v, const float* s, const float* dy2, float* dx2, float* dh, float clamp,

@@ -67,6 +67,8 @@ class InvBlockExp(nn.Module):
         if n % t:
             raise RuntimeError(f"{n} frames are not a multiple of the temporal length {t}")
         from .. import autograd as ag
+        if self.split_len1 > 3:
+            return self._forward_composed(x, bool(rev))
         if ag.module_needs_grad(x, self):          # training: buffers kept for the HIP backward (autograd.py)
             return ag.InvBlockFn.apply(x, self, bool(rev), t, *ag.block_params(self))
         ws = rt.workspace(x.device, self.F.kind, n, t, h, w, self.split_len1, self.split_len2)
@@ -76,6 +78,22 @@ class InvBlockExp(nn.Module):
         rt.call("selfc_invblock_run", bw, lat, 1 if rev else 0, _lib.stream_ptr())
         self.s = rt.s_to_nchw(ws)
         return rt.latent_to_nchw(ws)
+
+    def _forward_composed(self, x, rev):
+        """channel_split_num > 3 (Inv_arch.py:12-13 accepts any split): the fused block kernels keep x1 in a 4-float pixel, so a
+        wider split runs as the reference composes it - F, G, H as stand-alone subnets (selfc_subnet_run, HIP backward through
+        their autograd Functions) and the affine coupling as its own elementwise HIP pass (autograd.CouplingFn)."""
+        from .. import autograd as ag
+        s1 = self.split_len1
+        x1, x2 = x[:, :s1].contiguous(), x[:, s1:].contiguous()
+        if not rev:
+            y1 = x1 + self.F(x2)
+            y2, s = ag.CouplingFn.apply(x2, self.G(y1), self.H(y1), self.clamp, False)
+        else:
+            y2, s = ag.CouplingFn.apply(x2, self.G(x1), self.H(x1), self.clamp, True)
+            y1 = x1 - self.F(y2)
+        self.s = s.detach()
+        return torch.cat((y1, y2), 1)
 
     def jacobian(self, x, rev=False):
         jac = torch.sum(self.s)

@@ -274,7 +274,7 @@ def packed_block(blk) -> PackedBlock:
         for sub in (blk.F, blk.G, blk.H):
             sub._check()
         if blk.split_len1 > 3:
-            raise NotImplementedError("selfc_amd coupling kernels cover channel_split_num <= 3 (every shipped config uses 3)")
+            raise NotImplementedError("the fused block kernels cover channel_split_num <= 3; wider splits run composed (InvBlockExp._forward_composed)")
         params = _conv_params(blk.F) + _conv_params(blk.G) + _conv_params(blk.H)
         if getattr(blk, "_plan", None) is None or blk._plan_dev != params[0].device:
             blk._plan = PackPlan(params, lambda ps: _block_entries(blk, ps))

@@ -735,3 +735,39 @@ def test_stp_v1_gmm_head_trains(dev):
     worst = _check_module_grads(stp, g_ref, tol=5e-2)
     print("STP v1 gmm worst parameter-gradient rel L2", worst)
     assert torch.isfinite(stp.neg_llh(stp.sample().detach())).all()
+
+
+@pytest.mark.parametrize("kind,cnum,split", [("DBNet", 12, 6), ("D2DTNet", 20, 8), ("D2DTNet", 51, 4)])
+@pytest.mark.parametrize("rev", [False, True])
+def test_invblock_wide_split(dev, kind, cnum, split, rev):
+    """InvBlockExp with channel_split_num > 3 (Inv_arch.py:12-13 takes any split): composed from stand-alone subnets and the
+    stand-alone coupling pass - output, s, jacobian, exact-inverse property and every gradient against the oracle."""
+    from selfc_amd.modules.Inv_arch import InvBlockExp
+    from selfc_amd.modules.Subnet_constructor import subnet
+    torch.manual_seed(17)
+    blk = InvBlockExp(subnet(kind, "xavier"), cnum, split)
+    with torch.no_grad():                     # DBNet zero-initialises conv5: give the coupling something to do
+        for sub in (blk.F, blk.G, blk.H):
+            sub.conv5.weight.normal_(0, 0.02)
+            sub.conv5.bias.normal_(0, 0.02)
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    x = torch.randn(T, cnum, 12, 8) * 0.5
+    gy = torch.randn_like(x) * 0.02
+    (y_ref, s_ref) = O.invblock(kind, sd, x, split, T, rev=rev)
+    _, dx_ref, g_ref = _oracle_grads(lambda p, xx: O.invblock(kind, p, xx, split, T, rev=rev)[0], sd, x, gy)
+    blk.to(dev)
+    with torch.no_grad():
+        y0 = blk(x.to(dev), rev=rev)
+        assert rel_err(y0.cpu(), y_ref) < 1e-3 and rel_err(blk.s.cpu(), s_ref) < 1e-3
+        jac = blk.jacobian(x.to(dev), rev=rev)
+        assert abs(float(jac) - float(O.invblock_jacobian(s_ref, T, rev))) < 1e-3 * (abs(float(O.invblock_jacobian(s_ref, T, rev))) + 1)
+        back = blk(y0, rev=not rev)           # the coupling is exactly invertible
+        assert rel_err(back.cpu(), x) < 1e-3
+    xd = x.to(dev).requires_grad_(True)
+    y = blk(xd, rev=rev)
+    y.backward(gy.to(dev))
+    assert rel_l2(xd.grad.cpu(), dx_ref) < L2TOL
+    worst = _check_module_grads(blk, g_ref, tol=5e-2)
+    tot = _all_tensor_rel_l2(blk, g_ref)
+    print(kind, cnum, split, rev, "worst", worst, "all tensors", tot)
+    assert tot < 1.5e-2, tot
