@@ -76,6 +76,9 @@ int selfc_latent_to_nchw(const float* x1, const float* x2, float* y,
 /* Quantization.forward on the LR channels, in place on x1: Quantization.py:7-17
  * (clamp to [0,1], round-half-even(x*255)/255). n = number of floats. */
 int selfc_quantize_inplace(float* x, size_t n, void* stream);
+/* The same for any class-level setting of the reference (Quantization.quant_v, Quantization.is_clip: Quantization.py:9-13,20-22):
+ * optional clamp to [0,1], then round-half-even(x*quant_v)/quant_v. */
+int selfc_quantize_inplace_v(float* x, size_t n, float quant_v, int is_clip, void* stream);
 
 /* Y-channel squared error of test_rescaling.py's PSNR (rgb_to_ycbcr data/util.py:239-245, calculate_psnr
  * utils/util.py:198-221): a, b NCHW (N,3,H,W) RGB in [0,1]; partial[n][blk] (double, selfc_y_sse_blocks(HW)

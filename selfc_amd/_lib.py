@@ -31,7 +31,7 @@ ABI_VERSION = 7
 SYMBOLS = [
     "selfc_version", "selfc_abi_version",
     "selfc_haar_fwd_nchw", "selfc_haar_inv_nchw", "selfc_freq_fwd", "selfc_freq_inv",
-    "selfc_nchw_to_latent", "selfc_latent_to_nchw", "selfc_quantize_inplace",
+    "selfc_nchw_to_latent", "selfc_latent_to_nchw", "selfc_quantize_inplace", "selfc_quantize_inplace_v",
     "selfc_invblock_run", "selfc_invstack_run", "selfc_subnet_run",
     "selfc_nchw_to_nhwc4", "selfc_nhwc4_to_nchw",
     "selfc_profile_enable", "selfc_profile_read", "selfc_profile_reset",
@@ -93,6 +93,7 @@ def lib():
             "selfc_nchw_to_latent": [vp, vp, vp, vp, i, i, i, i, i, i, vp],
             "selfc_latent_to_nchw": [vp, vp, vp, i, i, i, i, i, vp],
             "selfc_quantize_inplace": [vp, sz, vp],
+            "selfc_quantize_inplace_v": [vp, sz, f, i, vp],
             "selfc_invblock_run": [C.POINTER(InvBlockW), C.POINTER(Latent), i, vp],
             "selfc_invstack_run": [C.POINTER(InvBlockW), i, C.POINTER(Latent), i, vp],
             "selfc_subnet_run": [C.POINTER(SubnetW), i, vp, vp, vp, i, i, i, i, i, i, vp],

@@ -766,7 +766,10 @@ class STPSampleFn(torch.autograd.Function):
             rt.call("selfc_pwconv_run", h2.data_ptr(), 0, raw.data_ptr(), 1, w2_.data_ptr(), b2_.data_ptr(), npix, ci2, co2, co2, 0, 0, sp)
             if eps is None:
                 eps = torch.randn((npix, stp.hf_dim * stp.K), dtype=torch.float32, device=dev)
-            rt.call("selfc_gmm_sample", raw.data_ptr(), eps.data_ptr(), hf.data_ptr(), npix, stp.hf_dim, stp.K, sp)
+            if stp.hf_dim == 48 and co2 == 48 * stp.K * 3:
+                rt.call("selfc_gmm_sample", raw.data_ptr(), eps.data_ptr(), hf.data_ptr(), npix, stp.hf_dim, stp.K, sp)
+            else:      # other scales (hf_dim = 3 scale^2): the generic sampler on rows padded to a multiple of 16 channels
+                rt.call("selfc_gmm_sample_generic", raw.data_ptr(), eps.data_ptr(), hf.data_ptr(), npix, stp.hf_dim, stp.K, co2, stp.hf_dim, 1.0, sp)
             acts = [h1, h2]
         y = torch.empty((n, stp.hf_dim, h, w), dtype=torch.float32, device=dev)
         rt.call("selfc_nhwc4_to_nchw", hf.data_ptr(), y.data_ptr(), n, stp.hf_dim, h, w, sp)
@@ -789,7 +792,11 @@ class STPSampleFn(torch.autograd.Function):
             dlast = dv
         else:
             dlast = torch.empty_like(ctx.raw)
-            rt.call("selfc_gmm_sample_bwd", ctx.raw.data_ptr(), ctx.eps.data_ptr(), dv.data_ptr(), dlast.data_ptr(), npix, stp.hf_dim, stp.K, sp)
+            if stp.hf_dim == 48 and ctx.raw.shape[-1] == 48 * stp.K * 3:
+                rt.call("selfc_gmm_sample_bwd", ctx.raw.data_ptr(), ctx.eps.data_ptr(), dv.data_ptr(), dlast.data_ptr(), npix, stp.hf_dim, stp.K, sp)
+            else:
+                rt.call("selfc_gmm_sample_generic_bwd", ctx.raw.data_ptr(), ctx.eps.data_ptr(), dv.data_ptr(), dlast.data_ptr(), npix,
+                        stp.hf_dim, stp.K, ctx.raw.shape[-1], stp.hf_dim, 1.0, sp)
         d, head_grads = _head_bwd(_head_convs(stp), ctx.feat, ctx.acts, dlast, n, t, h, w, relu_hidden=stp.fh_loss == "gmm_thin")
         grads: Dict[int, torch.Tensor] = {}
         for conv, (gw, gb) in zip(_head_convs(stp), [head_grads[i] for i in range(len(head_grads))]):

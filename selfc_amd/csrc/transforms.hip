@@ -240,15 +240,15 @@ __global__ void nhwc4_to_nchw_kernel(const float* __restrict__ x, float* __restr
 }
 
 // Quantization.py:7-17: clamp(x,0,1); round(x*255)/255 with round-half-to-even (torch.round).
-__global__ void quantize_kernel(float* __restrict__ x, size_t n4) {
+__global__ void quantize_kernel(float* __restrict__ x, size_t n4, const float qv, const int clip) {
   const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
   if (i >= n4) return;
   float4 v = reinterpret_cast<float4*>(x)[i];
   float* f = reinterpret_cast<float*>(&v);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float t = f[j] != f[j] ? f[j] : fminf(fmaxf(f[j], 0.f), 1.f);   // fminf / fmaxf would turn a NaN into 0: torch.clamp keeps it
-    f[j] = rintf(t * 255.0f) / 255.0f;
+    const float t = (f[j] != f[j] || !clip) ? f[j] : fminf(fmaxf(f[j], 0.f), 1.f);   // fminf / fmaxf would turn a NaN into 0: torch.clamp keeps it
+    f[j] = rintf(t * qv) / qv;
   }
   reinterpret_cast<float4*>(x)[i] = v;
 }
@@ -481,12 +481,14 @@ int selfc_nhwc4_to_nchw(const float* x, float* y, int N, int C, int H, int W, vo
   return hip_rc(hipGetLastError());
 }
 
-int selfc_quantize_inplace(float* x, size_t n, void* stream) {
-  if (!x || (n & 3)) return SELFC_EINVAL;
+int selfc_quantize_inplace_v(float* x, size_t n, float quant_v, int is_clip, void* stream) {
+  if (!x || (n & 3) || !(quant_v > 0.f)) return SELFC_EINVAL;
   if (n == 0) return SELFC_OK;
   ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
-  hipLaunchKernelGGL(quantize_kernel, dim3(nblocks(n / 4)), dim3(TPB), 0, (hipStream_t)stream, x, n / 4);
+  hipLaunchKernelGGL(quantize_kernel, dim3(nblocks(n / 4)), dim3(TPB), 0, (hipStream_t)stream, x, n / 4, quant_v, is_clip ? 1 : 0);
   return hip_rc(hipGetLastError());
 }
+
+int selfc_quantize_inplace(float* x, size_t n, void* stream) { return selfc_quantize_inplace_v(x, n, 255.0f, 1, stream); }
 
 }  // extern "C"

@@ -12,8 +12,6 @@ from .. import _lib, runtime as rt
 def _round_to_grid(values: torch.Tensor) -> torch.Tensor:
     """A quantised copy of `values` (any shape, fp32, on the GPU).  The kernel works on whole float4 groups, so a length
     that is not a multiple of 4 goes through a zero-padded staging buffer."""
-    if Quantization.quant_v != 255.0 or not Quantization.is_clip:
-        raise NotImplementedError("selfc_quantize_inplace implements the shipped setting quant_v=255, is_clip=True")
     count = values.numel()
     padded = (count + 3) // 4 * 4
     if padded == count:
@@ -21,7 +19,7 @@ def _round_to_grid(values: torch.Tensor) -> torch.Tensor:
     else:
         work = values.new_zeros(padded)
         work[:count].copy_(values.reshape(-1))
-    rt.call("selfc_quantize_inplace", work.data_ptr(), padded, _lib.stream_ptr())
+    rt.call("selfc_quantize_inplace_v", work.data_ptr(), padded, float(Quantization.quant_v), 1 if Quantization.is_clip else 0, _lib.stream_ptr())
     return work if padded == count else work[:count].reshape(values.shape)
 
 

@@ -217,20 +217,30 @@ class STPNet(nn.Module):
         return (m.channel_in if m.channel_in <= 3 else 64, 64)
 
     def _tail_packed(self):
+        """[(fragments, bias, cin, cout)] of the head's pointwise convs in the kernels' terms: the l2 head as it is (cout =
+        hf_dim); a GMM head with every width rounded up to what selfc_pwconv_run takes - input rows of 64 channels (the chain's
+        rows, zero beyond c), hidden widths to 32 / 64 / 128 / 256, the last layer to a multiple of 16 - by zero rows / columns, which is
+        exact (padded hidden units are act(0 + 0) = 0 and meet zero columns).  c = 64 with hf_dim = 48 (SelfC-large) needs no pad."""
         convs = [m for m in self._tail_seq() if isinstance(m, nn.Conv3d)]
         key = rt.params_key(*convs)
         if getattr(self, "_tail_key", None) != key:
             from ..packing import pack_pointwise, pad_bias, roundup
-            if self.c != 64 and len(convs) != 1:
-                raise NotImplementedError("selfc_amd: a GMM head on a hidden width other than 64 is not built (the codec variant ships fh_loss: l2)")
-
-            def wide(m):          # first layer of a c < 64 head: zero columns for the chain's padded channels
-                wt = m.weight.detach().float().reshape(m.out_channels, m.in_channels)
-                if m.in_channels % 32:
-                    wt = torch.cat((wt, wt.new_zeros(m.out_channels, roundup(m.in_channels, 64) - m.in_channels)), 1)
-                return wt
-            self._tail = [(pack_pointwise(wide(m)), pad_bias(m.bias, roundup(m.out_channels, 16)), roundup(m.in_channels, 32) if m.in_channels % 32 == 0 else roundup(m.in_channels, 64), m.out_channels)
-                          for m in convs]
+            tail, prev = [], 64
+            for i, m in enumerate(convs):
+                last = i == len(convs) - 1
+                cin_p = prev
+                if last:
+                    cout_p = m.out_channels if len(convs) == 1 else roundup(m.out_channels, 16)
+                else:         # a hidden width is the next layer's K: the pointwise kernel takes 32, 64, 128 or 256 input channels
+                    fits = [v for v in (32, 64, 128, 256) if v >= m.out_channels]
+                    if not fits:
+                        raise NotImplementedError("selfc_amd: hidden layers of the STP head hold at most 256 channels")
+                    cout_p = fits[0]
+                wt = torch.zeros(max(cout_p, m.out_channels), cin_p, dtype=torch.float32, device=m.weight.device)
+                wt[:m.out_channels, :m.in_channels] = m.weight.detach().float().reshape(m.out_channels, m.in_channels)
+                tail.append((pack_pointwise(wt), pad_bias(m.bias, roundup(cout_p, 16)), cin_p, cout_p))
+                prev = cout_p
+            self._tail = tail
             self._tail_fused = self._tail_fused_key = None
             self._tail_key = key
         return self._tail
@@ -262,8 +272,6 @@ class STPNet(nn.Module):
         buffer).  Returns the raw head output [n][h*w][Cp] when keep_raw (else None).
         scratch: a caller-owned dict for the intermediate buffers (one per stream when several calls overlap);
         eps: pre-allocated noise rows [n*h*w][hf_dim*K] to fill in place (hipGraph capture) instead of a fresh randn."""
-        if self.hf_dim != 48 and self.fh_loss != "l2":
-            raise NotImplementedError("the GMM head kernels are built for hf_dim = 48 (scale 4); other scales run the l2 head")
         dev, sp = x1.device, _lib.stream_ptr()
         sc = scratch if scratch is not None else self.__dict__.setdefault("_scratch", {})
         shape_key = (n, h, w, str(dev))
@@ -341,8 +349,15 @@ class STPNet(nn.Module):
             rt.call("selfc_stp_head_gmm", feat.data_ptr(), wf.data_ptr(), bfz.data_ptr(), eps.data_ptr(), hf_out.data_ptr(),
                     npix, self.hf_dim, self.K, hf_out.shape[-1], 1, sp)
             return None
-        rt.call("selfc_gmm_sample", sc["raw"].data_ptr(), eps.data_ptr(), hf_out.data_ptr(), npix, self.hf_dim, self.K, sp)
-        return sc["raw"] if keep_raw else None
+        creal = self.hf_dim * self.K * 3
+        if self.hf_dim == 48 and co2 == creal and self.K in (1, 3, 5):
+            rt.call("selfc_gmm_sample", sc["raw"].data_ptr(), eps.data_ptr(), hf_out.data_ptr(), npix, self.hf_dim, self.K, sp)
+        else:         # any other scale / mixture size (hf_dim = 3 scale^2): the one-thread-per-pixel sampler, padded raw rows
+            rt.call("selfc_gmm_sample_generic", sc["raw"].data_ptr(), eps.data_ptr(), hf_out.data_ptr(), npix, self.hf_dim, self.K,
+                    co2, hf_out.shape[-1], 1.0, sp)
+        if not keep_raw:
+            return None
+        return sc["raw"] if co2 == creal else sc["raw"][:, :creal]
 
     def _eps_rows(self, n, t, h, w, dev):
         """Injected noise (b, hf_dim, K, t, h, w) as kernel rows [npix][hf_dim*K], or None (device RNG)."""

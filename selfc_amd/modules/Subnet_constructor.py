@@ -198,12 +198,21 @@ class FeatureCalapseBlock(nn.Module):
         return y, dense
 
     def forward(self, x, io_type="2d"):
-        if io_type != "2d":
-            raise NotImplementedError("FeatureCalapseBlock: only the io_type='2d' call of the reference's STPNet is built")
         _lib.require_gpu(x)
+        if io_type != "2d":
+            # any other io_type: x is already (b, c, t, h, w) (Subnet_constructor.py:304-320 skips its reshapes).  SpaceToDepth
+            # unpacks four sizes (:247), so the reference itself only admits this call with scale == 1
+            if self.scale > 1:
+                raise ValueError("too many values to unpack (expected 4)")       # what SpaceToDepth.forward raises on a 5-D input
+            b, c, t, h, w = x.shape
+            y = self._forward_frames(x.transpose(1, 2).reshape(b * t, c, h, w), t)
+            return y.reshape(b, t, -1, h, w).transpose(1, 2)          # the residual (is_res) was added on the frame view
+        t = GlobalVar.get_Temporal_LEN() or 7
+        return self._forward_frames(x, t)
+
+    def _forward_frames(self, x, t):
         res = x
         xs = self.ds(x) if self.scale > 1 else x                     # SpaceToDepth / PixelShuffle: torch view ops (differentiable)
-        t = GlobalVar.get_Temporal_LEN() or 7
         n, c, h, w = xs.shape
         if c != self.cin or n % t:
             raise RuntimeError(f"FeatureCalapseBlock expects (b*{t},{self.cin // self.scale ** 2},H,W), got {tuple(x.shape)}")

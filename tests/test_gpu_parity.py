@@ -61,6 +61,20 @@ def test_quant_bit_exact(dev):
     assert torch.equal(Quantization()(g["x"].to(dev)).cpu(), g["y"])
 
 
+def test_quant_other_class_settings_bit_exact(dev):
+    """Quantization.quant_v / is_clip are class-level settings of the reference (Quantization.py:9-13,20-22): any grid, with or
+    without the clamp, bit-exact against the oracle (incl. half-way values, negatives, > 1 and the 15-level grid)."""
+    from selfc_amd.modules.Quantization import Quantization
+    g = load_golden("g9_quant")
+    x = torch.cat((g["x"].reshape(-1), torch.tensor([-0.7, 1.3, 0.5 / 15, 1.5 / 15, 2.5 / 15, 0.1234567]), torch.linspace(-0.5, 1.5, 37)))
+    try:
+        for qv, clip in ((15.0, True), (255.0, False), (1023.0, True), (7.0, False)):
+            q = Quantization(qv, clip)
+            assert torch.equal(q(x.to(dev)).cpu(), O.quantize(x, qv, clip)), (qv, clip)
+    finally:
+        Quantization(255.0, True)               # restore the shipped class-level setting
+
+
 def test_denseblock(dev):
     from selfc_amd.modules.Subnet_constructor import DenseBlock
     g = load_golden("g3_denseblock")

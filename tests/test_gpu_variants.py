@@ -156,3 +156,58 @@ def test_stp_v2_gmm_thin_head(dev):
     raw = stp.parameters[0].transpose(0, 1)
     assert rel_err(raw.cpu(), g["raw"]) < TOL and rel_l2(raw.cpu(), g["raw"]) < TOL
     assert rel_err(stp.sample()[0].transpose(0, 1).cpu(), g["v"]) < TOL
+
+
+def test_feature_calapse_block_3d_io(dev):
+    """FeatureCalapseBlock.forward(x, io_type='3d') (Subnet_constructor.py:304-320): x is (b, c, t, h, w) and the clip length is
+    x's own third axis, not GlobalVar's; the reference's SpaceToDepth unpacks four sizes, so the call only exists for scale == 1
+    (scale > 1 raises the same ValueError there)."""
+    from selfc_amd.modules.Subnet_constructor import FeatureCalapseBlock
+    torch.manual_seed(3)
+    blk = FeatureCalapseBlock(32, 32, scale=1, INN_init=False, is_res=True)
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    x5 = torch.randn(2, 32, 5, 8, 12) * 0.5                        # 2 clips of FIVE frames (GlobalVar says 7)
+    frames = x5.transpose(1, 2).reshape(10, 32, 8, 12)
+    ref = O.feature_calapse_block(sd, frames, 5, scale=1, is_res=True).reshape(2, 5, 32, 8, 12).transpose(1, 2)
+    blk.to(dev)
+    with torch.no_grad():
+        y = blk(x5.to(dev), io_type="3d")
+    assert y.shape == ref.shape and rel_err(y.cpu(), ref) < TOL and rel_l2(y.cpu(), ref) < TOL
+    with pytest.raises(ValueError):
+        FeatureCalapseBlock(3, 12).to(dev)(torch.zeros(1, 3, 7, 16, 16, device=dev), io_type="3d")
+
+
+@pytest.mark.parametrize("which", ["v2_scale2", "codec_gmm"])
+def test_gmm_head_other_widths(dev, which):
+    """The GMM head outside SelfC-large's shape: scale 2 (hf_dim = 12, head 64 -> 128 -> 256 -> 180: SelfC_GMM_arch_inv.py:331-344
+    with scale 2) and the codec variant's narrow head (24 -> 48 -> 96 -> 180, SelfC_Codec_arch_inv.py:263-272) - widths are padded
+    to the pointwise kernel's granules with zero rows / columns, the sample comes from the generic sampler."""
+    from selfc_amd import GlobalVar
+    torch.manual_seed(23)
+    if which == "v2_scale2":
+        from selfc_amd.modules.SelfC_GMM_arch_inv import STPNet
+        stp, tlen, prefix = STPNet({"global_module": "nonlocal", "stp_blk_num": 4, "fh_loss": "gmm", "scale": 2, "gmm_k": 5}), T, "tail_gmm"
+        fn = lambda p, x: O.stp_v2_parameters(p, x, tlen, stp_blk_num=4)                      # noqa: E731
+    else:
+        from selfc_amd.modules.SelfC_Codec_arch_inv import STPNet
+        stp, tlen, prefix = STPNet(dict(CODEC_OPT, fh_loss="gmm")), 3, "tail"
+        fn = lambda p, x: O.codec_stp_parameters(p, x, 3, 4)                                  # noqa: E731
+    sd = {k: v.detach().clone() for k, v in stp.state_dict().items()}
+    b, h, w = 2, 8, 12
+    lr = torch.rand(b * tlen, 3, h, w)
+    eps = torch.randn(b * tlen, 12, 5, h, w)
+    raw_ref = fn(sd, lr)
+    assert raw_ref.shape[1] == 180
+    v_ref = O.stp_v2_gmm_sample(raw_ref, eps, hf_dim=12, k=5)
+    stp.to(dev).eval()
+    stp.eps = eps.reshape(b, tlen, 12, 5, h, w).permute(0, 2, 3, 1, 4, 5).to(dev)             # (b, hf, K, t, h, w)
+    try:
+        GlobalVar.set_Temporal_LEN(tlen)
+        with torch.no_grad():
+            stp(lr.to(dev).reshape(b, tlen, 3, h, w).transpose(1, 2))
+    finally:
+        GlobalVar.set_Temporal_LEN(T)
+    raw = stp.parameters.transpose(1, 2).reshape(b * tlen, 180, h, w)
+    v = stp.sample().transpose(1, 2).reshape(b * tlen, 12, h, w)
+    assert rel_err(raw.cpu(), raw_ref) < TOL and rel_l2(raw.cpu(), raw_ref) < TOL
+    assert rel_err(v.cpu(), v_ref) < TOL
