@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--no-full-path", action="store_true", help="skip the extra netG(x) + Quantization + netG(LR, rev=True) timing (incl. STP sampler)")
     ap.add_argument("--streams", type=int, default=2, help="split the septuplets of a step over this many HIP streams (2 x 2 clips: measured best since the round-2 G/H kernel; 4 x 1 clip before)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the extra training-step timing (config 3: 8 x 7x3x144x144)")
+    ap.add_argument("--no-roofline-leg", action="store_true", help="profiling runs only (tools/profile_gpu.sh): skip the eager one-stream leg that times every launch, so that a trace holds the timed configuration alone; `roofline` is then null")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo rehearsal of launch, sharding and the timing protocol: no HIP call, value is null")
     args = ap.parse_args()
 
@@ -134,11 +135,12 @@ def main():
         # the stated pre-warm below) ahead of the timed region means the timed region is not the first GPU work of the
         # process: a 20-step run then measures the same steady state as a 200-step one (clocks and caches settled).
         L.selfc_profile_reset()
-        L.selfc_profile_enable(1)
-        for _ in range(args.steps):
-            rt.run(x)
-        torch.cuda.synchronize()
-        L.selfc_profile_enable(0)
+        if not args.no_roofline_leg:
+            L.selfc_profile_enable(1)
+            for _ in range(args.steps):
+                rt.run(x)
+            torch.cuda.synchronize()
+            L.selfc_profile_enable(0)
         cls_ms, cls_n = {}, {}
         for cls, name in [(0, "conv3x3"), (1, "conv5_F"), (2, "conv5_GH"), (3, "transforms"), (6, "fused_gh")]:
             ms, n = C.c_double(), C.c_longlong()
@@ -174,27 +176,38 @@ def main():
         kern[name] = {"bound": "mfma", "kernel": label, "achieved": round(tf, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                       "frac": round(tf / PEAK_F16_TFLOPS, 4), "traffic": None, "avg_launch_us": round(avg_ms * 1e3, 2),
                       "launches": cls_n[name], "flops_per_launch": fl, "ms_per_step": round(cls_ms[name] / args.steps, 3)}
-    # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/README.md)
-    # rocprofv3 cannot run inside this process: the counter-derived figures (HBM bytes, measured HBM GB/s, MFMA-busy %)
-    # come from the committed PMC passes of this same workload (tools/profile_gpu.sh -> tools/pmc_traffic.py)
-    traffic_all, pmc_src = {}, None
-    for rnd in ("r2", "r1"):
+    # Counter-derived figures cannot be collected inside this process (rocprofv3 wraps a whole run): they come from the
+    # committed PMC passes of this same workload (tools/profile_gpu.sh -> tools/pmc_traffic.py) and sit under `pmc_reference`
+    # with the configuration and commit they were taken at.  `traffic` (HBM bytes per launch) is only filled from them while the
+    # kernel sources still hash to what was profiled; otherwise it stays null.
+    import hashlib
+    traffic_all, pmc_meta = {}, {}
+    for rnd in ("r3", "r2"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as fh:
                 traffic_all = json.load(fh)
-            pmc_src = f"profiles/{rnd}/pmc_traffic.json (rocprofv3 --pmc passes of this workload, not re-measured in this run)"
+            pmc_meta = dict(traffic_all.pop("_meta", {}), file=f"profiles/{rnd}/pmc_traffic.json")
             break
         except (OSError, ValueError):
             continue
+    hsh = hashlib.sha256()
+    for f in ("common.hpp", "dense_conv.hip", "fused_f.hip", "fused_gh.hip"):
+        try:
+            hsh.update(open(os.path.join(ROOT, "selfc_amd", "csrc", f), "rb").read())
+        except OSError:
+            pass
+    same_sources = bool(pmc_meta.get("csrc_sha16")) and pmc_meta.get("csrc_sha16") == hsh.hexdigest()[:16]
+    pmc_meta["kernel_sources_unchanged_since"] = same_sources
 
     def add_pmc(entry, key):
         t = traffic_all.get(key)
         if t:
-            entry["traffic"] = t["hbm_bytes_per_launch"]
-            entry["traffic_source"] = pmc_src
-            for fld in ("hbm_GBps_measured", "mfma_busy_pct", "lds_bank_conflict_pct"):
-                if fld in t:
-                    entry[fld] = t[fld]
+            # per-launch byte counts scale with the frames of a launch: the passes ran `frames_per_launch` frames per launch,
+            # the eager roofline leg above launches all B_PER_GPU * T frames at once
+            scale = n_frames / float(pmc_meta.get("frames_per_launch") or n_frames)
+            if same_sources:
+                entry["traffic"] = t["hbm_bytes_per_launch"] * scale
+            entry["pmc_reference"] = dict({k: v for k, v in t.items() if k != "source"}, **{"meta": pmc_meta})
     if f_scopes == 1 and "fused_f" in traffic_all:
         traffic_all["conv3x3"] = traffic_all["fused_f"]
     for k in kern:
@@ -209,8 +222,8 @@ def main():
                             "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": None, "avg_launch_us": round(avg_ms * 1e3, 2),
                             "launches": cls_n["conv5_GH"], "bytes_per_launch": by, "ms_per_step": round(cls_ms["conv5_GH"] / args.steps, 3)}
         add_pmc(kern["conv5_GH"], "conv5_GH")
-    dominant = max(kern, key=lambda k: kern[k]["ms_per_step"])
-    roofline = kern[dominant]
+    dominant = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
+    roofline = kern[dominant] if kern else None
     value = launch.whole_job_rate(B_PER_GPU, world, args.steps, dt)
     whole_flops = 2.0 * MAC_BLOCK_PX * npx * 16
     out = {
