@@ -132,6 +132,9 @@ typedef struct {
   float* s_out;          /* optional: InvBlockExp.s as fp32 [N][H][W][c2p], or NULL */
   float* pf;             /* optional workspace: F conv5 partial products, fp32 [2 pairs][3 taps][N][H][W][4] (see w5p), or NULL */
   int flags;             /* SELFC_LAT_* (abi 7) */
+  void* fd_next;         /* optional (abi 8), rev == 0 only: where the G/H epilogue puts the f16 copy of the updated x2 (the NEXT
+                            block's F input) instead of this block's own `fd` - a training forward that keeps one private `fd` per
+                            block (its backward then finds F's input planes untouched).  NULL: `fd` (blocks chained in place). */
 } selfc_latent;
 
 /* The caller reads the dense feature buffers (fd / gd / hd planes f1..f4) after the call - the training forward, whose

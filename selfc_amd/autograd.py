@@ -439,56 +439,177 @@ class InvBlockFn(torch.autograd.Function):
         d1 = torch.empty((n, h, w, 4), dtype=torch.float32, device=dev)
         d2 = torch.empty((n, h, w, ws.c2p), dtype=torch.float32, device=dev)
         rt.call("selfc_nchw_to_latent", gy.data_ptr(), d1.data_ptr(), d2.data_ptr(), None, ws.FC, n, c1, c2, h, w, sp)
-        dx2 = torch.empty_like(d2)
-        dh = torch.empty_like(d2)
-        nel = d2.numel()
-        clamp = float(blk.clamp)
-        pb = rt.packed_block(blk)
-        side = side_stream(dev) if want else None
-        side_h = side_stream(dev, 1)
-        main = torch.cuda.current_stream()
-        ev_h = []
-
-        def h_backward(xin_gh):
-            """H's whole backward (data chain, then its weight gradients) next to G's: own stream, own dx buffer."""
-            if side_h is None:
-                return subnet_bwd(blk.H, ws.hd, xin_gh, dh, 1.0, d1, True, n, t, h, w, want, pb.H, side, "H"), None
-            d1h = torch.empty_like(d1)
-            side_h.wait_event(main.record_event())
-            with torch.cuda.stream(side_h):
-                g_ = subnet_bwd(blk.H, ws.hd, xin_gh, dh, 1.0, d1h, False, n, t, h, w, want, pb.H, None, "H",
-                                on_data_done=lambda: ev_h.append(side_h.record_event()))
-            return g_, d1h
-
-        if not rev:
-            # y1 = x1 + F(x2); y2 = x2*e^s + G(y1), s = s(H(y1)).  keep = x2 (input), ws.x1 = y1
-            rt.call("selfc_coupling_bwd", 0, keep.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel, sp)
-            gH, d1h = h_backward(ws.x1)
-            gG = subnet_bwd(blk.G, ws.gd, ws.x1, d2, 1.0, d1, True, n, t, h, w, want, pb.G, side, "G")
-            if d1h is not None:
-                main.wait_event(ev_h[0])
-                d1.add_(d1h)
-            # the forward's epilogue replaced F's f16 input copy by y2: put x2 back before F's weight gradients
-            rt.call("selfc_nhwc_to_planes", keep.data_ptr(), ws.fd.data_ptr(), n * h * w, c2, sp)
-            gF = subnet_bwd(blk.F, ws.fd, None, d1, 1.0, dx2, True, n, t, h, w, want, pb.F, side, "F")
-        else:
-            # y2 = (x2 - G(x1))*e^-s, s = s(H(x1)); y1 = x1 - F(y2).  keep = x1 (input), ws.x2 = y2 (also in fd)
-            gF = subnet_bwd(blk.F, ws.fd, None, d1, -1.0, d2, True, n, t, h, w, want, pb.F, side, "F")
-            rt.call("selfc_coupling_bwd", 1, ws.x2.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel, sp)
-            gH, d1h = h_backward(keep)
-            gG = subnet_bwd(blk.G, ws.gd, keep, dx2, -1.0, d1, True, n, t, h, w, want, pb.G, side, "G")
-            if d1h is not None:
-                main.wait_event(ev_h[0])
-                d1.add_(d1h)
+        d1, dx2, gF, gG, gH = _block_backward(blk, ws, keep, rev, t, d1, d2, want, restore_fd=True)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((n, c1 + c2, h, w), dtype=torch.float32, device=dev)
             rt.call("selfc_latent_to_nchw", d1.data_ptr(), dx2.data_ptr(), dx.data_ptr(), n, c1, c2, h, w, sp)
-        if side is not None:
-            main.wait_stream(side)                                 # the parameter gradients are complete from here on
-        if side_h is not None:
-            main.wait_stream(side_h)
+        _join_side_streams(dev, want)
         return (dx, None, None, None, *gF, *gG, *gH)
+
+
+def _join_side_streams(dev, want: bool):
+    main = torch.cuda.current_stream()
+    if want and side_stream(dev) is not None:
+        main.wait_stream(side_stream(dev))                         # the parameter gradients are complete from here on
+    if side_stream(dev, 1) is not None:
+        main.wait_stream(side_stream(dev, 1))
+
+
+def _block_backward(blk, ws, keep, rev, t, d1, d2, want, restore_fd):
+    """Gradient of one InvBlockExp call on the latent layout.  d1 / d2: gradients w.r.t. the block's outputs (y1, y2) as fp32
+    [n][h][w][4] / [n][h][w][c2p] (d1 is updated in place); ws: what the forward left - fd / gd / hd (dense features), s, and
+    the OUTPUT side the formulas need (forward: ws.x1 = y1; reverse: ws.x2 = y2); keep: the INPUT side the kernels overwrote
+    (forward: x2, reverse: x1).  Returns (d1, dx2, gF, gG, gH): gradients w.r.t. the inputs (x1, x2) and the parameters.
+    The weight-gradient phases run on the side stream and H's chain on a third one; the caller joins them
+    (_join_side_streams) before the gradients are used."""
+    n, h, w, c2 = ws.N, ws.H, ws.W, ws.c2
+    dev, sp = d1.device, _lib.stream_ptr()
+    dx2 = torch.empty_like(d2)
+    dh = torch.empty_like(d2)
+    nel = d2.numel()
+    clamp = float(blk.clamp)
+    pb = rt.packed_block(blk)
+    side = side_stream(dev) if want else None
+    side_h = side_stream(dev, 1)
+    main = torch.cuda.current_stream()
+    ev_h = []
+
+    def h_backward(xin_gh):
+        """H's whole backward (data chain, then its weight gradients) next to G's: own stream, own dx buffer."""
+        if side_h is None:
+            return subnet_bwd(blk.H, ws.hd, xin_gh, dh, 1.0, d1, True, n, t, h, w, want, pb.H, side, "H"), None
+        d1h = torch.empty_like(d1)
+        side_h.wait_event(main.record_event())
+        with torch.cuda.stream(side_h):
+            g_ = subnet_bwd(blk.H, ws.hd, xin_gh, dh, 1.0, d1h, False, n, t, h, w, want, pb.H, None, "H",
+                            on_data_done=lambda: ev_h.append(side_h.record_event()))
+        return g_, d1h
+
+    if not rev:
+        # y1 = x1 + F(x2); y2 = x2*e^s + G(y1), s = s(H(y1)).  keep = x2 (input), ws.x1 = y1
+        rt.call("selfc_coupling_bwd", 0, keep.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel, sp)
+        gH, d1h = h_backward(ws.x1)
+        gG = subnet_bwd(blk.G, ws.gd, ws.x1, d2, 1.0, d1, True, n, t, h, w, want, pb.G, side, "G")
+        if d1h is not None:
+            main.wait_event(ev_h[0])
+            d1.add_(d1h)
+        if restore_fd:
+            # the forward's epilogue replaced F's f16 input copy by y2: put x2 back before F's weight gradients
+            rt.call("selfc_nhwc_to_planes", keep.data_ptr(), ws.fd.data_ptr(), n * h * w, c2, sp)
+        gF = subnet_bwd(blk.F, ws.fd, None, d1, 1.0, dx2, True, n, t, h, w, want, pb.F, side, "F")
+    else:
+        # y2 = (x2 - G(x1))*e^-s, s = s(H(x1)); y1 = x1 - F(y2).  keep = x1 (input), ws.x2 = y2 (also in fd)
+        gF = subnet_bwd(blk.F, ws.fd, None, d1, -1.0, d2, True, n, t, h, w, want, pb.F, side, "F")
+        rt.call("selfc_coupling_bwd", 1, ws.x2.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel, sp)
+        gH, d1h = h_backward(keep)
+        gG = subnet_bwd(blk.G, ws.gd, keep, dx2, -1.0, d1, True, n, t, h, w, want, pb.G, side, "G")
+        if d1h is not None:
+            main.wait_event(ev_h[0])
+            d1.add_(d1h)
+    return d1, dx2, gF, gG, gH
+
+
+class InvStackFn(torch.autograd.Function):
+    """The whole op loop of SelfCInvNet as ONE differentiable op (SelfC_GMM_arch_inv.py:452-456 forward, :486-490 reverse):
+    FrequencyAnalyzer + every InvBlockExp, state kept in the kernels' latent layout from the first block to the last.
+
+      rev == False:  x (N,3,H,W) image  -> (N,3+c2,h,w) latent        (selfc_freq_fwd, blocks 0..n-1)
+      rev == True :  z (N,3+c2,h,w)     -> (N,3,H,W) reconstruction   (blocks n-1..0, selfc_freq_inv)
+
+    Against one InvBlockFn per block this drops, per block call and direction, the NCHW <-> latent conversions (4 launches),
+    the clone of the block's private x1 / x2 pair and the Python / autograd-node overhead; each block still owns the buffers its
+    backward needs (fd / gd / hd, s, the input side its kernels overwrite, the output side its formulas read).  The G/H epilogue
+    writes the f16 copy of the updated x2 straight into the NEXT block's F buffer (selfc_latent.fd_next), so F's input planes
+    are still there in the backward."""
+
+    @staticmethod
+    def forward(ctx, x, net, rev, t, *params):
+        from types import SimpleNamespace
+        x = rt.as_input(x)
+        freq = net.operations[0]
+        k = freq.k
+        blocks = net._blocks()
+        order = list(reversed(blocks)) if rev else blocks
+        c1, c2 = blocks[0].split_len1, blocks[0].split_len2
+        dev, sp = x.device, _lib.stream_ptr()
+        if not rev:
+            n, _, H, W = x.shape
+            h, w = H // k, W // k
+        else:
+            n, _, h, w = x.shape
+            H, W = h * k, w * k
+        kind = blocks[0].F.kind
+        f32, F16 = torch.float32, _lib.operand_dtype()
+        c2p, FC = roundup(c2, 4), dense_channels(c2)
+        x1 = torch.empty((n, h, w, 4), dtype=f32, device=dev)
+        x2 = torch.empty((n, h, w, c2p), dtype=f32, device=dev)
+        pf = torch.empty((2, n, h, w, 12), dtype=f32, device=dev) if c2 == 48 else None
+
+        def new_fd():          # only the pad channels of the input planes need the zero fill (features are fully written)
+            return (torch.zeros if c2 % 32 else torch.empty)((FC // 32, n, h, w, 32), dtype=F16, device=dev)
+        fds = [new_fd() for _ in order]
+        if not rev:
+            rt.call("selfc_freq_fwd", x.data_ptr(), x1.data_ptr(), x2.data_ptr(), fds[0].data_ptr(), FC, n, H, W, k, sp)
+        else:
+            rt.call("selfc_nchw_to_latent", x.data_ptr(), x1.data_ptr(), x2.data_ptr(), None, FC, n, c1, c2, h, w, sp)
+        saves = []
+        for i, blk in enumerate(order):
+            sv = SimpleNamespace(N=n, H=h, W=w, c1=c1, c2=c2, c2p=c2p, FC=FC, fd=fds[i],
+                                 gd=torch.empty((4, n, h, w, 32), dtype=F16, device=dev),
+                                 hd=torch.empty((4, n, h, w, 32), dtype=F16, device=dev),
+                                 s=torch.empty((n, h, w, c2p), dtype=f32, device=dev), x1=None, x2=None, device=dev)
+            keep = (x1 if rev else x2).clone()                    # the input side the kernels overwrite
+            nxt = fds[i + 1] if (not rev and i + 1 < len(order)) else None
+            lat = _lib.Latent(kind, n, t, h, w, c1, c2, x1.data_ptr(), x2.data_ptr(), sv.fd.data_ptr(), sv.gd.data_ptr(),
+                              sv.hd.data_ptr(), sv.s.data_ptr(), None if pf is None else pf.data_ptr(), _lib.LAT_KEEP_FEATURES,
+                              None if nxt is None else nxt.data_ptr())
+            rt.call("selfc_invblock_run", rt.packed_block(blk).struct(), lat, 1 if rev else 0, sp)
+            if rev:
+                sv.x2 = x2.clone()                                # y2: read by the coupling gradient
+            else:
+                sv.x1 = x1.clone()                                # y1: input of G / H
+            blk._set_s_lazy(sv)
+            saves.append((blk, sv, keep, nxt is not None))
+        if not rev:
+            out = torch.empty((n, c1 + c2, h, w), dtype=f32, device=dev)
+            rt.call("selfc_latent_to_nchw", x1.data_ptr(), x2.data_ptr(), out.data_ptr(), n, c1, c2, h, w, sp)
+        else:
+            out = torch.empty((n, 3, H, W), dtype=f32, device=dev)
+            rt.call("selfc_freq_inv", x1.data_ptr(), x2.data_ptr(), out.data_ptr(), n, h, w, k, sp)
+        ctx.saves, ctx.rev, ctx.t, ctx.dims, ctx.blocks = saves, bool(rev), t, (n, h, w, H, W, c1, c2, c2p, FC), blocks
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        n, h, w, H, W, c1, c2, c2p, FC = ctx.dims
+        rev, t = ctx.rev, ctx.t
+        gy = gy.contiguous().float()
+        dev, sp = gy.device, _lib.stream_ptr()
+        want = any(ctx.needs_input_grad[4:])
+        d1 = torch.empty((n, h, w, 4), dtype=torch.float32, device=dev)
+        d2 = torch.empty((n, h, w, c2p), dtype=torch.float32, device=dev)
+        if not rev:
+            rt.call("selfc_nchw_to_latent", gy.data_ptr(), d1.data_ptr(), d2.data_ptr(), None, FC, n, c1, c2, h, w, sp)
+        else:
+            rt.call("selfc_freq_inv_bwd", gy.data_ptr(), d1.data_ptr(), d2.data_ptr(), n, H, W, sp)
+        grads = {}
+        for blk, sv, keep, fd_intact in reversed(ctx.saves):
+            d1, d2, gF, gG, gH = _block_backward(blk, sv, keep, rev, t, d1, d2, want, restore_fd=not fd_intact)
+            grads[id(blk)] = (*gF, *gG, *gH)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if not rev:
+                dx = torch.empty((n, 3, H, W), dtype=torch.float32, device=dev)
+                rt.call("selfc_freq_fwd_bwd", d1.data_ptr(), d2.data_ptr(), dx.data_ptr(), n, H, W, sp)
+            else:
+                dx = torch.empty((n, c1 + c2, h, w), dtype=torch.float32, device=dev)
+                rt.call("selfc_latent_to_nchw", d1.data_ptr(), d2.data_ptr(), dx.data_ptr(), n, c1, c2, h, w, sp)
+        _join_side_streams(dev, want)
+        flat = []
+        for blk in ctx.blocks:                                    # parameter order of forward(): net._blocks() order
+            flat += list(grads[id(blk)])
+        return (dx, None, None, None, *flat)
 
 
 class CouplingFn(torch.autograd.Function):

@@ -968,7 +968,7 @@ int run_GH(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStrea
     a.w = (const f16*)blk->G.w5; a.bias[0] = blk->G.b5; a.bias[1] = blk->H.b5;
     a.x1 = l->x1;
     a.B = l->N / l->T; a.T = l->T; a.HW = l->H * l->W; a.plane = (size_t)l->N * l->H * l->W * 32;
-    a.x2io = l->x2; a.fd = (f16*)l->fd; a.s_out = l->s_out; a.c2p = c2p;
+    a.x2io = l->x2; a.fd = (f16*)((!rev && l->fd_next) ? l->fd_next : l->fd); a.s_out = l->s_out; a.c2p = c2p;
     a.rev = rev; a.clamp = blk->clamp;
     return dispatch_t5<2, 1, EPI_GH>(a, (l->c2 + 15) / 16, 4, s);
   }
@@ -979,7 +979,7 @@ int run_GH(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStrea
   a.x1 = l->x1; a.c1 = l->c1;
   a.N = l->N; a.H = l->H; a.W = l->W; a.plane = (size_t)l->N * l->H * l->W * 32;
   build_stages(a, l->c1, 5);
-  a.x2io = l->x2; a.fd = (f16*)l->fd; a.s_out = l->s_out; a.c2p = c2p;
+  a.x2io = l->x2; a.fd = (f16*)((!rev && l->fd_next) ? l->fd_next : l->fd); a.s_out = l->s_out; a.c2p = c2p;
   a.rev = rev; a.clamp = blk->clamp;
   return launch_conv3x3<EPI_GH>(a, 1, s);
 }
@@ -1026,8 +1026,8 @@ int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s)
 
 extern "C" {
 
-const char* selfc_version(void) { return "selfc_hip gfx950 abi7 operands=" SELFC_OPERAND_NAME; }
-int selfc_abi_version(void) { return 7; }
+const char* selfc_version(void) { return "selfc_hip gfx950 abi8 operands=" SELFC_OPERAND_NAME; }
+int selfc_abi_version(void) { return 8; }
 
 int selfc_invblock_run(const selfc_invblock_w* blk, const selfc_latent* lat, int rev, void* stream) {
   if (!blk || !latent_ok(lat)) return SELFC_EINVAL;

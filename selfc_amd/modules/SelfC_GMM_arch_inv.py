@@ -507,7 +507,15 @@ class SelfCInvNet(nn.Module):
         t = GlobalVar.get_Temporal_LEN()
         if not t or x.shape[0] % t:
             raise RuntimeError(f"GlobalVar temporal length {t!r} does not divide the {x.shape[0]} input frames")
+        # one op for FrequencyAnalyzer + every block (state stays in the latent layout between blocks) where its kernels
+        # apply: k = 4 (the split's adjoint kernels), channel split <= 3; otherwise the op loop, one differentiable op per module
+        blocks = self._blocks()
+        stack = self.operations[0].k == 4 and all(b.split_len1 <= 3 for b in blocks) and len(blocks) == len(self.operations) - 1
+        prm = [p for b in blocks for p in ag.block_params(b)] if stack else None
         if not rev:
+            if stack:
+                out = ag.InvStackFn.apply(x, self, False, t, *prm)
+                return out, out.new_zeros(())
             out = x
             for op in self.operations:
                 out = op.forward(out, False)
@@ -517,6 +525,8 @@ class SelfCInvNet(nn.Module):
         stp = self.stp_net
         recon_hf = ag.STPSampleFn.apply(lr, stp, t, stp._eps_rows(n, t, h, w, x.device), *rt.plist(stp))
         out = torch.cat((lr, recon_hf), dim=1)
+        if stack:
+            return ag.InvStackFn.apply(out, self, True, t, *prm), recon_hf
         for op in reversed(self.operations):
             out = op.forward(out, True)
         return out, recon_hf
