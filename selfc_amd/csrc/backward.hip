@@ -390,9 +390,8 @@ struct FinArgs {
 
 // thread = one element of the partial block layout (coalesced reads over the nW partials), scattered write;
 // the threads past the weight elements reduce the bias partials
-__global__ __launch_bounds__(256) void wgrad_finish_kernel(const FinArgs a) {
+__device__ __forceinline__ void wgrad_finish_body(const FinArgs& a, const size_t e) {
   const size_t per = (size_t)a.npairs * a.ttot * 1024;
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   const float inv = 1.f / grad_scale(*a.amax);
   if (e >= per) {
     const size_t o = e - per;
@@ -444,6 +443,22 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const FinArgs a) {
   float* dst = outp + ((size_t)o * Ctot + ci) * a.ttot + tap;
   const float v = ((s0 + s1) + (s2 + s3)) * inv;
   *dst = (a.beta != 0.f) ? a.beta * *dst + v : v;
+}
+
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const FinArgs a) {
+  wgrad_finish_body(a, (size_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+// two finish jobs in one launch (conv1..4 and conv5 of a subnet): blocks [0, nblk_a) do job a, the rest job b
+__global__ __launch_bounds__(256) void wgrad_finish2_kernel(const FinArgs a, const FinArgs b, const unsigned nblk_a) {
+  if (blockIdx.x < nblk_a) wgrad_finish_body(a, (size_t)blockIdx.x * 256 + threadIdx.x);
+  else wgrad_finish_body(b, (size_t)(blockIdx.x - nblk_a) * 256 + threadIdx.x);
+}
+
+inline unsigned fin_blocks(const FinArgs& f) {
+  const size_t per = (size_t)f.npairs * f.ttot * 1024;
+  const bool bias = f.multi ? (f.bout[0] || f.bout[1] || f.bout[2] || f.bout[3]) : f.bout[0] != nullptr;
+  return (unsigned)((per + (bias ? (f.multi ? 128 : f.O) : 0) + 255) / 256);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -538,7 +553,7 @@ __global__ __launch_bounds__(256) void freq_inv_bwd_kernel(const float* __restri
 struct BwdLayout {
   int nx, ng, hasx;
   size_t plane_b;       // bytes of one f16 plane
-  size_t off_g, off_t5, off_xplane, off_amax, off_wg, total;
+  size_t off_g, off_t5, off_xplane, off_amax, off_wg, off_wg5, total;
 };
 
 BwdLayout bwd_layout(int N, int H, int W, int cin, int cout) {
@@ -556,7 +571,8 @@ BwdLayout bwd_layout(int N, int H, int W, int cin, int cout) {
   // largest weight-gradient job: conv4 (1 P plane, nx+3 Q planes, 9 taps) or conv5 (ng P planes, nx+4 Q planes, 9 | 3 taps)
   const size_t a4 = bwd_wgrad14_scratch_bytes(N, H, W, L.nx);
   const size_t a5 = bwd_wgrad_scratch_bytes(N, H, W, L.ng, L.nx + 4, 9);
-  L.total = up256(L.off_wg + (a4 > a5 ? a4 : a5));
+  L.off_wg5 = up256(L.off_wg + a4);                   // own region each: both compute kernels run before ONE finish launch
+  L.total = up256(L.off_wg5 + a5);
   return L;
 }
 
@@ -610,7 +626,7 @@ int launch_wgrad_any(const WgArgs& a, int nsplit, int gy, int gz, hipStream_t s)
 }
 }  // namespace
 
-int bwd_wgrad(const WgradJob& j, const float* amax, void* scratch, int N, int T, int H, int W, hipStream_t s) {
+static int bwd_wgrad_impl(const WgradJob& j, const float* amax, void* scratch, int N, int T, int H, int W, hipStream_t s, FinArgs* defer) {
   const size_t npix = (size_t)N * H * W, plane = npix * 32;
   const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
   const int qtot = j.Qn[0] + j.Qn[1];
@@ -637,16 +653,20 @@ int bwd_wgrad(const WgradJob& j, const float* amax, void* scratch, int N, int T,
   FinArgs f{};
   f.part = part; f.bpart = bpart; f.out[0] = j.wout; f.bout[0] = j.bout; f.nW = nsplit; f.Pn = j.Pn; f.qtot = qtot; f.ttot = ttot;
   f.O = j.O; f.Ctot = j.Ctot; f.cin = j.cin; f.nx = j.nx; f.npairs = j.Pn * qtot; f.amax = amax; f.beta = j.beta;
-  const size_t per = (size_t)f.npairs * ttot * 1024;
-  hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((per + (j.bout ? j.O : 0) + 255) / 256)), dim3(256), 0, s, f);
+  if (defer) { *defer = f; return SELFC_OK; }          // the caller finishes this job together with another one
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(fin_blocks(f)), dim3(256), 0, s, f);
   return hip_rc(hipGetLastError());
+}
+
+int bwd_wgrad(const WgradJob& j, const float* amax, void* scratch, int N, int T, int H, int W, hipStream_t s) {
+  return bwd_wgrad_impl(j, amax, scratch, N, T, H, W, s, nullptr);
 }
 
 // conv1..conv4 of one dense block in one launch + one finish.  dpre: the four gradient planes [dpre4 dpre3 dpre2 dpre1];
 // inputs of conv k = the first (nqc1 + k - 1) planes of the run Q0 (nq0 planes) followed by Q1.
 int bwd_wgrad14(const void* dpre, const void* Q0, int nq0, const void* Q1, int nqc1, int cin, int nx,
                 float* const* wout, float* const* bout, float beta, const float* amax, void* scratch,
-                int N, int T, int H, int W, hipStream_t s) {
+                int N, int T, int H, int W, hipStream_t s, FinArgs* defer) {
   const size_t npix = (size_t)N * H * W, plane = npix * 32;
   const int npairs = 4 * nqc1 + 6;
   const int nsplit = wgrad_nsplit(N, H, W, npairs, 9);
@@ -663,8 +683,8 @@ int bwd_wgrad14(const void* dpre, const void* Q0, int nq0, const void* Q1, int n
   f.part = part; f.bpart = bpart; f.nW = nsplit; f.Pn = 4; f.ttot = 9; f.O = 32; f.cin = cin; f.nx = nx;
   f.multi = 1; f.nqc1 = nqc1; f.npairs = npairs; f.amax = amax; f.beta = beta;
   for (int k = 0; k < 4; ++k) { f.out[k] = wout ? wout[k] : nullptr; f.bout[k] = bout ? bout[k] : nullptr; }
-  const size_t per = (size_t)npairs * 9 * 1024;
-  hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((per + (bout ? 128 : 0) + 255) / 256)), dim3(256), 0, s, f);
+  if (defer) { *defer = f; return SELFC_OK; }
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(fin_blocks(f)), dim3(256), 0, s, f);
   return hip_rc(hipGetLastError());
 }
 
@@ -755,7 +775,8 @@ weights:
     // input planes: [x planes][f1..]; with cin <= 3 the x plane is the scratch copy and the features start `dense`
     const void* q0 = L.hasx ? (const void*)xpl : (const void*)dn;
     const int nq0 = L.hasx ? 1 : L.nx + 4;
-    if ((rc = bwd_wgrad14(gb, q0, nq0, feat, L.nx, cin, L.nx, wgrad, bgrad, beta, amax, wgs, N, T, H, W, s))) return rc;
+    FinArgs fa{}, fb{};
+    if ((rc = bwd_wgrad14(gb, q0, nq0, feat, L.nx, cin, L.nx, wgrad, bgrad, beta, amax, wgs, N, T, H, W, s, &fa))) return rc;
     WgradJob j{};
     j.P = gpl; j.Pn = L.ng;
     j.Q[0] = q0; j.Qn[0] = nq0;
@@ -765,7 +786,15 @@ weights:
     j.wout = wgrad ? wgrad[4] : nullptr;
     j.bout = bgrad ? bgrad[4] : nullptr;
     j.O = cout; j.Ctot = cin + 128; j.cin = cin; j.nx = L.nx; j.beta = beta;
-    if ((rc = bwd_wgrad(j, amax, wgs, N, T, H, W, s))) return rc;
+    const bool has5 = j.wout || j.bout;
+    if ((rc = bwd_wgrad_impl(j, amax, sb + L.off_wg5, N, T, H, W, s, &fb))) return rc;
+    if (has5) {
+      const unsigned na = fin_blocks(fa);
+      hipLaunchKernelGGL(wgrad_finish2_kernel, dim3(na + fin_blocks(fb)), dim3(256), 0, s, fa, fb, na);
+    } else {
+      hipLaunchKernelGGL(wgrad_finish_kernel, dim3(fin_blocks(fa)), dim3(256), 0, s, fa);
+    }
+    if ((rc = hip_rc(hipGetLastError()))) return rc;
   }
   return SELFC_OK;
 }
