@@ -23,6 +23,8 @@ namespace {
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 1000; }
 
 constexpr int POOL_CHUNK = 512;  // pixels per partial sum
+constexpr int BWD_CHUNK = 96;    // pixels per partial of the GlobalAgg backward reduction: a training frame (36x36 latent) is 14 chunks,
+                                 // 112 workgroups per 8 clips instead of 24 (the kernel was pure latency: 126 us)
 constexpr int TMAX = 8;
 
 // ---- (1) weighted global pooling: partial[n][chunk][64]
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(256) void gagg_bwd_reduce_kernel(const float* __res
   __shared__ float redY[16][TMAX][64];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int cq = threadIdx.x & 15, pr = threadIdx.x >> 4;
-  const int p0 = chunk * POOL_CHUNK, p1 = min(p0 + POOL_CHUNK, HW);
+  const int p0 = chunk * BWD_CHUNK, p1 = min(p0 + BWD_CHUNK, HW);
   float accA[TMAX][TMAX];
   float4 accY[TMAX];
 #pragma unroll
@@ -789,7 +791,7 @@ __global__ __launch_bounds__(256) void gagg_bwd_reduce_kernel(const float* __res
 }
 
 // step 2: per clip - recompute g, q, k, A; then the gradients of everything upstream of A (tiny)
-__global__ __launch_bounds__(64) void gagg_attn_bwd_kernel(const float* __restrict__ partial, int nchunk, const float* __restrict__ fcbp,
+__global__ __launch_bounds__(64) void gagg_attn_bwd_kernel(const float* __restrict__ partial, int nchunk, int nchunkb, const float* __restrict__ fcbp,
                                                            const float* __restrict__ w2, const float* __restrict__ b2,
                                                            const float* __restrict__ w3, const float* __restrict__ b3,
                                                            const float* __restrict__ b1, const float* __restrict__ pdA,
@@ -803,10 +805,8 @@ __global__ __launch_bounds__(64) void gagg_attn_bwd_kernel(const float* __restri
   for (int t = 0; t < T; ++t) {
     float s = 0.f, sy = 0.f;
     const float* p = partial + (size_t)(b * T + t) * nchunk * 64 + c;
-    for (int j = 0; j < nchunk; ++j) {
-      s += p[(size_t)j * 64];
-      sy += pdyo[(((size_t)b * nchunk + j) * TMAX + t) * 64 + c];
-    }
+    for (int j = 0; j < nchunk; ++j) s += p[(size_t)j * 64];
+    for (int j = 0; j < nchunkb; ++j) sy += pdyo[(((size_t)b * nchunkb + j) * TMAX + t) * 64 + c];
     g[t][c] = s + fcb;
     dyo[t][c] = sy;
   }
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(64) void gagg_attn_bwd_kernel(const float* __restri
     for (int j = 0; j < 64; ++j) s += q[t1][j] * k[t2][j];
     m[t1][t2] = s / 64.0f;
     float d = 0.f;
-    for (int j = 0; j < nchunk; ++j) d += pdA[((size_t)b * nchunk + j) * 64 + t1 * TMAX + t2];
+    for (int j = 0; j < nchunkb; ++j) d += pdA[((size_t)b * nchunkb + j) * 64 + t1 * TMAX + t2];
     dA[t1][t2] = d;
   }
   if (c < T) {
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(256) void gagg_bwd_dx_kernel(const float* __restric
 
 struct GaggBwdLayout {
   size_t plane_b, off_dyp, off_zp, off_dz, off_amax, off_pool, off_A, off_pdA, off_pdyo, off_dg, off_wg, total;
-  int nchunk;
+  int nchunk, nchunkb;
 };
 
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -963,6 +963,7 @@ GaggBwdLayout gagg_bwd_layout(int N, int T, int H, int W) {
   GaggBwdLayout L{};
   const int HW = H * W, B = N / T;
   L.nchunk = (HW + POOL_CHUNK - 1) / POOL_CHUNK;
+  L.nchunkb = (HW + BWD_CHUNK - 1) / BWD_CHUNK;
   L.plane_b = (size_t)N * HW * 64;
   size_t o = 0;
   L.off_dyp = o; o += 2 * L.plane_b;
@@ -971,8 +972,8 @@ GaggBwdLayout gagg_bwd_layout(int N, int T, int H, int W) {
   L.off_amax = o; o += 256;
   L.off_pool = o; o = up256(o + (size_t)N * L.nchunk * 64 * 4);
   L.off_A = o; o = up256(o + (size_t)B * T * T * 4);
-  L.off_pdA = o; o = up256(o + (size_t)B * L.nchunk * 64 * 4);
-  L.off_pdyo = o; o = up256(o + (size_t)B * L.nchunk * TMAX * 64 * 4);
+  L.off_pdA = o; o = up256(o + (size_t)B * L.nchunkb * 64 * 4);
+  L.off_pdyo = o; o = up256(o + (size_t)B * L.nchunkb * TMAX * 64 * 4);
   L.off_dg = o; o = up256(o + (size_t)N * 64 * 4);
   L.off_wg = o; o = up256(o + bwd_wgrad_scratch_bytes(N, H, W, 2, 2, 1));
   L.total = o;
@@ -1168,8 +1169,8 @@ int selfc_globalagg_bwd(const float* x, const float* dy, float* dx, const float*
     if ((rc = bwd_conv_planes(c, N, T, H, W, s))) return rc;
   }
   hipLaunchKernelGGL(gagg_pool_kernel, dim3(L.nchunk, N), dim3(256), 0, s, x, wmap, pool, HW, L.nchunk);
-  hipLaunchKernelGGL(gagg_bwd_reduce_kernel, dim3(L.nchunk, B), dim3(256), 0, s, x, dz, dy, pdA, pdyo, T, HW, L.nchunk);
-  hipLaunchKernelGGL(gagg_attn_bwd_kernel, dim3(B), dim3(64), 0, s, pool, L.nchunk, fc_bias, w2, b2, w3, b3, b1, pdA, pdyo, A, dg,
+  hipLaunchKernelGGL(gagg_bwd_reduce_kernel, dim3(L.nchunkb, B), dim3(256), 0, s, x, dz, dy, pdA, pdyo, T, HW, L.nchunkb);
+  hipLaunchKernelGGL(gagg_attn_bwd_kernel, dim3(B), dim3(64), 0, s, pool, L.nchunk, L.nchunkb, fc_bias, w2, b2, w3, b3, b1, pdA, pdyo, A, dg,
                      db1_clip, dw2_clip, db2_clip, dw3_clip, db3_clip, dfcb_clip, T);
   hipLaunchKernelGGL(gagg_bwd_dx_kernel, dim3((unsigned)((HW + 15) / 16), (unsigned)B), dim3(256), 0, s, x, dz, dy, A, dg, wmap, dx,
                      dwmap_clip, zp, T, HW, npix);
