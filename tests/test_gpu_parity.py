@@ -659,3 +659,41 @@ def test_pipeline_follows_weight_changes(dev):
         assert torch.equal(b, RescaleRoundTrip(net, T, 32, 48, dev).run(x))
         with pytest.raises(RuntimeError, match="capture"):
             rt_.replay()
+
+
+def test_latent_flags_and_fd_next_abi(dev):
+    """selfc_latent.flags / fd_next (ABI 7 / 8) through the C ABI on one SelfC-large block: without SELFC_LAT_KEEP_FEATURES the
+    pairwise-fused F launches leave the f3 / f4 planes of `fd` untouched (poison survives) and the block's outputs are the
+    same bits as with it (where f3 / f4 equal the layer-wise path's features); with fd_next the f16 copy of the updated x2
+    lands in the other buffer and this block's own F input planes keep x2."""
+    from selfc_amd import _lib, runtime as rt
+    g = load_golden("g8_large_stack")
+    net = _large_net(dev, g)
+    blk = net._blocks()[0]
+    pb = rt.packed_block(blk)
+    n, h, w = T, 16, 24
+    z = torch.randn(n, 51, h, w, generator=torch.Generator().manual_seed(12)) * 0.5
+    outs, fds = {}, {}
+    for name, keep, use_next in (("inference", False, False), ("keep", True, False), ("next", True, True)):
+        ws = rt.Workspace(dev, blk.F.kind, n, T, h, w, 3, 48)
+        rt.nchw_to_latent(z.to(dev), ws)
+        x2_planes = ws.fd[:2].clone()
+        ws.fd[4:6].fill_(777.0)                                          # poison f3 / f4
+        nxt = torch.full_like(ws.fd, -5.0) if use_next else None
+        lat = _lib.Latent(ws.kind, n, T, h, w, 3, 48, ws.x1.data_ptr(), ws.x2.data_ptr(), ws.fd.data_ptr(), ws.gd.data_ptr(),
+                          ws.hd.data_ptr(), None, ws.pf.data_ptr(), _lib.LAT_KEEP_FEATURES if keep else 0,
+                          None if nxt is None else nxt.data_ptr())
+        rt.call("selfc_invblock_run", pb.struct(), lat, 0, _lib.stream_ptr())
+        outs[name] = rt.latent_to_nchw(ws).cpu()
+        fds[name] = (ws.fd.clone(), x2_planes, nxt)
+    assert torch.equal(outs["inference"], outs["keep"]) and torch.equal(outs["keep"], outs["next"])
+    assert rel_err(outs["keep"], O.invblock("D2DTNet", {k[len("operations.1."):]: v for k, v in g.items() if k.startswith("operations.1.")}, z, 3, T)[0]) < TOL
+    fd_inf, fd_keep = fds["inference"][0], fds["keep"][0]
+    assert bool((fd_inf[4:6] == 777.0).all())                            # nothing stored f3 / f4
+    assert not bool((fd_keep[4:6] == 777.0).any())                       # the training forward has them
+    assert torch.equal(fd_inf[2:4], fd_keep[2:4])                        # f1 / f2 are written either way (pair 1 reads them)
+    # without fd_next the G/H epilogue replaced the block's own x2 planes by y2; with it they still hold x2 and y2 is in `nxt`
+    fd_next, x2_before, nxt = fds["next"]
+    assert torch.equal(fd_next[:2], x2_before)
+    assert torch.equal(nxt[0], fd_keep[0]) and torch.equal(nxt[1, ..., :16], fd_keep[1, ..., :16])      # the 48 real channels of y2
+    assert bool((nxt[1, ..., 16:] == -5.0).all()) and bool((nxt[2:] == -5.0).all())                      # nothing else is touched
