@@ -122,9 +122,106 @@ void run(const u32x4* src, float* out, unsigned long long* stamps, const char* l
   fflush(stdout);
 }
 
+
+// ---- a whole TILE of a single-conv, resident-weight, frame-walking kernel (the "persistent layer-wise" design): S k-steps of
+// NB MFMAs per wave (one weight fragment, NB activation fragments), no barrier inside the K loop; behind step i < NST one
+// halo piece of the next tile (global load into registers early, ds_write_b128 later); epilogue = LeakyReLU + pack + two
+// 16-byte global stores per lane and M-tile; two workgroup barriers per tile (image complete / image free).
+template <int WAVES, int NB, int S, int NST>
+__global__ __launch_bounds__(WAVES * 64) void tile_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ out, int tiles,
+                                                          unsigned long long* __restrict__ stamps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < LDS_BYTES / 16; i += WAVES * 64) *reinterpret_cast<u32x4*>(smem + i * 16) = src[i];
+  __syncthreads();
+  const unsigned char* wa = smem + lane * 16;
+  const unsigned char* wb = smem + NFRAG_A * 1024 + wave * (8 * 1024) + lane * 16;
+  unsigned char* wdst = smem + NFRAG_A * 1024 + 8 * 8 * 1024 + tid * 16;
+  unsigned long long t0, t1, r0, r1;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
+  u32x4 hv[NST];
+  for (int tl = 0; tl < tiles; ++tl) {
+    f32x16 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.01f * e;
+    f16x8 rA[3], rB[3][NB];
+    auto load_step = [&](const int st) __attribute__((always_inline)) {
+      const int s_ = st % 3;
+      rA[s_] = *reinterpret_cast<const f16x8*>(wa + (st % NFRAG_A) * 1024);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) rB[s_][j] = *reinterpret_cast<const f16x8*>(wb + ((st * NB + j) % 8) * 1024);
+    };
+    load_step(0);
+    load_step(1);
+    const u32x4* hsrc = src + ((size_t)(blockIdx.x * 131 + tl * 17) % 64) * 512 + tid;
+    static_for<0, S>([&](auto si) __attribute__((always_inline)) {
+      constexpr int st = decltype(si)::value;
+      if constexpr (st + 2 < S) load_step(st + 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rA[st % 3], rB[st % 3][j], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (st < NST) hv[st] = hsrc[st * 512];                       // next tile's halo: one load per step
+      if constexpr (st >= S - NST) *reinterpret_cast<u32x4*>(wdst + ((st - (S - NST)) % 2) * 8192) = hv[st - (S - NST)];   // ... stored late
+    });
+    // epilogue: LeakyReLU, f16 pack, two 16-byte stores per lane and M-tile
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      unsigned r[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a0 = acc[j][2 * e], a1 = acc[j][2 * e + 1];
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 hh = {(_Float16)fmaxf(a0, 0.2f * a0), (_Float16)fmaxf(a1, 0.2f * a1)};
+        r[e] = __builtin_bit_cast(unsigned, hh);
+      }
+      u32x4* o = out + ((size_t)blockIdx.x * WAVES * 64 + tid) * 2 * NB + 2 * j;
+      o[0] = u32x4{r[0], r[1], r[2], r[3]};
+      o[1] = u32x4{r[4], r[5], r[6], r[7]};
+    }
+    __syncthreads();
+    __syncthreads();
+  }
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+  if (lane == 0) {
+    stamps[((size_t)blockIdx.x * WAVES + wave) * 2 + 0] = t1 - t0;
+    stamps[((size_t)blockIdx.x * WAVES + wave) * 2 + 1] = r1 - r0;
+  }
+}
+
+template <int WAVES, int NB, int S, int NST>
+void run_tile(const u32x4* src, u32x4* out, unsigned long long* stamps, const char* label) {
+  const int grid = 256, tiles = 200;
+  auto kern = tile_kernel<WAVES, NB, S, NST>;
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), LDS_BYTES, 0, src, out, tiles, stamps);
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int reps = 10;
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), LDS_BYTES, 0, src, out, tiles, stamps);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> h((size_t)grid * WAVES * 2);
+  CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<double> cyc, clk;
+  for (size_t i = 0; i < h.size(); i += 2) { cyc.push_back((double)h[i]); clk.push_back((double)h[i] / (double)h[i + 1] * 0.1); }
+  std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
+  const double per_tile = cyc[cyc.size() / 2] / tiles, floor_ = (double)S * NB * (WAVES / 4) * 32.0;
+  const double tf = (double)grid * WAVES * tiles * S * NB * 32768.0 * reps / (ms * 1e-3) / 1e12;
+  printf("%-44s waves %d tiles/wave %d steps %3d halo pieces %2d | %7.0f cyc/tile  MFMA floor %6.0f (%.0f %%)  clock %.2f GHz  %7.1f TFLOP/s\n",
+         label, WAVES, NB, S, NST, per_tile, floor_, 100.0 * floor_ / per_tile, clk[clk.size() / 2], tf);
+  fflush(stdout);
+}
+
 int main() {
   u32x4* src; float* out; unsigned long long* stamps;
-  CK(hipMalloc(&src, LDS_BYTES)); CK(hipMalloc(&out, 256 * 512 * 4)); CK(hipMalloc(&stamps, 256 * 8 * 2 * 8));
+  CK(hipMalloc(&src, 4 << 20)); CK(hipMemset(src, 0x3c, 4 << 20)); CK(hipMalloc(&out, 32 << 20)); CK(hipMalloc(&stamps, 256 * 8 * 2 * 8));
   std::vector<f16> h(LDS_BYTES / 2);
   srand(1);
   for (auto& v : h) v = (f16)((rand() / (float)RAND_MAX) * 2.f - 1.f);
@@ -146,5 +243,13 @@ int main() {
   run<4, 2, 4, 1>(src, out, stamps, "4 waves, 4 M-tiles, reads");
   run<4, 1, 2, 1>(src, out, stamps, "4 waves, 1 conv 2 tiles, reads");
   run<4, 1, 4, 1>(src, out, stamps, "4 waves, 1 conv 4 tiles, reads");
+  // whole tiles of the single-conv design: S = 9 taps x (Cin / 16) k-steps; halo pieces = 16-byte pieces of an 18x18 image per thread
+  u32x4* out4 = (u32x4*)out;
+  run_tile<8, 1, 27, 4>(src, out4, stamps, "conv1 of F (48 ch), 8 waves x 1 tile");
+  run_tile<8, 1, 45, 6>(src, out4, stamps, "conv2 of F (80 ch), 8 waves x 1 tile");
+  run_tile<8, 1, 63, 9>(src, out4, stamps, "conv3 of F (112 ch), 8 waves x 1 tile");
+  run_tile<8, 1, 81, 12>(src, out4, stamps, "conv4 of F (144 ch), 8 waves x 1 tile");
+  run_tile<4, 2, 63, 18>(src, out4, stamps, "conv3 of F (112 ch), 4 waves x 2 tiles");
+  run_tile<4, 2, 81, 24>(src, out4, stamps, "conv4 of F (144 ch), 4 waves x 2 tiles");
   return 0;
 }
