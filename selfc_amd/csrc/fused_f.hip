@@ -665,13 +665,12 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
 // y1 = x1 +- (b5 + conv5 of F) from the partial products of the two pairs: out[t] = sum over pairs of
 // P[t-1][tap 0] + P[t][tap 1] + P[t+1][tap 2], zero outside the clip (Subnet_constructor.py:130, Inv_arch.py:25,31).
 __global__ __launch_bounds__(256) void f_couple_kernel(const float* __restrict__ pf, const float* __restrict__ bias, float* __restrict__ x1,
-                                                       const int N, const int T, const int HW, const float sgn) {
+                                                       const int N, const int T, const int HW, const float sgn, const int nsets) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, npx = (size_t)N * HW;
   if (i >= npx) return;
   const int t = (int)(i / HW) % T;
   float4 o = make_float4(bias[0], bias[1], bias[2], 0.f);
-#pragma unroll
-  for (int pair = 0; pair < 2; ++pair) {          // pf[pair][tap][N][H][W][4]
+  for (int pair = 0; pair < nsets; ++pair) {      // pf[set][tap][N][H][W][4]: two sets from the pair kernels, one from csrc/split_f.hip
     const float4* p = reinterpret_cast<const float4*>(pf) + (size_t)pair * 3 * npx + i;
     const float4 q1 = p[npx];
     o.x += q1.x; o.y += q1.y; o.z += q1.z;
@@ -772,9 +771,14 @@ int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, 
   }
   ProfScope prof(PROF_CONV5_F, s);
   const size_t npx = (size_t)N * H * W;
-  hipLaunchKernelGGL(f_couple_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, pf, b5, x1, N, T, H * W, rev ? -1.f : 1.f);
+  hipLaunchKernelGGL(f_couple_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, pf, b5, x1, N, T, H * W, rev ? -1.f : 1.f, 2);
   const int rc = hip_rc(hipGetLastError());
   return rc ? rc : 1;
+}
+
+void launch_f_couple(const float* pf, const float* b5, float* x1, int N, int T, int HW, float sgn, int nsets, hipStream_t s) {
+  const size_t npx = (size_t)N * HW;
+  hipLaunchKernelGGL(f_couple_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, pf, b5, x1, N, T, HW, sgn, nsets);
 }
 
 }  // namespace selfc
