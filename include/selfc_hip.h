@@ -111,8 +111,6 @@ typedef struct {
   const void* w5p;       /* optional (F with wfused, temporal conv5): packing.py:pack_f5_partial - the fused F
                             launches then also emit the conv5 partial products and a small kernel replaces the
                             conv5 pass over the 176 dense channels (needs selfc_latent.pf) */
-  const void* wsplit;    /* optional (abi 9; F with cin == 48): packing.py:pack_split_f - conv1..conv4 as four single-conv persistent
-                            launches with resident weights (csrc/split_f.hip) instead of the two pair launches */
 } selfc_subnet_w;
 
 typedef struct {

@@ -25,7 +25,7 @@ def operand_dtype():
 SUBNET_D2DT = 0
 SUBNET_DB2D = 1
 LAT_KEEP_FEATURES = 1      # selfc_latent.flags (SELFC_LAT_KEEP_FEATURES)
-ABI_VERSION = 9
+ABI_VERSION = 8
 
 #: every symbol include/selfc_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -46,7 +46,7 @@ SYMBOLS = [
 
 class SubnetW(C.Structure):
     _fields_ = [("w3", C.c_void_p * 4), ("b3", C.c_void_p * 4), ("w5", C.c_void_p), ("b5", C.c_void_p),
-                ("wfused", C.c_void_p), ("w5p", C.c_void_p), ("wsplit", C.c_void_p)]
+                ("wfused", C.c_void_p), ("w5p", C.c_void_p)]
 
 
 class SubnetBW(C.Structure):

@@ -39,8 +39,7 @@ int launch_fused_gh(FGArgs& a, hipStream_t s);
 // csrc/fused_f.hip
 int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, int H, int W, hipStream_t s,
                    const void* w5p, float* pf, const float* b5, float* x1, int T, int rev, int keep_features);
-int launch_split_f(void* dense, const void* w, const float* const* bias, int N, int H, int W, hipStream_t s,
-                   const void* w5p, float* pf, const float* b5, float* x1, int T, int rev, int keep_features);
+
 }  // namespace selfc
 #include "bwd_internal.hpp"
 
@@ -923,13 +922,7 @@ int check_subnet(const selfc_subnet_w* w, bool need5) {
 int run_F(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStream_t s) {
   static const bool no_fuse_f = getenv("SELFC_NO_FUSE_F") != nullptr;     // developer A/B switch
   int rc;
-  static const bool split_f = getenv("SELFC_F_SPLIT") != nullptr;         // developer A/B switch: four single-conv launches (csrc/split_f.hip)
-  if (split_f && blk->F.wsplit && l->c2 == 48 && !no_fuse_f) {
-    const bool t5 = l->kind == SELFC_SUBNET_D2DT && l->c1 <= 3;
-    rc = launch_split_f(l->fd, blk->F.wsplit, blk->F.b3, l->N, l->H, l->W, s, t5 ? blk->F.w5p : nullptr, t5 ? l->pf : nullptr,
-                        blk->F.b5, l->x1, l->T, rev, (l->flags & SELFC_LAT_KEEP_FEATURES) != 0);
-    if (rc == 1) return SELFC_OK;
-  } else if (blk->F.wfused && l->c2 == 48 && !no_fuse_f) {
+  if (blk->F.wfused && l->c2 == 48 && !no_fuse_f) {
     // two pairwise-fused launches; with the partial-product fragments they also cover the temporal conv5 (rc 1)
     const bool t5 = l->kind == SELFC_SUBNET_D2DT && l->c1 <= 3;
     rc = launch_fused_f(l->fd, blk->F.wfused, blk->F.b3, l->N, l->H, l->W, s, t5 ? blk->F.w5p : nullptr, t5 ? l->pf : nullptr,
@@ -1034,8 +1027,8 @@ int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s)
 
 extern "C" {
 
-const char* selfc_version(void) { return "selfc_hip gfx950 abi9 operands=" SELFC_OPERAND_NAME; }
-int selfc_abi_version(void) { return 9; }
+const char* selfc_version(void) { return "selfc_hip gfx950 abi8 operands=" SELFC_OPERAND_NAME; }
+int selfc_abi_version(void) { return 8; }
 
 int selfc_invblock_run(const selfc_invblock_w* blk, const selfc_latent* lat, int rev, void* stream) {
   if (!blk || !latent_ok(lat)) return SELFC_EINVAL;

@@ -270,28 +270,6 @@ def pack_fused_f(weights: Sequence[torch.Tensor], cin: int = 48) -> torch.Tensor
     return _operand(res)
 
 
-def pack_split_f(weights: Sequence[torch.Tensor], cin: int = 48) -> torch.Tensor:
-    """conv1..conv4 weights of a cin == 48 dense block -> the fragment streams of csrc/split_f.hip (four single-conv launches),
-    back to back: conv k = 9 * (cin + 32 (k - 1)) / 16 fragments in the kernels' K order - source group (x2, f1, ..) major,
-    tap-major inside a group, 16-channel k-step minor  -> f16 [27 + 45 + 63 + 81, 64, 8]."""
-    assert cin == 48 and len(weights) == 4
-    out = []
-    for k in range(1, 5):
-        w = weights[k - 1].detach().float()
-        if w.dim() == 5:
-            w = w[:, :, 0]
-        ctot = cin + 32 * (k - 1)
-        assert w.shape == (32, ctot, 3, 3), tuple(w.shape)
-        w9 = w.reshape(32, ctot, 9)
-        groups = [(0, cin)] + [(cin + 32 * i, cin + 32 * (i + 1)) for i in range(k - 1)]
-        km = torch.cat([w9[:, lo:hi].permute(0, 2, 1).reshape(32, 9 * (hi - lo)) for lo, hi in groups], dim=1)
-        nfrag = km.shape[1] // 16
-        out.append(km.reshape(32, nfrag, 2, 8).permute(1, 2, 0, 3).reshape(nfrag, 64, 8))
-    res = torch.cat(out, dim=0)
-    assert res.shape[0] == 216
-    return _operand(res)
-
-
 def pack_f5_partial(w5: torch.Tensor, cin: int = 48) -> torch.Tensor:
     """Temporal conv5 of F (cout, cin + 128, 3, 1, 1), cout <= 3, as the A fragments of the conv5 partial products the
     fused F launches emit (csrc/fused_f.hip): row = 4 tap + oc (rows 0-2, 4-6, 8-10 of 32 used), one 32x32x16 fragment per 16 input
@@ -490,7 +468,6 @@ def subnet_pack_entries(prefix: str, weights: Sequence[torch.Tensor], biases: Se
         e[f"{prefix}wfused"] = (pack_fused_gh(list(weights[:4]), 3), "w")
     if cin == 48:
         e[f"{prefix}wfused"] = (pack_fused_f(list(weights[:4]), 48), "w")
-        e[f"{prefix}wsplit"] = (pack_split_f(list(weights[:4]), 48), "w")
         if temporal and cout <= 3:
             e[f"{prefix}w5p"] = (pack_f5_partial(weights[4], 48), "w")
     if with_bwd and cout <= 96:

@@ -106,7 +106,6 @@ class PackedSubnet:
         self.w5, self.b5 = d[f"{prefix}w5"], d[f"{prefix}b5"]
         self.wfused = d.get(f"{prefix}wfused")
         self.w5p = d.get(f"{prefix}w5p")
-        self.wsplit = d.get(f"{prefix}wsplit")
         self.wt5 = d.get(f"{prefix}wt5")
         self.wtd = [d.get(f"{prefix}wtd_{i}") for i in range(3)]
         self.wtx = d.get(f"{prefix}wtx")
@@ -122,7 +121,6 @@ class PackedSubnet:
             s.b5 = _ptr(self.b5)
             s.wfused = _ptr(self.wfused)
             s.w5p = _ptr(self.w5p)
-            s.wsplit = _ptr(self.wsplit)
             self._struct = s
         return s
 
