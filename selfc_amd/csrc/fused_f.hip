@@ -244,8 +244,9 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
   // map A (64-byte planes: x2 channels 0..31, f1, f2): piece i = tid + 512 it (it < 4, i < 1600) = 16-byte piece i & 3 of
   // halo pixel i >> 2;  map B (x2 channels 32..47): i = tid + 512 it (it < 2, i < 800) = piece i & 1 of pixel i >> 1.
   // goff: byte offset inside one frame of a plane; ok: bit it set
-  // when the piece exists and its pixel lies inside the frame - pieces outside are never stored, the image is zeroed once.
-  unsigned goffA[4], goffB[2], okA = 0, okB = 0;
+  // when the piece exists and its pixel lies inside the frame; ex: bit it set when the piece exists.  Pieces outside the
+  // frame are the convs' zero padding: the workgroup's FIRST fill stores zeros there, later fills leave them alone.
+  unsigned goffA[4], goffB[2], okA = 0, okB = 0, exA = 0, exB = 0;
   {
     auto geom = [&](const int pix, const bool exists, unsigned& goff) __attribute__((always_inline)) {
       const int p = min(pix, IS * IS - 1);
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
       const bool ok = geom(i >> 2, i < 1600, goffA[it]);
       goffA[it] += (i & 3) * 16;
       okA |= (ok ? 1u : 0u) << it;
+      exA |= (i < 1600 ? 1u : 0u) << it;
     }
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -269,12 +271,14 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
       const bool ok = geom(i >> 1, i < 800, goffB[it]);
       goffB[it] += (i & 1) * 16;
       okB |= (ok ? 1u : 0u) << it;
+      exB |= (i < 800 ? 1u : 0u) << it;
     }
   }
   const size_t frame_bytes = (size_t)a.H * a.W * 64;
   const char* const dbase = reinterpret_cast<const char*>(a.dense);
   // part 0 = x2: items 0..3 map A on plane 0, items 4, 5 map B on plane 1; part 1 = f1 (plane 2), part 2 = f2 (plane 3)
   constexpr int XMAX = 6;
+  constexpr unsigned FILL_BITS = 0u;
   u32x4 xv[XMAX];
   const char* lframe = dbase;        // frame the next x_load_item reads (plane 0)
   auto x_target = [&](const int n) __attribute__((always_inline)) { lframe = dbase + (size_t)n * frame_bytes; };
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
     if (part == 0 && it >= 4) v[it] = *reinterpret_cast<const u32x4*>(lframe + pb + goffB[it - 4]);
     else v[it] = *reinterpret_cast<const u32x4*>(lframe + (part == 0 ? 0 : part + 1) * pb + goffA[it]);
   };
-  auto x_store_item_from = [&](const int part, const int it, const u32x4 (&v)[XMAX]) __attribute__((always_inline)) {
+  auto x_store_item_from = [&](const int part, const int it, const u32x4 (&v)[XMAX], const bool fill = false) __attribute__((always_inline)) {
     // the LDS offset is recomputed here (a handful of VALU instructions) rather than pinned in registers all kernel long
     int tidl = c.tid;
     asm volatile("" : "+v"(tidl));
@@ -297,7 +301,10 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(hx) : "v"(hy), "s"(-IS), "v"(p));
     const unsigned loff = __umul24(hy, (unsigned)G::ROWP) + __umul24(hx, (unsigned)G::PITCH) + piece * 16u +
                           (mb ? 64u : part == 0 ? 0u : part == 1 ? 96u : 160u);
-    if (((mb ? okB >> (it - 4) : okA >> it) & 1u)) *reinterpret_cast<u32x4*>(smem + G::OFF_IMG + loff) = v[it];
+    const bool ok = ((mb ? okB >> (it - 4) : okA >> it) & 1u) != 0;
+    if (fill) {
+      if ((mb ? exB >> (it - 4) : exA >> it) & 1u) *reinterpret_cast<u32x4*>(smem + G::OFF_IMG + loff) = ok ? v[it] : u32x4{FILL_BITS, FILL_BITS, FILL_BITS, FILL_BITS};
+    } else if (ok) *reinterpret_cast<u32x4*>(smem + G::OFF_IMG + loff) = v[it];
   };
   auto x_load_item = [&](const int part, const int it) __attribute__((always_inline)) { x_load_item_to(part, it, xv); };
   auto x_store_item = [&](const int part, const int it) __attribute__((always_inline)) { x_store_item_from(part, it, xv); };
@@ -306,14 +313,17 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
     for (int it = 0; it < XMAX; ++it)
       if (it < (part == 0 ? 6 : 4)) x_load_item_to(part, it, v);
   };
+  // the workgroup's first fill (prologue): every existing piece is written, zeros where the frame ends
   auto x_store_from = [&](const int part, const u32x4 (&v)[XMAX]) __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < XMAX; ++it)
-      if (it < (part == 0 ? 6 : 4)) x_store_item_from(part, it, v);
+      if (it < (part == 0 ? 6 : 4)) x_store_item_from(part, it, v, true);
   };
-  // the image is zeroed once: pieces outside the frame (the convs' zero padding) are never written afterwards
-  for (int i = c.tid; i < G::IMG_BYTES / 16; i += NTHR) *reinterpret_cast<u32x4*>(smem + G::OFF_IMG + i * 16) = u32x4{0u, 0u, 0u, 0u};
+#ifdef SELFC_POISON_LDS
+  // test build: the image starts as f16 NaNs, so a read of a byte no fill wrote shows up in the parity tests
+  for (int i = c.tid; i < G::IMG_BYTES / 16; i += NTHR) *reinterpret_cast<u32x4*>(smem + G::OFF_IMG + i * 16) = u32x4{0x7e007e00u, 0x7e007e00u, 0x7e007e00u, 0x7e007e00u};
   __syncthreads();
+#endif
 
   const unsigned char* const img = smem + G::OFF_IMG;
   const unsigned char* const bc = img + (c.py + 1) * G::ROWP + (c.px + 1) * G::PITCH + c.half * 16;
