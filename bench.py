@@ -157,6 +157,10 @@ def main():
         # ---- the timed region: W untimed warm-up steps, barrier + sync, EXACTLY K steps, barrier + sync, MAX over ranks
         dt = launch.timed_region(step, args.steps, args.warmup, ranks, torch.cuda.synchronize)
         rccl_ranks = ranks.count()
+        # ---- box calibration, AFTER the timed region (boxes of one pool differ by up to 10 % on one binary): a register-only
+        # MFMA loop and a 512-MiB device copy, so that a reader can tell a slow box from a slow build
+        cal_m, cal_c = C.c_double(0.0), C.c_double(0.0)
+        _lib.check(L.selfc_profile_calibrate(C.byref(cal_m), C.byref(cal_c), _lib.stream_ptr()), "selfc_profile_calibrate")
 
     npx = n_frames * (H // 4) * (W // 4)
     # per-kernel rooflines: algorithmic FLOPs per launch / live HIP-event duration of that launch
@@ -236,6 +240,8 @@ def main():
                    "prewarm": f"untimed, before the W warm-up steps: the eager roofline leg ({args.steps} steps) + {n_pw} steps over {args.prewarm_s} s of wall time",
                    "sharding": f"{world} rank(s) x {B_PER_GPU} independent septuplets, no data-path collective"},
         "rccl_ranks": rccl_ranks,
+        "box_calibration": {"mfma_f16_loop_TFLOPs": round(cal_m.value, 1), "device_copy_GBps": round(cal_c.value, 1),
+                            "what": "rank 0, right after the timed region: register-only 32x32x16 f16 MFMA loop; 512-MiB D2D copy, read + write bytes"},
         "roofline": roofline,
         "roofline_other": {k: v for k, v in kern.items() if k != dominant},
         "stack_tflops": round(whole_flops * world * args.steps / dt / 1e12, 1),

@@ -294,6 +294,11 @@ int selfc_stp_head_gmm(const float* feat, const void* w, const float* bias, cons
 int selfc_profile_enable(int on);
 int selfc_profile_read(int cls, double* total_ms, long long* launches);   /* waits for the recorded events */
 int selfc_profile_reset(void);
+/* Box calibration (bench.py prints it beside its value; boxes of one pool differ by up to 10 % on one binary): the f16
+ * MFMA rate of a register-only 32x32x16 loop (TFLOP/s at the clock the chip holds under full matrix load) and the rate
+ * of a 512-MiB device-to-device copy (read + write bytes, GB/s).  The ONE entry point that allocates (1 GiB, freed before
+ * it returns) and waits on the host; not capturable.  No reference counterpart. */
+int selfc_profile_calibrate(double* mfma_tflops, double* copy_GBps, void* stream);
 
 /* ---- STP gradients (csrc/stp.hip) ---- */
 /* d raw of selfc_gmm_sample given dv: raw/draw [npix][hf_dim*K*3], eps [npix][hf_dim*K], dv [npix][hf_dim]. */

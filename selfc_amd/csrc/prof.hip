@@ -1,6 +1,8 @@
 #include "prof.hpp"
+#include <algorithm>
 #include <vector>
 #include "../../include/selfc_hip.h"
+#include "common.hpp"
 
 namespace selfc {
 namespace {
@@ -58,6 +60,70 @@ int selfc_profile_read(int cls, double* total_ms, long long* launches) {
   *total_ms = ms;
   *launches = n;
   return SELFC_OK;
+}
+
+// ---- box calibration --------------------------------------------------------------------------------------------------
+// MI355X boxes of one pool differ by up to 10 % on the same binary (sustained clock under load).  bench.py prints these two
+// figures next to its value so that a reader can tell a slow box from a slow build: a register-only MFMA loop (no memory at
+// all: the matrix pipes at whatever clock the chip holds under full MFMA load) and a large device-to-device copy.
+namespace {
+__global__ __launch_bounds__(256) void calib_mfma_kernel(float* __restrict__ out, const int iters) {
+  f16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] = (f16)(float)((threadIdx.x + i) & 3);
+    b[i] = (f16)(float)((threadIdx.x * 3 + i) & 1);
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = mfma_32x32x16(a, b, acc[j]);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sum += acc[j][e];
+  if (sum == -1.f) out[0] = sum;     // never true (all products are >= 0): keeps the loop alive
+}
+}  // namespace
+
+int selfc_profile_calibrate(double* mfma_tflops, double* copy_GBps, void* stream) {
+  if (!mfma_tflops || !copy_GBps) return SELFC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -(int)hipErrorLaunchFailure - 1000;
+  constexpr size_t BYTES = (size_t)512 << 20;
+  char* buf = nullptr;
+  if (hipMalloc(&buf, 2 * BYTES + 64) != hipSuccess) return -(int)hipErrorLaunchFailure - 1000;
+  (void)hipMemsetAsync(buf, 0, 2 * BYTES + 64, s);
+  constexpr int GRID = 2048, ITERS = 2048;
+  const double flop = (double)GRID * 4 * ITERS * 4 * 32768.0;
+  double best_m = 0.0, best_c = 0.0;
+  int rc = SELFC_OK;
+  for (int rep = 0; rep < 4 && rc == SELFC_OK; ++rep) {      // rep 0 warms the clocks up and is not counted
+    float ms = 0.f;
+    (void)hipEventRecord(e0, s);
+    calib_mfma_kernel<<<GRID, 256, 0, s>>>(reinterpret_cast<float*>(buf + 2 * BYTES), ITERS);
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = -(int)hipErrorLaunchFailure - 1000; break; }
+    if (rep && ms > 0.f) best_m = std::max(best_m, flop / (ms * 1e-3) * 1e-12);
+    (void)hipEventRecord(e0, s);
+    (void)hipMemcpyAsync(buf + BYTES, buf, BYTES, hipMemcpyDeviceToDevice, s);
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = -(int)hipErrorLaunchFailure - 1000; break; }
+    if (rep && ms > 0.f) best_c = std::max(best_c, 2.0 * BYTES / (ms * 1e-3) * 1e-9);
+  }
+  (void)hipFree(buf);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *mfma_tflops = best_m;
+  *copy_GBps = best_c;
+  return rc;
 }
 
 int selfc_profile_reset(void) {
