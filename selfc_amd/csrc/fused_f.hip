@@ -786,9 +786,4 @@ int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, 
   return rc ? rc : 1;
 }
 
-void launch_f_couple(const float* pf, const float* b5, float* x1, int N, int T, int HW, float sgn, int nsets, hipStream_t s) {
-  const size_t npx = (size_t)N * HW;
-  hipLaunchKernelGGL(f_couple_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, pf, b5, x1, N, T, HW, sgn, nsets);
-}
-
 }  // namespace selfc
