@@ -13,8 +13,8 @@ instead hold one ``clip.npy`` (N,H,W,3) uint8 file, which avoids the PNG decode 
 Feeding the GPU (the reference: worker processes, codes/data/__init__.py:20-26, and a blocking ``.to(device)`` in feed_data,
 SelfC_model.py:114-115):
 
-  DevicePrefetcher    wraps any batch iterable: a background thread pulls batch k+1 (worker processes keep decoding), pins
-                      it and issues its host-to-device copy on a side stream while step k computes; order is preserved
+  DevicePrefetcher    wraps any batch iterable: a background thread pulls batch k+1 (worker processes keep decoding) and
+                      issues its host-to-device copy on a side stream while step k computes; order is preserved
   SyntheticSeptuplets the synthetic leg: uniform [0,1) clips drawn ON the device (no host work, no PCIe) from a per-rank seed"""
 from __future__ import annotations
 
@@ -162,11 +162,18 @@ def _map_tensors(obj, fn):
 class DevicePrefetcher:
     """Iterate `loader` with batch k+1 already on its way to `device` while step k runs.
 
-    A daemon thread pulls the next batch from the loader (so DataLoader workers never wait for the training step), pins
-    its tensors and enqueues the host-to-device copies on a side stream; ``__next__`` makes the consumer's current stream
-    wait for that copy's event.  At most `depth` batches are in flight.  Batches come out in exactly the loader's order
-    (one producer, one FIFO) - the DistIterSampler index streams are unchanged.  `device` "cpu": tensors pass through
-    untouched (tests, dry runs); exceptions raised by the loader are re-raised in the consumer."""
+    A daemon thread pulls the next batch from the loader (so DataLoader workers never wait for the training step) and
+    enqueues its host-to-device copies on a side stream; ``__next__`` makes the consumer's current stream wait for that
+    copy's event.  At most `depth` batches are in flight.  Batches come out in exactly the loader's order (one producer,
+    one FIFO) - the DistIterSampler index streams are unchanged.  `device` "cpu": tensors pass through untouched (tests,
+    dry runs); exceptions raised by the loader are re-raised in the consumer.
+
+    A host tensor reaches the device through a plain ``.to(device)`` issued by the producer thread on the side stream: the HIP
+    runtime stages the copy itself and blocks only that thread.  Measured on the training step of config 3
+    (`tools/loader_probe.py`, `profiles/r3/train_loader_and_dp_step.txt`): 16.5-18.0 ms per step against 16.3-17.7 with
+    device-generated data.  NOT done, on measurement: ``tensor.pin_memory()`` per batch (the first version of this class) or a
+    ring of pinned buffers allocated by the producer thread - torch's caching pinned-memory allocator used from a second thread
+    stalls the main thread's kernel launches, step 28-38 ms."""
 
     _END = object()
 
@@ -174,6 +181,10 @@ class DevicePrefetcher:
         self.loader, self.device, self.depth = loader, torch.device(device), max(1, int(depth))
         self.cuda = self.device.type == "cuda"
         self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+
+    def _to_device(self, t: torch.Tensor) -> torch.Tensor:
+        """producer thread, side stream current"""
+        return t.to(self.device, non_blocking=True) if t.is_cuda else t.to(self.device)
 
     def __len__(self):
         return len(self.loader)
@@ -185,7 +196,7 @@ class DevicePrefetcher:
             for batch in it:
                 if self.cuda:
                     with torch.cuda.stream(self.stream):
-                        moved = _map_tensors(batch, lambda t: t.pin_memory().to(self.device, non_blocking=True))
+                        moved = _map_tensors(batch, self._to_device)
                         ev = self.stream.record_event()
                     item = (moved, ev)
                 else:

@@ -73,3 +73,44 @@ def test_vid4_config4_if_assets_present(dev):
     rep = eval_vid4.run(root, ckpt, oracle_groups=1)
     for seq, r in rep.items():
         assert r["max_psnr_diff_vs_oracle_dB"] < 0.02, (seq, r)
+
+
+def test_host_fed_training_step_keeps_up_with_device_generated_data(dev):
+    """SURVEY 8 f3, second half: a loader that does not starve the GPU.  The same eager training step fed (a) by batches drawn
+    on the device and (b) by host batches through a DataLoader-style iterable + DevicePrefetcher must take about the same
+    time, and the prefetcher must deliver the loader's batches bit-exactly and in order.  (The first DevicePrefetcher pinned
+    every batch from its thread: torch's pinned-memory allocator used from a second thread stalled the main thread's
+    launches and the step took 2.2x as long - `tools/loader_probe.py`; the bar below is where that regression shows.)"""
+    import time
+    from selfc_amd import GlobalVar, data, train
+    from selfc_amd.modules.SelfC_GMM_arch_inv import SelfCInvNet
+    GlobalVar.set_Temporal_LEN(7)
+    torch.manual_seed(3)
+    opt = {"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": "gmm", "scale": 4, "gmm_k": 5}
+    net = SelfCInvNet(opt, 3, 3, "D2DTNet", [4, 4], 2).to(dev)
+    tr = train.RescaleTrainer(net, dict(train.TRAIN_OPT_LARGE))
+    gen = torch.Generator().manual_seed(5)
+    pool = [torch.rand((8, 3, 7, 144, 144), generator=gen) for _ in range(3)]
+
+    def host_batches(n):
+        for i in range(n):
+            yield {"GT": pool[i % 3], "index": torch.tensor([i])}
+
+    got = list(data.DevicePrefetcher(host_batches(5), dev, depth=2))
+    assert [int(b["index"]) for b in got] == list(range(5))
+    assert all(torch.equal(b["GT"].cpu(), pool[i % 3]) for i, b in enumerate(got))
+
+    def time_steps(feed, n=10, skip=4):
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            real_h, ref_l, _ = train.feed_data(next(feed)["GT"], "sr_bd", 4)
+            tr.optimize_parameters(real_h, ref_l)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts[skip:])[(n - skip) // 2]                      # median of the steady steps
+
+    t_dev = time_steps(iter(data.SyntheticSeptuplets(8, 7, 144, dev, 1)))
+    t_host = time_steps(iter(data.DevicePrefetcher(host_batches(64), dev, depth=2)))
+    assert t_host <= 1.35 * t_dev, (t_host, t_dev)

@@ -13,7 +13,7 @@ hipGraphs ([zero, forward, backward] - all-reduce - [clip, Adam]).  --ddp: the r
 
 Data: every rank draws its own 144x144 septuplet crops ON the device (selfc_amd.data.SyntheticSeptuplets, seeded by rank) -
 no host-side generation inside the step; --host-loader feeds the same shapes from a host DataLoader-style iterable through
-selfc_amd.data.DevicePrefetcher (pinned, H2D on a side stream one step ahead), the path real folders / .npy clips take.
+selfc_amd.data.DevicePrefetcher (H2D on a side stream one step ahead), the path real folders / .npy clips take.
 Rank 0 prints one JSON line with the aggregate training septuplets/s and every rank's ms per step."""
 import argparse
 import json
@@ -43,6 +43,23 @@ class _HostBatches:
             yield {"GT": self.pool[i % len(self.pool)]}
 
 
+class _DecodedCrops(torch.utils.data.Dataset):
+    """Stand-in for SeptupletDataset with the decode cost left in: every item is built in the WORKER process the way a
+    decoded crop is (uint8 frames -> float RGB in [0,1], (C,T,H,W)), from a per-index generator."""
+
+    def __init__(self, size, n, seed):
+        self.size, self.n, self.seed = size, n, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        import numpy as np
+        rng = np.random.default_rng(self.seed * 1000003 + i)
+        frames = rng.integers(0, 256, size=(7, self.size, self.size, 3), dtype=np.uint8)
+        return {"GT": torch.from_numpy(frames.astype(np.float32) / 255.0).permute(3, 0, 1, 2).contiguous()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
@@ -53,6 +70,7 @@ def main():
     ap.add_argument("--ddp", action="store_true", help="fallback: wrap the net in DistributedDataParallel as the reference does (eager, no flat gradient buffer)")
     ap.add_argument("--eager", action="store_true", help="no hipGraph capture of the step")
     ap.add_argument("--host-loader", action="store_true", help="host-generated batches through DevicePrefetcher instead of on-device generation")
+    ap.add_argument("--workers", type=int, default=0, help="> 0: the reference's loader factory (data.create_dataloader) with this many worker PROCESSES over a synthetic dataset that keeps the per-item host work, through DevicePrefetcher")
     ap.add_argument("--dist-1", action="store_true", help="with --gpus 1: still initialise a one-rank RCCL group and run the data-parallel code path (tests)")
     a = ap.parse_args()
     from selfc_amd import launch
@@ -89,7 +107,12 @@ def main():
     local_batch = max(1, a.global_batch // world)
     seed = launch.rank_seed(1234, rank)
     total = a.steps + a.warmup + 4
-    if a.host_loader:
+    if a.workers > 0:
+        ds = _DecodedCrops(a.size, total * local_batch * world, seed)
+        loader = data.create_dataloader(ds, {"phase": "train", "n_workers": a.workers, "batch_size": local_batch * world},
+                                        {"dist": dist.is_initialized(), "gpu_ids": [0]})
+        feed = iter(data.DevicePrefetcher(loader, dev, depth=2))
+    elif a.host_loader:
         feed = iter(data.DevicePrefetcher(_HostBatches(local_batch, a.size, seed, total), dev, depth=2))
     else:
         feed = iter(data.SyntheticSeptuplets(local_batch, 7, a.size, dev, seed))
@@ -123,7 +146,8 @@ def main():
                           "value": round(local_batch * world * a.steps / sec, 2), "unit": "septuplets/s", "n_gpus": world,
                           "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(sec / a.steps * 1e3, 2), "ms_per_step_per_rank": per_rank,
                           "local_batch": local_batch, "global_batch": local_batch * world, "dtype": _lib.OPERAND,
-                          "data": "synthetic, " + ("host batches through DevicePrefetcher" if a.host_loader else "generated on the device"),
+                          "data": "synthetic, " + (f"DataLoader with {a.workers} worker processes (per-item uint8 -> float work in the workers) through DevicePrefetcher" if a.workers > 0
+                                                else "host batches through DevicePrefetcher" if a.host_loader else "generated on the device"),
                           "launch": "hipGraph replay" if capture else "eager", "loss": log.get("loss"), "rccl_ranks": nranks,
                           "param_spread_over_ranks": spread, "param_sq_sum": checksum, "gradient_sync": mode}))
     if solo_group:
