@@ -299,6 +299,10 @@ int selfc_profile_reset(void);
  * of a 512-MiB device-to-device copy (read + write bytes, GB/s).  The ONE entry point that allocates (1 GiB, freed before
  * it returns) and waits on the host; not capturable.  No reference counterpart. */
 int selfc_profile_calibrate(double* mfma_tflops, double* copy_GBps, void* stream);
+/* Shader clock under load: enqueues ONE wave on `stream` that watches the shader-clock counter against the constant
+ * 100 MHz counter for `micros` microseconds (<= 500,000) and then writes out2[0] = shader cycles, out2[1] = 100 MHz ticks
+ * (device memory, 2 x u64).  Launch it on a side stream next to the workload; GHz = 0.1 * out2[0] / out2[1]. */
+int selfc_profile_clock_sample(unsigned long long* out2, int micros, void* stream);
 
 /* ---- STP gradients (csrc/stp.hip) ---- */
 /* d raw of selfc_gmm_sample given dv: raw/draw [npix][hf_dim*K*3], eps [npix][hf_dim*K], dv [npix][hf_dim]. */

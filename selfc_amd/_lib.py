@@ -34,7 +34,7 @@ SYMBOLS = [
     "selfc_nchw_to_latent", "selfc_latent_to_nchw", "selfc_quantize_inplace", "selfc_quantize_inplace_v",
     "selfc_invblock_run", "selfc_invstack_run", "selfc_subnet_run",
     "selfc_nchw_to_nhwc4", "selfc_nhwc4_to_nchw",
-    "selfc_profile_enable", "selfc_profile_read", "selfc_profile_reset", "selfc_profile_calibrate",
+    "selfc_profile_enable", "selfc_profile_read", "selfc_profile_reset", "selfc_profile_calibrate", "selfc_profile_clock_sample",
     "selfc_globalagg_run", "selfc_globalagg_run_d", "selfc_gmm_sample_generic", "selfc_globalagg_partial_floats", "selfc_pwconv_run", "selfc_gmm_sample", "selfc_stp_head_gmm",
     "selfc_conv_planes_run", "selfc_nhwc_to_planes", "selfc_y_sse", "selfc_y_sse_blocks", "selfc_y_ssim", "selfc_gauss_down4",
     "selfc_subnet_bwd_scratch_bytes", "selfc_subnet_bwd", "selfc_subnet_bwd_phase", "selfc_coupling_fwd", "selfc_coupling_bwd", "selfc_freq_fwd_bwd", "selfc_freq_inv_bwd",
@@ -103,6 +103,7 @@ def lib():
             "selfc_profile_read": [i, C.POINTER(C.c_double), C.POINTER(C.c_longlong)],
             "selfc_profile_reset": [],
             "selfc_profile_calibrate": [C.POINTER(C.c_double), C.POINTER(C.c_double), vp],
+            "selfc_profile_clock_sample": [vp, i, vp],
             "selfc_globalagg_run": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
             "selfc_globalagg_run_d": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp],
             "selfc_gmm_sample_generic": [vp, vp, vp, sz, i, i, i, i, f, vp],

@@ -92,6 +92,30 @@ __global__ __launch_bounds__(256) void calib_mfma_kernel(float* __restrict__ out
 }
 }  // namespace
 
+namespace {
+// one wave that watches the shader-clock counter against the constant 100 MHz counter for `ticks` of the latter, next to
+// whatever else the chip is running (MI355X_MICROARCH.md "DVFS give-back"); exits as soon as the time is up
+__global__ __launch_bounds__(64) void clock_sample_kernel(unsigned long long* __restrict__ out, const unsigned long long ticks) {
+  unsigned long long t0, r0, t1, r1;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
+  do {
+    __builtin_amdgcn_s_sleep(64);
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+  } while (r1 - r0 < ticks);
+  if (threadIdx.x == 0) {
+    out[0] = t1 - t0;
+    out[1] = r1 - r0;
+  }
+}
+}  // namespace
+
+int selfc_profile_clock_sample(unsigned long long* out2, int micros, void* stream) {
+  if (!out2 || micros <= 0 || micros > 500000) return SELFC_EINVAL;
+  clock_sample_kernel<<<1, 64, 0, (hipStream_t)stream>>>(out2, (unsigned long long)micros * 100ull);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SELFC_OK : -(int)e - 1000;
+}
+
 int selfc_profile_calibrate(double* mfma_tflops, double* copy_GBps, void* stream) {
   if (!mfma_tflops || !copy_GBps) return SELFC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
