@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed steps (2.8 ms each: the rate keeps rising until ~100 steps - clocks, caches - so short runs under-report the steady state by ~4 %%)")
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--graph-mode", choices=("auto", "single", "per-stream"), default="auto",
+                    help="multi-stream hipGraph form: one graph with a branch per stream, one graph per stream, or (auto) whichever is faster on this box - timed BEFORE the timed region, reported in config.launch")
     ap.add_argument("--prewarm-s", type=float, default=1.0, help="untimed pre-warm (seconds of steps) before the W warm-up steps and the timed region; reported in config.prewarm")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -147,6 +149,33 @@ def main():
             L.selfc_profile_read(cls, C.byref(ms), C.byref(n))
             cls_ms[name], cls_n[name] = ms.value, n.value
         L.selfc_profile_reset()
+        # ---- graph form (untimed tuning): a two-branch hipGraph runs at the one-stream rate on some boxes of the pool
+        graph_form, graph_probe = "one graph", None
+        if use_graph and args.streams > 1:
+            def rate(n=30):
+                for _ in range(10):
+                    step()
+                torch.cuda.synchronize()
+                best = 1e9
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    for _ in range(n):
+                        step()
+                    torch.cuda.synchronize()
+                    best = min(best, (time.perf_counter() - t0) / n)
+                return best * 1e3
+            if args.graph_mode == "auto":
+                t_single = rate()
+                runner.capture(x, per_stream=True)
+                t_per = rate()
+                graph_probe = {"one_graph_ms": round(t_single, 3), "graph_per_stream_ms": round(t_per, 3)}
+                if t_single <= t_per:
+                    runner.capture(x)
+                else:
+                    graph_form = "one graph per stream"
+            elif args.graph_mode == "per-stream":
+                runner.capture(x, per_stream=True)
+                graph_form = "one graph per stream"
         # ---- stated pre-warm: untimed steps for --prewarm-s seconds of wall time (in addition to the W warm-up steps)
         t_pw, n_pw = time.perf_counter(), 0
         while time.perf_counter() - t_pw < args.prewarm_s:
@@ -245,7 +274,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": _lib.OPERAND, "data": "synthetic",
         "config": {"workload": "SelfC-large FrequencyAnalyzer + 8 InvBlockExp(D2DTNet) fwd, Quantization, 8 InvBlockExp rev, "
                                "FrequencyAnalyzer rev; 4 septuplets 7x3x256x448 per GPU, inputs resident in HBM, seeded default-init weights",
-                   "septuplets_per_gpu": B_PER_GPU, "launch": "hipGraph replay" if use_graph else "eager", "streams": args.streams,
+                   "septuplets_per_gpu": B_PER_GPU, "launch": (f"hipGraph replay ({graph_form})" if args.streams > 1 else "hipGraph replay") if use_graph else "eager", "streams": args.streams,
+                   "graph_form_probe": graph_probe,
                    "prewarm": f"untimed, before the W warm-up steps: the eager roofline leg ({args.steps} steps) + {n_pw} steps over {args.prewarm_s} s of wall time",
                    "sharding": f"{world} rank(s) x {B_PER_GPU} independent septuplets, no data-path collective"},
         "rccl_ranks": rccl_ranks,

@@ -162,7 +162,7 @@ class MultiStreamRoundTrip:
         self.out = torch.empty((n_frames, 3, H, W), dtype=torch.float32, device=device)
         for i, p in enumerate(self.parts):           # parts write straight into slices of one output
             p.out = self.out[i * self.per:(i + 1) * self.per]
-        self.graph = None
+        self.graph, self.graphs = None, None
 
     def run(self, x: torch.Tensor) -> torch.Tensor:
         cur = torch.cuda.current_stream()
@@ -174,17 +174,40 @@ class MultiStreamRoundTrip:
             cur.wait_stream(st)
         return self.out
 
-    def capture(self, x: torch.Tensor):
+    def capture(self, x: torch.Tensor, per_stream: bool = False):
+        """One hipGraph with a branch per stream (default), or - per_stream - one hipGraph per stream, each replayed on its own
+        stream between an event fork and join.  The second form does not depend on how the runtime maps the branches of ONE
+        graph onto hardware queues (on some boxes of the pool a two-branch graph runs at the one-stream rate); bench.py times
+        both before its timed region and keeps the faster."""
         self.run(x)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.run(x)
-        self.graph = g
+        self.graph, self.graphs = None, None
+        if per_stream:
+            graphs = []
+            for i, p in enumerate(self.parts):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    p.run(x[i * self.per:(i + 1) * self.per])
+                graphs.append(g)
+            self.graphs = graphs
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.run(x)
+            self.graph = g
         for p in self.parts:
             p._graph_stamp = p._stamp
 
     def replay(self):
         self.parts[0]._fresh(replaying=True)
-        self.graph.replay()
+        if self.graphs is not None:
+            cur = torch.cuda.current_stream()
+            for g, st in zip(self.graphs, self.streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    g.replay()
+            for st in self.streams:
+                cur.wait_stream(st)
+        else:
+            self.graph.replay()
         return self.out
