@@ -52,6 +52,17 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 }
 
 __device__ __forceinline__ f32x16 mfma_32x32x16(const f16x8 a, const f16x8 b, const f32x16 c) {
+#ifdef SELFC_PROXY16
+  // TIMING-ONLY diagnostic build (results are wrong): the same operand registers and FLOP count issued as two 16x16x32 MFMAs -
+  // what the loops would cost (and what clock the chip would hold) on that instruction shape, before any kernel is rewritten
+  f32x4 lo = {c[0], c[1], c[2], c[3]}, hi = {c[4], c[5], c[6], c[7]};
+  lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, lo, 0, 0, 0);
+  hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, hi, 0, 0, 0);
+  f32x16 r = c;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+#endif
 #ifdef SELFC_OPERAND_BF16
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 #else

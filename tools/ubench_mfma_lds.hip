@@ -90,13 +90,81 @@ __global__ __launch_bounds__(WAVES * 64) void loop_kernel(const u32x4* __restric
   }
 }
 
+// The same loop on v_mfma_f32_16x16x32_f16 (MI355X_MICROARCH.md "DVFS give-back" item 7: the clock the chip holds can depend on the
+// MFMA shape).  One step = NA weight fragments (16 rows x 32 k) x NB activation fragments (32 k x 16 pixels) = NA x NB MFMAs of
+// 16,384 FLOP; a 32-channel x 32-pixel wave tile of TWO convs is <NA 4, NB 2> (6 reads / 8 MFMAs = the bytes per FLOP of the
+// 32x32x16 loop <NA 2, NB 1>), of one conv <NA 2, NB 2>.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int WAVES, int NA, int NB, int MODE>
+__global__ __launch_bounds__(WAVES * 64) void loop16_kernel(const u32x4* __restrict__ src, float* __restrict__ out, int outer,
+                                                            unsigned long long* __restrict__ stamps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < LDS_BYTES / 16; i += WAVES * 64) *reinterpret_cast<u32x4*>(smem + i * 16) = src[i];
+  __syncthreads();
+  const unsigned char* wa = smem + lane * 16;
+  const unsigned char* wb = smem + NFRAG_A * 1024 + wave * (8 * 1024) + lane * 16;
+  unsigned char* wdst = smem + NFRAG_A * 1024 + 8 * 8 * 1024 + tid * 16;
+  f32x4v acc[NA][NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+  f16x8 rA[3][NA], rB[3][NB];
+  constexpr int STEPS = 48;
+  auto load_step = [&](const int st) __attribute__((always_inline)) {
+    const int s = st % 3;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) rA[s][i] = *reinterpret_cast<const f16x8*>(wa + ((st * NA + i) % NFRAG_A) * 1024);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rB[s][j] = *reinterpret_cast<const f16x8*>(wb + ((st * NB + j) % 8) * 1024);
+  };
+  load_step(0);
+  load_step(1);
+  load_step(2);
+  unsigned long long t0, t1, r0, r1;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
+  const u32x4 hookv = {1u, 2u, 3u, 4u};
+  for (int it = 0; it < outer; ++it) {
+    static_for<0, STEPS>([&](auto si) __attribute__((always_inline)) {
+      constexpr int st = decltype(si)::value;
+      if constexpr ((MODE & 1) != 0) load_step(st + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int s = (MODE & 1) ? st % 3 : 0;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rA[s][i], rB[s][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((MODE & 4) != 0) *reinterpret_cast<u32x4*>(wdst + (st % 2) * 8192) = hookv;
+      if constexpr ((MODE & 2) != 0 && st % 6 == 2) __syncthreads();
+    });
+  }
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum += acc[i][j][e];
+  out[(size_t)blockIdx.x * WAVES * 64 + tid] = sum;
+  if (lane == 0) {
+    stamps[((size_t)blockIdx.x * WAVES + wave) * 2 + 0] = t1 - t0;
+    stamps[((size_t)blockIdx.x * WAVES + wave) * 2 + 1] = r1 - r0;
+  }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int WAVES, int NA, int NB, int MODE>
+template <int WAVES, int NA, int NB, int MODE, int SHAPE = 0>
 void run(const u32x4* src, float* out, unsigned long long* stamps, const char* label) {
   constexpr int STEPS = 48;
   const int grid = 256, outer = 400;
-  auto kern = loop_kernel<WAVES, NA, NB, MODE>;
+  auto kern = SHAPE ? loop16_kernel<WAVES, NA, NB, MODE> : loop_kernel<WAVES, NA, NB, MODE>;
+  constexpr double FLOP = SHAPE ? 16384.0 : 32768.0, CYC = SHAPE ? 0.5 : 1.0;      // a 16x16x32 MFMA is half a 32x32x16
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -115,8 +183,8 @@ void run(const u32x4* src, float* out, unsigned long long* stamps, const char* l
   for (size_t i = 0; i < h.size(); i += 2) { cyc.push_back((double)h[i]); clk.push_back((double)h[i] / (double)h[i + 1] * 0.1); }
   std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
   const double med_cyc = cyc[cyc.size() / 2], med_clk = clk[clk.size() / 2];
-  const double mfma_per_simd = (double)outer * STEPS * NA * NB * (WAVES / 4);
-  const double tf = (double)grid * WAVES * outer * STEPS * NA * NB * 32768.0 * reps / (ms * 1e-3) / 1e12;
+  const double mfma_per_simd = (double)outer * STEPS * NA * NB * (WAVES / 4) * CYC;     // in 32x32x16 equivalents
+  const double tf = (double)grid * WAVES * outer * STEPS * NA * NB * FLOP * reps / (ms * 1e-3) / 1e12;
   printf("%-58s waves %d NA %d NB %d reads/MFMA %.2f | %6.1f cyc/MFMA/SIMD  clock %.2f GHz  %7.1f TFLOP/s (chip, 256 WGs)  %.3f ms/launch\n",
          label, WAVES, NA, NB, (MODE & 1) ? (double)(NA + NB) / (NA * NB) : 0.0, med_cyc / mfma_per_simd, med_clk, tf, ms / reps);
   fflush(stdout);
@@ -235,6 +303,15 @@ int main() {
   run<8, 2, 2, 7>(src, out, stamps, "8 waves, 2 M-tiles, reads + barrier + store");
   run<8, 1, 1, 1>(src, out, stamps, "8 waves, 1 conv 1 tile (FM steps / G-H conv4), reads");
   run<8, 1, 2, 1>(src, out, stamps, "8 waves, 1 conv 2 tiles (G-H), reads");
+  // 16x16x32 twins (cycles per 32x32x16 EQUIVALENT, i.e. per 32,768 FLOP)
+  run<8, 4, 2, 0, 1>(src, out, stamps, "16x16x32: 8 waves, bare MFMA (no LDS)");
+  run<8, 4, 2, 1, 1>(src, out, stamps, "16x16x32: 8 waves, F non-ring shape (2 convs), reads");
+  run<8, 4, 2, 3, 1>(src, out, stamps, "16x16x32: 8 waves, F non-ring shape, reads + barrier");
+  run<8, 4, 2, 7, 1>(src, out, stamps, "16x16x32: 8 waves, F non-ring shape, reads + barrier + store");
+  run<8, 2, 2, 1, 1>(src, out, stamps, "16x16x32: 8 waves, 1 conv 1 tile (G-H conv4), reads");
+  run<8, 2, 4, 1, 1>(src, out, stamps, "16x16x32: 8 waves, 1 conv 2 tiles (G-H), reads");
+  run<8, 2, 1, 1>(src, out, stamps, "32x32x16 again: 8 waves, F non-ring shape, reads");
+  run<8, 1, 1, 1>(src, out, stamps, "32x32x16 again: 8 waves, 1 conv 1 tile, reads");
   run<4, 2, 1, 0>(src, out, stamps, "4 waves, bare MFMA (no LDS)");
   run<4, 2, 2, 1>(src, out, stamps, "4 waves, 2 M-tiles, reads");
   run<4, 2, 2, 7>(src, out, stamps, "4 waves, 2 M-tiles, reads + barrier + store");
