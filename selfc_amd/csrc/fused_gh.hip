@@ -267,8 +267,8 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int t0 = 4 * ks + e, t1 = 4 * ks + 2 + e;          // half 0 / half 1
-      const int o0 = t0 < 9 ? ((t0 / 3) * XS + t0 % 3) * 8 : -1;
-      const int o1 = t1 < 9 ? ((t1 / 3) * XS + t1 % 3) * 8 : -1;
+      const int o0 = t0 < 9 ? ((t0 / 3) * XS + t0 % 3) * 8 : 0;
+      const int o1 = t1 < 9 ? ((t1 / 3) * XS + t1 % 3) * 8 : 0;
       xo[ks][e] = c.half ? o1 : o0;
     }
 
@@ -313,9 +313,10 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
       if (st < NIM) {
 #pragma unroll
         for (int m = 0; m < MTE; ++m) {
-          uint2 p0 = make_uint2(0u, 0u), p1 = make_uint2(0u, 0u);
-          if (xo[st][0] >= 0) p0 = *reinterpret_cast<const uint2*>(xb + xbase[m] + xo[st][0]);
-          if (xo[st][1] >= 0) p1 = *reinterpret_cast<const uint2*>(xb + xbase[m] + xo[st][1]);
+          // tap slots 9..11 carry ZERO weights (packing.pack_fused_gh): their lanes read tap 0 instead of branching around the
+          // load - any finite value will do, and a branch per load split the step into basic blocks (no read / MFMA interleave)
+          const uint2 p0 = *reinterpret_cast<const uint2*>(xb + xbase[m] + xo[st][0]);
+          const uint2 p1 = *reinterpret_cast<const uint2*>(xb + xbase[m] + xo[st][1]);
           const u32x4 u = {p0.x, p0.y, p1.x, p1.y};
           B[m] = __builtin_bit_cast(f16x8, u);
         }
