@@ -430,6 +430,8 @@ class PackPlan:
         for name, (t, kind) in outs.items():
             idx = t.reshape(-1).round().long() - 1
             idx = torch.where(idx < 0, torch.full_like(idx, total), idx)          # zero fill -> the appended 0
+            if idx.numel() and int(idx.max()) > total:       # a pack function that rounded its stand-ins (not built on _operand): refuse
+                raise ValueError(f"PackPlan: {name} is not a pure gather of the parameters (index {int(idx.max())} > {total})")
             pad = (-idx.numel()) % self.ALIGN
             if pad:
                 idx = torch.cat((idx, torch.full((pad,), total, dtype=torch.long, device=dev)))

@@ -99,10 +99,17 @@ constexpr int LAYER_OFF[5] = {0, 0, 4, 26, 66};
 
 #ifdef SELFC_STAMPS
 #define STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#ifdef SELFC_STAMP_BYCONV      // the four slots = MFMA-loop cycles of conv1..conv4 instead of the four phases
+#define STAMP_ADD(k, a, b)
+#define STAMP_LOOP(K, a, b) c.phase[(K) - 1] += (b) - (a)
+#else
 #define STAMP_ADD(k, a, b) c.phase[k] += (b) - (a)
+#define STAMP_LOOP(K, a, b) c.phase[1] += (b) - (a)
+#endif
 #else
 #define STAMP(var)
 #define STAMP_ADD(k, a, b)
+#define STAMP_LOOP(K, a, b)
 #endif
 
 typedef __attribute__((address_space(1))) f16 gf16;                 // explicitly global: a laundered pointer would otherwise become flat
@@ -384,7 +391,7 @@ __device__ __forceinline__ void conv_fused(Ctx& c, const FGArgs& a, const int ne
     }
 
     STAMP(ts2);
-    STAMP_ADD(1, ts1, ts2);
+    STAMP_LOOP(K, ts1, ts2);
     // ---- hand the weight buffers over FIRST (next chunk -> the other buffer): global stores share the VM counter with
     // loads on gfx9, so waiting for the prefetched fragments behind the epilogue's feature stores meant waiting for
     // those stores to be acknowledged (~1-2 us at every conv boundary)

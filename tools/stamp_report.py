@@ -20,7 +20,7 @@ with torch.no_grad():
 torch.cuda.synchronize()
 d = np.loadtxt(os.environ["SELFC_STAMP_DUMP"])
 d = d[d[:, 4] > 0]
-names = ["setup+prefetch", "MFMA loop", "epilogue", "commit+barrier", "kernel total"]
+names = os.environ.get("SELFC_STAMP_NAMES", "setup+prefetch,MFMA loop,epilogue,commit+barrier").split(",") + ["kernel total"]
 print("waves with data:", len(d))
 tot = d[:, 4].mean()
 for i, n in enumerate(names):
