@@ -312,6 +312,18 @@ int selfc_gmm_sample_bwd(const float* raw, const float* eps, const float* dv, fl
 int selfc_gmm_sample_generic_bwd(const float* raw, const float* eps, const float* dv, float* draw, size_t npix, int hf_dim, int K,
                                  int raw_stride, int v_stride, float logsigma_scale, void* stream);
 int selfc_lrelu_bwd(float* dx, const float* x, size_t n, void* stream);       /* dx *= (x > 0 ? 1 : 0.2), n % 4 == 0 */
+/* dst_i[j] = beta_i * dst_i[j] + sum over rows_i of src_i[r][j] (src_i row-major [rows_i][len_i]) for n <= 8 small matrices in one
+ * launch: the per-clip partial gradients of selfc_globalagg_bwd summed over the clips straight into their destination
+ * (autograd.globalagg_bwd: the trainer's flat gradient buffer with beta = 1).  No reference counterpart (autograd does it). */
+#define SELFC_ROWSUM_MAX 8
+typedef struct {
+  const float* src[SELFC_ROWSUM_MAX];
+  float* dst[SELFC_ROWSUM_MAX];
+  int len[SELFC_ROWSUM_MAX], rows[SELFC_ROWSUM_MAX];
+  float beta[SELFC_ROWSUM_MAX];
+  int n;
+} selfc_rowsum;
+int selfc_rowsum_accum(const selfc_rowsum* job, void* stream);
 size_t selfc_globalagg_bwd_scratch_bytes(int N, int T, int H, int W);
 /* Backward of selfc_globalagg_run (GlobalAgg.forward, SelfC_GMM_arch_inv.py:265-285): x, dy, dx fp32 [N][H*W][64];
  * w1t = pack_planes_generic(proj1.weight^T).  Parameter gradients: dw1 (64,64) complete; the others per clip

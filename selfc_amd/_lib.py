@@ -40,7 +40,7 @@ SYMBOLS = [
     "selfc_subnet_bwd_scratch_bytes", "selfc_subnet_bwd", "selfc_subnet_bwd_phase", "selfc_coupling_fwd", "selfc_coupling_bwd", "selfc_freq_fwd_bwd", "selfc_freq_inv_bwd",
     "selfc_bwd_scale", "selfc_bwd_to_planes", "selfc_f16_rows_to_planes", "selfc_bwd_conv_planes",
     "selfc_bwd_wgrad_scratch_bytes", "selfc_bwd_wgrad", "selfc_gmm_sample_bwd", "selfc_gmm_sample_generic_bwd", "selfc_lrelu_bwd",
-    "selfc_globalagg_bwd_scratch_bytes", "selfc_globalagg_bwd",
+    "selfc_globalagg_bwd_scratch_bytes", "selfc_globalagg_bwd", "selfc_rowsum_accum",
 ]
 
 
@@ -51,6 +51,10 @@ class SubnetW(C.Structure):
 
 class SubnetBW(C.Structure):
     _fields_ = [("wt5", C.c_void_p), ("wtd", C.c_void_p * 3), ("wtx", C.c_void_p)]
+
+
+class RowSum(C.Structure):
+    _fields_ = [("src", C.c_void_p * 8), ("dst", C.c_void_p * 8), ("len", C.c_int * 8), ("rows", C.c_int * 8), ("beta", C.c_float * 8), ("n", C.c_int)]
 
 
 class InvBlockW(C.Structure):
@@ -132,6 +136,7 @@ def lib():
             "selfc_gmm_sample_bwd": [vp, vp, vp, vp, sz, i, i, vp],
             "selfc_gmm_sample_generic_bwd": [vp, vp, vp, vp, sz, i, i, i, i, f, vp],
             "selfc_lrelu_bwd": [vp, vp, sz, vp],
+            "selfc_rowsum_accum": [C.POINTER(RowSum), vp],
             "selfc_globalagg_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, i, vp],
         }
         for name, args in sigs.items():

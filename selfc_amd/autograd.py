@@ -14,7 +14,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _lib, runtime as rt
-from .packing import dense_channels, pack_planes_generic, pack_pointwise_T, pool_weight_map_grad, roundup
+from .packing import dense_channels, pack_planes_generic, pack_pointwise_T, pool_weight_map_grad, pool_weight_map_grad_batch, roundup
 
 _SCRATCH: Dict[Tuple, torch.Tensor] = {}
 
@@ -756,7 +756,7 @@ def _buf(cache: Dict, name: str, nbytes: int, device) -> torch.Tensor:
 _STP_CACHE: Dict = {}
 
 
-def globalagg_bwd(m, x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, n: int, t: int, h: int, w: int) -> Dict[str, torch.Tensor]:
+def globalagg_bwd(m, x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, n: int, t: int, h: int, w: int, defer_fc: Optional[list] = None) -> Dict[str, torch.Tensor]:
     """Backward of GlobalAgg.run_nhwc: x, dy, dx fp32 [n][h*w][64]; returns {parameter name: gradient}."""
     pk = m._packed(h, w)
     key = rt.params_key(m)
@@ -776,10 +776,33 @@ def globalagg_bwd(m, x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, n: int
             m._w1t.data_ptr(), pk["b1"].data_ptr(), pk["w2"].data_ptr(), pk["b2"].data_ptr(), pk["w3"].data_ptr(), pk["b3"].data_ptr(),
             dw1.data_ptr(), db1c.data_ptr(), dw2c.data_ptr(), db2c.data_ptr(), dw3c.data_ptr(), db3c.data_ptr(),
             dfcbc.data_ptr(), dwmapc.data_ptr(), sc.data_ptr(), sc.numel(), n, t, h, w, _lib.stream_ptr())
-    return {"proj1.weight": dw1.reshape(64, 64, 1, 1), "proj1.bias": db1c.sum(0),
-            "proj2.weight": dw2c.sum(0).reshape(64, 64), "proj2.bias": db2c.sum(0),
-            "proj3.weight": dw3c.sum(0).reshape(64, 64), "proj3.bias": db3c.sum(0),
-            "fc.weight": pool_weight_map_grad(dwmapc.sum(0), h, w), "fc.bias": dfcbc.sum().reshape(1)}
+    # the sums over the clips: ONE launch for the seven per-clip tensors (they were 7 torch sums + as many autograd accumulations);
+    # with the trainer's flat gradient buffer the results are ADDED straight into the parameters' views and autograd sees None
+    names = ["proj1.weight", "proj1.bias", "proj2.weight", "proj2.bias", "proj3.weight", "proj3.bias", "fc.bias"]
+    srcs = [dw1, db1c, dw2c, db2c, dw3c, db3c, dfcbc]
+    lens = [64 * 64, 64, 64 * 64, 64, 64 * 64, 64, 1]
+    rows = [1, b, b, b, b, b, b]
+    sunk = None
+    if _SINK is not None:
+        sunk = [_SINK.view_of(getattr(getattr(m, nm.split(".")[0]), nm.split(".")[1])) for nm in names]
+        if any(v is None for v in sunk):
+            sunk = None
+    dwmap = torch.empty((h * w,), **f32)
+    outs = sunk if sunk is not None else [torch.empty((ln,), **f32) for ln in lens]
+    job = _lib.RowSum()
+    for i, (src, dst, ln, rw) in enumerate(zip(srcs + [dwmapc], outs + [dwmap], lens + [h * w], rows + [b])):
+        job.src[i], job.dst[i], job.len[i], job.rows[i] = src.data_ptr(), dst.data_ptr(), ln, rw
+        job.beta[i] = 1.0 if (sunk is not None and i < 7) else 0.0
+    job.n = 8
+    rt.call("selfc_rowsum_accum", C.byref(job), _lib.stream_ptr())
+    if defer_fc is not None:          # the caller folds all its blocks' map gradients through the pooling map in one batch
+        defer_fc.append((m, dwmap))
+        g = {"fc.weight": None}
+    else:
+        g = {"fc.weight": pool_weight_map_grad(dwmap, h, w)}
+    for nm, o, p_shape in zip(names, outs, [(64, 64, 1, 1), (64,), (64, 64), (64,), (64, 64), (64,), (1,)]):
+        g[nm] = None if sunk is not None else o.reshape(p_shape)
+    return g
 
 
 class GlobalAggFn(torch.autograd.Function):
@@ -854,7 +877,7 @@ def _head_bwd(convs, feat, acts, dlast, n, t, h, w, relu_hidden: bool = False) -
         rt.call("selfc_bwd_wgrad", gp.data_ptr(), pn, q.data_ptr(), qn, 1, gw.data_ptr(), cout, cin, gb.data_ptr(), 0.0,
                 amax.data_ptr(), sc.data_ptr(), sc.numel(), n, t, h, w, sp)
         grads[li] = (gw.reshape(conv.weight.shape), gb)
-        wt = pack_pointwise_T(conv.weight)
+        wt = conv.__dict__.get("_wt_pk") if conv.__dict__.get("_wt_key") == rt.params_key(conv) else pack_pointwise_T(conv.weight)
         if li > 0:
             nxt = torch.empty((cin // 32, npix, 32), dtype=F16, device=dev)
             rt.call("selfc_bwd_conv_planes", gp.data_ptr(), pn, 1, 1, wt.data_ptr(), cin // 32, nxt.data_ptr(), None,
@@ -951,6 +974,7 @@ class STPSampleFn(torch.autograd.Function):
         d = d.reshape(n, h * w, 64)
         side = side_stream(dev)
         ring, turn = [None, None], 0                       # two scratch slots; a slot is reused only after its weight phase
+        fc_maps: list = []
         for m, xin, dense in reversed(ctx.stages):
             if isinstance(m, D2DTInput):
                 dxl = torch.empty((n, h, w, roundup(m.channel_in, 4)), dtype=torch.float32, device=dev)
@@ -965,10 +989,14 @@ class STPSampleFn(torch.autograd.Function):
                 d = dxl
             else:
                 dxl = torch.empty_like(d)
-                g = globalagg_bwd(m, xin, d.reshape(n, h * w, 64), dxl, n, t, h, w)
+                g = globalagg_bwd(m, xin, d.reshape(n, h * w, 64), dxl, n, t, h, w, defer_fc=fc_maps)
                 for name, prm in m.named_parameters():
                     grads[id(prm)] = g[name]
                 d = dxl
+        if fc_maps:                   # d fc.weight of every GlobalAgg: ONE batched fold (packing.pool_weight_map_grad_batch)
+            folded = pool_weight_map_grad_batch(torch.stack([dm for _, dm in fc_maps]), h, w)
+            for i, (m, _) in enumerate(fc_maps):
+                grads[id(m.fc.weight)] = folded[i].reshape(1, 32 * 32)
         dlr = None
         if ctx.needs_input_grad[0]:
             dlr = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)

@@ -952,6 +952,24 @@ __global__ __launch_bounds__(256) void gagg_bwd_dx_kernel(const float* __restric
   if (ok && cq == 0) dwmapc[(size_t)b * HW + p] = dw;
 }
 
+// dst_i[j] = beta * dst_i[j] + sum_r src_i[r][j] for up to 8 small row-major matrices in ONE launch: the per-clip partial
+// gradients of GlobalAgg summed over the clips straight into their destination (the trainer's flat gradient buffer)
+struct RowSumArgs { const float* src[SELFC_ROWSUM_MAX]; float* dst[SELFC_ROWSUM_MAX]; int rows[SELFC_ROWSUM_MAX]; int end[SELFC_ROWSUM_MAX]; float beta[SELFC_ROWSUM_MAX]; int n; };
+__global__ __launch_bounds__(256) void rowsum_accum_kernel(const RowSumArgs a) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.end[a.n - 1]) return;
+  int seg = 0;
+#pragma unroll
+  for (int i = 0; i < SELFC_ROWSUM_MAX - 1; ++i) seg += (i < a.n - 1 && j >= a.end[i]) ? 1 : 0;
+  const int lo = seg ? a.end[seg - 1] : 0, len = a.end[seg] - lo, col = j - lo;
+  const float* src = a.src[seg] + col;
+  float acc = 0.f;
+  for (int r = 0; r < a.rows[seg]; ++r) acc += src[(size_t)r * len];
+  float* d = a.dst[seg] + col;
+  const float beta = a.beta[seg];
+  *d = beta != 0.f ? beta * *d + acc : acc;
+}
+
 struct GaggBwdLayout {
   size_t plane_b, off_dyp, off_zp, off_dz, off_amax, off_pool, off_A, off_pdA, off_pdyo, off_dg, off_wg, total;
   int nchunk, nchunkb;
@@ -1126,6 +1144,20 @@ int selfc_f16_rows_to_planes(const void* rows, void* planes, size_t npix, int C,
   ProfScope prof(PROF_BWD, (hipStream_t)stream);
   const size_t items = npix * (size_t)(C / 8);
   hipLaunchKernelGGL(rows_to_planes_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)rows, (f16*)planes, npix, C);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_rowsum_accum(const selfc_rowsum* job, void* stream) {
+  if (!job || job->n <= 0 || job->n > SELFC_ROWSUM_MAX) return SELFC_EINVAL;
+  RowSumArgs a{};
+  int total = 0;
+  for (int i = 0; i < job->n; ++i) {
+    if (!job->src[i] || !job->dst[i] || job->len[i] <= 0 || job->rows[i] <= 0) return SELFC_EINVAL;
+    a.src[i] = job->src[i]; a.dst[i] = job->dst[i]; a.rows[i] = job->rows[i]; a.beta[i] = job->beta[i];
+    a.end[i] = (total += job->len[i]);
+  }
+  a.n = job->n;
+  hipLaunchKernelGGL(rowsum_accum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return hip_rc(hipGetLastError());
 }
 

@@ -87,20 +87,49 @@ class GlobalAgg(nn.Module):
         self.proj2 = nn.Linear(c, c)
         self.proj3 = nn.Linear(c, c)
 
-    def _packed(self, h, w):
-        key = rt.params_key(self) + (h, w)
-        if getattr(self, "_pk_key", None) != key:
-            from ..packing import pack_pointwise, pad_bias, pool_weight_map
-            c = self.c
+    def _gather_params(self):
+        return [self.fc.bias, self.proj1.weight, self.proj1.bias, self.proj2.weight, self.proj2.bias, self.proj3.weight, self.proj3.bias]
 
-            def sq64(wt):        # (c,c[,1,1]) -> zero-padded (64,64): the kernels' rows are 64 channels wide, pads stay 0
-                out = torch.zeros(64, 64, dtype=torch.float32, device=wt.device)
-                out[:c, :c] = wt.detach().float().reshape(c, c)
-                return out
-            self._pk = dict(wmap=pool_weight_map(self.fc.weight, h, w), fcb=self.fc.bias.detach().float().contiguous(),
-                            w1=pack_pointwise(sq64(self.proj1.weight)), b1=pad_bias(self.proj1.bias, 64),
-                            w2=sq64(self.proj2.weight), b2=pad_bias(self.proj2.bias, 64),
-                            w3=sq64(self.proj3.weight), b3=pad_bias(self.proj3.bias, 64))
+    def _gather_entries(self, ps):
+        """everything of the packed set that is a pure re-ordering of the parameters ({name: (tensor, kind)}, packing.PackPlan terms);
+        `wmap` (a weighted sum of fc.weight) is not"""
+        from ..packing import pack_planes_generic, pack_pointwise, pad_bias
+        c = self.c
+        fcb, w1, b1, w2, b2, w3, b3 = ps
+
+        def sq64(wt):        # (c,c[,1,1]) -> zero-padded (64,64): the kernels' rows are 64 channels wide, pads stay 0
+            out = torch.zeros(64, 64, dtype=torch.float32, device=wt.device)
+            out[:c, :c] = wt.detach().float().reshape(c, c)
+            return out
+        e = dict(fcb=(fcb.detach().float().contiguous(), "b"), w1=(pack_pointwise(sq64(w1)), "w"), b1=(pad_bias(b1, 64), "b"),
+                 w2=(sq64(w2), "b"), b2=(pad_bias(b2, 64), "b"), w3=(sq64(w3), "b"), b3=(pad_bias(b3, 64), "b"))
+        if c == 64:          # the gradient kernels' transposed proj1 (autograd.globalagg_bwd)
+            e["w1t"] = (pack_planes_generic(w1.detach().float().reshape(64, 64).t().reshape(64, 64, 1, 1).contiguous()), "w")
+        return e
+
+    def _install_gathered(self, d):
+        """runtime.PackGroup: the gather parts of this module arrived with the group's refresh"""
+        self._pkg, self._pkg_key = d, rt.params_key(self)
+        if "w1t" in d:
+            self._w1t, self._w1t_key = d["w1t"], self._pkg_key
+
+    def _packed(self, h, w):
+        pkey = rt.params_key(self)
+        key = pkey + (h, w)
+        if getattr(self, "_pk_key", None) != key:
+            from ..packing import pool_weight_map, pool_weight_map_batch
+            sib = self.__dict__.get("_siblings")          # the GlobalAgg blocks of one STP chain fold their pooling maps together
+            fkey = (rt.params_key(self.fc), h, w)
+            if sib and self.__dict__.get("_wmap_key") != fkey:
+                maps = pool_weight_map_batch([m.fc.weight for m in sib], h, w)
+                for i, m in enumerate(sib):
+                    m.__dict__["_wmap"], m.__dict__["_wmap_key"] = maps[i], (rt.params_key(m.fc), h, w)
+            if getattr(self, "_pkg_key", None) == pkey:
+                g = self._pkg
+            else:
+                g = {k: v[0] for k, v in self._gather_entries(self._gather_params()).items() if k != "w1t"}
+            wmap = self.__dict__["_wmap"] if self.__dict__.get("_wmap_key") == fkey else pool_weight_map(self.fc.weight, h, w)
+            self._pk = dict(g, wmap=wmap)
             self._pk_key = key
         return self._pk
 
@@ -221,29 +250,66 @@ class STPNet(nn.Module):
         hf_dim); a GMM head with every width rounded up to what selfc_pwconv_run takes - input rows of 64 channels (the chain's
         rows, zero beyond c), hidden widths to 32 / 64 / 128 / 256, the last layer to a multiple of 16 - by zero rows / columns, which is
         exact (padded hidden units are act(0 + 0) = 0 and meet zero columns).  c = 64 with hf_dim = 48 (SelfC-large) needs no pad."""
-        convs = [m for m in self._tail_seq() if isinstance(m, nn.Conv3d)]
+        convs = self._tail_convs()
         key = rt.params_key(*convs)
         if getattr(self, "_tail_key", None) != key:
-            from ..packing import pack_pointwise, pad_bias, roundup
-            tail, prev = [], 64
-            for i, m in enumerate(convs):
-                last = i == len(convs) - 1
-                cin_p = prev
-                if last:
-                    cout_p = m.out_channels if len(convs) == 1 else roundup(m.out_channels, 16)
-                else:         # a hidden width is the next layer's K: the pointwise kernel takes 32, 64, 128 or 256 input channels
-                    fits = [v for v in (32, 64, 128, 256) if v >= m.out_channels]
-                    if not fits:
-                        raise NotImplementedError("selfc_amd: hidden layers of the STP head hold at most 256 channels")
-                    cout_p = fits[0]
-                wt = torch.zeros(max(cout_p, m.out_channels), cin_p, dtype=torch.float32, device=m.weight.device)
-                wt[:m.out_channels, :m.in_channels] = m.weight.detach().float().reshape(m.out_channels, m.in_channels)
-                tail.append((pack_pointwise(wt), pad_bias(m.bias, roundup(cout_p, 16)), cin_p, cout_p))
-                prev = cout_p
-            self._tail = tail
-            self._tail_fused = self._tail_fused_key = None
-            self._tail_key = key
+            self._install_tail({k: v[0] for k, v in self._tail_entries([p_ for m in convs for p_ in (m.weight, m.bias)]).items()})
         return self._tail
+
+    def _tail_convs(self):
+        return [m for m in self._tail_seq() if isinstance(m, nn.Conv3d)]
+
+    def _tail_widths(self):
+        """[(cin_p, cout_p)] per conv of the head: the padded widths documented at _tail_packed"""
+        from ..packing import roundup
+        convs = self._tail_convs()
+        out, prev = [], 64
+        for i, m in enumerate(convs):
+            if i == len(convs) - 1:
+                cout_p = m.out_channels if len(convs) == 1 else roundup(m.out_channels, 16)
+            else:         # a hidden width is the next layer's K: the pointwise kernel takes 32, 64, 128 or 256 input channels
+                fits = [v for v in (32, 64, 128, 256) if v >= m.out_channels]
+                if not fits:
+                    raise NotImplementedError("selfc_amd: hidden layers of the STP head hold at most 256 channels")
+                cout_p = fits[0]
+            out.append((prev, cout_p))
+            prev = cout_p
+        return out
+
+    def _tail_entries(self, ps):
+        """{name: (tensor, kind)} of the head's packed convs from ps = [w0, b0, w1, b1, ..] (packing.PackPlan terms)"""
+        from ..packing import pack_pointwise, pad_bias, roundup
+        e = {}
+        for i, (m, (cin_p, cout_p)) in enumerate(zip(self._tail_convs(), self._tail_widths())):
+            wt = torch.zeros(max(cout_p, m.out_channels), cin_p, dtype=torch.float32, device=ps[2 * i].device)
+            wt[:m.out_channels, :m.in_channels] = ps[2 * i].detach().float().reshape(m.out_channels, m.in_channels)
+            e[f"w{i}"] = (pack_pointwise(wt), "w")
+            e[f"b{i}"] = (pad_bias(ps[2 * i + 1], roundup(cout_p, 16)), "b")
+        return e
+
+    def _install_tail(self, d):
+        self._tail = [(d[f"w{i}"], d[f"b{i}"], cin_p, cout_p) for i, (cin_p, cout_p) in enumerate(self._tail_widths())]
+        self._tail_fused = self._tail_fused_key = None
+        self._tail_key = rt.params_key(*self._tail_convs())
+
+    def add_to_pack_group(self, group):
+        """runtime.PackGroup membership of everything this net packs per set of weights: the chain's subnets (as the kernels see
+        them), the GlobalAgg blocks' gather parts, the head."""
+        from ..packing import pack_pointwise_T
+        aggs = [m for m in self._chain() if not isinstance(m, D2DTInput)]
+        for m in self._chain():
+            if isinstance(m, D2DTInput):
+                rt.group_add_subnet(group, m, self._virt(m))
+            else:
+                m.__dict__["_siblings"] = aggs
+                group.add(m._gather_params(), m._gather_entries, m._install_gathered)
+        convs = self._tail_convs()
+        group.add([p_ for m in convs for p_ in (m.weight, m.bias)], self._tail_entries, self._install_tail)
+
+        def install_t(d):          # the transposed head weights of autograd._head_bwd
+            for i, m in enumerate(convs):
+                m.__dict__["_wt_pk"], m.__dict__["_wt_key"] = d[f"wt{i}"], rt.params_key(m)
+        group.add([m.weight for m in convs], lambda ps: {f"wt{i}": (pack_pointwise_T(p_), "w") for i, p_ in enumerate(ps)}, install_t)
 
     def _head_fused(self):
         """(fragment stream, bias vector) of the whole-head + sampler kernel, or None when the head is not the shipped

@@ -208,6 +208,20 @@ def pool_weight_map_grad(dwmap: torch.Tensor, h: int, w: int) -> torch.Tensor:
     return (pool_bins(h, d.device) @ d @ pool_bins(w, d.device).t()).reshape(1, 32 * 32).float()
 
 
+def pool_weight_map_batch(fc_weights: Sequence[torch.Tensor], h: int, w: int) -> torch.Tensor:
+    """pool_weight_map of several GlobalAgg blocks in one batched product -> (G, h*w) (an STP chain has six; module by module
+    that is four small launches each, every training step)."""
+    dev = fc_weights[0].device
+    fcw = torch.stack([f.detach().reshape(32, 32) for f in fc_weights]).double()
+    return torch.matmul(torch.matmul(pool_bins(h, dev).t(), fcw), pool_bins(w, dev)).reshape(len(fc_weights), h * w).float().contiguous()
+
+
+def pool_weight_map_grad_batch(dwmaps: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """pool_weight_map_grad of a (G, h*w) stack of map gradients -> (G, 1024)."""
+    d = dwmaps.double().reshape(-1, h, w)
+    return torch.matmul(torch.matmul(pool_bins(h, d.device), d), pool_bins(w, d.device).t()).reshape(-1, 32 * 32).float()
+
+
 def pack_fused_gh(weights: Sequence[torch.Tensor], cin: int = 3) -> torch.Tensor:
     """conv1..conv4 weights of a cin == 3 dense block -> the fragment stream of csrc/fused_gh.hip:
     per conv [im2col48: K = 12 taps x 4 (c0 c1 c2 0), 3 fragments][feature j = 1..: tap-major, 18

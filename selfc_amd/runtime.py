@@ -284,6 +284,79 @@ def packed_block(blk) -> PackedBlock:
     return blk._pb
 
 
+class PackGroup:
+    """The kernel-layout weights of MANY modules as ONE gather (one PackPlan over all their parameters).
+
+    Every module's own cache (`packed_block`, `packed_subnet`, GlobalAgg._packed, STPNet._tail_packed) repacks when its
+    parameters' (address, version) key changes - in training that is every step, and module by module it costs ~250 small
+    device launches (pad / copy / cast per tensor; 3 per planned module).  A group learns one plan over all members, and
+    `refresh()` - three device ops whatever the number of members - installs each member's tensors together with the key
+    its own cache checks, so the per-module calls that follow are cache hits.  A member is (params, build(ps) -> {name:
+    (tensor, kind)}, install(dict)); build must be composed of packing.pack_* functions (pure gathers)."""
+
+    def __init__(self):
+        self.members, self.plan, self.dev = [], None, None
+
+    def add(self, params, build, install):
+        self.members.append((list(params), build, install))
+        self.plan = None
+
+    def refresh(self):
+        if not self.members:
+            return
+        allp = [p_ for ps, _, _ in self.members for p_ in ps]
+        dev = allp[0].device
+        if self.plan is None or self.dev != dev:
+            def build_all(ps):
+                e, lo = {}, 0
+                for i, (mp, build, _) in enumerate(self.members):
+                    for k, v in build(ps[lo:lo + len(mp)]).items():
+                        e[f"{i}|{k}"] = v
+                    lo += len(mp)
+                return e
+            self.plan, self.dev = PackPlan(allp, build_all), dev
+            self.names = [[] for _ in self.members]
+            for name, *_ in self.plan.items:
+                i, short = name.split("|", 1)
+                self.names[int(i)].append((name, short))
+        d = self.plan.run(allp)
+        for (_, _, install), names in zip(self.members, self.names):
+            install({short: d[full] for full, short in names})
+
+
+def group_add_block(group: PackGroup, blk):
+    """InvBlockExp member: what packed_block() would build, installed under the key packed_block() checks."""
+    if blk.split_len1 > 3:
+        return
+    for sub in (blk.F, blk.G, blk.H):
+        sub._check()
+
+    def install(d):
+        blk._pb = PackedBlock(blk, d)
+        blk._pb_key = params_key(blk) + (float(blk.clamp),)
+    group.add(_conv_params(blk.F) + _conv_params(blk.G) + _conv_params(blk.H), lambda ps: _block_entries(blk, ps), install)
+
+
+def group_add_subnet(group: PackGroup, mod, virt: Tuple[int, int] = None):
+    """stand-alone DenseBlock / D2DTInput member (packed_subnet's tensors and key)"""
+    cin_v, cout_v = virt if virt is not None else (mod.channel_in, mod.channel_out)
+    mod._check()
+    temporal = mod.kind == SUBNET_D2DT
+    widen = mod.gc != 32 or (cin_v, cout_v) != (mod.channel_in, mod.channel_out)
+
+    def build(ps):
+        ws, bs = ps[0::2], ps[1::2]
+        if widen:
+            from .packing import widen_dense_params
+            ws, bs = widen_dense_params(ws, bs, mod.channel_in, mod.channel_out, mod.gc, cin_v, cout_v)
+        return subnet_pack_entries("", ws, bs, cin_v, cout_v, temporal, with_bwd=not widen)
+
+    def install(d):
+        mod._pk = PackedSubnet(d, "", cin_v, cout_v, mod.kind)
+        mod._pk_key = params_key(mod) + (cin_v, cout_v)
+    group.add(_conv_params(mod), build, install)
+
+
 def block_array(blocks):
     """(selfc_invblock_w[n], keep-alive list) for selfc_invstack_run."""
     packs = [packed_block(b) for b in blocks]

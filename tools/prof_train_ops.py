@@ -27,3 +27,14 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     torch.cuda.synchronize()
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="count" if False else "self_cuda_time_total", row_limit=45, max_name_column_width=40, max_shapes_column_width=60))
 print(prof.key_averages(group_by_stack_n=4).table(sort_by="self_cuda_time_total", row_limit=30, max_name_column_width=30, max_src_column_width=90))
+
+# by source line: which Python lines of this package issue the small torch ops (count per two steps)
+from collections import Counter
+cnt = Counter()
+for ev in prof.events():
+    if ev.name in ("aten::copy_", "aten::add_", "aten::fill_", "aten::sum", "aten::cat", "aten::zero_", "aten::clone", "aten::mul", "aten::add", "aten::sub", "aten::div") and ev.stack:
+        line = next((fr for fr in ev.stack if "selfc_amd" in fr or "tools/" in fr), ev.stack[0] if ev.stack else "?")
+        cnt[(ev.name, line.strip()[-110:])] += 1
+print("\n# small torch ops by source line (two steps)")
+for (name, line), c in cnt.most_common(60):
+    print(f"{c:5d}  {name:14s} {line}")
