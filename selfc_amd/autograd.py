@@ -569,12 +569,12 @@ class InvStackFn(torch.autograd.Function):
         x2 = torch.empty((n, h, w, c2p), dtype=f32, device=dev)
         pf = torch.empty((2, n, h, w, 12), dtype=f32, device=dev) if c2 == 48 else None
 
-        def new_fd():          # only the pad channels of the last input plane need the zero fill (everything else is fully written)
-            fd = torch.empty((FC // 32, n, h, w, 32), dtype=F16, device=dev)
-            if c2 % 32:
-                fd[c2 // 32].zero_()
-            return fd
-        fds = [new_fd() for _ in order]
+        # the blocks' F buffers as one allocation: only the pad channels of the last input plane need a zero fill (everything else is
+        # fully written) - one strided fill for all blocks
+        fd_all = torch.empty((len(order), FC // 32, n, h, w, 32), dtype=F16, device=dev)
+        if c2 % 32:
+            fd_all[:, c2 // 32].zero_()
+        fds = list(fd_all.unbind(0))
         if not rev:
             rt.call("selfc_freq_fwd", x.data_ptr(), x1.data_ptr(), x2.data_ptr(), fds[0].data_ptr(), FC, n, H, W, k, sp)
         else:

@@ -52,7 +52,8 @@ class ReconstructionLoss(nn.Module):
         else:
             print("reconstruction loss type error!")
             return 0
-        return v.mean(-1).mean(-1).mean(-1).mean(-1)
+        # the reference's v.mean(-1).mean(-1).mean(-1).mean(-1) (loss.py): means of equal-sized groups = one mean over the four axes
+        return v.mean(dim=(-4, -3, -2, -1))
 
 
 class MultiStepLR_Restart(_LRScheduler):
