@@ -135,6 +135,8 @@ typedef struct {
   void* fd_next;         /* optional (abi 8), rev == 0 only: where the G/H epilogue puts the f16 copy of the updated x2 (the NEXT
                             block's F input) instead of this block's own `fd` - a training forward that keeps one private `fd` per
                             block (its backward then finds F's input planes untouched).  NULL: `fd` (blocks chained in place). */
+  float* x1_out;         /* optional (abi 9): where the updated x1 / x2 go instead of over their inputs, which then stay intact - a */
+  float* x2_out;         /* training forward keeps them for the backward pass without cloning.  NULL: in place. */
 } selfc_latent;
 
 /* The caller reads the dense feature buffers (fd / gd / hd planes f1..f4) after the call - the training forward, whose

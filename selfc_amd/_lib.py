@@ -25,7 +25,7 @@ def operand_dtype():
 SUBNET_D2DT = 0
 SUBNET_DB2D = 1
 LAT_KEEP_FEATURES = 1      # selfc_latent.flags (SELFC_LAT_KEEP_FEATURES)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 #: every symbol include/selfc_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -65,7 +65,8 @@ class Latent(C.Structure):
     _fields_ = [("kind", C.c_int), ("N", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("c1", C.c_int), ("c2", C.c_int),
                 ("x1", C.c_void_p), ("x2", C.c_void_p), ("fd", C.c_void_p), ("gd", C.c_void_p),
-                ("hd", C.c_void_p), ("s_out", C.c_void_p), ("pf", C.c_void_p), ("flags", C.c_int), ("fd_next", C.c_void_p)]
+                ("hd", C.c_void_p), ("s_out", C.c_void_p), ("pf", C.c_void_p), ("flags", C.c_int), ("fd_next", C.c_void_p),
+                ("x1_out", C.c_void_p), ("x2_out", C.c_void_p)]
 
 
 _lib = None

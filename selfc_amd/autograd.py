@@ -585,16 +585,21 @@ class InvStackFn(torch.autograd.Function):
                                  gd=torch.empty((4, n, h, w, 32), dtype=F16, device=dev),
                                  hd=torch.empty((4, n, h, w, 32), dtype=F16, device=dev),
                                  s=torch.empty((n, h, w, c2p), dtype=f32, device=dev), x1=None, x2=None, device=dev)
-            keep = (x1 if rev else x2).clone()                    # the input side the kernels overwrite
+            # the block writes its updated x1 / x2 into fresh buffers (selfc_latent.x1_out / x2_out): the input side its kernels
+            # would overwrite and the output side the gradient formulas read stay what they are - no clones
+            y1 = torch.empty_like(x1)
+            y2 = torch.empty_like(x2)
+            keep = x1 if rev else x2
             nxt = fds[i + 1] if (not rev and i + 1 < len(order)) else None
             lat = _lib.Latent(kind, n, t, h, w, c1, c2, x1.data_ptr(), x2.data_ptr(), sv.fd.data_ptr(), sv.gd.data_ptr(),
                               sv.hd.data_ptr(), sv.s.data_ptr(), None if pf is None else pf.data_ptr(), _lib.LAT_KEEP_FEATURES,
-                              None if nxt is None else nxt.data_ptr())
+                              None if nxt is None else nxt.data_ptr(), y1.data_ptr(), y2.data_ptr())
             rt.call("selfc_invblock_run", rt.packed_block(blk).struct(), lat, 1 if rev else 0, sp)
+            x1, x2 = y1, y2
             if rev:
-                sv.x2 = x2.clone()                                # y2: read by the coupling gradient
+                sv.x2 = x2                                        # y2: read by the coupling gradient
             else:
-                sv.x1 = x1.clone()                                # y1: input of G / H
+                sv.x1 = x1                                        # y1: input of G / H
             blk._set_s_lazy(sv)
             saves.append((blk, sv, keep, nxt is not None))
         if not rev:

@@ -38,7 +38,7 @@ struct FGArgs {
 int launch_fused_gh(FGArgs& a, hipStream_t s);
 // csrc/fused_f.hip
 int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, int H, int W, hipStream_t s,
-                   const void* w5p, float* pf, const float* b5, float* x1, int T, int rev, int keep_features);
+                   const void* w5p, float* pf, const float* b5, const float* x1, float* x1out, int T, int rev, int keep_features);
 
 }  // namespace selfc
 #include "bwd_internal.hpp"
@@ -102,8 +102,9 @@ struct C3Args {
   const float* bw_amax;
   int bw_mask_z, bw_acc;
   // coupling / plain epilogue (EPI != LRELU)
-  float* x1io;           // EPI_F: y1 = x1 +- F, in place          [N][H][W][4]
-  float* x2io;           // EPI_GH: y2, in place                   [N][H][W][c2p]
+  float* x1io;           // EPI_F: y1 = x1 +- F: read here ...     [N][H][W][4]
+  float* x2io;           // EPI_GH: x2 of the coupling: read here  [N][H][W][c2p]
+  float* x1out, *x2out;  // ... and written here (the same buffers unless selfc_latent.x1_out / x2_out are set)
   f16* fd;               // EPI_GH: f16 copy of y2 into planes 0.. of the F dense buffer, or null
   float* s_out;          // EPI_GH: optional s                      [N][H][W][c2p]
   float* plain;          // EPI_PLAIN: fp32 NHWC output, stride coutp
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
         v.y += sgn * (acc[0][m][1] + b.y);
         v.z += sgn * (acc[0][m][2] + b.z);
         v.w += sgn * (acc[0][m][3] + b.w);
-        *reinterpret_cast<float4*>(a.x1io + pix * 4) = v;
+        *reinterpret_cast<float4*>(a.x1out + pix * 4) = v;
       }
     } else {  // EPI_GH: s = clamp*(2*sigmoid(H)-1); y2 = x2*exp(s)+G  /  (x2-G)/exp(s)
 #pragma unroll
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
             so[j] = s;
             yo[j] = a.rev ? (xin[j] - gv) / expf(s) : xin[j] * expf(s) + gv;
           }
-          *reinterpret_cast<float4*>(a.x2io + pix * a.c2p + oc) = make_float4(yo[0], yo[1], yo[2], yo[3]);
+          *reinterpret_cast<float4*>(a.x2out + pix * a.c2p + oc) = make_float4(yo[0], yo[1], yo[2], yo[3]);
           if (a.s_out) *reinterpret_cast<float4*>(a.s_out + pix * a.c2p + oc) = make_float4(so[0], so[1], so[2], so[3]);
           if (a.fd) {
             uint2 u;
@@ -551,6 +552,7 @@ struct T5Args {
   size_t plane;           // halfs per 32-channel plane = B*T*HW*32
   float* x1io;
   float* x2io;
+  float* x1out, *x2out;
   f16* fd;
   float* s_out;
   float* plain;
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(t5_waves<EPI>() * 64) void tconv5_kernel(const T5Ar
         v.y += sgn * (acc[0][0][1] + bb.y);
         v.z += sgn * (acc[0][0][2] + bb.z);
         v.w += sgn * (acc[0][0][3] + bb.w);
-        *reinterpret_cast<float4*>(a.x1io + pix * 4) = v;
+        *reinterpret_cast<float4*>(a.x1out + pix * 4) = v;
       }
     } else {
 #pragma unroll
@@ -702,7 +704,7 @@ __global__ __launch_bounds__(t5_waves<EPI>() * 64) void tconv5_kernel(const T5Ar
             const float es = __builtin_amdgcn_exp2f(esgn * s);
             yo[j] = a.rev ? (xin[j] - gv) * es : xin[j] * es + gv;
           }
-          *reinterpret_cast<float4*>(a.x2io + pix * a.c2p + oc) = make_float4(yo[0], yo[1], yo[2], yo[3]);
+          *reinterpret_cast<float4*>(a.x2out + pix * a.c2p + oc) = make_float4(yo[0], yo[1], yo[2], yo[3]);
           if (a.s_out) *reinterpret_cast<float4*>(a.s_out + pix * a.c2p + oc) = make_float4(so[0], so[1], so[2], so[3]);
           if (a.fd) {
             uint2 u;
@@ -919,14 +921,14 @@ int check_subnet(const selfc_subnet_w* w, bool need5) {
   return SELFC_OK;
 }
 
-int run_F(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStream_t s) {
+int run_F(const selfc_invblock_w* blk, const selfc_latent* l, int rev, float* x1in, float* x1out, hipStream_t s) {
   static const bool no_fuse_f = getenv("SELFC_NO_FUSE_F") != nullptr;     // developer A/B switch
   int rc;
   if (blk->F.wfused && l->c2 == 48 && !no_fuse_f) {
     // two pairwise-fused launches; with the partial-product fragments they also cover the temporal conv5 (rc 1)
     const bool t5 = l->kind == SELFC_SUBNET_D2DT && l->c1 <= 3;
     rc = launch_fused_f(l->fd, blk->F.wfused, blk->F.b3, l->N, l->H, l->W, s, t5 ? blk->F.w5p : nullptr, t5 ? l->pf : nullptr,
-                        blk->F.b5, l->x1, l->T, rev, (l->flags & SELFC_LAT_KEEP_FEATURES) != 0);
+                        blk->F.b5, x1in, x1out, l->T, rev, (l->flags & SELFC_LAT_KEEP_FEATURES) != 0);
     if (rc == 1) return SELFC_OK;
   } else
     rc = run_conv1to4(&blk->F, nullptr, l->fd, nullptr, nullptr, l->c2, l->N, l->H, l->W, s);
@@ -936,30 +938,31 @@ int run_F(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStream
     T5Args a{};
     a.dense[0] = (const f16*)l->fd; a.w = (const f16*)blk->F.w5; a.bias[0] = blk->F.b5;
     a.B = l->N / l->T; a.T = l->T; a.HW = l->H * l->W; a.plane = (size_t)l->N * l->H * l->W * 32;
-    a.x1io = l->x1; a.rev = rev;
+    a.x1io = x1in; a.x1out = x1out; a.rev = rev;
     return dispatch_t5<1, 0, EPI_F>(a, 1, FC / 32, s);
   }
   C3Args a{};
   a.dense[0] = (const f16*)l->fd; a.w[0] = (const f16*)blk->F.w5; a.bias[0] = blk->F.b5;
   a.N = l->N; a.H = l->H; a.W = l->W; a.plane = (size_t)l->N * l->H * l->W * 32;
   build_stages(a, l->c2, 5);
-  a.x1io = l->x1; a.rev = rev;
+  a.x1io = x1in; a.x1out = x1out; a.rev = rev;
   return launch_conv3x3<EPI_F>(a, 1, s);
 }
 
-int run_GH(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStream_t s) {
+// x1: the side G / H read (forward: the y1 run_F just wrote); x2in -> x2out: the coupling
+int run_GH(const selfc_invblock_w* blk, const selfc_latent* l, int rev, const float* x1, float* x2in, float* x2out, hipStream_t s) {
   int rc;
   static const bool no_fuse = getenv("SELFC_NO_FUSE") != nullptr;     // developer A/B switch
   if (blk->G.wfused && blk->H.wfused && l->c1 == 3 && !no_fuse) {
     FGArgs fa{};
-    fa.x1 = l->x1;
+    fa.x1 = x1;
     fa.w[0] = (const f16*)blk->G.wfused; fa.w[1] = (const f16*)blk->H.wfused;
     for (int i = 0; i < 4; ++i) { fa.bias[0][i] = blk->G.b3[i]; fa.bias[1][i] = blk->H.b3[i]; }
     fa.dense[0] = (f16*)l->gd; fa.dense[1] = (f16*)l->hd;
     fa.N = l->N; fa.H = l->H; fa.W = l->W;
     rc = launch_fused_gh(fa, s);
   } else {
-    rc = run_conv1to4(&blk->G, &blk->H, l->gd, l->hd, l->x1, l->c1, l->N, l->H, l->W, s);
+    rc = run_conv1to4(&blk->G, &blk->H, l->gd, l->hd, x1, l->c1, l->N, l->H, l->W, s);
   }
   if (rc) return rc;
   const int c2p = (l->c2 + 3) & ~3;
@@ -967,9 +970,9 @@ int run_GH(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStrea
     T5Args a{};
     a.dense[0] = (const f16*)l->gd; a.dense[1] = (const f16*)l->hd;
     a.w = (const f16*)blk->G.w5; a.bias[0] = blk->G.b5; a.bias[1] = blk->H.b5;
-    a.x1 = l->x1;
+    a.x1 = x1;
     a.B = l->N / l->T; a.T = l->T; a.HW = l->H * l->W; a.plane = (size_t)l->N * l->H * l->W * 32;
-    a.x2io = l->x2; a.fd = (f16*)((!rev && l->fd_next) ? l->fd_next : l->fd); a.s_out = l->s_out; a.c2p = c2p;
+    a.x2io = x2in; a.x2out = x2out; a.fd = (f16*)((!rev && l->fd_next) ? l->fd_next : l->fd); a.s_out = l->s_out; a.c2p = c2p;
     a.rev = rev; a.clamp = blk->clamp;
     return dispatch_t5<2, 1, EPI_GH>(a, (l->c2 + 15) / 16, 4, s);
   }
@@ -977,10 +980,10 @@ int run_GH(const selfc_invblock_w* blk, const selfc_latent* l, int rev, hipStrea
   a.dense[0] = (const f16*)l->gd; a.dense[1] = (const f16*)l->hd;
   a.w[0] = (const f16*)blk->G.w5; a.w[1] = (const f16*)blk->H.w5;
   a.bias[0] = blk->G.b5; a.bias[1] = blk->H.b5;
-  a.x1 = l->x1; a.c1 = l->c1;
+  a.x1 = x1; a.c1 = l->c1;
   a.N = l->N; a.H = l->H; a.W = l->W; a.plane = (size_t)l->N * l->H * l->W * 32;
   build_stages(a, l->c1, 5);
-  a.x2io = l->x2; a.fd = (f16*)((!rev && l->fd_next) ? l->fd_next : l->fd); a.s_out = l->s_out; a.c2p = c2p;
+  a.x2io = x2in; a.x2out = x2out; a.fd = (f16*)((!rev && l->fd_next) ? l->fd_next : l->fd); a.s_out = l->s_out; a.c2p = c2p;
   a.rev = rev; a.clamp = blk->clamp;
   return launch_conv3x3<EPI_GH>(a, 1, s);
 }
@@ -1027,8 +1030,8 @@ int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s)
 
 extern "C" {
 
-const char* selfc_version(void) { return "selfc_hip gfx950 abi8 operands=" SELFC_OPERAND_NAME; }
-int selfc_abi_version(void) { return 8; }
+const char* selfc_version(void) { return "selfc_hip gfx950 abi9 operands=" SELFC_OPERAND_NAME; }
+int selfc_abi_version(void) { return 9; }
 
 int selfc_invblock_run(const selfc_invblock_w* blk, const selfc_latent* lat, int rev, void* stream) {
   if (!blk || !latent_ok(lat)) return SELFC_EINVAL;
@@ -1036,12 +1039,15 @@ int selfc_invblock_run(const selfc_invblock_w* blk, const selfc_latent* lat, int
   if (check_subnet(&blk->F, true) || check_subnet(&blk->G, true) || check_subnet(&blk->H, db2d)) return SELFC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   int rc;
+  // in place unless the caller names separate output buffers (autograd keeps the inputs for the backward pass instead of cloning them)
+  float* const x1in = (float*)lat->x1, *const x2in = (float*)lat->x2;
+  float* const x1o = lat->x1_out ? (float*)lat->x1_out : x1in, *const x2o = lat->x2_out ? (float*)lat->x2_out : x2in;
   if (!rev) {
-    if ((rc = run_F(blk, lat, 0, s))) return rc;   // y1 = x1 + F(x2)
-    return run_GH(blk, lat, 0, s);                 // y2 = x2*exp(s(y1)) + G(y1)
+    if ((rc = run_F(blk, lat, 0, x1in, x1o, s))) return rc;        // y1 = x1 + F(x2)
+    return run_GH(blk, lat, 0, x1o, x2in, x2o, s);                 // y2 = x2*exp(s(y1)) + G(y1)
   }
-  if ((rc = run_GH(blk, lat, 1, s))) return rc;    // y2 = (x2 - G(x1)) / exp(s(x1))
-  return run_F(blk, lat, 1, s);                    // y1 = x1 - F(y2)
+  if ((rc = run_GH(blk, lat, 1, x1in, x2in, x2o, s))) return rc;   // y2 = (x2 - G(x1)) / exp(s(x1))
+  return run_F(blk, lat, 1, x1in, x1o, s);                         // y1 = x1 - F(y2)
 }
 
 int selfc_invstack_run(const selfc_invblock_w* blks, int nblk, const selfc_latent* lat, int rev, void* stream) {

@@ -674,7 +674,7 @@ __global__ __launch_bounds__(NTHR) void fused_f_kernel(const FFArgs a) {
 
 // y1 = x1 +- (b5 + conv5 of F) from the partial products of the two pairs: out[t] = sum over pairs of
 // P[t-1][tap 0] + P[t][tap 1] + P[t+1][tap 2], zero outside the clip (Subnet_constructor.py:130, Inv_arch.py:25,31).
-__global__ __launch_bounds__(256) void f_couple_kernel(const float* __restrict__ pf, const float* __restrict__ bias, float* __restrict__ x1,
+__global__ __launch_bounds__(256) void f_couple_kernel(const float* __restrict__ pf, const float* __restrict__ bias, const float* x1, float* x1out,
                                                        const int N, const int T, const int HW, const float sgn, const int nsets) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, npx = (size_t)N * HW;
   if (i >= npx) return;
@@ -693,9 +693,9 @@ __global__ __launch_bounds__(256) void f_couple_kernel(const float* __restrict__
       o.x += q.x; o.y += q.y; o.z += q.z;
     }
   }
-  float4 v = *reinterpret_cast<float4*>(x1 + i * 4);
+  float4 v = *reinterpret_cast<const float4*>(x1 + i * 4);
   v.x += sgn * o.x; v.y += sgn * o.y; v.z += sgn * o.z;
-  *reinterpret_cast<float4*>(x1 + i * 4) = v;
+  *reinterpret_cast<float4*>(x1out + i * 4) = v;
 }
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 1000; }
@@ -748,7 +748,7 @@ int launch_pair(FFArgs& a, int maxwg, hipStream_t s) {
 // With w5p (11 partial-product fragments), pf and x1 the temporal conv5 + coupling y1 = x1 +- F is done here as well:
 // the two launches emit the conv5 partial products and f_couple_kernel sums them (returns 1: conv5 handled).
 int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, int H, int W, hipStream_t s,
-                   const void* w5p, float* pf, const float* b5, float* x1, int T, int rev, int keep_features) {
+                   const void* w5p, float* pf, const float* b5, const float* x1, float* x1out, int T, int rev, int keep_features) {
   static const int maxwg = getenv("SELFC_FUSEDF_MAXWG") ? atoi(getenv("SELFC_FUSEDF_MAXWG")) : 256;
   static const bool no_p = getenv("SELFC_NO_F5P") != nullptr;     // developer A/B switch
   const bool with_p = w5p && pf && b5 && x1 && T > 0 && !no_p;
@@ -781,7 +781,7 @@ int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, 
   }
   ProfScope prof(PROF_CONV5_F, s);
   const size_t npx = (size_t)N * H * W;
-  hipLaunchKernelGGL(f_couple_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, pf, b5, x1, N, T, H * W, rev ? -1.f : 1.f, 2);
+  hipLaunchKernelGGL(f_couple_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, pf, b5, x1, x1out, N, T, H * W, rev ? -1.f : 1.f, 2);
   const int rc = hip_rc(hipGetLastError());
   return rc ? rc : 1;
 }

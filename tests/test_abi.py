@@ -17,7 +17,7 @@ def test_exports_match_header():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _lib.lib().selfc_abi_version() == _lib.ABI_VERSION == 8
+    assert _lib.lib().selfc_abi_version() == _lib.ABI_VERSION == 9
     assert b"gfx950" in _lib.lib().selfc_version() and b"operands=f16" in _lib.lib().selfc_version()
     bf = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libselfc_hip_bf16.so"))     # the bf16-operand build
     bf.selfc_version.restype = ctypes.c_char_p
@@ -31,7 +31,7 @@ def test_struct_layout_matches_header():
     p = ctypes.sizeof(ctypes.c_void_p)
     assert ctypes.sizeof(_lib.SubnetW) == 12 * p
     assert ctypes.sizeof(_lib.InvBlockW) == 36 * p + 8        # float + tail padding
-    assert ctypes.sizeof(_lib.Latent) == 8 * 4 + 7 * p + 8 + p    # 7 ints padded to 8, 7 pointers, flags (padded), fd_next
+    assert ctypes.sizeof(_lib.Latent) == 8 * 4 + 7 * p + 8 + 3 * p    # 7 ints padded to 8, 7 pointers, flags (padded), fd_next, x1_out, x2_out
 
 
 def test_product_does_not_import_oracle():

@@ -697,3 +697,34 @@ def test_latent_flags_and_fd_next_abi(dev):
     assert torch.equal(fd_next[:2], x2_before)
     assert torch.equal(nxt[0], fd_keep[0]) and torch.equal(nxt[1, ..., :16], fd_keep[1, ..., :16])      # the 48 real channels of y2
     assert bool((nxt[1, ..., 16:] == -5.0).all()) and bool((nxt[2:] == -5.0).all())                      # nothing else is touched
+
+
+@pytest.mark.parametrize("rev", [0, 1])
+def test_latent_out_of_place_abi(dev, rev):
+    """selfc_latent.x1_out / x2_out (ABI 9): the block writes its updated x1 / x2 into the named buffers, bit for bit what the
+    in-place call produces, and leaves its inputs untouched (the training forward keeps them for the backward pass)."""
+    from selfc_amd import _lib, runtime as rt
+    g = load_golden("g8_large_stack")
+    net = _large_net(dev, g)
+    blk = net._blocks()[0]
+    pb = rt.packed_block(blk)
+    n, h, w = T, 16, 24
+    z = torch.randn(n, 51, h, w, generator=torch.Generator().manual_seed(13)) * 0.5
+    res = {}
+    for mode in ("in_place", "out_of_place"):
+        ws = rt.Workspace(dev, blk.F.kind, n, T, h, w, 3, 48)
+        rt.nchw_to_latent(z.to(dev), ws)
+        x1_in, x2_in = ws.x1.clone(), ws.x2.clone()
+        y1, y2 = torch.full_like(ws.x1, 9.0), torch.full_like(ws.x2, 9.0)
+        lat = _lib.Latent(ws.kind, n, T, h, w, 3, 48, ws.x1.data_ptr(), ws.x2.data_ptr(), ws.fd.data_ptr(), ws.gd.data_ptr(),
+                          ws.hd.data_ptr(), None, ws.pf.data_ptr(), _lib.LAT_KEEP_FEATURES, None,
+                          y1.data_ptr() if mode == "out_of_place" else None, y2.data_ptr() if mode == "out_of_place" else None)
+        rt.call("selfc_invblock_run", pb.struct(), lat, rev, _lib.stream_ptr())
+        if mode == "out_of_place":
+            assert torch.equal(ws.x1, x1_in) and torch.equal(ws.x2, x2_in)           # inputs intact
+            res[mode] = (y1.clone(), y2.clone())
+        else:
+            assert bool((y1 == 9.0).all()) and bool((y2 == 9.0).all())
+            res[mode] = (ws.x1.clone(), ws.x2.clone())
+    assert torch.equal(res["in_place"][0][..., :3], res["out_of_place"][0][..., :3])
+    assert torch.equal(res["in_place"][1], res["out_of_place"][1])
