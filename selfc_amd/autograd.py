@@ -877,11 +877,19 @@ def _head_bwd(convs, feat, acts, dlast, n, t, h, w, relu_hidden: bool = False) -
         pn, qn = gp.shape[0], q.shape[0]
         need = L.selfc_bwd_wgrad_scratch_bytes(n, h, w, pn, qn, 1)
         sc = _buf(_STP_CACHE, "wgrad", need, dev)
-        gw = torch.empty((cout, cin), dtype=torch.float32, device=dev)
-        gb = torch.empty((cout,), dtype=torch.float32, device=dev)
-        rt.call("selfc_bwd_wgrad", gp.data_ptr(), pn, q.data_ptr(), qn, 1, gw.data_ptr(), cout, cin, gb.data_ptr(), 0.0,
-                amax.data_ptr(), sc.data_ptr(), sc.numel(), n, t, h, w, sp)
-        grads[li] = (gw.reshape(conv.weight.shape), gb)
+        sw = sb = None
+        if _SINK is not None:          # the trainer's flat gradient buffer: the kernel ADDS into the parameters' views, autograd sees None
+            sw, sb = _SINK.view_of(conv.weight), _SINK.view_of(conv.bias)
+        if sw is not None and sb is not None:
+            rt.call("selfc_bwd_wgrad", gp.data_ptr(), pn, q.data_ptr(), qn, 1, sw.data_ptr(), cout, cin, sb.data_ptr(), 1.0,
+                    amax.data_ptr(), sc.data_ptr(), sc.numel(), n, t, h, w, sp)
+            grads[li] = (None, None)
+        else:
+            gw = torch.empty((cout, cin), dtype=torch.float32, device=dev)
+            gb = torch.empty((cout,), dtype=torch.float32, device=dev)
+            rt.call("selfc_bwd_wgrad", gp.data_ptr(), pn, q.data_ptr(), qn, 1, gw.data_ptr(), cout, cin, gb.data_ptr(), 0.0,
+                    amax.data_ptr(), sc.data_ptr(), sc.numel(), n, t, h, w, sp)
+            grads[li] = (gw.reshape(conv.weight.shape), gb)
         wt = conv.__dict__.get("_wt_pk") if conv.__dict__.get("_wt_key") == rt.params_key(conv) else pack_pointwise_T(conv.weight)
         if li > 0:
             nxt = torch.empty((cin // 32, npix, 32), dtype=F16, device=dev)
