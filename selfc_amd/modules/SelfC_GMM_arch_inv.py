@@ -125,7 +125,7 @@ class GlobalAgg(nn.Module):
                 for i, m in enumerate(sib):
                     m.__dict__["_wmap"], m.__dict__["_wmap_key"] = maps[i], (rt.params_key(m.fc), h, w)
             if getattr(self, "_pkg_key", None) == pkey:
-                g = self._pkg
+                g = {k: v for k, v in self._pkg.items() if k != "w1t"}
             else:
                 g = {k: v[0] for k, v in self._gather_entries(self._gather_params()).items() if k != "w1t"}
             wmap = self.__dict__["_wmap"] if self.__dict__.get("_wmap_key") == fkey else pool_weight_map(self.fc.weight, h, w)

@@ -771,3 +771,25 @@ def test_invblock_wide_split(dev, kind, cnum, split, rev):
     tot = _all_tensor_rel_l2(blk, g_ref)
     print(kind, cnum, split, rev, "worst", worst, "all tensors", tot)
     assert tot < 1.5e-2, tot
+
+
+def test_rowsum_accum_kernel(dev):
+    """selfc_rowsum_accum: dst_i = beta_i * dst_i + column sums of up to eight small row-major matrices in one launch (the per-clip
+    GlobalAgg gradients summed straight into the flat gradient buffer) against torch."""
+    import ctypes as C
+    from selfc_amd import _lib, runtime as rt
+    g = torch.Generator().manual_seed(21)
+    shapes = [(1, 4096), (8, 64), (8, 4096), (8, 64), (8, 4096), (8, 64), (8, 1), (8, 1296)]
+    betas = [1.0, 1.0, 0.0, 1.0, 1.0, 0.0, 1.0, 0.0]
+    srcs = [torch.randn(s, generator=g).to(dev) for s in shapes]
+    dsts = [torch.randn(s[1], generator=g).to(dev) for s in shapes]
+    want = [b * d + s.sum(0) for s, d, b in zip(srcs, dsts, betas)]
+    job = _lib.RowSum()
+    for i, (s, d, b) in enumerate(zip(srcs, dsts, betas)):
+        job.src[i], job.dst[i], job.len[i], job.rows[i], job.beta[i] = s.data_ptr(), d.data_ptr(), s.shape[1], s.shape[0], b
+    job.n = len(shapes)
+    rt.call("selfc_rowsum_accum", C.byref(job), _lib.stream_ptr())
+    for d, w_ in zip(dsts, want):
+        assert torch.allclose(d, w_, rtol=1e-5, atol=1e-5)
+    job.n = 9
+    assert _lib.lib().selfc_rowsum_accum(C.byref(job), _lib.stream_ptr()) == -1          # SELFC_EINVAL, nothing launched

@@ -386,3 +386,62 @@ def test_grad_sink_views_and_zero():
     with ag.grad_sink(sink) as s_:
         assert ag._SINK is sink and s_ is sink
     assert ag._SINK is None
+
+
+def test_pack_group_equals_per_module_packing():
+    """runtime.PackGroup (one gather for a whole net, used by the trainer every step) must install, module by module, exactly the
+    tensors the modules' own caches would build - blocks, the STP chain's subnets, GlobalAgg gather parts (+ the transposed proj1
+    of its backward), the head and its transposed convs - under the keys those caches check (no repack afterwards)."""
+    import copy
+    import torch
+    from selfc_amd import GlobalVar, runtime as rt
+    from selfc_amd.modules.SelfC_GMM_arch_inv import SelfCInvNet
+    from selfc_amd.modules.Subnet_constructor import D2DTInput
+    from selfc_amd.packing import pack_pointwise_T
+    GlobalVar.set_Temporal_LEN(7)
+    torch.manual_seed(5)
+    opt = {"global_module": "nonlocal", "stp_blk_num": 4, "fh_loss": "gmm", "scale": 4, "gmm_k": 5}
+    net = SelfCInvNet(opt, 3, 3, "D2DTNet", [2, 2], 2)
+    with torch.no_grad():
+        for p in torch.nn.Module.parameters(net):
+            p.add_(torch.randn_like(p) * 0.05)                 # INN_init zeroes conv5: make every tensor distinctive
+    stp = net.stp_net
+    grp = rt.PackGroup()
+    for blk in net._blocks():
+        rt.group_add_block(grp, blk)
+    stp.add_to_pack_group(grp)
+    for step in range(2):                                       # second round: same plan, new values
+        with torch.no_grad():
+            for p in torch.nn.Module.parameters(net):
+                p.mul_(0.9)
+        grp.refresh()
+        ref = copy.deepcopy(net)                                # fresh addresses: every cache of the copy misses and packs eagerly
+        for blk, rblk in zip(net._blocks(), ref._blocks()):
+            pb = blk._pb
+            assert rt.packed_block(blk) is pb                   # the group's install IS the cache entry
+            want = rt.packed_block(rblk)
+            for sub in "FGH":
+                a, b = getattr(pb, sub), getattr(want, sub)
+                for x, y in zip(a.w3 + a.b3 + [a.w5, a.b5, a.wfused, a.w5p, a.wt5, a.wtx] + a.wtd,
+                                b.w3 + b.b3 + [b.w5, b.b5, b.wfused, b.w5p, b.wt5, b.wtx] + b.wtd):
+                    assert (x is None) == (y is None)
+                    assert x is None or (x.dtype == y.dtype and torch.equal(x, y))
+        for m, rm in zip(stp._chain(), ref.stp_net._chain()):
+            if isinstance(m, D2DTInput):
+                pk = m._pk
+                assert rt.packed_subnet(m, stp._virt(m)) is pk
+                want = rt.packed_subnet(rm, stp._virt(m))
+                for x, y in zip(pk.w3 + pk.b3 + [pk.w5, pk.b5], want.w3 + want.b3 + [want.w5, want.b5]):
+                    assert torch.equal(x, y)
+            else:
+                got, want = m._packed(36, 36), rm._packed(36, 36)
+                assert set(got) == set(want)
+                for k_ in got:
+                    assert got[k_].dtype == want[k_].dtype and torch.equal(got[k_], want[k_]), k_
+                assert m._w1t_key == rt.params_key(m)
+                assert torch.equal(m._w1t, rm._gather_entries(rm._gather_params())["w1t"][0])
+        tail, rtail = stp._tail_packed(), ref.stp_net._tail_packed()
+        for (w_, b_, ci, co), (rw, rb, rci, rco) in zip(tail, rtail):
+            assert (ci, co) == (rci, rco) and torch.equal(w_, rw) and torch.equal(b_, rb)
+        for conv in stp._tail_convs():
+            assert conv._wt_key == rt.params_key(conv) and torch.equal(conv._wt_pk, pack_pointwise_T(conv.weight))
