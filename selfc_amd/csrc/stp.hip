@@ -183,7 +183,9 @@ __global__ __launch_bounds__(256) void gagg_mix_kernel(const float* __restrict__
     for (int ks = 0; ks < 2; ++ks)
       wf[o][ks] = *reinterpret_cast<const f16x8*>(w1 + ((size_t)(o * 2 + ks) * 64 + lane) * 8);
 
-  for (int t2 = 0; t2 < T; ++t2) {
+#pragma unroll
+  for (int t2 = 0; t2 < TMAX; ++t2) {
+    if (t2 >= T) break;
     float xm[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) xm[j] = 0.f;
@@ -203,22 +205,26 @@ __global__ __launch_bounds__(256) void gagg_mix_kernel(const float* __restrict__
 #pragma unroll
       for (int j = 0; j < 8; ++j) bf[ks][j] = (f16)xm[8 * ks + j];
     const size_t pix = (size_t)(b * T + t2) * HW + pc;   // masked lanes: clamped address, store suppressed
+    // proj1's output rows are PERMUTED at packing time (packing.gagg_row_perm): row 4 kq + i of output tile o is channel
+    // oc + i with oc = 32 (o >> 1) + 8 kq + 4 (o & 1) - one of the 16 channels this lane already holds in xs (the residual
+    // comes from registers; it used to be four dependent L2 reads per frame, the kernel's longest wait)
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = mfma_16x16x32(wf[o][0], bf[0], acc);
       acc = mfma_16x16x32(wf[o][1], bf[1], acc);
-      const int oc = o * 16 + kq * 4;
-      const float4 xr = *reinterpret_cast<const float4*>(x + pix * 64 + oc);
+      const int oc = 32 * (o >> 1) + 8 * kq + 4 * (o & 1);
+      const int xi = 8 * (o >> 1) + 4 * (o & 1);          // index of channel oc in xs[.][16]
+      const float xr[4] = {xs[t2][xi], xs[t2][xi + 1], xs[t2][xi + 2], xs[t2][xi + 3]};      // t2 is unrolled: plain registers
       const float4 bb = *reinterpret_cast<const float4*>(b1 + oc);
-      const float4 r = make_float4(xr.x + acc[0] + bb.x * colsum, xr.y + acc[1] + bb.y * colsum,
-                                   xr.z + acc[2] + bb.z * colsum, xr.w + acc[3] + bb.w * colsum);
+      const float4 r = make_float4(xr[0] + acc[0] + bb.x * colsum, xr[1] + acc[1] + bb.y * colsum,
+                                   xr[2] + acc[2] + bb.z * colsum, xr[3] + acc[3] + bb.w * colsum);
       if (pvalid) {
         if constexpr (DENSE) {
           uint2 h;
           h.x = pack2(r.x, r.y);
           h.y = pack2(r.z, r.w);
-          *reinterpret_cast<uint2*>(dense + (size_t)(o >> 1) * plane + pix * 32 + (o & 1) * 16 + kq * 4) = h;
+          *reinterpret_cast<uint2*>(dense + (size_t)(oc >> 5) * plane + pix * 32 + (oc & 31)) = h;
         } else {
           *reinterpret_cast<float4*>(y + pix * 64 + oc) = r;
         }

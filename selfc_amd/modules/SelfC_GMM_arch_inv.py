@@ -93,7 +93,7 @@ class GlobalAgg(nn.Module):
     def _gather_entries(self, ps):
         """everything of the packed set that is a pure re-ordering of the parameters ({name: (tensor, kind)}, packing.PackPlan terms);
         `wmap` (a weighted sum of fc.weight) is not"""
-        from ..packing import pack_planes_generic, pack_pointwise, pad_bias
+        from ..packing import gagg_row_perm, pack_planes_generic, pack_pointwise, pad_bias
         c = self.c
         fcb, w1, b1, w2, b2, w3, b3 = ps
 
@@ -101,11 +101,19 @@ class GlobalAgg(nn.Module):
             out = torch.zeros(64, 64, dtype=torch.float32, device=wt.device)
             out[:c, :c] = wt.detach().float().reshape(c, c)
             return out
-        e = dict(fcb=(fcb.detach().float().contiguous(), "b"), w1=(pack_pointwise(sq64(w1)), "w"), b1=(pad_bias(b1, 64), "b"),
+        e = dict(fcb=(fcb.detach().float().contiguous(), "b"), w1=(pack_pointwise(sq64(w1)[self._row_perm(w1.device)]), "w"), b1=(pad_bias(b1, 64), "b"),
                  w2=(sq64(w2), "b"), b2=(pad_bias(b2, 64), "b"), w3=(sq64(w3), "b"), b3=(pad_bias(b3, 64), "b"))
         if c == 64:          # the gradient kernels' transposed proj1 (autograd.globalagg_bwd)
             e["w1t"] = (pack_planes_generic(w1.detach().float().reshape(64, 64).t().reshape(64, 64, 1, 1).contiguous()), "w")
         return e
+
+    def _row_perm(self, dev):
+        """packing.gagg_row_perm on the weights' device, made once (an index tensor's host -> device copy cannot be captured)"""
+        cache = self.__dict__.setdefault("_row_perms", {})
+        if str(dev) not in cache:
+            from ..packing import gagg_row_perm
+            cache[str(dev)] = gagg_row_perm(dev)
+        return cache[str(dev)]
 
     def _install_gathered(self, d):
         """runtime.PackGroup: the gather parts of this module arrived with the group's refresh"""

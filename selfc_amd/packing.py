@@ -160,6 +160,16 @@ def pack_pointwise(weight: torch.Tensor) -> torch.Tensor:
     return _operand(frag)
 
 
+def gagg_row_perm(device=None) -> torch.Tensor:
+    """Output-row order of GlobalAgg's proj1 for gagg_mix_kernel (stp.hip): MFMA tile o, row 4 kq + i holds output channel
+    32 (o >> 1) + 8 kq + 4 (o & 1) + i - the lane that computes it (k octet kq) already holds that channel of x in registers,
+    so the residual needs no second read.  Returns perm with packed_row[16 o + r] = W[perm[16 o + r]]."""
+    idx = torch.arange(64)
+    o, r = idx // 16, idx % 16
+    perm = 32 * (o // 2) + 8 * (r // 4) + 4 * (o % 2) + (r % 4)
+    return perm.to(device) if device is not None else perm
+
+
 def gmm_head_perm(hf_dim: int, K: int, device=None) -> torch.Tensor:
     """Output-channel permutation of the GMM head's last conv for the fused head + sampler kernel (stp.hip:
     stp_head_gmm_kernel): new channel (3 k + j) * hf_dim + c  <-  reference channel (c * K + k) * 3 + j
