@@ -2,10 +2,13 @@
 from the reference and against the CPU oracle.  Tolerances: bit-exact for the
 index shuffles; "1e-3 relative fp32" (BASELINE.json) for float paths, measured as
 max|a-b| / max|b| (conftest.rel_err).  Run with `-m gpu` on the MI355X box."""
+import os
+import sys
+
 import pytest
 import torch
 
-from conftest import group_err, load_golden, rel_err, rel_l2, seeded_fill, subdict
+from conftest import ROOT, group_err, load_golden, rel_err, rel_l2, seeded_fill, subdict
 from oracle import selfc_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -728,3 +731,13 @@ def test_latent_out_of_place_abi(dev, rev):
             res[mode] = (ws.x1.clone(), ws.x2.clone())
     assert torch.equal(res["in_place"][0][..., :3], res["out_of_place"][0][..., :3])
     assert torch.equal(res["in_place"][1], res["out_of_place"][1])
+
+
+def test_latent_out_of_place_on_the_layerwise_kernels(dev):
+    """The same ABI-9 contract on the layer-wise kernels (conv3x3 / tconv5 epilogues instead of the fused launches' f_couple and
+    conv5 epilogue): the developer switches are read once per process, hence a child process."""
+    import subprocess
+    env = dict(os.environ, SELFC_NO_FUSE="1", SELFC_NO_FUSE_F="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_latent_out_of_place_abi"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and "2 passed" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
