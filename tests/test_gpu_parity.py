@@ -741,3 +741,26 @@ def test_latent_out_of_place_on_the_layerwise_kernels(dev):
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_latent_out_of_place_abi"],
                          env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0 and "2 passed" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
+def test_profile_calibration_exports(dev):
+    """selfc_profile_calibrate / selfc_profile_clock_sample (bench.py's box_calibration): plausible figures on an MI355X, argument
+    checks, and the clock sampler ends after the time it was given."""
+    import ctypes as C
+    import time
+    from selfc_amd import _lib
+    L = _lib.lib()
+    m, c = C.c_double(0.0), C.c_double(0.0)
+    assert L.selfc_profile_calibrate(C.byref(m), C.byref(c), _lib.stream_ptr()) == 0
+    assert 300.0 < m.value < 4000.0 and 500.0 < c.value < 12000.0, (m.value, c.value)
+    assert L.selfc_profile_calibrate(None, C.byref(c), _lib.stream_ptr()) == -1
+    out = torch.zeros(2, dtype=torch.int64, device=dev)
+    assert L.selfc_profile_clock_sample(out.data_ptr(), 0, _lib.stream_ptr()) == -1
+    assert L.selfc_profile_clock_sample(out.data_ptr(), 600000, _lib.stream_ptr()) == -1
+    t0 = time.perf_counter()
+    assert L.selfc_profile_clock_sample(out.data_ptr(), 2000, _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.5
+    cycles, ticks = int(out[0]), int(out[1])
+    assert 200000 <= ticks < 400000                                  # 2,000 us of the 100 MHz counter (the wave checks it every ~64 sleep units)
+    assert 0.3 < 0.1 * cycles / ticks < 3.0                          # GHz
