@@ -445,3 +445,39 @@ def test_pack_group_equals_per_module_packing():
             assert (ci, co) == (rci, rco) and torch.equal(w_, rw) and torch.equal(b_, rb)
         for conv in stp._tail_convs():
             assert conv._wt_key == rt.params_key(conv) and torch.equal(conv._wt_pk, pack_pointwise_T(conv.weight))
+
+
+def test_pool_weight_map_batch_and_adjoint_batch():
+    """The batched pooling-map fold and its adjoint (one product for all GlobalAgg blocks of a chain) equal the per-module
+    functions, and the two are adjoint to each other: <fold(W), D> == <W, fold^T(D)>."""
+    import torch
+    from selfc_amd import packing as P
+    g = torch.Generator().manual_seed(9)
+    for h, w in ((36, 36), (64, 112), (9, 20)):
+        ws = [torch.randn(1, 1024, generator=g) for _ in range(4)]
+        maps = P.pool_weight_map_batch(ws, h, w)
+        assert maps.shape == (4, h * w)
+        for i, fw in enumerate(ws):
+            assert torch.equal(maps[i], P.pool_weight_map(fw, h, w))
+        d = torch.randn(4, h * w, generator=g)
+        folded = P.pool_weight_map_grad_batch(d, h, w)
+        for i in range(4):
+            assert torch.equal(folded[i].reshape(1, 1024), P.pool_weight_map_grad(d[i], h, w))
+        lhs = (maps.double() * d.double()).sum()
+        rhs = (torch.stack([fw.reshape(-1) for fw in ws]).double() * folded.double()).sum()
+        assert abs(float(lhs - rhs)) < 1e-4 * max(1.0, abs(float(lhs)))
+
+
+def test_gagg_row_perm_keeps_a_lanes_channels():
+    """proj1's output-row order for gagg_mix_kernel: a permutation of 0..63 in which rows 4 kq .. 4 kq + 3 of output tile o are the
+    four consecutive channels 32 (o >> 1) + 8 kq + 4 (o & 1) + i - channels the lane with k octet kq reads as its B operand
+    (k = 32 ks + 8 kq + j), so that the residual is in its registers."""
+    from selfc_amd.packing import gagg_row_perm
+    perm = gagg_row_perm().tolist()
+    assert sorted(perm) == list(range(64))
+    for o in range(4):
+        for kq in range(4):
+            rows = perm[16 * o + 4 * kq: 16 * o + 4 * kq + 4]
+            assert rows == list(range(rows[0], rows[0] + 4)) and rows[0] % 4 == 0
+            held = {32 * ks + 8 * kq + j for ks in (0, 1) for j in range(8)}        # the lane's input channels
+            assert set(rows) <= held
