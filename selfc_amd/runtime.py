@@ -357,6 +357,19 @@ def group_add_subnet(group: PackGroup, mod, virt: Tuple[int, int] = None):
     group.add(_conv_params(mod), build, install)
 
 
+def pack_group_for(net) -> PackGroup:
+    """A PackGroup over everything `net` repacks when its weights change: its InvBlockExp blocks (`net._blocks()`) and, when it has
+    one that can join, its STP net (`stp_net.add_to_pack_group`).  A training loop calls `.refresh()` once per step, before the
+    forward (RescaleTrainer does); modules that are not members keep repacking themselves on first use."""
+    grp = PackGroup()
+    for blk in (net._blocks() if hasattr(net, "_blocks") else []):
+        group_add_block(grp, blk)
+    stp = getattr(net, "stp_net", None)
+    if stp is not None and hasattr(stp, "add_to_pack_group"):
+        stp.add_to_pack_group(grp)
+    return grp
+
+
 def block_array(blocks):
     """(selfc_invblock_w[n], keep-alive list) for selfc_invstack_run."""
     packs = [packed_block(b) for b in blocks]

@@ -219,14 +219,7 @@ class RescaleTrainer:
         group (other net classes) keep repacking themselves."""
         grp = self.__dict__.get("_pack_group")
         if grp is None:
-            grp = self._pack_group = rt.PackGroup()
-            net = self.netG.module if hasattr(self.netG, "module") else self.netG
-            blocks = net._blocks() if hasattr(net, "_blocks") else []
-            for blk in blocks:
-                rt.group_add_block(grp, blk)
-            stp = getattr(net, "stp_net", None)
-            if stp is not None and hasattr(stp, "add_to_pack_group"):
-                stp.add_to_pack_group(grp)
+            grp = self._pack_group = rt.pack_group_for(self.netG.module if hasattr(self.netG, "module") else self.netG)
         grp.refresh()
 
     def _per_tensor_optimizer(self):
