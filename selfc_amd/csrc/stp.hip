@@ -797,34 +797,76 @@ __global__ __launch_bounds__(256) void gagg_bwd_reduce_kernel(const float* __res
 }
 
 // step 2: per clip - recompute g, q, k, A; then the gradients of everything upstream of A (tiny)
+// TT: the clip length as a compile-time constant (0: run time).  With a run-time T every per-frame statement of this kernel sat
+// behind its own `t < T` branch - 367 branches, as many drained wait counters, no load issued ahead of its use: 80 us for one wave.
+template <int TT>
 __global__ __launch_bounds__(64) void gagg_attn_bwd_kernel(const float* __restrict__ partial, int nchunk, int nchunkb, const float* __restrict__ fcbp,
                                                            const float* __restrict__ w2, const float* __restrict__ b2,
                                                            const float* __restrict__ w3, const float* __restrict__ b3,
                                                            const float* __restrict__ b1, const float* __restrict__ pdA,
                                                            const float* __restrict__ pdyo, float* __restrict__ A, float* __restrict__ dg,
                                                            float* __restrict__ db1c, float* __restrict__ dw2c, float* __restrict__ db2c,
-                                                           float* __restrict__ dw3c, float* __restrict__ db3c, float* __restrict__ dfcbc, int T) {
+                                                           float* __restrict__ dw3c, float* __restrict__ db3c, float* __restrict__ dfcbc, int Trt) {
+  const int T = TT ? TT : Trt;
   __shared__ float g[TMAX][64], q[TMAX][64], k[TMAX][64], m[TMAX][TMAX], a[TMAX][TMAX], dA[TMAX][TMAX], dm[TMAX][TMAX];
   __shared__ float dyo[TMAX][64], dq[TMAX][64], dk[TMAX][64], dyb[TMAX], red[64];
+  // one wave per clip and nothing to hide latency behind: everything that comes from global memory is fetched up front with
+  // independent wide loads and then lives in LDS / registers (a dependent global load per loop iteration - proj2 / proj3 columns,
+  // b1, the chunk sums - made this launch 80 us on the training step's main queue)
+  __shared__ __attribute__((aligned(16))) float w2s[64][64], w3s[64][64];
+  __shared__ float b1s[64];
   const int b = blockIdx.x, c = threadIdx.x;
   const float fcb = *fcbp;
-  for (int t = 0; t < T; ++t) {
-    float s = 0.f, sy = 0.f;
-    const float* p = partial + (size_t)(b * T + t) * nchunk * 64 + c;
-    for (int j = 0; j < nchunk; ++j) s += p[(size_t)j * 64];
-    for (int j = 0; j < nchunkb; ++j) sy += pdyo[(((size_t)b * nchunkb + j) * TMAX + t) * 64 + c];
-    g[t][c] = s + fcb;
-    dyo[t][c] = sy;
+  float4 w2r[16], w3r[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    w2r[j] = *reinterpret_cast<const float4*>(w2 + c * 64 + 4 * j);
+    w3r[j] = *reinterpret_cast<const float4*>(w3 + c * 64 + 4 * j);
+  }
+  b1s[c] = b1[c];
+  // the chunk sums: every frame's loads are issued together (eight partial accumulators per frame; one load - wait - add at a time
+  // over ~35 chunks x 7 frames was most of this launch's 80 us)
+  {
+    float sg[TMAX], sy[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) sg[t] = sy[t] = 0.f;
+#pragma unroll 4
+    for (int j = 0; j < nchunk; ++j) {
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t)
+        if (t < T) sg[t] += partial[((size_t)(b * T + t) * nchunk + j) * 64 + c];
+    }
+#pragma unroll 4
+    for (int j = 0; j < nchunkb; ++j) {
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t)
+        if (t < T) sy[t] += pdyo[(((size_t)b * nchunkb + j) * TMAX + t) * 64 + c];
+    }
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+      if (t < T) { g[t][c] = sg[t] + fcb; dyo[t][c] = sy[t]; }
   }
   __syncthreads();
-  for (int t = 0; t < T; ++t) {
-    float sq = b2[c], sk = b3[c];
-    for (int j = 0; j < 64; ++j) {
-      sq += g[t][j] * w2[c * 64 + j];
-      sk += g[t][j] * w3[c * 64 + j];
+  // this thread's rows of proj2 / proj3 are read ONCE, as 16-byte loads, and stay in registers (they used to be re-read
+  // scalar by scalar for every frame: ~1,800 dependent loads per thread made this 8-wave launch 78 us of pure latency)
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {                  // rows -> LDS: the columns (d g) are read from there
+    *reinterpret_cast<float4*>(&w2s[c][4 * j]) = w2r[j];
+    *reinterpret_cast<float4*>(&w3s[c][4 * j]) = w3r[j];
+  }
+  {
+    const float bq = b2[c], bk = b3[c];
+    for (int t = 0; t < T; ++t) {
+      float sq = bq, sk = bk;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float4 gv = *reinterpret_cast<const float4*>(&g[t][4 * j]);
+        sq += gv.x * w2r[j].x + gv.y * w2r[j].y + gv.z * w2r[j].z + gv.w * w2r[j].w;
+        sk += gv.x * w3r[j].x + gv.y * w3r[j].y + gv.z * w3r[j].z + gv.w * w3r[j].w;
+      }
+      q[t][c] = sq;
+      k[t][c] = sk;
     }
-    q[t][c] = sq;
-    k[t][c] = sk;
   }
   __syncthreads();
   if (c < T * T) {
@@ -832,13 +874,20 @@ __global__ __launch_bounds__(64) void gagg_attn_bwd_kernel(const float* __restri
     float s = 0.f;
     for (int j = 0; j < 64; ++j) s += q[t1][j] * k[t2][j];
     m[t1][t2] = s / 64.0f;
-    float d = 0.f;
-    for (int j = 0; j < nchunkb; ++j) d += pdA[((size_t)b * nchunkb + j) * 64 + t1 * TMAX + t2];
-    dA[t1][t2] = d;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    int j = 0;
+    for (; j + 3 < nchunkb; j += 4) {
+      d0 += pdA[((size_t)b * nchunkb + j) * 64 + t1 * TMAX + t2];
+      d1 += pdA[((size_t)b * nchunkb + j + 1) * 64 + t1 * TMAX + t2];
+      d2 += pdA[((size_t)b * nchunkb + j + 2) * 64 + t1 * TMAX + t2];
+      d3 += pdA[((size_t)b * nchunkb + j + 3) * 64 + t1 * TMAX + t2];
+    }
+    for (; j < nchunkb; ++j) d0 += pdA[((size_t)b * nchunkb + j) * 64 + t1 * TMAX + t2];
+    dA[t1][t2] = (d0 + d1) + (d2 + d3);
   }
   if (c < T) {
     float s = 0.f;
-    for (int o = 0; o < 64; ++o) s += dyo[c][o] * b1[o];
+    for (int o = 0; o < 64; ++o) s += dyo[c][o] * b1s[o];
     dyb[c] = s;
   }
   __syncthreads();
@@ -880,18 +929,43 @@ __global__ __launch_bounds__(64) void gagg_attn_bwd_kernel(const float* __restri
   db2c[(size_t)b * 64 + c] = sq2;
   db3c[(size_t)b * 64 + c] = sk2;
   __syncthreads();
-  for (int j = 0; j < 64; ++j) {
-    float v2 = 0.f, v3 = 0.f;
-    for (int t = 0; t < T; ++t) { v2 += dq[t][c] * g[t][j]; v3 += dk[t][c] * g[t][j]; }
-    dw2c[((size_t)b * 64 + c) * 64 + j] = v2;
-    dw3c[((size_t)b * 64 + c) * 64 + j] = v3;
+  {
+    float dqc[TMAX], dkc[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) { dqc[t] = t < T ? dq[t][c] : 0.f; dkc[t] = t < T ? dk[t][c] : 0.f; }
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {                 // row c of the two outer products, 16 bytes at a time
+      float4 v2 = make_float4(0.f, 0.f, 0.f, 0.f), v3 = v2;
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        if (t < T) {
+          const float4 gv = *reinterpret_cast<const float4*>(&g[t][4 * j]);
+          v2.x += dqc[t] * gv.x; v2.y += dqc[t] * gv.y; v2.z += dqc[t] * gv.z; v2.w += dqc[t] * gv.w;
+          v3.x += dkc[t] * gv.x; v3.y += dkc[t] * gv.y; v3.z += dkc[t] * gv.z; v3.w += dkc[t] * gv.w;
+        }
+      }
+      *reinterpret_cast<float4*>(dw2c + ((size_t)b * 64 + c) * 64 + 4 * j) = v2;
+      *reinterpret_cast<float4*>(dw3c + ((size_t)b * 64 + c) * 64 + 4 * j) = v3;
+    }
   }
   float tot = 0.f;
-  for (int t = 0; t < T; ++t) {
-    float v = 0.f;
-    for (int o = 0; o < 64; ++o) v += dq[t][o] * w2[o * 64 + c] + dk[t][o] * w3[o * 64 + c];
-    dg[((size_t)b * T + t) * 64 + c] = v;
-    tot += v;
+  {
+    float vt[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) vt[t] = 0.f;
+#pragma unroll 8
+    for (int o = 0; o < 64; ++o) {                 // column c of proj2 / proj3 from the LDS copy, all frames from one read
+      const float a2 = w2s[o][c], a3 = w3s[o][c];
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t)
+        if (t < T) vt[t] += dq[t][o] * a2 + dk[t][o] * a3;
+    }
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+      if (t < T) {
+        dg[((size_t)b * T + t) * 64 + c] = vt[t];
+        tot += vt[t];
+      }
   }
   red[c] = tot;
   __syncthreads();
@@ -1208,8 +1282,12 @@ int selfc_globalagg_bwd(const float* x, const float* dy, float* dx, const float*
   }
   hipLaunchKernelGGL(gagg_pool_kernel, dim3(L.nchunk, N), dim3(256), 0, s, x, wmap, pool, HW, L.nchunk);
   hipLaunchKernelGGL(gagg_bwd_reduce_kernel, dim3(L.nchunkb, B), dim3(256), 0, s, x, dz, dy, pdA, pdyo, T, HW, L.nchunkb);
-  hipLaunchKernelGGL(gagg_attn_bwd_kernel, dim3(B), dim3(64), 0, s, pool, L.nchunk, L.nchunkb, fc_bias, w2, b2, w3, b3, b1, pdA, pdyo, A, dg,
-                     db1_clip, dw2_clip, db2_clip, dw3_clip, db3_clip, dfcb_clip, T);
+#define SELFC_GATTN(TT_) hipLaunchKernelGGL(gagg_attn_bwd_kernel<TT_>, dim3(B), dim3(64), 0, s, pool, L.nchunk, L.nchunkb, fc_bias, w2, b2, w3, b3, b1, pdA, \
+                                             pdyo, A, dg, db1_clip, dw2_clip, db2_clip, dw3_clip, db3_clip, dfcb_clip, T)
+  if (T == 7) SELFC_GATTN(7);                 // GlobalVar temporal length of the shipped configurations (3: the codec variant's segments)
+  else if (T == 3) SELFC_GATTN(3);
+  else SELFC_GATTN(0);
+#undef SELFC_GATTN
   hipLaunchKernelGGL(gagg_bwd_dx_kernel, dim3((unsigned)((HW + 15) / 16), (unsigned)B), dim3(256), 0, s, x, dz, dy, A, dg, wmap, dx,
                      dwmap_clip, zp, T, HW, npix);
   if ((rc = hip_rc(hipGetLastError()))) return rc;
