@@ -63,9 +63,11 @@ struct AttnLds {
   float g[TMAX][64], q[TMAX][64], k[TMAX][64], m[TMAX][TMAX];
 };
 
+template <int TT>
 __device__ __forceinline__ void clip_attention(AttnLds& L, int b, int tid, const float* __restrict__ partial, int nchunk,
                                                const float* __restrict__ fcbp, const float* __restrict__ w2, const float* __restrict__ b2,
-                                               const float* __restrict__ w3, const float* __restrict__ b3, int T, float creal) {
+                                               const float* __restrict__ w3, const float* __restrict__ b3, int Trt, float creal) {
+  const int T = TT ? TT : Trt;          // clip length as a compile-time constant where the launcher knows it (see gagg_attn_bwd_kernel)
   const int mat = tid >> 7, c = (tid >> 1) & 63, jh = tid & 1;
   float4 wr[8];
   {
@@ -134,19 +136,20 @@ __device__ __forceinline__ void clip_attention(AttnLds& L, int b, int tid, const
 // ---- (3) temporal mix + 64x64 projection + residual.  Wave = 16 pixels of one clip.
 // DENSE: the consumer is a D2DTInput - the result goes straight into planes 0..1 of ITS plane-blocked f16 operand buffer
 // ([plane][N][HW][32], the rounding its nhwc_to_dense pass would apply) instead of an fp32 row the next launch converts.
-template <bool DENSE>
+template <bool DENSE, int TT>
 __global__ __launch_bounds__(256) void gagg_mix_kernel(const float* __restrict__ x, float* __restrict__ y, f16* __restrict__ dense,
                                                        size_t plane, const float* __restrict__ partial, int nchunk,
                                                        const float* __restrict__ fcbp, const float* __restrict__ w2,
                                                        const float* __restrict__ b2, const float* __restrict__ w3,
                                                        const float* __restrict__ b3, float* __restrict__ attn_out,
-                                                       const f16* __restrict__ w1, const float* __restrict__ b1, int T, int HW,
+                                                       const f16* __restrict__ w1, const float* __restrict__ b1, int Trt, int HW,
                                                        float creal) {
+  const int T = TT ? TT : Trt;
   __shared__ AttnLds L;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tiles = (HW + 63) / 64;
   const int b = blockIdx.x / tiles;
-  clip_attention(L, b, threadIdx.x, partial, nchunk, fcbp, w2, b2, w3, b3, T, creal);
+  clip_attention<TT>(L, b, threadIdx.x, partial, nchunk, fcbp, w2, b2, w3, b3, T, creal);
   if (attn_out && blockIdx.x % tiles == 0 && threadIdx.x < T * T)
     attn_out[(size_t)b * T * T + threadIdx.x] = L.m[threadIdx.x / T][threadIdx.x % T];
   const int p0 = (blockIdx.x % tiles) * 64 + wave * 16;
@@ -734,8 +737,10 @@ __global__ __launch_bounds__(256) void rows_to_planes_kernel(const f16* __restri
 }
 
 // GlobalAgg backward, step 1: per clip and 512-pixel chunk, dAx[t1][t2] = sum_{px,c} x[t1] dz[t2] and dyo[t][o] = sum_px dy[t][o]
+template <int TT>
 __global__ __launch_bounds__(256) void gagg_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dz, const float* __restrict__ dy,
-                                                              float* __restrict__ pdA, float* __restrict__ pdyo, int T, int HW, int nchunk) {
+                                                              float* __restrict__ pdA, float* __restrict__ pdyo, int Trt, int HW, int nchunk) {
+  const int T = TT ? TT : Trt;
   __shared__ float redA[16][TMAX * TMAX + 1];
   __shared__ float redY[16][TMAX][64];
   const int b = blockIdx.y, chunk = blockIdx.x;
@@ -978,9 +983,11 @@ __global__ __launch_bounds__(64) void gagg_attn_bwd_kernel(const float* __restri
 
 // step 3: dx[t1] = dy[t1] + sum_t2 A[t1][t2] dz[t2] + dg[t1] wmap[px];  dwmap[b][px] = sum_{t,c} dg[t][c] x[t][px][c];
 // z[t2] = sum_t1 A[t1][t2] x[t1] as f16 planes (the activation operand of proj1's weight gradient)
+template <int TT>
 __global__ __launch_bounds__(256) void gagg_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dz, const float* __restrict__ dy,
                                                           const float* __restrict__ A, const float* __restrict__ dg, const float* __restrict__ wmap,
-                                                          float* __restrict__ dx, float* __restrict__ dwmapc, f16* __restrict__ zp, int T, int HW, size_t npix_all) {
+                                                          float* __restrict__ dx, float* __restrict__ dwmapc, f16* __restrict__ zp, int Trt, int HW, size_t npix_all) {
+  const int T = TT ? TT : Trt;
   const int b = blockIdx.y;
   const int cq = threadIdx.x & 15;
   const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -1121,12 +1128,19 @@ int selfc_globalagg_run_d(const float* x, float* y, void* dense_out, const float
     ProfScope prof(PROF_STP, s);
     const int tiles = (HW + 63) / 64;
     const size_t plane = (size_t)N * HW * 32;
-    if (dense_out)
-      hipLaunchKernelGGL(gagg_mix_kernel<true>, dim3((unsigned)(tiles * B)), dim3(256), 0, s, x, nullptr, (f16*)dense_out, plane, partial,
-                         nchunk, fc_bias, w2, b2, w3, b3, attn, (const f16*)w1, b1, T, HW, (float)c_real);
-    else
-      hipLaunchKernelGGL(gagg_mix_kernel<false>, dim3((unsigned)(tiles * B)), dim3(256), 0, s, x, y, nullptr, plane, partial,
-                         nchunk, fc_bias, w2, b2, w3, b3, attn, (const f16*)w1, b1, T, HW, (float)c_real);
+#define SELFC_GMIX(D_, TT_, Y_, DN_) hipLaunchKernelGGL((gagg_mix_kernel<D_, TT_>), dim3((unsigned)(tiles * B)), dim3(256), 0, s, x, Y_, DN_, plane, partial, \
+                                                     nchunk, fc_bias, w2, b2, w3, b3, attn, (const f16*)w1, b1, T, HW, (float)c_real)
+    // clip length 7 (GlobalVar temporal length of the shipped configurations) and 3 (the codec variant's segments) are compiled in
+    if (dense_out) {
+      if (T == 7) SELFC_GMIX(true, 7, nullptr, (f16*)dense_out);
+      else if (T == 3) SELFC_GMIX(true, 3, nullptr, (f16*)dense_out);
+      else SELFC_GMIX(true, 0, nullptr, (f16*)dense_out);
+    } else {
+      if (T == 7) SELFC_GMIX(false, 7, y, nullptr);
+      else if (T == 3) SELFC_GMIX(false, 3, y, nullptr);
+      else SELFC_GMIX(false, 0, y, nullptr);
+    }
+#undef SELFC_GMIX
   }
   return hip_rc(hipGetLastError());
 }
@@ -1281,15 +1295,25 @@ int selfc_globalagg_bwd(const float* x, const float* dy, float* dx, const float*
     if ((rc = bwd_conv_planes(c, N, T, H, W, s))) return rc;
   }
   hipLaunchKernelGGL(gagg_pool_kernel, dim3(L.nchunk, N), dim3(256), 0, s, x, wmap, pool, HW, L.nchunk);
-  hipLaunchKernelGGL(gagg_bwd_reduce_kernel, dim3(L.nchunkb, B), dim3(256), 0, s, x, dz, dy, pdA, pdyo, T, HW, L.nchunkb);
+  if (T == 7) hipLaunchKernelGGL(gagg_bwd_reduce_kernel<7>, dim3(L.nchunkb, B), dim3(256), 0, s, x, dz, dy, pdA, pdyo, T, HW, L.nchunkb);
+  else if (T == 3) hipLaunchKernelGGL(gagg_bwd_reduce_kernel<3>, dim3(L.nchunkb, B), dim3(256), 0, s, x, dz, dy, pdA, pdyo, T, HW, L.nchunkb);
+  else hipLaunchKernelGGL(gagg_bwd_reduce_kernel<0>, dim3(L.nchunkb, B), dim3(256), 0, s, x, dz, dy, pdA, pdyo, T, HW, L.nchunkb);
 #define SELFC_GATTN(TT_) hipLaunchKernelGGL(gagg_attn_bwd_kernel<TT_>, dim3(B), dim3(64), 0, s, pool, L.nchunk, L.nchunkb, fc_bias, w2, b2, w3, b3, b1, pdA, \
                                              pdyo, A, dg, db1_clip, dw2_clip, db2_clip, dw3_clip, db3_clip, dfcb_clip, T)
   if (T == 7) SELFC_GATTN(7);                 // GlobalVar temporal length of the shipped configurations (3: the codec variant's segments)
   else if (T == 3) SELFC_GATTN(3);
   else SELFC_GATTN(0);
 #undef SELFC_GATTN
-  hipLaunchKernelGGL(gagg_bwd_dx_kernel, dim3((unsigned)((HW + 15) / 16), (unsigned)B), dim3(256), 0, s, x, dz, dy, A, dg, wmap, dx,
+  if (T == 7) {
+    hipLaunchKernelGGL(gagg_bwd_dx_kernel<7>, dim3((unsigned)((HW + 15) / 16), (unsigned)B), dim3(256), 0, s, x, dz, dy, A, dg, wmap, dx,
                      dwmap_clip, zp, T, HW, npix);
+  } else if (T == 3) {
+    hipLaunchKernelGGL(gagg_bwd_dx_kernel<3>, dim3((unsigned)((HW + 15) / 16), (unsigned)B), dim3(256), 0, s, x, dz, dy, A, dg, wmap, dx,
+                     dwmap_clip, zp, T, HW, npix);
+  } else {
+    hipLaunchKernelGGL(gagg_bwd_dx_kernel<0>, dim3((unsigned)((HW + 15) / 16), (unsigned)B), dim3(256), 0, s, x, dz, dy, A, dg, wmap, dx,
+                     dwmap_clip, zp, T, HW, npix);
+  }
   if ((rc = hip_rc(hipGetLastError()))) return rc;
   WgradJob j{};
   j.P = dyp; j.Pn = 2; j.Q[0] = zp; j.Qn[0] = 2; j.taps = 1; j.temporal = 0;
