@@ -17,6 +17,10 @@ from . import _lib, runtime as rt
 from .packing import dense_channels, pack_planes_generic, pack_pointwise_T, pool_weight_map_grad, pool_weight_map_grad_batch, roundup
 
 _SCRATCH: Dict[Tuple, torch.Tensor] = {}
+#: (device, slot) -> event recorded on the side stream behind the LAST weight-gradient phase that read that slot's scratch.  The
+#: next data phase on the same slot (any stream) waits for it before it overwrites amax / the gradient planes; cleared when the
+#: side streams are joined (_join_side_streams), so no event outlives the backward (or the hipGraph capture) that recorded it.
+_SLOT_BUSY: Dict[Tuple, "torch.cuda.Event"] = {}
 
 
 def _scratch(device, n, h, w, cin, cout, slot="") -> torch.Tensor:
@@ -115,6 +119,31 @@ class GradSink:
             self.flat_param = torch.nn.Parameter(buf, requires_grad=True)
             self.flat_param.grad = self.flat
         return self.flat_param
+
+    def params_attached(self) -> bool:
+        """With flatten_params(): do the parameters still alias the flat buffer?  (netG.to() / .half() after flattening
+        re-points every `.data` at fresh storage and silently detaches the optimizer's tensor from the net.)"""
+        if self.flat_param is None:
+            return True
+        base = self.flat_param.data_ptr()
+        return all(p_.data_ptr() == base + 4 * v.storage_offset() for p_, v in ((self.params[0], self.views[0]), (self.params[-1], self.views[-1])))
+
+    def assert_touched_equal(self, group=None):
+        """Data parallel: the set of parameters that received a gradient must be the same on every rank (it selects the flat or
+        the per-tensor optimizer and what Adam skips).  One MIN / MAX all-reduce of the bitmap; raises on a mismatch."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+            return
+        bits = torch.zeros(len(self.params), dtype=torch.int32, device=self.flat.device)
+        if self.touched:
+            bits[torch.tensor(sorted(self.touched), device=self.flat.device)] = 1
+        lo, hi = bits.clone(), bits.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        if not torch.equal(lo, hi):
+            bad = torch.nonzero(lo != hi).flatten().tolist()
+            raise RuntimeError(f"data-parallel ranks disagree on which parameters received a gradient (parameter indices {bad[:8]}...): "
+                               "they would run different optimizers")
 
     def zero(self):
         """Once per step, instead of optimizer.zero_grad(): one memset; re-attaches views somebody replaced (or that
@@ -228,6 +257,11 @@ def subnet_bwd(mod, dense: torch.Tensor, xin: Optional[torch.Tensor], dout: torc
             grads[i] = flat[offs[i]:offs[i] + p_.numel()].view(p_.shape)
             (wg if i % 2 == 0 else bg)[i // 2] = base + 4 * offs[i]
     scratch = _scratch(dev, n, h, w, cin, cout, slot)
+    busy = _SLOT_BUSY.pop((str(dev), slot), None)
+    if busy is not None:
+        # an earlier call's weight-gradient phase (side stream) may still be reading this slot's scratch: order this call's
+        # data phase, which overwrites it, behind that phase
+        torch.cuda.current_stream().wait_event(busy)
     bw = pk.bwd_struct()
     args = (bw, mod.kind, dense.data_ptr(), None if xin is None else xin.data_ptr(), dout.data_ptr(),
             float(sign), None if dx is None else dx.data_ptr(), 1 if accumulate_dx else 0,
@@ -247,6 +281,7 @@ def subnet_bwd(mod, dense: torch.Tensor, xin: Optional[torch.Tensor], dout: torc
     side.wait_event(torch.cuda.current_stream().record_event())
     with torch.cuda.stream(side):
         rt.call("selfc_subnet_bwd_phase", 2, *args, _lib.stream_ptr())
+        _SLOT_BUSY[(str(dev), slot)] = side.record_event()
     return grads
 
 
@@ -475,17 +510,21 @@ def _join_side_streams(dev, want: bool):
     main = torch.cuda.current_stream()
     if want and side_stream(dev) is not None:
         main.wait_stream(side_stream(dev))                         # the parameter gradients are complete from here on
+        for key in [k for k in _SLOT_BUSY if k[0] == str(dev)]:    # every slot's last reader is behind that join
+            del _SLOT_BUSY[key]
     if side_stream(dev, 1) is not None:
         main.wait_stream(side_stream(dev, 1))
 
 
-def _block_backward(blk, ws, keep, rev, t, d1, d2, want, restore_fd):
+def _block_backward(blk, ws, keep, rev, t, d1, d2, want, restore_fd, tag=""):
     """Gradient of one InvBlockExp call on the latent layout.  d1 / d2: gradients w.r.t. the block's outputs (y1, y2) as fp32
     [n][h][w][4] / [n][h][w][c2p] (d1 is updated in place); ws: what the forward left - fd / gd / hd (dense features), s, and
     the OUTPUT side the formulas need (forward: ws.x1 = y1; reverse: ws.x2 = y2); keep: the INPUT side the kernels overwrote
     (forward: x2, reverse: x1).  Returns (d1, dx2, gF, gG, gH): gradients w.r.t. the inputs (x1, x2) and the parameters.
     The weight-gradient phases run on the side stream and H's chain on a third one; the caller joins them
-    (_join_side_streams) before the gradients are used."""
+    (_join_side_streams) before the gradients are used.  `tag` picks the scratch set: a caller that walks several blocks
+    alternates two sets, so that block i's weight-gradient phases (side stream) and block i-1's data phases (main stream)
+    work on different buffers; a set is only reused behind the event of its last reader (subnet_bwd)."""
     n, h, w, c2 = ws.N, ws.H, ws.W, ws.c2
     dev, sp = d1.device, _lib.stream_ptr()
     dx2 = torch.empty_like(d2)
@@ -501,11 +540,11 @@ def _block_backward(blk, ws, keep, rev, t, d1, d2, want, restore_fd):
     def h_backward(xin_gh):
         """H's whole backward (data chain, then its weight gradients) next to G's: own stream, own dx buffer."""
         if side_h is None:
-            return subnet_bwd(blk.H, ws.hd, xin_gh, dh, 1.0, d1, True, n, t, h, w, want, pb.H, side, "H"), None
+            return subnet_bwd(blk.H, ws.hd, xin_gh, dh, 1.0, d1, True, n, t, h, w, want, pb.H, side, "H" + tag), None
         d1h = torch.empty_like(d1)
         side_h.wait_event(main.record_event())
         with torch.cuda.stream(side_h):
-            g_ = subnet_bwd(blk.H, ws.hd, xin_gh, dh, 1.0, d1h, False, n, t, h, w, want, pb.H, None, "H",
+            g_ = subnet_bwd(blk.H, ws.hd, xin_gh, dh, 1.0, d1h, False, n, t, h, w, want, pb.H, None, "H" + tag,
                             on_data_done=lambda: ev_h.append(side_h.record_event()))
         return g_, d1h
 
@@ -513,20 +552,20 @@ def _block_backward(blk, ws, keep, rev, t, d1, d2, want, restore_fd):
         # y1 = x1 + F(x2); y2 = x2*e^s + G(y1), s = s(H(y1)).  keep = x2 (input), ws.x1 = y1
         rt.call("selfc_coupling_bwd", 0, keep.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel, sp)
         gH, d1h = h_backward(ws.x1)
-        gG = subnet_bwd(blk.G, ws.gd, ws.x1, d2, 1.0, d1, True, n, t, h, w, want, pb.G, side, "G")
+        gG = subnet_bwd(blk.G, ws.gd, ws.x1, d2, 1.0, d1, True, n, t, h, w, want, pb.G, side, "G" + tag)
         if d1h is not None:
             main.wait_event(ev_h[0])
             d1.add_(d1h)
         if restore_fd:
             # the forward's epilogue replaced F's f16 input copy by y2: put x2 back before F's weight gradients
             rt.call("selfc_nhwc_to_planes", keep.data_ptr(), ws.fd.data_ptr(), n * h * w, c2, sp)
-        gF = subnet_bwd(blk.F, ws.fd, None, d1, 1.0, dx2, True, n, t, h, w, want, pb.F, side, "F")
+        gF = subnet_bwd(blk.F, ws.fd, None, d1, 1.0, dx2, True, n, t, h, w, want, pb.F, side, "F" + tag)
     else:
         # y2 = (x2 - G(x1))*e^-s, s = s(H(x1)); y1 = x1 - F(y2).  keep = x1 (input), ws.x2 = y2 (also in fd)
-        gF = subnet_bwd(blk.F, ws.fd, None, d1, -1.0, d2, True, n, t, h, w, want, pb.F, side, "F")
+        gF = subnet_bwd(blk.F, ws.fd, None, d1, -1.0, d2, True, n, t, h, w, want, pb.F, side, "F" + tag)
         rt.call("selfc_coupling_bwd", 1, ws.x2.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel, sp)
         gH, d1h = h_backward(keep)
-        gG = subnet_bwd(blk.G, ws.gd, keep, dx2, -1.0, d1, True, n, t, h, w, want, pb.G, side, "G")
+        gG = subnet_bwd(blk.G, ws.gd, keep, dx2, -1.0, d1, True, n, t, h, w, want, pb.G, side, "G" + tag)
         if d1h is not None:
             main.wait_event(ev_h[0])
             d1.add_(d1h)
@@ -625,8 +664,8 @@ class InvStackFn(torch.autograd.Function):
         else:
             rt.call("selfc_freq_inv_bwd", gy.data_ptr(), d1.data_ptr(), d2.data_ptr(), n, H, W, sp)
         grads = {}
-        for blk, sv, keep, fd_intact in reversed(ctx.saves):
-            d1, d2, gF, gG, gH = _block_backward(blk, sv, keep, rev, t, d1, d2, want, restore_fd=not fd_intact)
+        for i, (blk, sv, keep, fd_intact) in enumerate(reversed(ctx.saves)):
+            d1, d2, gF, gG, gH = _block_backward(blk, sv, keep, rev, t, d1, d2, want, restore_fd=not fd_intact, tag=str(i & 1))
             grads[id(blk)] = (*gF, *gG, *gH)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -986,17 +1025,13 @@ class STPSampleFn(torch.autograd.Function):
             grads[id(conv.weight)], grads[id(conv.bias)] = gw, gb
         d = d.reshape(n, h * w, 64)
         side = side_stream(dev)
-        ring, turn = [None, None], 0                       # two scratch slots; a slot is reused only after its weight phase
+        turn = 0                                           # two scratch slots; subnet_bwd reuses a slot only behind its last weight phase
         fc_maps: list = []
         for m, xin, dense in reversed(ctx.stages):
             if isinstance(m, D2DTInput):
                 dxl = torch.empty((n, h, w, roundup(m.channel_in, 4)), dtype=torch.float32, device=dev)
-                if side is not None and ring[turn] is not None:
-                    torch.cuda.current_stream().wait_event(ring[turn])
                 g = subnet_bwd(m, dense, xin, d, 1.0, dxl, False, n, t, h, w, True, None, side, f"stp{turn}")
-                if side is not None:
-                    ring[turn] = side.record_event()
-                    turn ^= 1
+                turn ^= 1
                 for prm, gg in zip(subnet_params(m), g):
                     grads[id(prm)] = gg
                 d = dxl
@@ -1014,8 +1049,7 @@ class STPSampleFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dlr = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
             rt.call("selfc_nhwc4_to_nchw", d.data_ptr(), dlr.data_ptr(), n, 3, h, w, sp)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+        _join_side_streams(dev, True)
         return (dlr, None, None, None, *[grads.get(id(p)) for p in rt.plist(stp)])
 
 

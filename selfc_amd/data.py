@@ -23,6 +23,7 @@ import os
 import queue
 import random
 import threading
+import time
 from typing import Iterable, Iterator, List, Optional
 
 import numpy as np
@@ -177,8 +178,9 @@ class DevicePrefetcher:
 
     _END = object()
 
-    def __init__(self, loader: Iterable, device, depth: int = 2):
+    def __init__(self, loader: Iterable, device, depth: int = 2, join_timeout_s: float = 5.0):
         self.loader, self.device, self.depth = loader, torch.device(device), max(1, int(depth))
+        self.join_timeout_s = float(join_timeout_s)      # how long leaving the iteration waits for the producer thread
         self.cuda = self.device.type == "cuda"
         self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
 
@@ -232,7 +234,11 @@ class DevicePrefetcher:
                 yield item
         finally:
             stop.set()
-            while th.is_alive():           # unblock a producer waiting on a full queue
+            # unblock a producer waiting on a full queue - for a bounded time: one stuck inside the wrapped loader's next()
+            # (a stalled worker, an endless source) cannot be interrupted, and the consumer leaving its loop (break, an
+            # exception in the train step, KeyboardInterrupt) must not hang on it.  The thread is a daemon: it is abandoned.
+            deadline = time.monotonic() + self.join_timeout_s
+            while th.is_alive() and time.monotonic() < deadline:
                 try:
                     q.get_nowait()
                 except queue.Empty:

@@ -56,3 +56,9 @@ class HeadOutput(torch.Tensor):
 
     def __deepcopy__(self, memo):
         return self.detach().clone().as_subclass(torch.Tensor)
+
+    def __reduce_ex__(self, protocol):
+        # pickling a module after its first forward (torch.save(net), a spawn-based DataLoader / multiprocessing hand-off): the
+        # weak reference to the owner cannot be pickled and the non-leaf tensor carries its graph - hand over a detached plain
+        # tensor instead (the next forward publishes a fresh head output)
+        return self.detach().as_subclass(torch.Tensor).__reduce_ex__(protocol)

@@ -198,6 +198,9 @@ class RescaleTrainer:
 
     def _forward_backward(self, real_H: torch.Tensor, ref_L: torch.Tensor):
         """optimize_parameters (SelfC_model.py:153-170) up to and including loss.backward(); returns the loss tensors."""
+        if self.flat_optimizer and not self.sink.params_attached():
+            raise RuntimeError("the net's parameters no longer alias the trainer's flat buffer (netG.to() / .half() / a re-wrap after "
+                               "RescaleTrainer was built): construct the trainer after moving the net, or pass flat_params=False")
         self._repack()
         output, loss_c = self.netG(x=real_H, rev=False)
         loss_c = loss_c.mean() * self.train_opt.get("lambda_cond_prob", 0)
@@ -209,6 +212,11 @@ class RescaleTrainer:
         with ag.grad_sink(self.sink):
             loss.backward()
         if self.sink is not None:
+            if self.data_parallel and not self.__dict__.get("_touched_checked"):
+                # every rank must decide "flat or per-tensor optimizer" (and which tensors Adam skips) the same way: compare
+                # the touched bitmaps once, at the first step (they are a function of the graph, not of the data)
+                self._touched_checked = True
+                self.sink.assert_touched_equal(self.process_group)
             if self.sink.detach_untouched() and self.flat_optimizer:
                 self._per_tensor_optimizer()   # tensors without a gradient must be skipped: one flat tensor cannot do that
         return l_forw_fit.detach(), l_back_rec.detach(), loss_c.detach(), loss.detach()
@@ -242,6 +250,58 @@ class RescaleTrainer:
         self.optimizer_G, self.flat_optimizer = new, False
         for sch in self.schedulers:
             sch.optimizer = new
+
+    # -- optimizer state in the reference's layout ------------------------------------------------------------------
+    def optimizer_state_dict(self) -> dict:
+        """`optimizer_G.state_dict()` in the layout the reference saves and resumes from (base_model.py save_training_state /
+        resume_training: one entry per parameter, in `optim_params` order) - also when Adam runs on the ONE flat tensor: its
+        exp_avg / exp_avg_sq are split along the flat buffer's slices and `step` is repeated per parameter."""
+        sd = self.optimizer_G.state_dict()
+        if not self.flat_optimizer:
+            return sd
+        st = sd["state"].get(0)
+        state = {}
+        if st:
+            for i, (p_, v) in enumerate(zip(self.sink.params, self.sink.views)):
+                off, n_ = v.storage_offset(), p_.numel()
+                state[i] = {k_: (val[off:off + n_].view(p_.shape).clone() if torch.is_tensor(val) and val.dim() == 1 and val.numel() == self.sink.flat.numel()
+                                 else (val.clone() if torch.is_tensor(val) else val)) for k_, val in st.items()}
+        groups = [dict(g_, params=list(range(len(self.sink.params)))) for g_ in sd["param_groups"]]
+        return {"state": state, "param_groups": groups}
+
+    def load_optimizer_state_dict(self, sd: dict):
+        """Inverse of `optimizer_state_dict`: accepts a per-parameter Adam state (a reference `.state` file's 'optimizers' entry,
+        or one saved here).  With the flat optimizer the per-parameter moments are merged into the flat tensor's; that needs one
+        common `step` - if the file's steps differ between parameters the trainer falls back to the per-tensor optimizer."""
+        if not self.flat_optimizer:
+            return self.optimizer_G.load_state_dict(sd)
+        n_par = len(self.sink.params)
+        ids = [i for g_ in sd["param_groups"] for i in g_["params"]]
+        if len(ids) != n_par:
+            raise ValueError(f"optimizer state holds {len(ids)} parameters, the net has {n_par}")
+        state = sd.get("state", {})
+        steps = {float(state[i]["step"]) for i in ids if i in state}
+        if state and (len(steps) != 1 or any(i not in state for i in ids)):
+            self._per_tensor_optimizer()
+            return self.optimizer_G.load_state_dict(sd)
+        flat_sd = self.optimizer_G.state_dict()
+        flat_sd["param_groups"] = [dict(g_, params=[0]) for g_ in sd["param_groups"][:1]]
+        if state:
+            dev, first = self.sink.flat.device, state[ids[0]]
+            merged = {}
+            for k_, val in first.items():
+                if torch.is_tensor(val) and val.shape == self.sink.params[0].shape and k_ != "step":
+                    buf = torch.zeros_like(self.sink.flat)
+                    for i, (p_, v) in zip(ids, zip(self.sink.params, self.sink.views)):
+                        off = v.storage_offset()
+                        buf[off:off + p_.numel()].view(p_.shape).copy_(state[i][k_].to(dev))
+                    merged[k_] = buf
+                else:
+                    merged[k_] = val.clone() if torch.is_tensor(val) else val
+            flat_sd["state"] = {0: merged}
+        else:
+            flat_sd["state"] = {}
+        return self.optimizer_G.load_state_dict(flat_sd)
 
     def _sync_grads(self):
         """The data-parallel step's one collective: all-reduce (SUM, / world) of the flat gradient buffer."""

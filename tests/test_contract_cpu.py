@@ -114,3 +114,22 @@ def test_head_output_is_a_tensor_and_still_yields_module_parameters():
     assert m.weight.grad is not None
     c = copy.deepcopy(m)                                                                    # non-leaf attribute: copied detached
     assert type(c.parameters) is torch.Tensor and not c.parameters.requires_grad
+
+
+def test_module_with_published_head_output_pickles():
+    """After its first forward an STP net carries `parameters` = HeadOutput (a non-leaf tensor with a weak reference to the module):
+    torch.save(net) / a spawn hand-off must still work - the head output goes over as a detached plain tensor."""
+    import io
+    import pickle
+    import torch
+    import torch.nn as nn
+    from selfc_amd.modules.module_util import HeadOutput
+    m = nn.Linear(2, 2)
+    m.parameters = HeadOutput.wrap(torch.randn(3, 2) @ m.weight, m)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m2 = torch.load(buf, weights_only=False)
+    got = m2.__dict__["parameters"]
+    assert type(got) is torch.Tensor and not got.requires_grad and torch.equal(got, m.parameters.detach())
+    assert pickle.loads(pickle.dumps(m.parameters)).shape == (3, 2)

@@ -171,3 +171,24 @@ def test_prefetcher_preserves_sampler_order_and_batches():
         raise AssertionError("loader exception was swallowed")
     except ValueError as e:
         assert "decode failed" in str(e)
+
+
+def test_prefetcher_does_not_hang_on_a_stalled_source():
+    """Leaving the consumer loop (break, an exception in the train step) while the producer thread is stuck INSIDE the wrapped
+    loader's next() - a stalled worker, an endless source - must return after the bounded join, not spin forever."""
+    import threading
+    import time
+    from selfc_amd.data import DevicePrefetcher
+    release = threading.Event()
+
+    def stalled():
+        yield {"GT": torch.zeros(1)}
+        release.wait(30.0)             # the "stalled worker": far longer than the join timeout below
+        yield {"GT": torch.ones(1)}
+
+    it = iter(DevicePrefetcher(stalled(), "cpu", depth=1, join_timeout_s=0.3))
+    next(it)
+    t0 = time.monotonic()
+    it.close()                         # what `break` / an exception does to the generator
+    assert time.monotonic() - t0 < 3.0
+    release.set()

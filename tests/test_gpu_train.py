@@ -243,3 +243,83 @@ def test_feed_data_variants(dev):
     assert torch.equal(real_h.reshape(2, 7, 3, 16, 24)[:, 6], gt[:, :, 4])
     want = torch.nn.functional.avg_pool2d(real_h.cpu(), 4)
     assert float((ref_l.cpu() - want).abs().max()) < 1e-6
+
+
+def test_weight_gradients_do_not_depend_on_side_stream_timing(dev):
+    """InvStackFn.backward runs every block's weight-gradient phases on a side stream while the main stream goes on to the next
+    block's data phases.  Both use per-slot scratch (absmax, gradient planes): a slot may only be overwritten behind the event
+    of its last reader (autograd._SLOT_BUSY) - round 3 joined the streams once, after the loop, and nothing ordered block i's
+    weight phase against block i-1's data phase.  Expose that ordering: stall the side stream with a 30-ms delay kernel so the
+    main stream runs as far ahead as its dependencies allow; the gradients must be the ones of the undisturbed run, bit for bit
+    (the kernels are deterministic)."""
+    import ctypes as C
+    from selfc_amd import _lib, autograd as ag, train
+    x = load_golden("g8_large_stack")["x"]
+    gt = x.reshape(1, T, 3, 32, 48).transpose(1, 2).to(dev)
+    real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
+
+    def grads(delay_us):
+        net = _net(dev)
+        tr = train.RescaleTrainer(net, dict(train.TRAIN_OPT_LARGE), flat_params=False)
+        tr._zero_grad()
+        if delay_us:
+            side = ag.side_stream(dev)
+            assert side is not None
+            clk = torch.zeros(2, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            _lib.check(_lib.lib().selfc_profile_clock_sample(clk.data_ptr(), delay_us, C.c_void_p(side.cuda_stream)), "clock_sample")
+        tr._forward_backward(real_h, ref_l)
+        torch.cuda.synchronize()
+        assert not ag._SLOT_BUSY, "slot events must not outlive the backward that recorded them"
+        return {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    ref = grads(0)
+    late = grads(30000)
+    assert ref.keys() == late.keys() and len(ref) > 300
+    bad = [n for n in ref if not torch.equal(ref[n], late[n])]
+    assert not bad, f"{len(bad)} gradients changed with the side stream delayed, e.g. {bad[:4]}"
+
+
+def test_flat_optimizer_state_round_trips_through_the_reference_layout(dev):
+    """Adam on the ONE flat tensor keeps a single state entry; the reference saves / resumes `optimizers` per
+    parameter (base_model.py save_training_state / resume_training).  optimizer_state_dict() must have the per-parameter
+    layout a stock Adam over the net's parameters accepts, and load_optimizer_state_dict() must bring a fresh trainer to the
+    same next step."""
+    from selfc_amd import train
+    x = load_golden("g8_large_stack")["x"]
+    gt = x.reshape(1, T, 3, 32, 48).transpose(1, 2).to(dev)
+    real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
+    net = _net(dev)
+    tr = train.RescaleTrainer(net, dict(train.TRAIN_OPT_LARGE))
+    assert tr.flat_optimizer
+    tr.optimize_parameters(real_h, ref_l)
+    sd = tr.optimizer_state_dict()
+    params = [p for p in net.parameters() if p.requires_grad]
+    assert len(sd["state"]) == len(params) == len(sd["param_groups"][0]["params"])
+    assert all(sd["state"][i]["exp_avg"].shape == p.shape for i, p in enumerate(params))
+    # (a) a stock per-tensor Adam - what the reference constructs - loads it
+    stock = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in params], lr=1e-4)
+    stock.load_state_dict(sd)
+    assert float(stock.state[stock.param_groups[0]["params"][3]]["step"]) == 1.0
+    # (b) resume: a fresh trainer on a copy of the weights, fed that state, takes the same second step
+    weights = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net2 = _net(dev)
+    net2.load_state_dict(weights)
+    tr2 = train.RescaleTrainer(net2, dict(train.TRAIN_OPT_LARGE))
+    tr2.load_optimizer_state_dict(sd)
+    assert tr2.flat_optimizer
+    tr.optimize_parameters(real_h, ref_l)
+    tr2.optimize_parameters(real_h, ref_l)
+    worst = max(float((a - b).abs().max()) for a, b in zip(net.state_dict().values(), net2.state_dict().values()))
+    assert worst < 1e-7, worst
+    # (c) a per-tensor state whose steps differ between parameters cannot live on one flat tensor: per-tensor fallback
+    sd["state"][0]["step"] = sd["state"][0]["step"] + 1
+    tr2.load_optimizer_state_dict(sd)
+    assert not tr2.flat_optimizer
+    # (d) moving the net after the trainer flattened its parameters is refused, not silently ignored
+    net.float().to(dev)                                  # same dtype / device: storage unchanged, still attached
+    assert tr.sink.params_attached()
+    for p in net.parameters():
+        p.data = p.data.clone()
+    with pytest.raises(RuntimeError, match="no longer alias"):
+        tr.optimize_parameters(real_h, ref_l)
