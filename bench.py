@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-path", action="store_true", help="skip the extra netG(x) + Quantization + netG(LR, rev=True) timing (incl. STP sampler)")
     ap.add_argument("--streams", type=int, default=2, help="split the septuplets of a step over this many HIP streams (2 x 2 clips: measured best since the round-2 G/H kernel; 4 x 1 clip before)")
+    ap.add_argument("--no-uvg", action="store_true", help="skip the 1080p leg (config 5, bounded sample: 6 GOPs through the whole test path)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the extra training-step timing (config 3: 8 x 7x3x144x144)")
     ap.add_argument("--no-roofline-leg", action="store_true", help="profiling runs only (tools/profile_gpu.sh): skip the eager one-stream leg that times every launch, so that a trace holds the timed configuration alone; `roofline` is then null")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo rehearsal of launch, sharding and the timing protocol: no HIP call, value is null")
@@ -230,7 +231,7 @@ def main():
     # kernel sources still hash to what was profiled; otherwise it stays null.
     import hashlib
     traffic_all, pmc_meta = {}, {}
-    for rnd in ("r3", "r2"):
+    for rnd in ("r4", "r3", "r2"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as fh:
                 traffic_all = json.load(fh)
@@ -239,11 +240,10 @@ def main():
         except (OSError, ValueError):
             continue
     hsh = hashlib.sha256()
-    for f in ("common.hpp", "dense_conv.hip", "fused_f.hip", "fused_gh.hip"):
-        try:
-            hsh.update(open(os.path.join(ROOT, "selfc_amd", "csrc", f), "rb").read())
-        except OSError:
-            pass
+    csrc = os.path.join(ROOT, "selfc_amd", "csrc")
+    for f in sorted(n_ for n_ in os.listdir(csrc) if n_.endswith((".hip", ".hpp"))):      # every kernel source and header
+        hsh.update(f.encode())
+        hsh.update(open(os.path.join(csrc, f), "rb").read())
     same_sources = bool(pmc_meta.get("csrc_sha16")) and pmc_meta.get("csrc_sha16") == hsh.hexdigest()[:16]
     pmc_meta["kernel_sources_unchanged_since"] = same_sources
 
@@ -303,24 +303,43 @@ def main():
         "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in cls_ms.items()},
     }
     if not args.no_full_path and world == 1:
-        # SelfCModel.test()'s two netG calls through the module API (eager, NCHW in/out, STP + GMM sampler on the reverse)
+        # SelfCModel.test()'s two netG calls through the MODULE API (SelfC_model.py:213-230): netG(x) -> Quantization -> netG(LR, rev=True),
+        # NCHW fp32 in, fresh NCHW tensors out, STP + GMM sampler on the reverse.  In eval / no_grad the modules route through their
+        # cached two-stream hipGraph (pipeline.ModuleGraph) from the second call of a shape on - this is what a maintainer who makes
+        # the three import changes of INTEGRATION.md runs.
+        from selfc_amd import pipeline as PL
         from selfc_amd.modules.Quantization import Quantization
         quant = Quantization()
+
+        def time_calls(fn, n_warm, n_timed):
+            for _ in range(n_warm):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_timed):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n_timed
         with torch.no_grad():
             def full():
                 z, _ = net(x=x, rev=False)
                 return net(x=quant(z[:, :3]), rev=True)[0]
-            for _ in range(3):
-                full()
+
+            def stack_only():          # the headline's unit of work through the module API: STP bypassed, the forward's own HF channels fed back
+                z, _ = net(x=x, rev=False)
+                return net.inverse_from_latent(torch.cat((quant(z[:, :3]), z[:, 3:]), 1))
+            tf = time_calls(full, 5, 40)
+            ts = time_calls(stack_only, 5, 40)
+            # the same calls on the eager single-stream launches (first-use / fallback path), with HIP events around every launch
+            PL.MODULE_GRAPH = False
+            te = time_calls(full, 2, 5)
             L.selfc_profile_reset()
             L.selfc_profile_enable(1)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
             for _ in range(5):
                 full()
             torch.cuda.synchronize()
-            tf = (time.perf_counter() - t0) / 5
             L.selfc_profile_enable(0)
+            PL.MODULE_GRAPH = True
             fp = {}
             for cls, name in [(0, "conv3x3"), (1, "conv5_F"), (2, "conv5_GH"), (3, "transforms"), (4, "conv5_plain"), (5, "stp"), (6, "fused_gh")]:
                 ms, n = C.c_double(), C.c_longlong()
@@ -328,25 +347,43 @@ def main():
                 fp[name] = round(ms.value / 5, 3)
             L.selfc_profile_reset()
         out["full_test_path"] = {"septuplets_per_s": round(B_PER_GPU / tf, 1), "ms_per_batch": round(tf * 1e3, 3),
-                                 "kernel_ms": fp, "note": "module API, eager, single stream, fh_loss gmm with device RNG"}
+                                 "note": "module API: netG(x=x) -> Quantization -> netG(x=LR, rev=True), fresh NCHW tensors in and out, fh_loss gmm with device RNG; "
+                                         "each call replays its cached two-stream hipGraph (pipeline.ModuleGraph), 40 timed batches after 5",
+                                 "eager": {"septuplets_per_s": round(B_PER_GPU / te, 1), "ms_per_batch": round(te * 1e3, 3), "kernel_ms": fp,
+                                           "note": "the same calls with SELFC_MODULE_GRAPH=0: eager launches on one stream (the first-use / fallback path)"}}
+        out["headline_through_module_api"] = {"septuplets_per_s": round(B_PER_GPU / ts, 1), "ms_per_batch": round(ts * 1e3, 3),
+                                              "note": "the headline's unit of work through the drop-in calls: netG(x=x) -> Quantization of the LR channels -> "
+                                                      "netG.inverse_from_latent(cat(LR, the forward's own HF)): STP BYPASSED as in the headline; includes the NCHW "
+                                                      "conversions, the cat and the fresh output tensors the headline's pre-bound pipeline does not pay"}
         # the same work as a pre-bound pipeline: hipGraph, one septuplet per stream (pipeline.FullTestPath)
         try:
             from selfc_amd.pipeline import FullTestPath
             with torch.no_grad():
                 ftp = MultiStreamRoundTrip(net, n_frames, H, W, dev, args.streams if args.streams > 1 else 1, part_cls=FullTestPath)
                 ftp.capture(x)
-                for _ in range(10):
-                    ftp.replay()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(100):
-                    ftp.replay()
-                torch.cuda.synchronize()
-                tg = (time.perf_counter() - t0) / 100
+                tg = time_calls(ftp.replay, 10, 100)
             out["full_test_path"]["pipeline"] = {"septuplets_per_s": round(B_PER_GPU / tg, 1), "ms_per_batch": round(tg * 1e3, 3),
                                                   "launch": f"hipGraph replay, {ftp.nstreams} streams"}
+            out["full_test_path"]["module_over_pipeline"] = round(tg / tf, 4)
+            del ftp
         except Exception as e:  # noqa: BLE001
             out["full_test_path"]["pipeline"] = {"error": repr(e)[:300]}
+    if not args.no_uvg and world == 1:
+        # config 5 of BASELINE.json, bounded sample: 1080p GOPs (7x3x1080x1920) through the whole test path, two GOPs per hipGraph
+        # replay on two streams (tools/bench_uvg.py measure(); the full 100-frame clips / --gpus N live there).  Secondary leg.
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        try:
+            import bench_uvg
+            torch.cuda.empty_cache()
+            frames = 42                                                   # 6 GOPs = 3 replays
+            sec, ngop = bench_uvg.measure(net, dev, 1, frames, 1080, 1920, 2, ranks)
+            out["uvg_1080p"] = dict({"frames_per_s": round(frames / sec, 1), "gops_per_s": round(ngop / sec, 2), "seconds": round(sec, 4),
+                                     "sample": f"{ngop} GOPs of 7x3x1080x1920 (one synthetic {frames}-frame clip), whole test path (fwd stack, Quantization, STP sample, rev stack), "
+                                               "2 GOPs per hipGraph replay on 2 streams, incl. the device copies of each GOP into the graph's input"},
+                                    **bench_uvg.roofline_fracs(ngop, 1, sec, 1080, 1920))
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            out["uvg_1080p"] = {"error": repr(e)[:300]}
     if not args.no_train_step and world == 1:
         # config 3 of BASELINE.json: one optimize_parameters step (fwd, quantise, STP sample, reverse, backward, clip, Adam)
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))

@@ -545,13 +545,28 @@ class SelfCInvNet(nn.Module):
         from .. import autograd as ag
         if ag.module_needs_grad(x, self):
             return self._forward_train(x, rev)
-        sp = _lib.stream_ptr()
-        arr, nblk = self._stack()
+        # eval / no_grad: the cached two-stream hipGraph of this call (pipeline.ModuleGraph) from its second use on; the eager
+        # single-stream path below is the first-use / fallback path and computes the same thing with the same kernels
+        from ..pipeline import module_graph
         k = self.operations[0].k
         if not rev:
             n, c, H, W = x.shape
             if c != 3 or H % k or W % k:
                 raise RuntimeError(f"SelfCInvNet forward expects (N,3,{k}a,{k}b), got {tuple(x.shape)}")
+            mg = module_graph(self, "fwd", n, H // k, W // k, x.device)
+            if mg is not None:
+                out = mg(x)
+                return out, out.new_zeros(())
+        else:
+            n, c, h, w = x.shape
+            if c < 3:
+                raise RuntimeError(f"SelfCInvNet reverse expects the 3 LR channels, got {tuple(x.shape)}")
+            mg = module_graph(self, "rev", n, h, w, x.device)
+            if mg is not None:
+                return mg(x if c == 3 else x[:, 0:3].contiguous())
+        sp = _lib.stream_ptr()
+        arr, nblk = self._stack()
+        if not rev:
             ws = self._workspace(x, n, H // k, W // k)
             rt.call("selfc_freq_fwd", x.data_ptr(), ws.x1.data_ptr(), ws.x2.data_ptr(), ws.fd.data_ptr(), ws.FC, n, H, W, k, sp)
             lat = ws.latent()
@@ -610,6 +625,11 @@ class SelfCInvNet(nn.Module):
         'inv' half of BASELINE.json's metric."""
         z = rt.as_input(z)
         n, c, h, w = z.shape
+        if not (torch.is_grad_enabled() and z.requires_grad):
+            from ..pipeline import module_graph
+            mg = module_graph(self, "revlat", n, h, w, z.device) if c == 3 + self._blocks()[0].split_len2 else None
+            if mg is not None:
+                return mg(z)
         arr, nblk = self._stack()
         ws = self._workspace(z, n, h, w)
         sp = _lib.stream_ptr()

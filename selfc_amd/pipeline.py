@@ -11,6 +11,8 @@ captured into a hipGraph (``capture()``).
 from __future__ import annotations
 
 import ctypes as C
+import os
+import weakref
 
 import torch
 
@@ -211,3 +213,175 @@ class MultiStreamRoundTrip:
         else:
             self.graph.replay()
         return self.out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The drop-in call as the fast call.  The reference's callers only ever do `netG(x=..., rev=...)` (SelfC_model.py:213-230,
+# :141,153); in eval / no_grad `SelfCInvNet.forward` routes through a cached ModuleGraph: the call's block stack (and, on
+# the reverse, the STP chain + sampler) replayed as ONE hipGraph with the clips split over two HIP streams - the launch
+# configuration of the headline - while the kernels that touch the caller's tensors (the split of x on the way in, the
+# NCHW conversions / the merge on the way out) run eagerly around the replay, straight from x and straight into FRESH
+# output tensors.  Nothing the caller holds is ever overwritten by a later call, and no copy is added.
+# ----------------------------------------------------------------------------------------------------------------------
+class ModuleGraph:
+    """One (mode, shape) instance of SelfCInvNet's inference call.
+
+      mode 'fwd'    : x (N,3,H,W)                -> (N,3+c2,h,w)                 forward(x, rev=False)
+      mode 'rev'    : LR (N,>=3,h,w)             -> (N,3,H,W), recon_hf (N,c2,h,w)   forward(x, rev=True): STP sample + reversed stack
+      mode 'revlat' : latent (N,3+c2,h,w)        -> (N,3,H,W)                    inverse_from_latent(z): reversed stack, STP bypassed
+    """
+
+    def __init__(self, net, mode: str, n: int, h: int, w: int, device, nstreams: int):
+        t = GlobalVar.get_Temporal_LEN()
+        self._net = weakref.ref(net)       # the cache is keyed weakly on the net: an instance must not keep it alive
+        self.mode, self.N, self.h, self.w, self.T = mode, n, h, w, t
+        self.k = net.operations[0].k
+        self.H, self.W = h * self.k, w * self.k
+        self.device = device
+        self.nstreams = nstreams
+        self.per = n // nstreams
+        blk = net._blocks()[0]
+        self.c1, self.c2 = blk.split_len1, blk.split_len2
+        self.ws = [rt.Workspace(device, blk.F.kind, self.per, t, h, w, self.c1, self.c2) for _ in range(nstreams)]
+        self.lat = [ws.latent() for ws in self.ws]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(nstreams)] if nstreams > 1 else []
+        self._params = [p for b in net._blocks() for p in rt.plist(b)]
+        if mode == "rev":
+            stp = net.stp_net
+            self._params = self._params + rt.plist(stp)
+            self.stp_scratch = [{} for _ in range(nstreams)]
+            self.eps = [torch.empty((self.per * h * w, stp.hf_dim * stp.K), dtype=torch.float32, device=device)
+                        if stp.fh_loss != "l2" else None for _ in range(nstreams)]
+            self.hf = [torch.empty_like(ws.x2) for ws in self.ws]      # the STP's sample, kept for `recon_hf` (the stack rewrites x2)
+        self.graph = None
+        self.stamp = None
+        self.calls = 0
+
+    @property
+    def net(self):
+        return self._net()
+
+    # -- the captured middle ---------------------------------------------------------------------------------------------
+    def _middle(self, i: int):
+        ws, sp = self.ws[i], _lib.stream_ptr()
+        if self.mode == "fwd":
+            _lib.check(_lib.lib().selfc_invstack_run(self.arr, self.nblk, C.byref(self.lat[i]), 0, sp), "selfc_invstack_run fwd")
+            return
+        if self.mode == "rev":
+            self.net.stp_net.run_nhwc(ws.x1, ws.x2, self.per, self.T, self.h, self.w, scratch=self.stp_scratch[i], eps=self.eps[i])
+            self.hf[i].copy_(ws.x2)
+        _lib.check(_lib.lib().selfc_invstack_run(self.arr, self.nblk, C.byref(self.lat[i]), 1, sp), "selfc_invstack_run rev")
+
+    def _run_middle(self):
+        if self.nstreams == 1:
+            self._middle(0)
+            return
+        cur = torch.cuda.current_stream()
+        for i, st in enumerate(self.streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                self._middle(i)
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    def _capture(self):
+        self.arr, self.keep = rt.block_array(self.net._blocks())
+        self.nblk = len(self.keep)
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._run_middle()             # warm-up outside capture: lazy packs, scratch allocation, function attributes
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._run_middle()
+        self.graph = g
+        self.stamp = rt.weights_stamp(self._params)
+
+    # -- one call ---------------------------------------------------------------------------------------------------------
+    def __call__(self, x: torch.Tensor):
+        if self.graph is None or rt.weights_stamp(self._params) != self.stamp:
+            self._capture()                # first use, or the weights changed: the graph holds the old packed buffers
+        L, sp, per = _lib.lib(), _lib.stream_ptr(), self.per
+        chk = _lib.check
+        dev = self.device
+        if self.mode == "fwd":
+            for i, ws in enumerate(self.ws):
+                chk(L.selfc_freq_fwd(x[i * per:(i + 1) * per].data_ptr(), ws.x1.data_ptr(), ws.x2.data_ptr(), ws.fd.data_ptr(), ws.FC,
+                                     per, self.H, self.W, self.k, sp), "selfc_freq_fwd")
+            self.graph.replay()
+            out = torch.empty((self.N, self.c1 + self.c2, self.h, self.w), dtype=torch.float32, device=dev)
+            for i, ws in enumerate(self.ws):
+                chk(L.selfc_latent_to_nchw(ws.x1.data_ptr(), ws.x2.data_ptr(), out[i * per:(i + 1) * per].data_ptr(), per, self.c1, self.c2,
+                                           self.h, self.w, sp), "selfc_latent_to_nchw")
+            return out
+        if self.mode == "rev":
+            for i, ws in enumerate(self.ws):
+                chk(L.selfc_nchw_to_nhwc4(x[i * per:(i + 1) * per].data_ptr(), ws.x1.data_ptr(), per, 3, self.h, self.w, sp), "selfc_nchw_to_nhwc4")
+        else:
+            for i, ws in enumerate(self.ws):
+                chk(L.selfc_nchw_to_latent(x[i * per:(i + 1) * per].data_ptr(), ws.x1.data_ptr(), ws.x2.data_ptr(), None, ws.FC,
+                                           per, self.c1, self.c2, self.h, self.w, sp), "selfc_nchw_to_latent")
+        self.graph.replay()
+        out = torch.empty((self.N, 3, self.H, self.W), dtype=torch.float32, device=dev)
+        for i, ws in enumerate(self.ws):
+            chk(L.selfc_freq_inv(ws.x1.data_ptr(), ws.x2.data_ptr(), out[i * per:(i + 1) * per].data_ptr(), per, self.h, self.w, self.k, sp),
+                "selfc_freq_inv")
+        if self.mode != "rev":
+            return out
+        hf = torch.empty((self.N, self.c2, self.h, self.w), dtype=torch.float32, device=dev)
+        for i in range(self.nstreams):
+            chk(L.selfc_nhwc4_to_nchw(self.hf[i].data_ptr(), hf[i * per:(i + 1) * per].data_ptr(), per, self.c2, self.h, self.w, sp),
+                "selfc_nhwc4_to_nchw")
+        return out, hf
+
+    def nbytes(self) -> int:
+        return sum(ws.nbytes() for ws in self.ws)
+
+
+#: net -> {(mode, shape, ...): 1 (seen once) | ModuleGraph}; weak on the net, so deepcopy / pickling / deletion of a net never
+#: meets a hipGraph
+_MODULE_GRAPHS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+#: SELFC_MODULE_GRAPH=0 keeps the module API on its eager single-stream path (debugging, profiling of single launches)
+MODULE_GRAPH = os.environ.get("SELFC_MODULE_GRAPH", "1") != "0"
+#: at most this many bytes of cached workspaces per net (least recently used instances are dropped first)
+MODULE_GRAPH_BYTES = int(float(os.environ.get("SELFC_MODULE_GRAPH_GB", "8")) * 2 ** 30)
+
+
+def module_graph(net, mode: str, n: int, h: int, w: int, device):
+    """The cached ModuleGraph of this call, or None when the call has to run eagerly: fast path switched off, a capture by
+    somebody else in progress on this stream (pipeline.*, RescaleTrainer.capture), injected STP noise (`stp_net.eps`, a
+    host-side test hook), a clip length that does not divide the batch, or the FIRST call of a shape - a shape is captured
+    on its second call, so one-off calls do not pay for a capture."""
+    if not MODULE_GRAPH or torch.cuda.is_current_stream_capturing():
+        return None
+    t = GlobalVar.get_Temporal_LEN()
+    if not t or n % t:
+        return None
+    if mode == "rev" and getattr(net.stp_net, "eps", None) is not None:
+        return None
+    blocks = net._blocks()
+    if not blocks or any(b.split_len1 > 3 for b in blocks) or len(blocks) != len(net.operations) - 1:
+        return None
+    cache = _MODULE_GRAPHS.get(net)
+    if cache is None:
+        cache = _MODULE_GRAPHS[net] = {}
+    key = (mode, n, h, w, t, str(device), getattr(net.stp_net, "fh_loss", None) if mode == "rev" else None)
+    ent = cache.get(key)
+    if ent is None:
+        cache[key] = 1                    # seen once: next time it is captured
+        return None
+    if ent == 1:
+        clips = n // t
+        ent = ModuleGraph(net, mode, n, h, w, device, 2 if clips % 2 == 0 else 1)
+        cache[key] = ent
+        live = [(k_, v) for k_, v in cache.items() if isinstance(v, ModuleGraph)]
+        total = sum(v.nbytes() for _, v in live)
+        for k_, v in sorted(live, key=lambda kv: kv[1].calls):         # over budget: drop the least used instances
+            if total <= MODULE_GRAPH_BYTES or v is ent:
+                continue
+            total -= v.nbytes()
+            del cache[k_]
+    ent.calls += 1
+    return ent

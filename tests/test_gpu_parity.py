@@ -764,3 +764,68 @@ def test_profile_calibration_exports(dev):
     cycles, ticks = int(out[0]), int(out[1])
     assert 200000 <= ticks < 400000                                  # 2,000 us of the 100 MHz counter (the wave checks it every ~64 sleep units)
     assert 0.3 < 0.1 * cycles / ticks < 3.0                          # GHz
+
+
+def test_module_call_is_the_cached_graph_and_stays_a_drop_in(dev):
+    """The reference's callers only do netG(x=..., rev=...) (SelfC_model.py:213-230).  In eval / no_grad that call goes through a
+    cached two-stream hipGraph from its second use on (pipeline.ModuleGraph).  Held to: (1) the graph path returns what the eager
+    first call returns, bit for bit, and what the oracle-pinned fixtures say; (2) outputs are FRESH tensors - a later call does not
+    touch what an earlier one returned; (3) changed weights re-capture; (4) a call made while the caller captures falls back to
+    the eager launches (no nested capture); (5) SELFC-side state: the cache holds hipGraphs, so it is weak on the net and a
+    deepcopy of the net works."""
+    import copy
+    from selfc_amd import pipeline
+    g = load_golden("g8_large_stack")
+    s = load_golden("g7_stp_l2_full_rev")
+    net = _large_net(dev, g, "l2", s)                       # l2 head: deterministic reverse
+    gen = torch.Generator().manual_seed(11)
+    xs = [torch.rand(2 * T, 3, 32, 48, generator=gen).to(dev) for _ in range(3)]
+    with torch.no_grad():
+        assert pipeline.MODULE_GRAPH
+        pipeline.MODULE_GRAPH = False
+        want = [(net(x=x, rev=False)[0], *net(x=net(x=x, rev=False)[0][:, :3], rev=True)) for x in xs]     # eager references
+        lat = [net.inverse_from_latent(w[0]) for w in want]
+        pipeline.MODULE_GRAPH = True
+        got = []
+        for x in xs:                                          # call 1 eager (shape seen once), 2 captures, 3 replays
+            z, zero = net(x=x, rev=False)
+            assert float(zero) == 0.0
+            xr, hf = net(x=z[:, :3], rev=True)
+            got.append((z, xr, hf, net.inverse_from_latent(z)))
+        cache = pipeline._MODULE_GRAPHS[net]
+        live = {k[0]: v for k, v in cache.items() if isinstance(v, pipeline.ModuleGraph)}
+        assert set(live) == {"fwd", "rev", "revlat"} and all(v.graph is not None and v.nstreams == 2 for v in live.values())
+        for (z, xr, hf, xl), (wz, wxr, whf), wl in zip(got, want, lat):
+            assert torch.equal(z, wz) and torch.equal(xr, wxr) and torch.equal(hf, whf) and torch.equal(xl, wl)
+        ptrs = {t.data_ptr() for tup in got for t in tup}
+        assert len(ptrs) == 12                                # (2): twelve live results, twelve buffers
+        # the fixtures (one clip -> a single-stream graph)
+        for _ in range(3):
+            z1, _ = net(x=g["x"].to(dev), rev=False)
+            xr1, hf1 = net(x=s["lr"].to(dev), rev=True)
+        assert rel_err(z1.cpu(), g["z"]) < TOL and rel_err(xr1.cpu(), s["x_rev"]) < TOL and rel_err(hf1.cpu(), s["hf"]) < TOL
+        # (3) weights change between two calls: the next call re-captures and follows them
+        for p in net.operations[2].G.parameters():
+            p.mul_(1.25)
+        z_new, _ = net(x=xs[0], rev=False)
+        pipeline.MODULE_GRAPH = False
+        z_ref, _ = net(x=xs[0], rev=False)
+        pipeline.MODULE_GRAPH = True
+        assert torch.equal(z_new, z_ref) and not torch.equal(z_new, got[0][0])
+        sd = {k: v for k, v in net.state_dict().items()}
+        z_or = O.large_fwd({k: v.cpu() for k, v in sd.items()}, xs[0].cpu(), T)
+        assert rel_err(z_new.cpu(), z_or) < TOL
+        # (4) inside somebody else's capture the module launches eagerly into that capture
+        static_x = xs[1].clone()
+        net(x=static_x, rev=False)
+        torch.cuda.synchronize()
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            z_cap, _ = net(x=static_x, rev=False)
+        cg.replay()
+        pipeline.MODULE_GRAPH = False
+        assert torch.equal(z_cap, net(x=static_x, rev=False)[0])
+        pipeline.MODULE_GRAPH = True
+    # (5)
+    net2 = copy.deepcopy(net)
+    assert net2 not in pipeline._MODULE_GRAPHS

@@ -19,6 +19,43 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch  # noqa: E402
 
 
+def measure(net, dev, clips, frames, H, W, S, ranks, rank=0, world=1):
+    """This rank's share of `clips` clips of `frames` frames HxW through the whole test path, S GOPs per hipGraph replay; returns
+    the seconds of the timed region (max over ranks) - also what bench.py's `uvg_1080p` leg calls with a bounded sample."""
+    from selfc_amd import harness, launch
+    from selfc_amd.pipeline import FullTestPath, MultiStreamRoundTrip
+    mine = launch.shard(range(clips), rank, world)
+    gops = harness.gop_slices(frames)
+    S = max(1, S)
+    path = MultiStreamRoundTrip(net, 7 * S, H, W, dev, S, part_cls=FullTestPath) if S > 1 else FullTestPath(net, 7, H, W, dev)
+    gen = torch.Generator().manual_seed(launch.rank_seed(99, rank))
+    clip = torch.rand(frames, 3, H, W, generator=gen).to(dev)                    # one resident clip, reused per owned clip
+    work = [g for _ in mine for g in gops]                                       # this rank's GOPs, S per replay
+    with torch.no_grad():
+        # S GOPs = one hipGraph replay: their frames are copied into the graph's static input first (0.17 GB each, device
+        # to device); the last GOP of a clip is padded by repeating its final frame, so every GOP has 7 frames; a last,
+        # incomplete group of GOPs re-runs the first ones in its free slots (not counted)
+        xs = torch.empty(7 * S, 3, H, W, device=dev)
+        for j in range(S):
+            xs[7 * j:7 * j + 7].copy_(clip[gops[0]])
+        path.capture(xs)
+        def all_my_clips():
+            for i in range(0, len(work), S):
+                for j in range(S):
+                    xs[7 * j:7 * j + 7].copy_(clip[work[i + j] if i + j < len(work) else work[j]])
+                path.replay()
+        path.replay()                                                            # warm-up
+        sec = launch.timed_region(all_my_clips, 1, 0, ranks, torch.cuda.synchronize)
+    return sec, len(gops)
+
+
+def roofline_fracs(ngop, world, sec, H, W):
+    npx = 7 * (H // 4) * (W // 4)
+    flops = 2.0 * 267408 * npx * 16                                              # InvBlock stack fwd + inv per GOP (STP not counted)
+    return {"mfma_frac": round(flops * ngop / world / sec / 1e12 / 2500.0, 4),
+            "hbm_frac_layer_granular": round(2 * 8 * 1815 * 2 * npx * ngop / world / sec / 8.0e12, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--clips", type=int, default=2)
@@ -38,9 +75,8 @@ def main():
     dev = torch.device("cuda", local)
     ranks = launch.Ranks(a.gpus, "nccl", dev)
     rank, world = ranks.rank, ranks.world
-    from selfc_amd import GlobalVar, _lib, harness
+    from selfc_amd import GlobalVar, _lib
     from selfc_amd.modules.SelfC_GMM_arch_inv import SelfCInvNet
-    from selfc_amd.pipeline import FullTestPath, MultiStreamRoundTrip
     GlobalVar.set_Temporal_LEN(7)
     torch.manual_seed(10)
     opt = {"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": "gmm", "scale": 4, "gmm_k": 5}
@@ -48,38 +84,15 @@ def main():
     H, W = a.height, a.width
     if H % 4 or W % 4:
         raise SystemExit("frame size must be a multiple of 4 (the reference tiles / pads outside the network)")
-    mine = launch.shard(range(a.clips), rank, world)
-    gops = harness.gop_slices(a.frames)
+    sec, ngops_clip = measure(net, dev, a.clips, a.frames, H, W, a.streams, ranks, rank, world)
     S = max(1, a.streams)
-    path = MultiStreamRoundTrip(net, 7 * S, H, W, dev, S, part_cls=FullTestPath) if S > 1 else FullTestPath(net, 7, H, W, dev)
-    gen = torch.Generator().manual_seed(launch.rank_seed(99, rank))
-    clip = torch.rand(a.frames, 3, H, W, generator=gen).to(dev)                  # one resident clip, reused per owned clip
-    work = [g for _ in mine for g in gops]                                       # this rank's GOPs, S per replay
-    with torch.no_grad():
-        # S GOPs = one hipGraph replay: their frames are copied into the graph's static input first (0.17 GB each, device
-        # to device); the last GOP of a clip is padded by repeating its final frame, so every GOP has 7 frames; a last,
-        # incomplete group of GOPs re-runs the first ones in its free slots (not counted)
-        xs = torch.empty(7 * S, 3, H, W, device=dev)
-        for j in range(S):
-            xs[7 * j:7 * j + 7].copy_(clip[gops[0]])
-        path.capture(xs)
-        def all_my_clips():
-            for i in range(0, len(work), S):
-                for j in range(S):
-                    xs[7 * j:7 * j + 7].copy_(clip[work[i + j] if i + j < len(work) else work[j]])
-                path.replay()
-        path.replay()                                                            # warm-up
-        sec = launch.timed_region(all_my_clips, 1, 0, ranks, torch.cuda.synchronize)
     nranks = ranks.count()
     if rank == 0:
-        ngop = a.clips * len(gops)
-        npx = 7 * (H // 4) * (W // 4)
-        flops = 2.0 * 267408 * npx * 16                                          # InvBlock stack fwd + inv per GOP (STP not counted)
+        ngop = a.clips * ngops_clip
         print(json.dumps({"metric": "1080p test path (fwd, quantise, STP, rev), shard-by-clip", "frames_per_s": round(a.clips * a.frames / sec, 2),
                           "gops_per_s": round(ngop / sec, 2), "unit": "7x3x%dx%d septuplets/s" % (H, W), "n_gpus": world, "clips": a.clips,
-                          "frames_per_clip": a.frames, "gops_per_clip": len(gops), "seconds": round(sec, 3), "dtype": _lib.OPERAND,
-                          "stack_roofline_per_gpu": {"mfma_frac": round(flops * ngop / world / sec / 1e12 / 2500.0, 4),
-                                                     "hbm_frac_layer_granular": round(2 * 8 * 1815 * 2 * npx * ngop / world / sec / 8.0e12, 4)},
+                          "frames_per_clip": a.frames, "gops_per_clip": ngops_clip, "seconds": round(sec, 3), "dtype": _lib.OPERAND,
+                          "stack_roofline_per_gpu": roofline_fracs(ngop, world, sec, H, W),
                           "streams_per_gpu": S, "sharding": f"{world} rank(s), clips round-robin, no data-path collective", "rccl_ranks": nranks, "data": "synthetic"}))
     ranks.close()
 

@@ -8,8 +8,8 @@ STREAMS=${2:-2}          # the headline runs 2 streams of 2 clips; eager multi-s
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-TRACE_ARGS="bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-full-path --no-train-step --no-roofline-leg --prewarm-s 0 --streams $STREAMS"
-PMC_ARGS="bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-full-path --no-train-step --no-roofline-leg --prewarm-s 0 --streams $STREAMS"
+TRACE_ARGS="bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-full-path --no-uvg --no-train-step --no-roofline-leg --prewarm-s 0 --streams $STREAMS"
+PMC_ARGS="bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-full-path --no-uvg --no-train-step --no-roofline-leg --prewarm-s 0 --streams $STREAMS"
 echo "streams=$STREAMS launch=eager (--no-graph) steps_trace=5 steps_pmc=1" > $OUT/config.txt
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $TRACE_ARGS > $OUT/trace.log 2>&1
 python3 tools/prof_summary.py $OUT/trace > $OUT/kernel_trace_summary.txt 2>&1

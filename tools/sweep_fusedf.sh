@@ -1,7 +1,7 @@
 #!/bin/bash
 # developer sweep: bash tools/sweep_fusedf.sh "<streams list>" "<maxwg list>"
 mkdir -p gpurun_out
-B="python bench.py --no-cpu-baseline --no-full-path --no-train-step"
+B="python bench.py --no-cpu-baseline --no-full-path --no-uvg --no-train-step"
 for st in ${1:-4}; do
  for mw in ${2:-256}; do
   SELFC_FUSEDF_MAXWG=$mw timeout -k 10 120 $B --streams $st > gpurun_out/sw_${st}_${mw}.log 2>&1 || exit 1

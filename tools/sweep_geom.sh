@@ -1,6 +1,6 @@
 #!/bin/bash
 # developer sweep of the persistent kernels' launch geometry in the 4-stream bench
-B="python bench.py --no-cpu-baseline --no-full-path --no-train-step --streams 4"
+B="python bench.py --no-cpu-baseline --no-full-path --no-uvg --no-train-step --streams 4"
 for fr in 1 2 3 4; do for gr in 1 2 3 4; do
   SELFC_FUSEDF_MINROUNDS=$fr SELFC_FUSEDGH_MINROUNDS=$gr timeout -k 10 120 $B > gpurun_out/sg.log 2>&1 || exit 1
   python - <<P
