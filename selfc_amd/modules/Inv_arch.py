@@ -7,11 +7,14 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .module_util import cache_free_state
+
 from .. import _lib, runtime as rt
 from ..global_var import GlobalVar
 
 
 class InvBlockExp(nn.Module):
+    __getstate__ = cache_free_state      # deepcopy / pickle leave the runtime's caches behind (module_util)
     """Affine coupling layer (Inv_arch.py:8-41).
 
     forward : y1 = x1 + F(x2); s = clamp*(2*sigmoid(H(y1))-1); y2 = x2*exp(s) + G(y1)
@@ -152,6 +155,7 @@ class HaarDownsampling(nn.Module):
 
 
 class InvRescaleNet(nn.Module):
+    __getstate__ = cache_free_state      # deepcopy / pickle leave the runtime's caches behind (module_util)
     """IRN-style [Haar, block_num[i] x InvBlockExp] x down_num (Inv_arch.py:87-127)."""
 
     def __init__(self, channel_in=3, channel_out=3, subnet_constructor=None, block_num=[], down_num=2):

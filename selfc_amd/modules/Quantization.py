@@ -9,13 +9,14 @@ import torch.nn as nn
 from .. import _lib, runtime as rt
 
 
-def _round_to_grid(values: torch.Tensor) -> torch.Tensor:
+def _round_to_grid(values: torch.Tensor, private: bool = False) -> torch.Tensor:
     """A quantised copy of `values` (any shape, fp32, on the GPU).  The kernel works on whole float4 groups, so a length
-    that is not a multiple of 4 goes through a zero-padded staging buffer."""
+    that is not a multiple of 4 goes through a zero-padded staging buffer.  private: `values` already is a copy nobody else
+    holds (the contiguous copy of a sliced view, e.g. out[:, :3]) and is rounded in place."""
     count = values.numel()
     padded = (count + 3) // 4 * 4
     if padded == count:
-        work = values.clone()
+        work = values if private else values.clone()
     else:
         work = values.new_zeros(padded)
         work[:count].copy_(values.reshape(-1))
@@ -28,7 +29,8 @@ class Quant(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, input):
-        return _round_to_grid(rt.as_input(input))
+        dense = rt.as_input(input)
+        return _round_to_grid(dense, private=dense is not input and dense.data_ptr() != input.data_ptr())
 
     @staticmethod
     def backward(ctx, grad_output):

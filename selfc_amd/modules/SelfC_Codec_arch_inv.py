@@ -17,6 +17,8 @@ video.  Inference only (the reference trains this net through its H.265 surrogat
 import torch
 import torch.nn as nn
 
+from .module_util import cache_free_state
+
 from ..global_var import GlobalVar
 from .Inv_arch import InvBlockExp
 from .Quantization import Quantization
@@ -107,6 +109,7 @@ def seg_remove_pad(video, pad, seg_len):
 
 
 class SelfCInvNet(nn.Module):
+    __getstate__ = cache_free_state      # deepcopy / pickle leave the runtime's caches behind (module_util)
     """:379-416 (constructor), :446-500 (forward_train without the codec surrogates), :502-640 (forward_test).
 
     ``lr_codec``: optional callable applied to the 8-bit-quantised LR frames where the reference runs its H.265 stream

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 from .. import _lib, runtime as rt
 from ..global_var import GlobalVar
-from .module_util import HeadOutput
+from .module_util import HeadOutput, cache_free_state
 from .Inv_arch import InvBlockExp  # noqa: F401  (same class, as in the reference's three copies)
 from .Subnet_constructor import D2DTInput, subnet
 
@@ -69,6 +69,7 @@ class FrequencyAnalyzer(nn.Module):
 
 
 class GlobalAgg(nn.Module):
+    __getstate__ = cache_free_state      # deepcopy / pickle leave the runtime's caches behind (module_util)
     """Temporal TxT attention over globally pooled descriptors (:257-285) on the kernels of
     csrc/stp.hip: weighted pooling (fc folded through adaptive_avg_pool2d into one HxW map),
     a tiny per-clip attention kernel, and a fused temporal-mix + 1x1 projection + residual."""
@@ -189,6 +190,7 @@ class GlobalAgg(nn.Module):
 
 
 class STPNet(nn.Module):
+    __getstate__ = cache_free_state      # deepcopy / pickle leave the runtime's caches behind (module_util)
     """Self-conditioned latent predictor v2 (:289-430): 6 x [D2DTInput + GlobalAgg] + 1x1x1 MLP
     head; GMM sample v = sum_k pi*(eps*exp(clamp(logsigma,-7,7)) + mu) with pi = softmax over the
     hf_dim axis (trap 6).  Runs end to end on HIP kernels in fp32 NHWC (``run_nhwc``): the dense
@@ -508,6 +510,7 @@ class STPNet(nn.Module):
 
 
 class SelfCInvNet(nn.Module):
+    __getstate__ = cache_free_state      # deepcopy / pickle leave the runtime's caches behind (module_util)
     """SelfC-large: [FrequencyAnalyzer] + sum(block_num) x InvBlockExp(51|3) + STPNet (:432-494)."""
 
     def __init__(self, opt, channel_in, channel_out, subnet_type, block_num, down_num):

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .. import _lib, runtime as rt
 from ..global_var import GlobalVar
-from .module_util import HeadOutput
+from .module_util import HeadOutput, cache_free_state
 from .Inv_arch import HaarDownsampling, InvBlockExp
 from .Subnet_constructor import D2DTInput, FeatureCalapseBlock, subnet
 
@@ -28,6 +28,7 @@ def _tlen():
 
 
 class STPNet(nn.Module):
+    __getstate__ = cache_free_state      # deepcopy / pickle leave the runtime's caches behind (module_util)
     def __init__(self, opt):
         super().__init__()
         self.stp_d2d_inner_c = opt["stp_d2d_inner_c"]
@@ -163,6 +164,7 @@ class STPNet(nn.Module):
 
 
 class SelfCInvNet(nn.Module):
+    __getstate__ = cache_free_state      # deepcopy / pickle leave the runtime's caches behind (module_util)
     def __init__(self, opt, channel_in, channel_out, subnet_type, block_num, down_num):
         super().__init__()
         operations = []

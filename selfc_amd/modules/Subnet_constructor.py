@@ -10,6 +10,8 @@ fragments (selfc_amd/packing.py) and runs csrc/dense_conv.hip through the C ABI.
 import torch
 import torch.nn as nn
 
+from .module_util import cache_free_state
+
 from .. import _lib, runtime as rt
 from ..global_var import GlobalVar
 from ..packing import dense_channels, roundup
@@ -17,6 +19,7 @@ from . import module_util as mutil
 
 
 class _DenseSubnet(nn.Module):
+    __getstate__ = cache_free_state      # deepcopy / pickle leave the runtime's caches behind (module_util)
     kind = None  # SUBNET_DB2D / SUBNET_D2DT
 
     def _check(self):
@@ -135,6 +138,7 @@ class SpaceToDepth(nn.Module):
 
 
 class FeatureCalapseBlock(nn.Module):
+    __getstate__ = cache_free_state      # deepcopy / pickle leave the runtime's caches behind (module_util)
     """Space-to-depth dense block of STP v1 (Subnet_constructor.py:280-324): at 1/scale resolution, channels
     scale^2*cin -> [4 x (scale*gc) features] -> scale^2*cout, conv1 and conv5 are (3,3,3) Conv3d, conv2-4
     (1,3,3); then PixelShuffle back.  The five convs run on selfc_conv_planes_run (dense_conv.hip in its

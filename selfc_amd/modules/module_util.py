@@ -31,6 +31,24 @@ def initialize_weights_xavier(net_l, scale=1):
     _apply(net_l, init.xavier_normal_, scale)
 
 
+_MODULE_BASE_KEYS = frozenset(nn.Module().__dict__)
+
+
+def cache_free_state(self):
+    """``__getstate__`` of the HIP-backed modules: copy.deepcopy(net), torch.save(net) and a spawn hand-off take the module's
+    registered state (parameters, buffers, sub-modules, public attributes) and leave behind everything the runtime cached on
+    it under a private name - packed weights, ctypes views of them, workspaces, gather plans (ctypes pointers and hipGraphs
+    cannot be pickled, and the copies would alias the original's device buffers).  Every such cache is rebuilt on first use.
+    ``InvBlockExp.s`` (public, reference-visible state) is materialised before its lazy view is dropped."""
+    d = self.__dict__
+    if d.get("_s_ws") is not None:
+        _ = self.s                           # NCHW tensor from the kernel's buffer (InvBlockExp)
+    keep = {k: v for k, v in d.items() if not k.startswith("_") or k in _MODULE_BASE_KEYS}
+    if d.get("_s_nchw") is not None:
+        keep["_s_nchw"] = d["_s_nchw"]
+    return keep
+
+
 class HeadOutput(torch.Tensor):
     """The tensor an STP net publishes as ``self.parameters`` (the reference assigns the raw head output to that name,
     SelfC_GMM_arch_inv.py:377 / SelfC_arch_inv.py:149,153, shadowing ``nn.Module.parameters`` on the instance).  Reading it

@@ -242,7 +242,15 @@ class ModuleGraph:
         self.per = n // nstreams
         blk = net._blocks()[0]
         self.c1, self.c2 = blk.split_len1, blk.split_len2
-        self.ws = [rt.Workspace(device, blk.F.kind, self.per, t, h, w, self.c1, self.c2) for _ in range(nstreams)]
+        # x1 / x2 of the parts are slices of ONE whole-batch buffer each (the latent rows are frame-major), so the eager
+        # kernels around the replay run once over the batch; the plane-blocked dense buffers stay per part
+        per = self.per
+        self.ws = [rt.Workspace(device, blk.F.kind, per, t, h, w, self.c1, self.c2) for _ in range(nstreams)]
+        c2p = self.ws[0].c2p
+        self.X1 = torch.zeros((n, h, w, 4), dtype=torch.float32, device=device)
+        self.X2 = torch.zeros((n, h, w, c2p), dtype=torch.float32, device=device)
+        for i, ws in enumerate(self.ws):
+            ws.x1, ws.x2 = self.X1[i * per:(i + 1) * per], self.X2[i * per:(i + 1) * per]
         self.lat = [ws.latent() for ws in self.ws]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(nstreams)] if nstreams > 1 else []
         self._params = [p for b in net._blocks() for p in rt.plist(b)]
@@ -250,9 +258,15 @@ class ModuleGraph:
             stp = net.stp_net
             self._params = self._params + rt.plist(stp)
             self.stp_scratch = [{} for _ in range(nstreams)]
-            self.eps = [torch.empty((self.per * h * w, stp.hf_dim * stp.K), dtype=torch.float32, device=device)
+            self.eps = [torch.empty((per * h * w, stp.hf_dim * stp.K), dtype=torch.float32, device=device)
                         if stp.fh_loss != "l2" else None for _ in range(nstreams)]
-            self.hf = [torch.empty_like(ws.x2) for ws in self.ws]      # the STP's sample, kept for `recon_hf` (the stack rewrites x2)
+            # the STP's sample goes to its own buffer and stays there for `recon_hf`: the first block of the reversed stack reads
+            # x2 from it and writes its y2 into the latent x2 (selfc_latent.x2_out), the other blocks work in place
+            self.HF = torch.zeros((n, h, w, c2p), dtype=torch.float32, device=device)
+            self.hf = [self.HF[i * per:(i + 1) * per] for i in range(nstreams)]
+            self.lat_first = [_lib.Latent(blk.F.kind, per, t, h, w, self.c1, self.c2, ws.x1.data_ptr(), hf.data_ptr(), ws.fd.data_ptr(),
+                                          ws.gd.data_ptr(), ws.hd.data_ptr(), None, None if ws.pf is None else ws.pf.data_ptr(), 0, None,
+                                          None, ws.x2.data_ptr()) for ws, hf in zip(self.ws, self.hf)]
         self.graph = None
         self.stamp = None
         self.calls = 0
@@ -267,10 +281,13 @@ class ModuleGraph:
         if self.mode == "fwd":
             _lib.check(_lib.lib().selfc_invstack_run(self.arr, self.nblk, C.byref(self.lat[i]), 0, sp), "selfc_invstack_run fwd")
             return
+        L = _lib.lib()
         if self.mode == "rev":
-            self.net.stp_net.run_nhwc(ws.x1, ws.x2, self.per, self.T, self.h, self.w, scratch=self.stp_scratch[i], eps=self.eps[i])
-            self.hf[i].copy_(ws.x2)
-        _lib.check(_lib.lib().selfc_invstack_run(self.arr, self.nblk, C.byref(self.lat[i]), 1, sp), "selfc_invstack_run rev")
+            self.net.stp_net.run_nhwc(ws.x1, self.hf[i], self.per, self.T, self.h, self.w, scratch=self.stp_scratch[i], eps=self.eps[i])
+            _lib.check(L.selfc_invblock_run(C.byref(self.arr[self.nblk - 1]), C.byref(self.lat_first[i]), 1, sp), "selfc_invblock_run rev (first)")
+            _lib.check(L.selfc_invstack_run(self.arr, self.nblk - 1, C.byref(self.lat[i]), 1, sp), "selfc_invstack_run rev")
+            return
+        _lib.check(L.selfc_invstack_run(self.arr, self.nblk, C.byref(self.lat[i]), 1, sp), "selfc_invstack_run rev")
 
     def _run_middle(self):
         if self.nstreams == 1:
@@ -305,39 +322,32 @@ class ModuleGraph:
             self._capture()                # first use, or the weights changed: the graph holds the old packed buffers
         L, sp, per = _lib.lib(), _lib.stream_ptr(), self.per
         chk = _lib.check
-        dev = self.device
+        dev, n = self.device, self.N
         if self.mode == "fwd":
-            for i, ws in enumerate(self.ws):
+            for i, ws in enumerate(self.ws):       # per part: it also writes the part's plane-blocked F input
                 chk(L.selfc_freq_fwd(x[i * per:(i + 1) * per].data_ptr(), ws.x1.data_ptr(), ws.x2.data_ptr(), ws.fd.data_ptr(), ws.FC,
                                      per, self.H, self.W, self.k, sp), "selfc_freq_fwd")
             self.graph.replay()
-            out = torch.empty((self.N, self.c1 + self.c2, self.h, self.w), dtype=torch.float32, device=dev)
-            for i, ws in enumerate(self.ws):
-                chk(L.selfc_latent_to_nchw(ws.x1.data_ptr(), ws.x2.data_ptr(), out[i * per:(i + 1) * per].data_ptr(), per, self.c1, self.c2,
-                                           self.h, self.w, sp), "selfc_latent_to_nchw")
+            out = torch.empty((n, self.c1 + self.c2, self.h, self.w), dtype=torch.float32, device=dev)
+            chk(L.selfc_latent_to_nchw(self.X1.data_ptr(), self.X2.data_ptr(), out.data_ptr(), n, self.c1, self.c2, self.h, self.w, sp),
+                "selfc_latent_to_nchw")
             return out
         if self.mode == "rev":
-            for i, ws in enumerate(self.ws):
-                chk(L.selfc_nchw_to_nhwc4(x[i * per:(i + 1) * per].data_ptr(), ws.x1.data_ptr(), per, 3, self.h, self.w, sp), "selfc_nchw_to_nhwc4")
+            chk(L.selfc_nchw_to_nhwc4(x.data_ptr(), self.X1.data_ptr(), n, 3, self.h, self.w, sp), "selfc_nchw_to_nhwc4")
         else:
-            for i, ws in enumerate(self.ws):
-                chk(L.selfc_nchw_to_latent(x[i * per:(i + 1) * per].data_ptr(), ws.x1.data_ptr(), ws.x2.data_ptr(), None, ws.FC,
-                                           per, self.c1, self.c2, self.h, self.w, sp), "selfc_nchw_to_latent")
+            chk(L.selfc_nchw_to_latent(x.data_ptr(), self.X1.data_ptr(), self.X2.data_ptr(), None, self.ws[0].FC,
+                                       n, self.c1, self.c2, self.h, self.w, sp), "selfc_nchw_to_latent")
         self.graph.replay()
-        out = torch.empty((self.N, 3, self.H, self.W), dtype=torch.float32, device=dev)
-        for i, ws in enumerate(self.ws):
-            chk(L.selfc_freq_inv(ws.x1.data_ptr(), ws.x2.data_ptr(), out[i * per:(i + 1) * per].data_ptr(), per, self.h, self.w, self.k, sp),
-                "selfc_freq_inv")
+        out = torch.empty((n, 3, self.H, self.W), dtype=torch.float32, device=dev)
+        chk(L.selfc_freq_inv(self.X1.data_ptr(), self.X2.data_ptr(), out.data_ptr(), n, self.h, self.w, self.k, sp), "selfc_freq_inv")
         if self.mode != "rev":
             return out
-        hf = torch.empty((self.N, self.c2, self.h, self.w), dtype=torch.float32, device=dev)
-        for i in range(self.nstreams):
-            chk(L.selfc_nhwc4_to_nchw(self.hf[i].data_ptr(), hf[i * per:(i + 1) * per].data_ptr(), per, self.c2, self.h, self.w, sp),
-                "selfc_nhwc4_to_nchw")
+        hf = torch.empty((n, self.c2, self.h, self.w), dtype=torch.float32, device=dev)
+        chk(L.selfc_nhwc4_to_nchw(self.HF.data_ptr(), hf.data_ptr(), n, self.c2, self.h, self.w, sp), "selfc_nhwc4_to_nchw")
         return out, hf
 
     def nbytes(self) -> int:
-        return sum(ws.nbytes() for ws in self.ws)
+        return sum(ws.nbytes() for ws in self.ws) + (self.HF.numel() * 4 if self.mode == "rev" else 0)
 
 
 #: net -> {(mode, shape, ...): 1 (seen once) | ModuleGraph}; weak on the net, so deepcopy / pickling / deletion of a net never
