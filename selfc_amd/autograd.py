@@ -138,8 +138,8 @@ class GradSink:
         if self.touched:
             bits[torch.tensor(sorted(self.touched), device=self.flat.device)] = 1
         lo, hi = bits.clone(), bits.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        device_collective(lo, lambda t_: dist.all_reduce(t_, op=dist.ReduceOp.MIN, group=group), group)
+        device_collective(hi, lambda t_: dist.all_reduce(t_, op=dist.ReduceOp.MAX, group=group), group)
         if not torch.equal(lo, hi):
             bad = torch.nonzero(lo != hi).flatten().tolist()
             raise RuntimeError(f"data-parallel ranks disagree on which parameters received a gradient (parameter indices {bad[:8]}...): "
@@ -181,10 +181,24 @@ class GradSink:
             return 1
         world = dist.get_world_size(group)
         if world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            device_collective(self.flat, lambda t_: dist.all_reduce(t_, op=dist.ReduceOp.SUM, group=group), group)
             if average:
                 self.flat.mul_(1.0 / world)
         return world
+
+
+def device_collective(tensor: torch.Tensor, fn, group=None):
+    """Run the in-place collective `fn(tensor)` (all_reduce / broadcast) on a tensor that may live on the GPU while the
+    process group is gloo: RCCL ("nccl") takes device tensors as they are; gloo - the CPU rehearsal backend, and the one that
+    lets several ranks share ONE GPU (tests/test_gpu_multi.py) - goes through a host copy.  The round trip synchronises with
+    the host, which is fine where it is used: the data-parallel step keeps its collective outside the captured graphs."""
+    import torch.distributed as dist
+    if tensor.is_cuda and dist.get_backend(group) == "gloo":
+        host = tensor.detach().to("cpu")
+        fn(host)
+        tensor.detach().copy_(host)
+    else:
+        fn(tensor)
 
 
 _SINK: Optional[GradSink] = None
@@ -523,8 +537,9 @@ def _block_backward(blk, ws, keep, rev, t, d1, d2, want, restore_fd, tag=""):
     (forward: x2, reverse: x1).  Returns (d1, dx2, gF, gG, gH): gradients w.r.t. the inputs (x1, x2) and the parameters.
     The weight-gradient phases run on the side stream and H's chain on a third one; the caller joins them
     (_join_side_streams) before the gradients are used.  `tag` picks the scratch set: a caller that walks several blocks
-    alternates two sets, so that block i's weight-gradient phases (side stream) and block i-1's data phases (main stream)
-    work on different buffers; a set is only reused behind the event of its last reader (subnet_bwd)."""
+    gives every block its own, so that block i's weight-gradient phases (side stream) and the data phases of the blocks
+    behind it (main stream) never share a buffer and no ordering between the two streams is needed before the join
+    (~70 MB per subnet at 8 x 7 x 36 x 36; a set that IS reused before a join waits for its last reader: subnet_bwd)."""
     n, h, w, c2 = ws.N, ws.H, ws.W, ws.c2
     dev, sp = d1.device, _lib.stream_ptr()
     dx2 = torch.empty_like(d2)
@@ -665,7 +680,7 @@ class InvStackFn(torch.autograd.Function):
             rt.call("selfc_freq_inv_bwd", gy.data_ptr(), d1.data_ptr(), d2.data_ptr(), n, H, W, sp)
         grads = {}
         for i, (blk, sv, keep, fd_intact) in enumerate(reversed(ctx.saves)):
-            d1, d2, gF, gG, gH = _block_backward(blk, sv, keep, rev, t, d1, d2, want, restore_fd=not fd_intact, tag=str(i & 1))
+            d1, d2, gF, gG, gH = _block_backward(blk, sv, keep, rev, t, d1, d2, want, restore_fd=not fd_intact, tag=str(i))
             grads[id(blk)] = (*gF, *gG, *gH)
         dx = None
         if ctx.needs_input_grad[0]:

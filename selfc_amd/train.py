@@ -185,7 +185,7 @@ class RescaleTrainer:
             src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
             with torch.no_grad():
                 for t_ in list(nn.Module.parameters(netG)) + list(netG.buffers()):
-                    dist.broadcast(t_.data, src, group=process_group)
+                    ag.device_collective(t_.data, lambda h_: dist.broadcast(h_, src, group=process_group), process_group)
             rt.invalidate_weights()
         self.before_clip = None          # optional callable(trainer): runs after backward, before clipping (tests, logging)
 

@@ -62,3 +62,39 @@ def test_ddp_two_ranks_keep_equal_parameters():
     assert "DistributedDataParallel" in ddp["gradient_sync"]
     assert abs(flat["param_sq_sum"] - ddp["param_sq_sum"]) < 1e-6 * ddp["param_sq_sum"]
     assert abs(graphs["param_sq_sum"] - ddp["param_sq_sum"]) < 1e-5 * ddp["param_sq_sum"]
+
+
+def _train_line(*extra):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_synthetic.py"), "--steps", "2", "--warmup", "1",
+                        "--global-batch", "2", "--size", "64", "--fh-loss", "l2", *extra],
+                       env=_clean_env(), capture_output=True, text=True, timeout=900)
+    return _json_line(p)
+
+
+def test_two_ranks_on_one_gpu_data_parallel_step():
+    """Hardware evidence for the data-parallel step where only ONE MI355X is visible (SelfC_model.py:41-44, data/__init__.py:13-14:
+    DistributedDataParallel, global batch split over the ranks): two CHILD ranks share cuda:0 over a gloo process group (device
+    tensors staged through the host for the collective - everything except RCCL itself runs as on a multi-GPU node): rank-0
+    broadcast, the flat HIP gradient sink, ONE all-reduce of the flat buffer, the step captured as two hipGraphs around it.
+    Ranks start from different seeds and draw different data, so identical parameters afterwards can only come from the
+    broadcast + the averaged gradients; and the result must be the single-process step on the CONCATENATED batch."""
+    if not torch.cuda.device_count():
+        pytest.skip("needs an MI355X")
+    graphs = _train_line("--gpus", "2", "--share-gpu")
+    eager = _train_line("--gpus", "2", "--share-gpu", "--eager")
+    one = _train_line("--emulate-ranks", "2")                   # captured: capture()'s two warm-up steps are real steps (5 in all)
+    one_eager = _train_line("--emulate-ranks", "2", "--eager")  # 3 steps, like the eager two-rank run
+    for d in (graphs, eager):
+        assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo" and d["global_batch"] == 2 and d["local_batch"] == 1
+        assert "ONE all-reduce" in d["gradient_sync"] and d["param_spread_over_ranks"] == 0.0
+        assert d["loss"] == d["loss"]
+    assert graphs["launch"] == "hipGraph replay" and "two hipGraphs" in graphs["gradient_sync"] and eager["launch"] == "eager"
+    assert one["n_gpus"] == 1 and one["global_batch"] == 2 and one["gradient_sync"] == "single GPU"
+    # same rank-0 weights, same global batch, l2 head (no sampling noise): the ranks' averaged gradients are the single process's
+    # gradients up to the per-rank gradient scaling (absmax is taken per local batch) and fp32 summation order
+    # (bar: one Adam step moves sum(p^2) by about n_params * lr^2 = 0.034 of ~2,085, i.e. 1.6e-5 relative: a missing or doubled step,
+    # a gradient that was not averaged or a rank that kept its own weights are all far outside 2e-6)
+    print("param_sq_sum: 2 ranks graphs / eager", graphs["param_sq_sum"], eager["param_sq_sum"], "one process graphs / eager", one["param_sq_sum"], one_eager["param_sq_sum"])
+    assert abs(graphs["param_sq_sum"] - one["param_sq_sum"]) < 2e-6 * one["param_sq_sum"], (graphs["param_sq_sum"], one["param_sq_sum"])
+    assert abs(eager["param_sq_sum"] - one_eager["param_sq_sum"]) < 2e-6 * one_eager["param_sq_sum"], (eager["param_sq_sum"], one_eager["param_sq_sum"])
+    assert abs(graphs["loss"] - one["loss"]) < 0.2 * abs(one["loss"])         # the LAST step's loss: rank 0's clip vs the mean over both clips

@@ -71,16 +71,21 @@ def main():
     ap.add_argument("--eager", action="store_true", help="no hipGraph capture of the step")
     ap.add_argument("--host-loader", action="store_true", help="host-generated batches through DevicePrefetcher instead of on-device generation")
     ap.add_argument("--workers", type=int, default=0, help="> 0: the reference's loader factory (data.create_dataloader) with this many worker PROCESSES over a synthetic dataset that keeps the per-item host work, through DevicePrefetcher")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks on cuda:0 with a gloo process group (device tensors staged through the host for the collective): "
+                    "the data-parallel step - broadcast, flat gradient sink, all-reduce between the two captured graphs - on real kernels where only ONE GPU is visible")
+    ap.add_argument("--emulate-ranks", type=int, default=0, help="single process: draw the batches R ranks would draw (their seeds) and train on the concatenation - "
+                    "the reference point for --share-gpu (same global batch, same rank-0 weights)")
+    ap.add_argument("--fh-loss", default="gmm", choices=("gmm", "l2"), help="STP head (l2: no sampling noise, for run-to-run comparisons)")
     ap.add_argument("--dist-1", action="store_true", help="with --gpus 1: still initialise a one-rank RCCL group and run the data-parallel code path (tests)")
     a = ap.parse_args()
     from selfc_amd import launch
     rc = launch.self_launch(a.gpus, os.path.abspath(__file__), sys.argv[1:])      # before anything touches the GPU
     if rc is not None:
         sys.exit(rc)
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    ranks = launch.Ranks(a.gpus, "nccl", dev)
+    ranks = launch.Ranks(a.gpus, "gloo" if a.share_gpu else "nccl", dev)
     rank, world = ranks.rank, ranks.world
     import torch.distributed as dist
     solo_group = False
@@ -91,7 +96,7 @@ def main():
     from selfc_amd.modules.SelfC_GMM_arch_inv import SelfCInvNet
     GlobalVar.set_Temporal_LEN(7)
     torch.manual_seed(10 + rank)      # ranks start DIFFERENT on purpose: the trainer's (or DDP's) rank-0 broadcast must make them equal
-    opt = {"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": "gmm", "scale": 4, "gmm_k": 5}
+    opt = {"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": a.fh_loss, "scale": 4, "gmm_k": 5}
     net = SelfCInvNet(opt, 3, 3, "D2DTNet", [4, 4], 2).to(dev)
     model, mode = net, "single GPU"
     capture = not a.eager and not a.ddp
@@ -104,7 +109,8 @@ def main():
     if tr.data_parallel:
         mode = f"flat gradient buffer, ONE all-reduce of {tr.sink.flat.numel() * 4 / 1e6:.2f} MB per step" + \
                (", step = two hipGraphs around it" if capture else ", eager")
-    local_batch = max(1, a.global_batch // world)
+    emu = max(1, a.emulate_ranks) if world == 1 else 1
+    local_batch = max(1, a.global_batch // (world * emu))
     seed = launch.rank_seed(1234, rank)
     total = a.steps + a.warmup + 4
     if a.workers > 0:
@@ -114,6 +120,9 @@ def main():
         feed = iter(data.DevicePrefetcher(loader, dev, depth=2))
     elif a.host_loader:
         feed = iter(data.DevicePrefetcher(_HostBatches(local_batch, a.size, seed, total), dev, depth=2))
+    elif emu > 1:
+        srcs = [iter(data.SyntheticSeptuplets(local_batch, 7, a.size, dev, launch.rank_seed(1234, r))) for r in range(emu)]
+        feed = iter(lambda: {"GT": torch.cat([next(s_)["GT"] for s_ in srcs], 0)}, None)
     else:
         feed = iter(data.SyntheticSeptuplets(local_batch, 7, a.size, dev, seed))
     log = {}
@@ -143,9 +152,9 @@ def main():
         per_rank = [round(my_ms, 3)]
     if rank == 0:
         print(json.dumps({"metric": "training septuplets/s (train_rescaling_selfc_large, synthetic 144x144 crops)",
-                          "value": round(local_batch * world * a.steps / sec, 2), "unit": "septuplets/s", "n_gpus": world,
+                          "value": round(local_batch * emu * world * a.steps / sec, 2), "unit": "septuplets/s", "n_gpus": world,
                           "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(sec / a.steps * 1e3, 2), "ms_per_step_per_rank": per_rank,
-                          "local_batch": local_batch, "global_batch": local_batch * world, "dtype": _lib.OPERAND,
+                          "local_batch": local_batch * emu, "global_batch": local_batch * world * emu, "backend": ranks.backend if world > 1 else None, "dtype": _lib.OPERAND,
                           "data": "synthetic, " + (f"DataLoader with {a.workers} worker processes (per-item uint8 -> float work in the workers) through DevicePrefetcher" if a.workers > 0
                                                 else "host batches through DevicePrefetcher" if a.host_loader else "generated on the device"),
                           "launch": "hipGraph replay" if capture else "eager", "loss": log.get("loss"), "rccl_ranks": nranks,
