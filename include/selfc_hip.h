@@ -306,6 +306,21 @@ int selfc_profile_calibrate(double* mfma_tflops, double* copy_GBps, void* stream
  * (device memory, 2 x u64).  Launch it on a side stream next to the workload; GHz = 0.1 * out2[0] / out2[1]. */
 int selfc_profile_clock_sample(unsigned long long* out2, int micros, void* stream);
 
+/* ---- indirect tensor addresses (abi 10): the module API as ONE replayed hipGraph ----
+ * The reference's callers pass a new input tensor to every netG(x=..., rev=...) call and own the tensors it returns
+ * (SelfC_model.py:213-230; torch.cat / convs always return fresh storage, SURVEY 8b "ownership").  A hipGraph bakes kernel
+ * arguments in, so the graph-side transforms that touch a CALLER's tensor take the device address of a pointer SLOT
+ * instead of the tensor: selfc_set_pointers (one tiny launch on the same stream, right before the replay) stores the
+ * call's base addresses into slots 0..n-1 of `table`, and each *_ind transform reads `*slot + off` elements (off = the
+ * part of the batch this launch owns).  Same arithmetic, same layouts, same error codes as the direct entry points. */
+int selfc_set_pointers(void** table, int n, const void* p0, const void* p1, const void* p2, const void* p3, void* stream);
+int selfc_freq_fwd_ind(const float* const* xslot, size_t xoff, float* x1, float* x2, void* fd, int FC, int N, int H, int W, int k, void* stream);
+int selfc_freq_inv_ind(const float* x1, const float* x2, float* const* xslot, size_t xoff, int N, int h, int w, int k, void* stream);
+int selfc_nchw_to_latent_ind(const float* const* xslot, size_t xoff, float* x1, float* x2, void* fd, int FC, int N, int c1, int c2, int H, int W, void* stream);
+int selfc_latent_to_nchw_ind(const float* x1, const float* x2, float* const* yslot, size_t yoff, int N, int c1, int c2, int H, int W, void* stream);
+int selfc_nchw_to_nhwc4_ind(const float* const* xslot, size_t xoff, float* y, int N, int C, int H, int W, void* stream);
+int selfc_nhwc4_to_nchw_ind(const float* x, float* const* yslot, size_t yoff, int N, int C, int H, int W, void* stream);
+
 /* ---- STP gradients (csrc/stp.hip) ---- */
 /* d raw of selfc_gmm_sample given dv: raw/draw [npix][hf_dim*K*3], eps [npix][hf_dim*K], dv [npix][hf_dim]. */
 int selfc_gmm_sample_bwd(const float* raw, const float* eps, const float* dv, float* draw, size_t npix, int hf_dim, int K, void* stream);

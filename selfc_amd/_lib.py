@@ -25,7 +25,7 @@ def operand_dtype():
 SUBNET_D2DT = 0
 SUBNET_DB2D = 1
 LAT_KEEP_FEATURES = 1      # selfc_latent.flags (SELFC_LAT_KEEP_FEATURES)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 #: every symbol include/selfc_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -41,6 +41,8 @@ SYMBOLS = [
     "selfc_bwd_scale", "selfc_bwd_to_planes", "selfc_f16_rows_to_planes", "selfc_bwd_conv_planes",
     "selfc_bwd_wgrad_scratch_bytes", "selfc_bwd_wgrad", "selfc_gmm_sample_bwd", "selfc_gmm_sample_generic_bwd", "selfc_lrelu_bwd",
     "selfc_globalagg_bwd_scratch_bytes", "selfc_globalagg_bwd", "selfc_rowsum_accum",
+    "selfc_set_pointers", "selfc_freq_fwd_ind", "selfc_freq_inv_ind", "selfc_nchw_to_latent_ind", "selfc_latent_to_nchw_ind",
+    "selfc_nchw_to_nhwc4_ind", "selfc_nhwc4_to_nchw_ind",
 ]
 
 
@@ -138,6 +140,13 @@ def lib():
             "selfc_gmm_sample_generic_bwd": [vp, vp, vp, vp, sz, i, i, i, i, f, vp],
             "selfc_lrelu_bwd": [vp, vp, sz, vp],
             "selfc_rowsum_accum": [C.POINTER(RowSum), vp],
+            "selfc_set_pointers": [vp, i, vp, vp, vp, vp, vp],
+            "selfc_freq_fwd_ind": [vp, sz, vp, vp, vp, i, i, i, i, i, vp],
+            "selfc_freq_inv_ind": [vp, vp, vp, sz, i, i, i, i, vp],
+            "selfc_nchw_to_latent_ind": [vp, sz, vp, vp, vp, i, i, i, i, i, i, vp],
+            "selfc_latent_to_nchw_ind": [vp, vp, vp, sz, i, i, i, i, i, vp],
+            "selfc_nchw_to_nhwc4_ind": [vp, sz, vp, i, i, i, i, vp],
+            "selfc_nhwc4_to_nchw_ind": [vp, vp, sz, i, i, i, i, vp],
             "selfc_globalagg_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, i, vp],
         }
         for name, args in sigs.items():

@@ -66,12 +66,23 @@ __global__ void haar_inv_kernel(const float* __restrict__ y, float* __restrict__
   *reinterpret_cast<float2*>(o + W) = r1;
 }
 
+// Indirect tensor addresses (abi 10).  A hipGraph bakes kernel arguments in; the module API must read the caller's tensor and
+// write a FRESH output tensor on every call.  With IND the pointer argument is the device address of a SLOT that holds the
+// real base address (written by selfc_set_pointers on the same stream right before the replay), plus an element offset
+// (the part of the batch this launch owns): one scalar load per wave, no copy of the tensor, the graph stays as captured.
+template <bool IND, class T>
+__device__ __forceinline__ T* resolve(T* p, const size_t off) {
+  if (!IND) return p;
+  return *reinterpret_cast<T* const*>(p) + off;
+}
+
 // ---------------------------------------------------------------- FrequencyAnalyzer
 // forward: lo = KxK block mean (row-major sequential sum / K^2, the order of
 // torch's CPU avg_pool2d), hi[(sy*K+sx)*3+c] = x - lo.
-template <int K>
-__global__ void freq_fwd_kernel(const float* __restrict__ x, float* __restrict__ x1, float* __restrict__ x2,
-                                f16* __restrict__ fd, int FC, int N, int h, int w) {
+template <int K, bool IND = false>
+__global__ void freq_fwd_kernel(const float* __restrict__ xarg, float* __restrict__ x1, float* __restrict__ x2,
+                                f16* __restrict__ fd, int FC, int N, int h, int w, size_t ioff = 0) {
+  const float* __restrict__ x = resolve<IND>(xarg, ioff);
   constexpr int C2 = 3 * K * K;
   const size_t total = (size_t)N * h * w;
   const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
@@ -124,9 +135,10 @@ __global__ void freq_fwd_kernel(const float* __restrict__ x, float* __restrict__
 }
 
 // reverse: out[c][K*y+sy][K*x+sx] = lo[c] + hf[c*K^2 + sy*K + sx]  (nn.PixelShuffle order)
-template <int K>
+template <int K, bool IND = false>
 __global__ void freq_inv_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
-                                float* __restrict__ x, int N, int h, int w) {
+                                float* __restrict__ xarg, int N, int h, int w, size_t ioff = 0) {
+  float* __restrict__ x = resolve<IND>(xarg, ioff);
   constexpr int C2 = 3 * K * K;
   const size_t total = (size_t)N * h * w;
   const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
@@ -167,8 +179,10 @@ __global__ void freq_inv_kernel(const float* __restrict__ x1, const float* __res
 }
 
 // ---------------------------------------------------------------- NCHW <-> latent
-__global__ void nchw_to_latent_kernel(const float* __restrict__ x, float* __restrict__ x1, float* __restrict__ x2,
-                                      f16* __restrict__ fd, int FC, int N, int c1, int c2, int c2p, size_t HW) {
+template <bool IND = false>
+__global__ void nchw_to_latent_kernel(const float* __restrict__ xarg, float* __restrict__ x1, float* __restrict__ x2,
+                                      f16* __restrict__ fd, int FC, int N, int c1, int c2, int c2p, size_t HW, size_t ioff = 0) {
+  const float* __restrict__ x = resolve<IND>(xarg, ioff);
   const size_t total = (size_t)N * HW;
   const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
   if (i >= total) return;
@@ -191,8 +205,10 @@ __global__ void nchw_to_latent_kernel(const float* __restrict__ x, float* __rest
   }
 }
 
+template <bool IND = false>
 __global__ void latent_to_nchw_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
-                                      float* __restrict__ y, int N, int c1, int c2, int c2p, size_t HW) {
+                                      float* __restrict__ yarg, int N, int c1, int c2, int c2p, size_t HW, size_t ioff = 0) {
+  float* __restrict__ y = resolve<IND>(yarg, ioff);
   const size_t total = (size_t)N * HW;
   const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
   if (i >= total) return;
@@ -210,7 +226,9 @@ __global__ void latent_to_nchw_kernel(const float* __restrict__ x1, const float*
   }
 }
 
-__global__ void nchw_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int Cp, size_t HW) {
+template <bool IND = false>
+__global__ void nchw_to_nhwc4_kernel(const float* __restrict__ xarg, float* __restrict__ y, int N, int C, int Cp, size_t HW, size_t ioff = 0) {
+  const float* __restrict__ x = resolve<IND>(xarg, ioff);
   const size_t total = (size_t)N * HW;
   const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
   if (i >= total) return;
@@ -224,7 +242,9 @@ __global__ void nchw_to_nhwc4_kernel(const float* __restrict__ x, float* __restr
   }
 }
 
-__global__ void nhwc4_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int Cp, size_t HW) {
+template <bool IND = false>
+__global__ void nhwc4_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ yarg, int N, int C, int Cp, size_t HW, size_t ioff = 0) {
+  float* __restrict__ y = resolve<IND>(yarg, ioff);
   const size_t total = (size_t)N * HW;
   const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
   if (i >= total) return;
@@ -429,9 +449,9 @@ int selfc_freq_fwd(const float* x, float* x1, float* x2, void* fd, int FC, int N
   const size_t total = (size_t)N * h * w;
   ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
   if (k == 4)
-    hipLaunchKernelGGL(freq_fwd_kernel<4>, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x, x1, x2, (f16*)fd, FC, N, h, w);
+    hipLaunchKernelGGL((freq_fwd_kernel<4, false>), dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x, x1, x2, (f16*)fd, FC, N, h, w, (size_t)0);
   else
-    hipLaunchKernelGGL(freq_fwd_kernel<2>, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x, x1, x2, (f16*)fd, FC, N, h, w);
+    hipLaunchKernelGGL((freq_fwd_kernel<2, false>), dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x, x1, x2, (f16*)fd, FC, N, h, w, (size_t)0);
   return hip_rc(hipGetLastError());
 }
 
@@ -440,9 +460,9 @@ int selfc_freq_inv(const float* x1, const float* x2, float* x, int N, int h, int
   const size_t total = (size_t)N * h * w;
   ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
   if (k == 4)
-    hipLaunchKernelGGL(freq_inv_kernel<4>, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x1, x2, x, N, h, w);
+    hipLaunchKernelGGL((freq_inv_kernel<4, false>), dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x1, x2, x, N, h, w, (size_t)0);
   else
-    hipLaunchKernelGGL(freq_inv_kernel<2>, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x1, x2, x, N, h, w);
+    hipLaunchKernelGGL((freq_inv_kernel<2, false>), dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x1, x2, x, N, h, w, (size_t)0);
   return hip_rc(hipGetLastError());
 }
 
@@ -452,7 +472,7 @@ int selfc_nchw_to_latent(const float* x, float* x1, float* x2, void* fd, int FC,
   if (fd && (FC < c2p || (FC & 3))) return SELFC_EINVAL;
   const size_t HW = (size_t)H * W;
   ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
-  hipLaunchKernelGGL(nchw_to_latent_kernel, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x, x1, x2, (f16*)fd, FC, N, c1, c2, c2p, HW);
+  hipLaunchKernelGGL(nchw_to_latent_kernel<false>, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x, x1, x2, (f16*)fd, FC, N, c1, c2, c2p, HW, (size_t)0);
   return hip_rc(hipGetLastError());
 }
 
@@ -461,7 +481,7 @@ int selfc_latent_to_nchw(const float* x1, const float* x2, float* y, int N, int 
   const int c2p = (c2 + 3) & ~3;
   const size_t HW = (size_t)H * W;
   ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
-  hipLaunchKernelGGL(latent_to_nchw_kernel, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x1, x2, y, N, c1, c2, c2p, HW);
+  hipLaunchKernelGGL(latent_to_nchw_kernel<false>, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x1, x2, y, N, c1, c2, c2p, HW, (size_t)0);
   return hip_rc(hipGetLastError());
 }
 
@@ -469,7 +489,7 @@ int selfc_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, vo
   if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0) return SELFC_EINVAL;
   const size_t HW = (size_t)H * W;
   ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
-  hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x, y, N, C, (C + 3) & ~3, HW);
+  hipLaunchKernelGGL(nchw_to_nhwc4_kernel<false>, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x, y, N, C, (C + 3) & ~3, HW, (size_t)0);
   return hip_rc(hipGetLastError());
 }
 
@@ -477,7 +497,90 @@ int selfc_nhwc4_to_nchw(const float* x, float* y, int N, int C, int H, int W, vo
   if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0) return SELFC_EINVAL;
   const size_t HW = (size_t)H * W;
   ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
-  hipLaunchKernelGGL(nhwc4_to_nchw_kernel, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x, y, N, C, (C + 3) & ~3, HW);
+  hipLaunchKernelGGL(nhwc4_to_nchw_kernel<false>, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x, y, N, C, (C + 3) & ~3, HW, (size_t)0);
+  return hip_rc(hipGetLastError());
+}
+
+// ---- the same transforms with the tensor that belongs to the CALLER addressed through a pointer slot (abi 10) ----
+namespace {
+__global__ void set_pointers_kernel(void** table, const void* p0, const void* p1, const void* p2, const void* p3, const int n) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (n > 0) table[0] = const_cast<void*>(p0);
+    if (n > 1) table[1] = const_cast<void*>(p1);
+    if (n > 2) table[2] = const_cast<void*>(p2);
+    if (n > 3) table[3] = const_cast<void*>(p3);
+  }
+}
+}  // namespace
+
+int selfc_set_pointers(void** table, int n, const void* p0, const void* p1, const void* p2, const void* p3, void* stream) {
+  if (!table || n < 1 || n > 4) return SELFC_EINVAL;
+  hipLaunchKernelGGL(set_pointers_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, table, p0, p1, p2, p3, n);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_freq_fwd_ind(const float* const* xslot, size_t xoff, float* x1, float* x2, void* fd, int FC, int N, int H, int W, int k, void* stream) {
+  if (!xslot || !x1 || !x2 || N <= 0 || H <= 0 || W <= 0 || (k != 4 && k != 2) || H % k || W % k) return SELFC_EINVAL;
+  if (fd && (FC < 3 * k * k || (FC & 3))) return SELFC_EINVAL;
+  const int h = H / k, w = W / k;
+  const size_t total = (size_t)N * h * w;
+  const float* xa = reinterpret_cast<const float*>(xslot);
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
+  if (k == 4)
+    hipLaunchKernelGGL((freq_fwd_kernel<4, true>), dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, xa, x1, x2, (f16*)fd, FC, N, h, w, xoff);
+  else
+    hipLaunchKernelGGL((freq_fwd_kernel<2, true>), dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, xa, x1, x2, (f16*)fd, FC, N, h, w, xoff);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_freq_inv_ind(const float* x1, const float* x2, float* const* xslot, size_t xoff, int N, int h, int w, int k, void* stream) {
+  if (!xslot || !x1 || !x2 || N <= 0 || h <= 0 || w <= 0 || (k != 4 && k != 2)) return SELFC_EINVAL;
+  const size_t total = (size_t)N * h * w;
+  float* xa = reinterpret_cast<float*>(const_cast<float**>(xslot));
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
+  if (k == 4)
+    hipLaunchKernelGGL((freq_inv_kernel<4, true>), dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x1, x2, xa, N, h, w, xoff);
+  else
+    hipLaunchKernelGGL((freq_inv_kernel<2, true>), dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, x1, x2, xa, N, h, w, xoff);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_nchw_to_latent_ind(const float* const* xslot, size_t xoff, float* x1, float* x2, void* fd, int FC, int N, int c1, int c2, int H, int W, void* stream) {
+  if (!xslot || !x1 || !x2 || N <= 0 || c1 < 1 || c1 > 4 || c2 < 1 || H <= 0 || W <= 0) return SELFC_EINVAL;
+  const int c2p = (c2 + 3) & ~3;
+  if (fd && (FC < c2p || (FC & 3))) return SELFC_EINVAL;
+  const size_t HW = (size_t)H * W;
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
+  hipLaunchKernelGGL(nchw_to_latent_kernel<true>, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, reinterpret_cast<const float*>(xslot), x1, x2,
+                     (f16*)fd, FC, N, c1, c2, c2p, HW, xoff);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_latent_to_nchw_ind(const float* x1, const float* x2, float* const* yslot, size_t yoff, int N, int c1, int c2, int H, int W, void* stream) {
+  if (!yslot || !x1 || !x2 || N <= 0 || c1 < 1 || c1 > 4 || c2 < 1 || H <= 0 || W <= 0) return SELFC_EINVAL;
+  const int c2p = (c2 + 3) & ~3;
+  const size_t HW = (size_t)H * W;
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
+  hipLaunchKernelGGL(latent_to_nchw_kernel<true>, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x1, x2,
+                     reinterpret_cast<float*>(const_cast<float**>(yslot)), N, c1, c2, c2p, HW, yoff);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_nchw_to_nhwc4_ind(const float* const* xslot, size_t xoff, float* y, int N, int C, int H, int W, void* stream) {
+  if (!xslot || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0) return SELFC_EINVAL;
+  const size_t HW = (size_t)H * W;
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
+  hipLaunchKernelGGL(nchw_to_nhwc4_kernel<true>, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, reinterpret_cast<const float*>(xslot), y, N, C,
+                     (C + 3) & ~3, HW, xoff);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_nhwc4_to_nchw_ind(const float* x, float* const* yslot, size_t yoff, int N, int C, int H, int W, void* stream) {
+  if (!x || !yslot || N <= 0 || C <= 0 || H <= 0 || W <= 0) return SELFC_EINVAL;
+  const size_t HW = (size_t)H * W;
+  ProfScope prof(PROF_TRANSFORM, (hipStream_t)stream);
+  hipLaunchKernelGGL(nhwc4_to_nchw_kernel<true>, dim3(nblocks(N * HW)), dim3(TPB), 0, (hipStream_t)stream, x,
+                     reinterpret_cast<float*>(const_cast<float**>(yslot)), N, C, (C + 3) & ~3, HW, yoff);
   return hip_rc(hipGetLastError());
 }
 

@@ -219,9 +219,11 @@ class MultiStreamRoundTrip:
 # The drop-in call as the fast call.  The reference's callers only ever do `netG(x=..., rev=...)` (SelfC_model.py:213-230,
 # :141,153); in eval / no_grad `SelfCInvNet.forward` routes through a cached ModuleGraph: the call's block stack (and, on
 # the reverse, the STP chain + sampler) replayed as ONE hipGraph with the clips split over two HIP streams - the launch
-# configuration of the headline - while the kernels that touch the caller's tensors (the split of x on the way in, the
-# NCHW conversions / the merge on the way out) run eagerly around the replay, straight from x and straight into FRESH
-# output tensors.  Nothing the caller holds is ever overwritten by a later call, and no copy is added.
+# configuration of the headline.  The kernels that touch the CALLER's tensors (the split of x on the way in, the NCHW
+# conversions / the merge on the way out) are part of the graph too and address those tensors through pointer slots
+# (include/selfc_hip.h, abi 10: selfc_set_pointers + the *_ind transforms): one tiny launch in front of the replay stores
+# this call's input address and the addresses of its FRESH output tensors.  Nothing the caller holds is ever overwritten by
+# a later call, and no copy is added.
 # ----------------------------------------------------------------------------------------------------------------------
 class ModuleGraph:
     """One (mode, shape) instance of SelfCInvNet's inference call.
@@ -242,8 +244,8 @@ class ModuleGraph:
         self.per = n // nstreams
         blk = net._blocks()[0]
         self.c1, self.c2 = blk.split_len1, blk.split_len2
-        # x1 / x2 of the parts are slices of ONE whole-batch buffer each (the latent rows are frame-major), so the eager
-        # kernels around the replay run once over the batch; the plane-blocked dense buffers stay per part
+        # x1 / x2 of the parts are slices of ONE whole-batch buffer each (the latent rows are frame-major); the plane-blocked
+        # dense buffers are per part
         per = self.per
         self.ws = [rt.Workspace(device, blk.F.kind, per, t, h, w, self.c1, self.c2) for _ in range(nstreams)]
         c2p = self.ws[0].c2p
@@ -267,84 +269,97 @@ class ModuleGraph:
             self.lat_first = [_lib.Latent(blk.F.kind, per, t, h, w, self.c1, self.c2, ws.x1.data_ptr(), hf.data_ptr(), ws.fd.data_ptr(),
                                           ws.gd.data_ptr(), ws.hd.data_ptr(), None, None if ws.pf is None else ws.pf.data_ptr(), 0, None,
                                           None, ws.x2.data_ptr()) for ws, hf in zip(self.ws, self.hf)]
+        self.slots = torch.zeros(4, dtype=torch.int64, device=device)       # pointer slots the graph's *_ind transforms read
         self.graph = None
         self.stamp = None
         self.calls = 0
+        self._last_x = None
 
     @property
     def net(self):
         return self._net()
 
-    # -- the captured middle ---------------------------------------------------------------------------------------------
-    def _middle(self, i: int):
-        ws, sp = self.ws[i], _lib.stream_ptr()
+    # -- the captured call ------------------------------------------------------------------------------------------------
+    # slots: 0 = the caller's input tensor, 1 = the first output, 2 = recon_hf (mode 'rev')
+    def _part(self, i: int):
+        ws, sp, per = self.ws[i], _lib.stream_ptr(), self.per
+        L, chk = _lib.lib(), _lib.check
+        h, w, k = self.h, self.w, self.k
+        slot = lambda j: C.c_void_p(self.slots.data_ptr() + 8 * j)      # noqa: E731
         if self.mode == "fwd":
-            _lib.check(_lib.lib().selfc_invstack_run(self.arr, self.nblk, C.byref(self.lat[i]), 0, sp), "selfc_invstack_run fwd")
+            chk(L.selfc_freq_fwd_ind(slot(0), i * per * 3 * self.H * self.W, ws.x1.data_ptr(), ws.x2.data_ptr(), ws.fd.data_ptr(), ws.FC,
+                                     per, self.H, self.W, k, sp), "selfc_freq_fwd_ind")
+            chk(L.selfc_invstack_run(self.arr, self.nblk, C.byref(self.lat[i]), 0, sp), "selfc_invstack_run fwd")
+            chk(L.selfc_latent_to_nchw_ind(ws.x1.data_ptr(), ws.x2.data_ptr(), slot(1), i * per * (self.c1 + self.c2) * h * w,
+                                           per, self.c1, self.c2, h, w, sp), "selfc_latent_to_nchw_ind")
             return
-        L = _lib.lib()
         if self.mode == "rev":
-            self.net.stp_net.run_nhwc(ws.x1, self.hf[i], self.per, self.T, self.h, self.w, scratch=self.stp_scratch[i], eps=self.eps[i])
-            _lib.check(L.selfc_invblock_run(C.byref(self.arr[self.nblk - 1]), C.byref(self.lat_first[i]), 1, sp), "selfc_invblock_run rev (first)")
-            _lib.check(L.selfc_invstack_run(self.arr, self.nblk - 1, C.byref(self.lat[i]), 1, sp), "selfc_invstack_run rev")
-            return
-        _lib.check(L.selfc_invstack_run(self.arr, self.nblk, C.byref(self.lat[i]), 1, sp), "selfc_invstack_run rev")
+            chk(L.selfc_nchw_to_nhwc4_ind(slot(0), i * per * 3 * h * w, ws.x1.data_ptr(), per, 3, h, w, sp), "selfc_nchw_to_nhwc4_ind")
+            self.net.stp_net.run_nhwc(ws.x1, self.hf[i], per, self.T, h, w, scratch=self.stp_scratch[i], eps=self.eps[i])
+            chk(L.selfc_nhwc4_to_nchw_ind(self.hf[i].data_ptr(), slot(2), i * per * self.c2 * h * w, per, self.c2, h, w, sp), "selfc_nhwc4_to_nchw_ind")
+            chk(L.selfc_invblock_run(C.byref(self.arr[self.nblk - 1]), C.byref(self.lat_first[i]), 1, sp), "selfc_invblock_run rev (first)")
+            chk(L.selfc_invstack_run(self.arr, self.nblk - 1, C.byref(self.lat[i]), 1, sp), "selfc_invstack_run rev")
+        else:
+            chk(L.selfc_nchw_to_latent_ind(slot(0), i * per * (self.c1 + self.c2) * h * w, ws.x1.data_ptr(), ws.x2.data_ptr(), None, ws.FC,
+                                           per, self.c1, self.c2, h, w, sp), "selfc_nchw_to_latent_ind")
+            chk(L.selfc_invstack_run(self.arr, self.nblk, C.byref(self.lat[i]), 1, sp), "selfc_invstack_run rev")
+        chk(L.selfc_freq_inv_ind(ws.x1.data_ptr(), ws.x2.data_ptr(), slot(1), i * per * 3 * self.H * self.W, per, h, w, k, sp), "selfc_freq_inv_ind")
 
-    def _run_middle(self):
+    def _run_parts(self):
         if self.nstreams == 1:
-            self._middle(0)
+            self._part(0)
             return
         cur = torch.cuda.current_stream()
         for i, st in enumerate(self.streams):
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                self._middle(i)
+                self._part(i)
         for st in self.streams:
             cur.wait_stream(st)
 
-    def _capture(self):
+    def _io(self, x: torch.Tensor):
+        """This call's fresh output tensors, and their addresses (with x's) into the pointer slots - on the current stream, i.e.
+        ordered behind the previous replay's reads and in front of the next one's."""
+        dev, n = self.device, self.N
+        if self.mode == "fwd":
+            outs = (torch.empty((n, self.c1 + self.c2, self.h, self.w), dtype=torch.float32, device=dev),)
+        elif self.mode == "rev":
+            outs = (torch.empty((n, 3, self.H, self.W), dtype=torch.float32, device=dev),
+                    torch.empty((n, self.c2, self.h, self.w), dtype=torch.float32, device=dev))
+        else:
+            outs = (torch.empty((n, 3, self.H, self.W), dtype=torch.float32, device=dev),)
+        _lib.check(_lib.lib().selfc_set_pointers(self.slots.data_ptr(), 1 + len(outs), x.data_ptr(), outs[0].data_ptr(),
+                                                 outs[1].data_ptr() if len(outs) > 1 else None, None, _lib.stream_ptr()), "selfc_set_pointers")
+        return outs
+
+    def _capture(self, x: torch.Tensor):
         self.arr, self.keep = rt.block_array(self.net._blocks())
         self.nblk = len(self.keep)
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self._run_middle()             # warm-up outside capture: lazy packs, scratch allocation, function attributes
+            warm = self._io(x)             # warm-up outside capture: lazy packs, scratch allocation, function attributes
+            self._run_parts()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize(self.device)
+        del warm
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._run_middle()
+            self._run_parts()
         self.graph = g
         self.stamp = rt.weights_stamp(self._params)
 
     # -- one call ---------------------------------------------------------------------------------------------------------
     def __call__(self, x: torch.Tensor):
         if self.graph is None or rt.weights_stamp(self._params) != self.stamp:
-            self._capture()                # first use, or the weights changed: the graph holds the old packed buffers
-        L, sp, per = _lib.lib(), _lib.stream_ptr(), self.per
-        chk = _lib.check
-        dev, n = self.device, self.N
-        if self.mode == "fwd":
-            for i, ws in enumerate(self.ws):       # per part: it also writes the part's plane-blocked F input
-                chk(L.selfc_freq_fwd(x[i * per:(i + 1) * per].data_ptr(), ws.x1.data_ptr(), ws.x2.data_ptr(), ws.fd.data_ptr(), ws.FC,
-                                     per, self.H, self.W, self.k, sp), "selfc_freq_fwd")
-            self.graph.replay()
-            out = torch.empty((n, self.c1 + self.c2, self.h, self.w), dtype=torch.float32, device=dev)
-            chk(L.selfc_latent_to_nchw(self.X1.data_ptr(), self.X2.data_ptr(), out.data_ptr(), n, self.c1, self.c2, self.h, self.w, sp),
-                "selfc_latent_to_nchw")
-            return out
-        if self.mode == "rev":
-            chk(L.selfc_nchw_to_nhwc4(x.data_ptr(), self.X1.data_ptr(), n, 3, self.h, self.w, sp), "selfc_nchw_to_nhwc4")
-        else:
-            chk(L.selfc_nchw_to_latent(x.data_ptr(), self.X1.data_ptr(), self.X2.data_ptr(), None, self.ws[0].FC,
-                                       n, self.c1, self.c2, self.h, self.w, sp), "selfc_nchw_to_latent")
+            self._capture(x)               # first use, or the weights changed: the graph holds the old packed buffers
+        outs = self._io(x)
         self.graph.replay()
-        out = torch.empty((n, 3, self.H, self.W), dtype=torch.float32, device=dev)
-        chk(L.selfc_freq_inv(self.X1.data_ptr(), self.X2.data_ptr(), out.data_ptr(), n, self.h, self.w, self.k, sp), "selfc_freq_inv")
-        if self.mode != "rev":
-            return out
-        hf = torch.empty((n, self.c2, self.h, self.w), dtype=torch.float32, device=dev)
-        chk(L.selfc_nhwc4_to_nchw(self.HF.data_ptr(), hf.data_ptr(), n, self.c2, self.h, self.w, sp), "selfc_nhwc4_to_nchw")
-        return out, hf
+        # x must outlive the replay's reads: the caller's reference may die right after this returns (e.g. the contiguous copy of
+        # a sliced view made at the boundary), and the caching allocator could hand its memory to a tensor written on ANOTHER
+        # stream; on the calling stream itself reuse is ordered behind the replay.  Outputs are ordinary tensors of this stream.
+        self._last_x = x
+        return outs[0] if len(outs) == 1 else outs
 
     def nbytes(self) -> int:
         return sum(ws.nbytes() for ws in self.ws) + (self.HF.numel() * 4 if self.mode == "rev" else 0)
