@@ -91,6 +91,25 @@ inline hipError_t lds_optin(const void* fn, int bytes, std::atomic<unsigned long
   return e;
 }
 
+// Raw BUFFER loads (SGPR descriptor + one 32-bit per-lane byte offset + an SGPR byte offset): the weight-fragment streams are read
+// at `uniform base + chunk offset + 16 * tid`.  As flat / global loads hipcc materialises one 64-bit per-lane address PER CHUNK and
+// keeps them all live across the tile loop (20-48 VGPRs in the 256-register fused kernels: fused_f_kernel<1> spilled); as buffer
+// loads the chunk offset is an SGPR add and the lane offset is ONE VGPR.  Out-of-range lanes read zeros (num_records), which also
+// replaces the min() clamps on the last partial piece.
+typedef __amdgpu_buffer_rsrc_t buf_rsrc;
+__device__ __forceinline__ buf_rsrc make_rsrc(const void* base, const unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);     // gfx9 word 3: 32-bit data format, no swizzle
+}
+__device__ __forceinline__ u32x4 buffer_load_b128(const buf_rsrc r, const unsigned lane_off, const unsigned uniform_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, uniform_off, 0);
+}
+
+// Store with the same addressing; a lane whose offset is >= num_records (BUF_OOB) stores nothing - masked lanes need no branch.
+constexpr unsigned BUF_OOB = 0x80000000u;       // resources built by make_rsrc are kept below 2 GiB where this is used
+__device__ __forceinline__ void buffer_store_b128(const u32x4 v, const buf_rsrc r, const unsigned lane_off, const unsigned uniform_off) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, lane_off, uniform_off, 0);
+}
+
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
   f16x2 h = {(f16)a, (f16)b};
   return __builtin_bit_cast(uint32_t, h);

@@ -744,7 +744,13 @@ int launch_pair(FFArgs& a, int maxwg, hipStream_t s) {
 
 }  // namespace
 
-// conv1..conv4 of F (cin = 48) on its dense buffer: two launches.  w = [pair 0: 72 fragments][pair 1: 144 fragments].
+// csrc/fused_f16.hip: the same two pair launches on the 16x16x32 kernels
+int launch_fused_f16_pairs(void* dense, const void* w16, const float* const* bias, int N, int H, int W, hipStream_t s,
+                           const void* w5p16, float* pf, int keep_features);
+
+// conv1..conv4 of F (cin = 48) on its dense buffer: two launches.  w = [pair 0: 72 fragments][pair 1: 144 fragments]
+// [the 16x16x32 stream: 74 + 146 fragments], w5p = [11 fragments][6 fragments of the 16x16x32 kernels] (packing.subnet_pack_entries).
+// The 16x16x32 kernels (csrc/fused_f16.hip) are the default; SELFC_F_MFMA32=1 selects the 32x32x16 kernels of this file.
 // With w5p (11 partial-product fragments), pf and x1 the temporal conv5 + coupling y1 = x1 +- F is done here as well:
 // the two launches emit the conv5 partial products and f_couple_kernel sums them (returns 1: conv5 handled).
 int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, int H, int W, hipStream_t s,
@@ -759,7 +765,13 @@ int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, 
   a.tiles_y = (H + TS - 1) / TS;
   a.ntiles = a.tiles_x * a.tiles_y;
   a.plane = (size_t)N * H * W * 32;
-  {
+  static const bool mfma32 = getenv("SELFC_F_MFMA32") != nullptr;
+  if (!mfma32) {
+    ProfScope prof(PROF_CONV3X3, s);
+    const int rc = launch_fused_f16_pairs(dense, (const f16*)w + (size_t)(Geo<0>::NFRAG + Geo<1>::NFRAG) * 512, bias, N, H, W, s,
+                                          with_p ? (const f16*)w5p + (size_t)(Geo<0>::NP + Geo<1>::NP) * 512 : nullptr, with_p ? pf : nullptr, keep_features);
+    if (rc || !with_p) return rc;
+  } else {
     ProfScope prof(PROF_CONV3X3, s);
     a.w = (const f16*)w;
     a.bias[0] = bias[0]; a.bias[1] = bias[1];

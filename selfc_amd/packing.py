@@ -294,6 +294,78 @@ def pack_fused_f(weights: Sequence[torch.Tensor], cin: int = 48) -> torch.Tensor
     return _operand(res)
 
 
+# ---- fragment streams of csrc/fused_f16.hip (the pair kernels laid out for v_mfma_f32_16x16x32) -------------------------
+def f16_steps(pair: int, cin: int = 48):
+    """K schedule of the 16x16x32 pair kernels: (merged steps, FM steps), each step = four octet descriptors (tap, first input
+    channel) | None, one per lane group q = lane >> 4 (8 input channels each).  x part (cin = 48): nine steps of 32 channels
+    of one tap, then the taps' last 16 channels paired (taps 3r / 3r+1: next pixel; taps 2 / 5: next row; tap 8 alone, upper
+    half zero) - the byte offsets of a lane group then differ by per-lane constants only (csrc/fused_f16.hip: bA / bP / bR /
+    bS).  f1, f2 (pair 1) and the FM part: one 32-channel step per tap."""
+    assert cin == 48
+    merged = [[(t, 0), (t, 8), (t, 16), (t, 24)] for t in range(9)]
+    merged += [[(3 * r, 32), (3 * r, 40), (3 * r + 1, 32), (3 * r + 1, 40)] for r in range(3)]
+    merged += [[(2, 32), (2, 40), (5, 32), (5, 40)], [(8, 32), (8, 40), None, None]]
+    for f in range(2 * pair):
+        merged += [[(t, cin + 32 * f + 8 * q) for q in range(4)] for t in range(9)]
+    nin = cin + 64 * pair
+    fm = [[(t, nin + 8 * q) for q in range(4)] for t in range(9)]
+    return merged, fm
+
+
+def _frag16(w9: torch.Tensor, step, rb: int) -> torch.Tensor:
+    """One A fragment [64 lanes][8] of v_mfma_f32_16x16x32: lane (q, i): output row i of block rb = channel 8 (i >> 2) + 4 rb + (i & 3)
+    (so that a lane's accumulators of the two blocks are 8 CONSECUTIVE channels), k = the 8 input channels of octet q."""
+    rows = torch.tensor([8 * (i >> 2) + 4 * rb + (i & 3) for i in range(16)], device=w9.device)
+    out = torch.zeros(4, 16, 8, dtype=w9.dtype, device=w9.device)
+    for q, d in enumerate(step):
+        if d is not None:
+            tap, c0 = d
+            out[q] = w9[rows][:, c0:c0 + 8, tap]
+    return out.reshape(64, 8)
+
+
+def pack_fused_f16(weights: Sequence[torch.Tensor], cin: int = 48) -> torch.Tensor:
+    """conv1..conv4 of a cin == 48 dense block -> the fragment stream of csrc/fused_f16.hip: per pair (conv a, conv b) the merged
+    steps [a rb0, a rb1, b rb0, b rb1] followed by the FM steps [b rb0, b rb1]: 74 + 146 fragments -> f16 [220, 64, 8]."""
+    assert cin == 48 and len(weights) == 4
+    out = []
+    for pair in (0, 1):
+        nin = cin + 64 * pair
+        ws = []
+        for j in (0, 1):
+            w = weights[2 * pair + j].detach().float()
+            if w.dim() == 5:
+                w = w[:, :, 0]
+            assert w.shape == (32, nin + 32 * j, 3, 3), tuple(w.shape)
+            ws.append(w.reshape(32, nin + 32 * j, 9))
+        merged, fm = f16_steps(pair, cin)
+        for st in merged:
+            out += [_frag16(ws[0], st, 0), _frag16(ws[0], st, 1), _frag16(ws[1], st, 0), _frag16(ws[1], st, 1)]
+        for st in fm:
+            out += [_frag16(ws[1], st, 0), _frag16(ws[1], st, 1)]
+    res = torch.stack(out)
+    assert res.shape[0] == 220
+    return _operand(res)
+
+
+def pack_f5_partial16(w5: torch.Tensor, cin: int = 48) -> torch.Tensor:
+    """F's temporal conv5 (cout <= 3, cin + 128, 3, 1, 1) as the A fragments of the 16x16x32 partial products: row 4 tap + oc
+    (12 of 16 used), K = 32 input channels in the reference's concat order: x2[0:32], x2[32:48] (upper half zero), f1, f2 (pair
+    0), f3, f4 (pair 1) -> f16 [6, 64, 8]."""
+    w = w5.detach().float()
+    cout, ctot = w.shape[0], w.shape[1]
+    assert w.shape[2:] == (3, 1, 1) and cout <= 3 and ctot == cin + 128 and cin == 48, tuple(w.shape)
+    wk = torch.zeros(16, ctot + 16, dtype=torch.float32, device=w.device)       # + 16 zero columns behind the last channel
+    for tap in range(3):
+        wk[tap * 4: tap * 4 + cout, :ctot] = w[:, :, tap, 0, 0]
+    zero = ctot
+    frags = []
+    for c0, nreal in ((0, 32), (32, 16), (48, 32), (80, 32), (112, 32), (144, 32)):
+        cols = [c0 + k if k < nreal else zero for k in range(32)]
+        frags.append(wk[:, cols].reshape(16, 4, 8).permute(1, 0, 2).reshape(64, 8))
+    return _operand(torch.stack(frags))
+
+
 def pack_f5_partial(w5: torch.Tensor, cin: int = 48) -> torch.Tensor:
     """Temporal conv5 of F (cout, cin + 128, 3, 1, 1), cout <= 3, as the A fragments of the conv5 partial products the
     fused F launches emit (csrc/fused_f.hip): row = 4 tap + oc (rows 0-2, 4-6, 8-10 of 32 used), one 32x32x16 fragment per 16 input
@@ -493,9 +565,10 @@ def subnet_pack_entries(prefix: str, weights: Sequence[torch.Tensor], biases: Se
     if cin == 3 and temporal:
         e[f"{prefix}wfused"] = (pack_fused_gh(list(weights[:4]), 3), "w")
     if cin == 48:
-        e[f"{prefix}wfused"] = (pack_fused_f(list(weights[:4]), 48), "w")
+        # [the 32x32x16 stream (csrc/fused_f.hip): 216 fragments | the 16x16x32 stream (csrc/fused_f16.hip): 220 fragments]
+        e[f"{prefix}wfused"] = (torch.cat((pack_fused_f(list(weights[:4]), 48), pack_fused_f16(list(weights[:4]), 48))), "w")
         if temporal and cout <= 3:
-            e[f"{prefix}w5p"] = (pack_f5_partial(weights[4], 48), "w")
+            e[f"{prefix}w5p"] = (torch.cat((pack_f5_partial(weights[4], 48), pack_f5_partial16(weights[4], 48))), "w")
     if with_bwd and cout <= 96:
         wt5, wtd, wtx = pack_subnet_bwd(weights, cin, cout, temporal)
         e[f"{prefix}wt5"] = (wt5, "w")

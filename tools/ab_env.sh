@@ -11,7 +11,7 @@ for r in $(seq 1 $ROUNDS); do
     env $v timeout -k 10 180 python3 $ARGS 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readlines()[-1]); k=d['kernel_ms_per_step']
-print('[$v]', 'round $r', 'value', d['value'], 'ms', d['ms_per_step'], 'gh', k.get('fused_gh'), 'f', k.get('conv3x3'), 'c5gh', k.get('conv5_GH'), 'c5f', k.get('conv5_F'), flush=True)
+print('[$v]', 'round $r', 'value', d['value'], 'ms', d['ms_per_step'], 'gh', k.get('fused_gh'), 'f', k.get('conv3x3'), 'c5gh', k.get('conv5_GH'), 'c5f', k.get('conv5_F'), 'clk', d['box_calibration']['shader_clock_GHz_under_the_workload'], 'par', d.get('parity'), flush=True)
 " || exit 1
   done
 done
