@@ -41,7 +41,7 @@ SYMBOLS = [
     "selfc_bwd_scale", "selfc_bwd_to_planes", "selfc_f16_rows_to_planes", "selfc_bwd_conv_planes",
     "selfc_bwd_wgrad_scratch_bytes", "selfc_bwd_wgrad", "selfc_gmm_sample_bwd", "selfc_gmm_sample_generic_bwd", "selfc_lrelu_bwd",
     "selfc_globalagg_bwd_scratch_bytes", "selfc_globalagg_bwd", "selfc_rowsum_accum",
-    "selfc_set_pointers", "selfc_freq_fwd_ind", "selfc_freq_inv_ind", "selfc_nchw_to_latent_ind", "selfc_latent_to_nchw_ind",
+    "selfc_stream_create", "selfc_stream_destroy", "selfc_set_pointers", "selfc_freq_fwd_ind", "selfc_freq_inv_ind", "selfc_nchw_to_latent_ind", "selfc_latent_to_nchw_ind",
     "selfc_nchw_to_nhwc4_ind", "selfc_nhwc4_to_nchw_ind",
 ]
 
@@ -140,6 +140,8 @@ def lib():
             "selfc_gmm_sample_generic_bwd": [vp, vp, vp, vp, sz, i, i, i, i, f, vp],
             "selfc_lrelu_bwd": [vp, vp, sz, vp],
             "selfc_rowsum_accum": [C.POINTER(RowSum), vp],
+            "selfc_stream_create": [C.POINTER(vp)],
+            "selfc_stream_destroy": [vp],
             "selfc_set_pointers": [vp, i, vp, vp, vp, vp, vp],
             "selfc_freq_fwd_ind": [vp, sz, vp, vp, vp, i, i, i, i, i, vp],
             "selfc_freq_inv_ind": [vp, vp, vp, sz, i, i, i, i, vp],

@@ -48,7 +48,9 @@ def side_stream(device, which: int = 0):
         return None
     key = (str(device), which)
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
+        # both side streams at once: different from each other and from torch's capture stream (runtime.distinct_streams)
+        a, b = rt.distinct_streams(2, device)
+        _SIDE[(str(device), 0)], _SIDE[(str(device), 1)] = a, b
     return _SIDE[key]
 
 

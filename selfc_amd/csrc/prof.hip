@@ -116,6 +116,20 @@ int selfc_profile_clock_sample(unsigned long long* out2, int micros, void* strea
   return e == hipSuccess ? SELFC_OK : -(int)e - 1000;
 }
 
+// A HIP stream of the caller's own (non-blocking), outside torch's 32-entry pool: runtime.own_stream wraps it as a
+// torch.cuda.ExternalStream.  Graph captures of this package fork onto / capture on such streams only - see runtime.own_stream.
+int selfc_stream_create(void** out) {
+  if (!out) return SELFC_EINVAL;
+  hipStream_t s = nullptr;
+  const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  *out = (void*)s;
+  return e == hipSuccess ? SELFC_OK : -(int)e - 1000;
+}
+int selfc_stream_destroy(void* stream) {
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  return e == hipSuccess ? SELFC_OK : -(int)e - 1000;
+}
+
 int selfc_profile_calibrate(double* mfma_tflops, double* copy_GBps, void* stream) {
   if (!mfma_tflops || !copy_GBps) return SELFC_EINVAL;
   hipStream_t s = (hipStream_t)stream;

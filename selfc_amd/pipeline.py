@@ -93,14 +93,14 @@ class RescaleRoundTrip:
     def capture(self, x: torch.Tensor):
         """Record one run into a hipGraph (replay with ``replay()``); x must stay at this address."""
         self.static_x = x
-        s = torch.cuda.Stream()
+        s = rt.warmup_stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self.run(x)                    # warm-up outside capture (lazy function attributes etc.)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        g = rt.new_graph()
+        with rt.graph_capture(g, x.device):
             self.run(x)
         self.graph = g
         self._graph_stamp = self._stamp
@@ -160,7 +160,8 @@ class MultiStreamRoundTrip:
         self.per = n_frames // nstreams
         part_cls = part_cls or RescaleRoundTrip          # e.g. FullTestPath
         self.parts = [part_cls(net, self.per, H, W, device) for _ in range(nstreams)]
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(nstreams)]
+        self._own_streams = [rt.OwnStream(device) for _ in range(nstreams)]      # the package's own HIP streams (runtime.graph_capture)
+        self.streams = [o.stream for o in self._own_streams]
         self.out = torch.empty((n_frames, 3, H, W), dtype=torch.float32, device=device)
         for i, p in enumerate(self.parts):           # parts write straight into slices of one output
             p.out = self.out[i * self.per:(i + 1) * self.per]
@@ -187,14 +188,14 @@ class MultiStreamRoundTrip:
         if per_stream:
             graphs = []
             for i, p in enumerate(self.parts):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                g = rt.new_graph()
+                with rt.graph_capture(g, x.device):
                     p.run(x[i * self.per:(i + 1) * self.per])
                 graphs.append(g)
             self.graphs = graphs
         else:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            g = rt.new_graph()
+            with rt.graph_capture(g, x.device):
                 self.run(x)
             self.graph = g
         for p in self.parts:
@@ -254,7 +255,8 @@ class ModuleGraph:
         for i, ws in enumerate(self.ws):
             ws.x1, ws.x2 = self.X1[i * per:(i + 1) * per], self.X2[i * per:(i + 1) * per]
         self.lat = [ws.latent() for ws in self.ws]
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(nstreams)] if nstreams > 1 else []
+        self._own_streams = [rt.OwnStream(device) for _ in range(nstreams)] if nstreams > 1 else []
+        self.streams = [o.stream for o in self._own_streams]
         self._params = [p for b in net._blocks() for p in rt.plist(b)]
         if mode == "rev":
             stp = net.stp_net
@@ -335,7 +337,7 @@ class ModuleGraph:
     def _capture(self, x: torch.Tensor):
         self.arr, self.keep = rt.block_array(self.net._blocks())
         self.nblk = len(self.keep)
-        s = torch.cuda.Stream(device=self.device)
+        s = rt.warmup_stream(self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             warm = self._io(x)             # warm-up outside capture: lazy packs, scratch allocation, function attributes
@@ -343,8 +345,8 @@ class ModuleGraph:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize(self.device)
         del warm
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        g = rt.new_graph()
+        with rt.graph_capture(g, self.device):
             self._run_parts()
         self.graph = g
         self.stamp = rt.weights_stamp(self._params)

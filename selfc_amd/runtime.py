@@ -200,6 +200,115 @@ def params_key(*mods) -> Tuple:
     return (_WEIGHT_EPOCH,) + tuple((p.data_ptr(), p._version) for m in mods for p in plist(m))
 
 
+def new_graph() -> "torch.cuda.CUDAGraph":
+    """A fresh torch.cuda.CUDAGraph to capture into, behind a garbage collection and a device sync.
+
+    Why: on this stack (ROCm 7.0 runtime bundled with torch 2.10) replaying a just-instantiated hipGraph crashed inside
+    hip::Graph::UpdateStreams (host segfault in hipGraphLaunch) when OTHER graph execs had been destroyed between its
+    instantiation and its first launch - which is what Python's cyclic garbage collector does at a random later moment to
+    graphs that died inside reference cycles (optimizer <-> LR scheduler is one).  Collecting first means every dead graph is
+    destroyed BEFORE the new one is instantiated; seen only in long processes (the whole GPU test suite), never in a
+    fresh one.  Every capture site of the package goes through here."""
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    return torch.cuda.CUDAGraph()
+
+
+class OwnStream:
+    """A non-blocking HIP stream of the package's own (selfc_stream_create), outside torch's 32-entry round-robin pool,
+    wrapped as a torch.cuda.ExternalStream (`.stream`); destroyed with `close()` / when the object dies."""
+
+    def __init__(self, device=None):
+        p = C.c_void_p()
+        _lib.check(_lib.lib().selfc_stream_create(C.byref(p)), "selfc_stream_create")
+        self.handle = p.value
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.stream = torch.cuda.ExternalStream(self.handle, device=dev)
+
+    def close(self):
+        if self.handle:
+            try:
+                self.stream.synchronize()
+                _lib.lib().selfc_stream_destroy(C.c_void_p(self.handle))
+            except Exception:      # noqa: BLE001  (interpreter shutdown)
+                pass
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
+class graph_capture:
+    """`with graph_capture(g, device): ...` = `with torch.cuda.graph(g): ...` on a capture stream created for THIS capture and
+    destroyed behind it.
+
+    torch.cuda.graph captures every graph of a process on ONE stream of its shared pool, and forks go to other pool streams.
+    In a long process (the whole GPU test suite: ~30 captures of two- and three-branch graphs before it) the captured
+    training step then segfaulted at its first replay - hip::Graph::UpdateStreams indexed past the exec's parallel streams
+    (ROCm 7.0 runtime of torch 2.10; native backtrace in DESIGN.md section 4b) - although the streams, waits and events of
+    the capture were call for call those of a fresh process, where it replays fine.  With a capture stream (or fork streams)
+    that no earlier capture has touched the same sequence is fine too: what differs is state the runtime keeps on long-lived
+    streams across captures.  So: a fresh capture stream per capture, and (`side_streams`) fresh fork streams for the
+    captures that fork onto module-level streams."""
+
+    def __init__(self, g, device=None, pool=None, fresh_side=None):
+        self.g, self.device, self.pool, self.fresh_side = g, device, pool, fresh_side
+        self.own, self.ctx, self.swapped = None, None, None
+
+    def __enter__(self):
+        self.own = OwnStream(self.device)
+        if self.fresh_side is not None:       # dict of module-level side streams to replace for the duration of the capture
+            self.swapped = dict(self.fresh_side)
+            self.side_own = {k: OwnStream(self.device) for k in self.fresh_side}
+            for k, o in self.side_own.items():
+                self.fresh_side[k] = o.stream
+        kw = {} if self.pool is None else {"pool": self.pool}
+        self.ctx = torch.cuda.graph(self.g, stream=self.own.stream, **kw)
+        return self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        r = self.ctx.__exit__(*exc)
+        torch.cuda.synchronize()
+        if self.swapped is not None:
+            self.fresh_side.update(self.swapped)
+            for o in self.side_own.values():
+                o.close()
+        self.own.close()
+        return r
+
+
+def warmup_stream(device=None) -> "torch.cuda.Stream":
+    """A side stream for the eager warm-up run in front of a capture that is NOT the stream torch will capture on.
+
+    torch.cuda.Stream() hands out the 32 streams of a per-device pool round-robin, and torch.cuda.graph captures on one pool
+    stream it keeps for the life of the process.  In a long process (the whole GPU test suite) the warm-up stream therefore
+    comes out as that very capture stream every 32nd time - and the training step captured right after such a warm-up
+    segfaulted at its first replay (hip::Graph::UpdateStreams read past the exec's parallel streams; ROCm 7.0 runtime of torch
+    2.10).  Warm-up work bound to the capture stream (autograd's gradient accumulators remember the stream they were created
+    on) is the difference between the two cases; a distinct stream avoids it."""
+    return distinct_streams(1, device)[0]
+
+
+def distinct_streams(n: int, device=None, avoid=()) -> list:
+    """n streams of torch's pool that are pairwise different HIP streams and different from the capture stream, the current
+    stream and `avoid` (the pool is a 32-entry round robin: two torch.cuda.Stream() objects can be ONE stream - a fork onto
+    "another" stream is then no fork at all, and see warmup_stream for what the capture stream itself as a side stream does)."""
+    cap = torch.cuda.graphs.graph.default_capture_stream
+    if cap is None:                     # torch creates it at the first capture: make that happen now, so that it can be told apart
+        cap = torch.cuda.graphs.graph.default_capture_stream = torch.cuda.Stream()
+    taken = {cap.cuda_stream, torch.cuda.current_stream(device).cuda_stream} | {a.cuda_stream for a in avoid}
+    out = []
+    for _ in range(64):
+        st = torch.cuda.Stream(device=device)
+        if st.cuda_stream not in taken:
+            taken.add(st.cuda_stream)
+            out.append(st)
+            if len(out) == n:
+                return out
+    raise RuntimeError("torch's stream pool ran out of distinct streams")
+
+
 _FN: Dict[str, object] = {}
 
 

@@ -23,6 +23,7 @@ through autograd and DDP's buckets (no flat buffer, no capture).
 """
 from __future__ import annotations
 
+import os
 from collections import Counter, OrderedDict, defaultdict
 from typing import Optional
 
@@ -359,7 +360,7 @@ class RescaleTrainer:
         if not self.capturable:
             raise RuntimeError("construct RescaleTrainer(..., capturable=True) to capture the step")
         self._static_h, self._static_l = real_H.clone(), ref_L.clone()
-        s = torch.cuda.Stream()
+        s = rt.warmup_stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
@@ -369,9 +370,10 @@ class RescaleTrainer:
         torch.cuda.synchronize()
         if self.sink is None:
             self.optimizer_G.zero_grad(set_to_none=True)
-        g = torch.cuda.CUDAGraph()
+        g = rt.new_graph()
+        # every capture of the step: own capture stream, own side streams for its duration (runtime.graph_capture)
         if not self.data_parallel:
-            with torch.cuda.graph(g):
+            with rt.graph_capture(g, self._static_h.device, fresh_side=ag._SIDE):
                 if self.sink is not None:
                     self.sink.zero()                 # part of the replayed step
                 self._static_losses = self._step(self._static_h, self._static_l)
@@ -379,12 +381,12 @@ class RescaleTrainer:
             return self
         # data parallel: the collective stays OUTSIDE the captured regions (an RCCL call inside a hipGraph is not something
         # this stack promises): graph 1 = zero + forward + backward, eager all-reduce of the flat buffer, graph 2 = clip + Adam
-        with torch.cuda.graph(g):
+        with rt.graph_capture(g, self._static_h.device, fresh_side=ag._SIDE):
             self.sink.zero()
             self._static_losses = self._forward_backward(self._static_h, self._static_l)
         self._sync_grads()
-        g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2, pool=g.pool()):
+        g2 = rt.new_graph()
+        with rt.graph_capture(g2, self._static_h.device, pool=g.pool()):
             self._clip_and_step()
         self.graph, self.graph_tail = g, g2
         return self
