@@ -213,7 +213,7 @@ def main():
     # class "conv3x3" = conv1-4 of F: one timed scope per block and direction when the pairwise-fused kernels run
     # (fused_f_kernel<0> + fused_f_kernel<1>, two launches under one scope), four (one per conv) on the layer-wise path
     f_scopes = max(1, round(cls_n.get("conv3x3", 0) / (16.0 * args.steps)))
-    f_label = ("fused_f_kernel<0> + <1> (conv1-4 of F, pairwise fused, two launches timed as one)" if f_scopes == 1
+    f_label = ("fused_f16_kernel<0> + <1> (conv1-4 of F, pairwise fused on v_mfma_f32_16x16x32, two launches timed as one)" if f_scopes == 1
                else "conv3x3_kernel (conv1-4 of F, layer-wise)")
     for name, mac_px, per_blockdir, label in (("conv3x3", MAC_F14_PX, f_scopes, f_label),
                                               ("fused_gh", MAC_GH14_PX, 1, "fused_gh_kernel (conv1-4 of G+H, fused)")):

@@ -305,7 +305,7 @@ int selfc_profile_calibrate(double* mfma_tflops, double* copy_GBps, void* stream
  * 100 MHz counter for `micros` microseconds (<= 500,000) and then writes out2[0] = shader cycles, out2[1] = 100 MHz ticks
  * (device memory, 2 x u64).  Launch it on a side stream next to the workload; GHz = 0.1 * out2[0] / out2[1]. */
 int selfc_profile_clock_sample(unsigned long long* out2, int micros, void* stream);
-/* A non-blocking HIP stream owned by the caller (hipStreamCreateWithFlags / hipStreamDestroy).  The host side captures its
+/* (abi 11) A non-blocking HIP stream owned by the caller (hipStreamCreateWithFlags / hipStreamDestroy).  The host side captures its
  * hipGraphs on, and forks onto, streams of its own rather than streams of torch's shared 32-entry pool (runtime.own_stream). */
 int selfc_stream_create(void** out);
 int selfc_stream_destroy(void* stream);

@@ -25,7 +25,7 @@ def operand_dtype():
 SUBNET_D2DT = 0
 SUBNET_DB2D = 1
 LAT_KEEP_FEATURES = 1      # selfc_latent.flags (SELFC_LAT_KEEP_FEATURES)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 #: every symbol include/selfc_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

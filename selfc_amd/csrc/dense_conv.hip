@@ -1030,8 +1030,8 @@ int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s)
 
 extern "C" {
 
-const char* selfc_version(void) { return "selfc_hip gfx950 abi10 operands=" SELFC_OPERAND_NAME; }
-int selfc_abi_version(void) { return 10; }
+const char* selfc_version(void) { return "selfc_hip gfx950 abi11 operands=" SELFC_OPERAND_NAME; }
+int selfc_abi_version(void) { return 11; }
 
 int selfc_invblock_run(const selfc_invblock_w* blk, const selfc_latent* lat, int rev, void* stream) {
   if (!blk || !latent_ok(lat)) return SELFC_EINVAL;

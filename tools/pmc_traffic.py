@@ -1,6 +1,6 @@
 """profiles/rN/pmc_traffic.json from the PMC and kernel-trace summaries of tools/profile_gpu.sh.
 
-  python tools/pmc_traffic.py gpurun_out/prof_<tag> profiles/r3/pmc_traffic.json <source label> [frames per launch = 14]
+  python tools/pmc_traffic.py gpurun_out/prof_<tag> profiles/r4/pmc_traffic.json <source label> [frames per launch = 14]
 
 Per kernel of the hot path (mean per dispatch):
   hbm_bytes_per_launch   FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KiB
@@ -32,12 +32,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def csrc_sha():
+    """the hash bench.py compares: every kernel source and header of csrc/, names included"""
     h = hashlib.sha256()
-    for f in ("common.hpp", "dense_conv.hip", "fused_f.hip", "fused_gh.hip"):
-        h.update(open(os.path.join(ROOT, "selfc_amd", "csrc", f), "rb").read())
+    csrc = os.path.join(ROOT, "selfc_amd", "csrc")
+    for f in sorted(n_ for n_ in os.listdir(csrc) if n_.endswith((".hip", ".hpp"))):
+        h.update(f.encode())
+        h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 
-NAMES = {"fused_gh": r"fused_gh_kernel", "fused_f<0>": r"fused_f_kernel<0>", "fused_f<1>": r"fused_f_kernel<1>",
+NAMES = {"fused_gh": r"fused_gh_kernel", "fused_f<0>": r"fused_f(16)?_kernel<0", "fused_f<1>": r"fused_f(16)?_kernel<1",
          "conv3x3": r"^conv3x3_kernel<16, 16, 4, 2, 0, false>", "conv5_GH": r"tconv5_kernel<2, 3, 4, 1, 3>", "conv5_F": r"tconv5_kernel<1, 1, 6, 0, 2>",
          "f_couple": r"f_couple_kernel"}
 
