@@ -606,7 +606,8 @@ inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 
 template <int PAIR>
 int launch_pair16(F16Args& a, int maxwg, hipStream_t s) {
   using G = Geo<PAIR>;
-  const bool big = (size_t)a.plane * 2 * (G::NPLANE_IN + 2) >= 0x7fff0000ull ||      // beyond what the buffer-resource path addresses
+  static const bool force_flat = getenv("SELFC_F16_FLAT") != nullptr;                 // developer / test switch
+  const bool big = force_flat || (size_t)a.plane * 2 * (G::NPLANE_IN + 2) >= 0x7fff0000ull ||      // beyond what the buffer-resource path addresses
                    (size_t)a.N * a.H * a.W * 48 >= 0x7fff0000ull;
   static std::atomic<unsigned long long> optin{0}, optin_flat{0};
   if (hipError_t e = big ? lds_optin(reinterpret_cast<const void*>(&fused_f16_kernel<PAIR, false>), G::LDS, optin_flat)

@@ -304,11 +304,12 @@ np.savez(sys.argv[2], z=z.cpu().numpy(), xr=xr.cpu().numpy())
 """
 
 
-@pytest.mark.parametrize("switch", ["SELFC_NO_FUSE_F=1", "SELFC_NO_F5P=1", "SELFC_NO_FUSE=1"])
+@pytest.mark.parametrize("switch", ["SELFC_NO_FUSE_F=1", "SELFC_NO_F5P=1", "SELFC_NO_FUSE=1", "SELFC_F_MFMA32=1", "SELFC_F16_FLAT=1"])
 def test_fused_paths_agree_with_alternative_paths(dev, tmp_path, switch):
-    """The default kernels (F's conv1-4 as two pairwise-fused launches with conv5 as partial products, G/H's conv1-4 as one
-    depth-4 fused launch) against the alternative paths of the library - layer-wise conv3x3 / temporal-conv5 kernels, the
-    depth-3 + conv4 split of G/H - run in a child process with the developer switch set: same f16 operands,
+    """The default kernels (F's conv1-4 as two pairwise-fused 16x16x32 launches with conv5 as partial products, G/H's conv1-4 as
+    one depth-4 fused launch) against the alternative paths of the library - layer-wise conv3x3 / temporal-conv5 kernels, the
+    32x32x16 pair kernels of F (SELFC_F_MFMA32), the flat-address instantiation of the 16x16x32 kernels that buffers beyond 2 GiB
+    take (SELFC_F16_FLAT) - run in a child process with the developer switch set: same f16 operands,
     different fp32 summation order (which flips some f16 roundings of the features): the two paths are each within
     ~3.5e-4 of the fp32 oracle and must agree with each other inside the parity tolerance.  Ragged size (18 x 25 latent)."""
     import os
