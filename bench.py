@@ -391,7 +391,13 @@ def main():
             import bench_train
             tg = bench_train.run(batch=8, size=144, steps=20, warmup=3, fh_loss="gmm", profile=False, graph=True)
             te = bench_train.run(batch=8, size=144, steps=20, warmup=3, fh_loss="gmm", profile=False)
+            by_batch = {}
+            for lb in (1, 2, 4):       # the reference's global batch 8 split over 8 / 4 / 2 ranks (train_rescaling_selfc_large.yml:12,26: 2 GPUs x 4)
+                r_ = bench_train.run(batch=lb, size=144, steps=20, warmup=2, fh_loss="gmm", profile=False, graph=True)
+                by_batch[str(lb)] = round(r_["ms_per_step"], 2)
+            by_batch["8"] = round(tg["ms_per_step"], 2)
             out["train_step"] = {"septuplets_per_s": round(tg["value"], 1), "ms_per_step": round(tg["ms_per_step"], 2),
+                                 "captured_ms_per_step_by_local_batch": by_batch,
                                  "launch": "RescaleTrainer.capture(): the whole optimisation step replayed as one hipGraph",
                                  "eager_ms_per_step": round(te["ms_per_step"], 2), "eager_septuplets_per_s": round(te["value"], 1),
                                  "config": "8 x 7x3x144x144 crops, fh_loss gmm, l2 + l1 losses, clip 10, Adam (one flat tensor); 3 streams",
