@@ -215,6 +215,18 @@ int selfc_coupling_fwd(int rev, const float* x2, const float* g, const float* h,
  * rev != 0: v = y2 (output), dx2 = dy2*e^-s, dh = -dy2*y2*ds/dh (dG = -dx2); ds/dh = clamp*(1-(s/clamp)^2)/2. */
 int selfc_coupling_bwd(int rev, const float* v, const float* s, const float* dy2, float* dx2, float* dh, float clamp,
                        size_t n, void* stream);
+/* (abi 12) max|dOut| where dOut is produced, instead of a pass over it per subnet call: a training step issues 61 such passes on
+ * its critical path.  `selfc_coupling_bwd_x` also takes max|dx2| / max|dh| (either pointer may be NULL), `selfc_add_absmax` is
+ * a += b with max|a|, and `selfc_subnet_bwd_phase_x` takes the finished max of its dOut (`dout_amax`, NULL: it takes the max itself)
+ * and leaves max|dx| of what it stored in `dx_amax_out` (NULL: not wanted).  Every max slot is one float the CALLER zeroes first; all
+ * use atomic max on the float bits with the NaN convention of the internal pass, so gradients are bit-identical either way. */
+int selfc_coupling_bwd_x(int rev, const float* v, const float* s, const float* dy2, float* dx2, float* dh, float clamp,
+                         size_t n, float* dx2_amax, float* dh_amax, void* stream);
+int selfc_add_absmax(float* a, const float* b, size_t n, float* amax, void* stream);
+int selfc_subnet_bwd_phase_x(int phases, const selfc_subnet_bw* bw, int kind, const void* dense, const float* xin, const float* dout,
+                             float sign, float* dx, int accumulate_dx, float* const* wgrad, float* const* bgrad, float beta,
+                             void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout,
+                             const float* dout_amax, float* dx_amax_out, void* stream);
 /* Adjoint of selfc_freq_fwd (latent grads d1 [N][h][w][4], d2 [N][h][w][48] -> dx NCHW (N,3,H,W)) and of selfc_freq_inv
  * (dout NCHW -> d1, d2). */
 int selfc_freq_fwd_bwd(const float* d1, const float* d2, float* dx, int N, int H, int W, void* stream);

@@ -25,7 +25,7 @@ def operand_dtype():
 SUBNET_D2DT = 0
 SUBNET_DB2D = 1
 LAT_KEEP_FEATURES = 1      # selfc_latent.flags (SELFC_LAT_KEEP_FEATURES)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 #: every symbol include/selfc_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -41,7 +41,7 @@ SYMBOLS = [
     "selfc_bwd_scale", "selfc_bwd_to_planes", "selfc_f16_rows_to_planes", "selfc_bwd_conv_planes",
     "selfc_bwd_wgrad_scratch_bytes", "selfc_bwd_wgrad", "selfc_gmm_sample_bwd", "selfc_gmm_sample_generic_bwd", "selfc_lrelu_bwd",
     "selfc_globalagg_bwd_scratch_bytes", "selfc_globalagg_bwd", "selfc_rowsum_accum",
-    "selfc_stream_create", "selfc_stream_destroy", "selfc_set_pointers", "selfc_freq_fwd_ind", "selfc_freq_inv_ind", "selfc_nchw_to_latent_ind", "selfc_latent_to_nchw_ind",
+    "selfc_coupling_bwd_x", "selfc_add_absmax", "selfc_subnet_bwd_phase_x", "selfc_stream_create", "selfc_stream_destroy", "selfc_set_pointers", "selfc_freq_fwd_ind", "selfc_freq_inv_ind", "selfc_nchw_to_latent_ind", "selfc_latent_to_nchw_ind",
     "selfc_nchw_to_nhwc4_ind", "selfc_nhwc4_to_nchw_ind",
 ]
 
@@ -127,6 +127,10 @@ def lib():
                                  vp, sz, i, i, i, i, i, i, vp],
             "selfc_subnet_bwd_phase": [i, C.POINTER(SubnetBW), i, vp, vp, vp, f, vp, i, C.POINTER(vp), C.POINTER(vp), f,
                                        vp, sz, i, i, i, i, i, i, vp],
+            "selfc_subnet_bwd_phase_x": [i, C.POINTER(SubnetBW), i, vp, vp, vp, f, vp, i, C.POINTER(vp), C.POINTER(vp), f,
+                                         vp, sz, i, i, i, i, i, i, vp, vp, vp],
+            "selfc_coupling_bwd_x": [i, vp, vp, vp, vp, vp, f, sz, vp, vp, vp],
+            "selfc_add_absmax": [vp, vp, sz, vp, vp],
             "selfc_coupling_fwd": [i, vp, vp, vp, vp, vp, f, sz, vp],
             "selfc_coupling_bwd": [i, vp, vp, vp, vp, vp, f, sz, vp],
             "selfc_freq_fwd_bwd": [vp, vp, vp, i, i, i, vp],

@@ -239,10 +239,13 @@ def subnet_params(mod) -> List[torch.Tensor]:
 
 def subnet_bwd(mod, dense: torch.Tensor, xin: Optional[torch.Tensor], dout: torch.Tensor, sign: float,
                dx: Optional[torch.Tensor], accumulate_dx: bool, n: int, t: int, h: int, w: int,
-               want_params: bool = True, pk=None, side=None, slot: str = "", on_data_done=None) -> List[Optional[torch.Tensor]]:
+               want_params: bool = True, pk=None, side=None, slot: str = "", on_data_done=None,
+               dout_amax: Optional[torch.Tensor] = None, dx_amax_out: Optional[torch.Tensor] = None) -> List[Optional[torch.Tensor]]:
     """Backward of one DenseBlock / D2DTInput on kernel-layout buffers; returns the 10 parameter gradients
     (reference layouts) or Nones.  With `side` (a stream) the weight-gradient phase is enqueued there, ordered after the
-    data phase; the caller joins the streams before it hands the gradients on and must not reuse `slot` before that."""
+    data phase; the caller joins the streams before it hands the gradients on and must not reuse `slot` before that.
+    dout_amax: one-float tensor holding max|dout|, taken by whoever produced dout (selfc_coupling_bwd_x, selfc_add_absmax, another
+    call's dx_amax_out) - the call then skips its own pass over dout; dx_amax_out: zeroed one-float tensor that receives max|dx|."""
     cin, cout = mod.channel_in, mod.channel_out
     pk = pk if pk is not None else mod.packed()             # inside an InvBlockExp the block's plan owns the tensors
     dev = dout.device
@@ -282,21 +285,22 @@ def subnet_bwd(mod, dense: torch.Tensor, xin: Optional[torch.Tensor], dout: torc
     args = (bw, mod.kind, dense.data_ptr(), None if xin is None else xin.data_ptr(), dout.data_ptr(),
             float(sign), None if dx is None else dx.data_ptr(), 1 if accumulate_dx else 0,
             wg if want_params else None, bg if want_params else None, beta,
-            scratch.data_ptr(), scratch.numel(), n, t, h, w, cin, cout)
+            scratch.data_ptr(), scratch.numel(), n, t, h, w, cin, cout,
+            None if dout_amax is None else dout_amax.data_ptr(), None if dx_amax_out is None else dx_amax_out.data_ptr())
     if (side is None or not want_params) and on_data_done is None:
-        rt.call("selfc_subnet_bwd", *args, _lib.stream_ptr())
+        rt.call("selfc_subnet_bwd_phase_x", 3, *args, _lib.stream_ptr())
         return grads
-    rt.call("selfc_subnet_bwd_phase", 1, *args, _lib.stream_ptr())
+    rt.call("selfc_subnet_bwd_phase_x", 1, *args, _lib.stream_ptr())
     if on_data_done is not None:
         on_data_done()
     if not want_params:
         return grads
     if side is None:
-        rt.call("selfc_subnet_bwd_phase", 2, *args, _lib.stream_ptr())
+        rt.call("selfc_subnet_bwd_phase_x", 2, *args, _lib.stream_ptr())
         return grads
     side.wait_event(torch.cuda.current_stream().record_event())
     with torch.cuda.stream(side):
-        rt.call("selfc_subnet_bwd_phase", 2, *args, _lib.stream_ptr())
+        rt.call("selfc_subnet_bwd_phase_x", 2, *args, _lib.stream_ptr())
         _SLOT_BUSY[(str(dev), slot)] = side.record_event()
     return grads
 
@@ -513,7 +517,7 @@ class InvBlockFn(torch.autograd.Function):
         d1 = torch.empty((n, h, w, 4), dtype=torch.float32, device=dev)
         d2 = torch.empty((n, h, w, ws.c2p), dtype=torch.float32, device=dev)
         rt.call("selfc_nchw_to_latent", gy.data_ptr(), d1.data_ptr(), d2.data_ptr(), None, ws.FC, n, c1, c2, h, w, sp)
-        d1, dx2, gF, gG, gH = _block_backward(blk, ws, keep, rev, t, d1, d2, want, restore_fd=True)
+        d1, dx2, gF, gG, gH, _ = _block_backward(blk, ws, keep, rev, t, d1, d2, want, restore_fd=True)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((n, c1 + c2, h, w), dtype=torch.float32, device=dev)
@@ -532,16 +536,28 @@ def _join_side_streams(dev, want: bool):
         main.wait_stream(side_stream(dev, 1))
 
 
-def _block_backward(blk, ws, keep, rev, t, d1, d2, want, restore_fd, tag=""):
+#: SELFC_BWD_FOLD_AMAX=0: every subnet backward takes max|dOut| with its own pass again (A/B, and the reference for the
+#: bit-equality test of the folded path)
+_FOLD_AMAX = os.environ.get("SELFC_BWD_FOLD_AMAX", "1") != "0"
+
+
+def _block_backward(blk, ws, keep, rev, t, d1, d2, want, restore_fd, tag="", amax_in=None, amax_slots=None):
     """Gradient of one InvBlockExp call on the latent layout.  d1 / d2: gradients w.r.t. the block's outputs (y1, y2) as fp32
     [n][h][w][4] / [n][h][w][c2p] (d1 is updated in place); ws: what the forward left - fd / gd / hd (dense features), s, and
     the OUTPUT side the formulas need (forward: ws.x1 = y1; reverse: ws.x2 = y2); keep: the INPUT side the kernels overwrote
-    (forward: x2, reverse: x1).  Returns (d1, dx2, gF, gG, gH): gradients w.r.t. the inputs (x1, x2) and the parameters.
+    (forward: x2, reverse: x1).  Returns (d1, dx2, gF, gG, gH, amax_out): gradients w.r.t. the inputs (x1, x2), the parameters,
+    and (folded path) the one-float max of the gradient the NEXT block's first subnet backward scales by.
     The weight-gradient phases run on the side stream and H's chain on a third one; the caller joins them
     (_join_side_streams) before the gradients are used.  `tag` picks the scratch set: a caller that walks several blocks
     gives every block its own, so that block i's weight-gradient phases (side stream) and the data phases of the blocks
     behind it (main stream) never share a buffer and no ordering between the two streams is needed before the join
-    (~70 MB per subnet at 8 x 7 x 36 x 36; a set that IS reused before a join waits for its last reader: subnet_bwd)."""
+    (~70 MB per subnet at 8 x 7 x 36 x 36; a set that IS reused before a join waits for its last reader: subnet_bwd).
+
+    max|dOut| (every subnet backward scales its f16 gradient operands by a power of two taken from it) is taken where dOut is
+    PRODUCED - in the coupling gradient kernel (dh; reverse: also dx2), in the kernel that adds the two halves of y1's gradient
+    (F's dOut) and in F's dx epilogue (forward: the next block's d2) - instead of a pass over dOut per call (61 launches + 61
+    memsets per training step on the critical path).  amax_in: the max of this block's first dOut (forward: d2, reverse: d1)
+    from the previous block's call, or None (first block: that subnet takes it itself); amax_slots: three zeroed floats."""
     n, h, w, c2 = ws.N, ws.H, ws.W, ws.c2
     dev, sp = d1.device, _lib.stream_ptr()
     dx2 = torch.empty_like(d2)
@@ -553,40 +569,58 @@ def _block_backward(blk, ws, keep, rev, t, d1, d2, want, restore_fd, tag=""):
     side_h = side_stream(dev, 1)
     main = torch.cuda.current_stream()
     ev_h = []
+    fold = amax_slots is not None
+    A = [amax_slots[i:i + 1] for i in range(3)] if fold else [None, None, None]
+    ptr = lambda t_: None if t_ is None else t_.data_ptr()      # noqa: E731
 
-    def h_backward(xin_gh):
+    def h_backward(xin_gh, amax_dh, dx_amax=None):
         """H's whole backward (data chain, then its weight gradients) next to G's: own stream, own dx buffer."""
         if side_h is None:
-            return subnet_bwd(blk.H, ws.hd, xin_gh, dh, 1.0, d1, True, n, t, h, w, want, pb.H, side, "H" + tag), None
+            return subnet_bwd(blk.H, ws.hd, xin_gh, dh, 1.0, d1, True, n, t, h, w, want, pb.H, side, "H" + tag, dout_amax=amax_dh), None
         d1h = torch.empty_like(d1)
         side_h.wait_event(main.record_event())
         with torch.cuda.stream(side_h):
             g_ = subnet_bwd(blk.H, ws.hd, xin_gh, dh, 1.0, d1h, False, n, t, h, w, want, pb.H, None, "H" + tag,
-                            on_data_done=lambda: ev_h.append(side_h.record_event()))
+                            on_data_done=lambda: ev_h.append(side_h.record_event()), dout_amax=amax_dh)
         return g_, d1h
+
+    def join_d1(d1h, slot):
+        """d1 += d1h (H's half of y1's gradient, from its own stream) with max|d1| of the sum; returns that max (or None)"""
+        main.wait_event(ev_h[0])
+        if fold:
+            rt.call("selfc_add_absmax", d1.data_ptr(), d1h.data_ptr(), d1.numel(), ptr(slot), sp)
+            return slot
+        d1.add_(d1h)
+        return None
 
     if not rev:
         # y1 = x1 + F(x2); y2 = x2*e^s + G(y1), s = s(H(y1)).  keep = x2 (input), ws.x1 = y1
-        rt.call("selfc_coupling_bwd", 0, keep.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel, sp)
-        gH, d1h = h_backward(ws.x1)
-        gG = subnet_bwd(blk.G, ws.gd, ws.x1, d2, 1.0, d1, True, n, t, h, w, want, pb.G, side, "G" + tag)
+        rt.call("selfc_coupling_bwd_x", 0, keep.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel,
+                None, ptr(A[0]), sp)
+        gH, d1h = h_backward(ws.x1, A[0])
+        # G: dOut = d2 (max from the previous block's F epilogue).  Without the third stream H has already added its dx to d1 and
+        # G's dx epilogue is the last writer of d1: its max is then F's
+        gG = subnet_bwd(blk.G, ws.gd, ws.x1, d2, 1.0, d1, True, n, t, h, w, want, pb.G, side, "G" + tag, dout_amax=amax_in,
+                        dx_amax_out=A[1] if (fold and d1h is None) else None)
+        amax_d1 = A[1] if (fold and d1h is None) else None
         if d1h is not None:
-            main.wait_event(ev_h[0])
-            d1.add_(d1h)
+            amax_d1 = join_d1(d1h, A[1])
         if restore_fd:
             # the forward's epilogue replaced F's f16 input copy by y2: put x2 back before F's weight gradients
             rt.call("selfc_nhwc_to_planes", keep.data_ptr(), ws.fd.data_ptr(), n * h * w, c2, sp)
-        gF = subnet_bwd(blk.F, ws.fd, None, d1, 1.0, dx2, True, n, t, h, w, want, pb.F, side, "F" + tag)
-    else:
-        # y2 = (x2 - G(x1))*e^-s, s = s(H(x1)); y1 = x1 - F(y2).  keep = x1 (input), ws.x2 = y2 (also in fd)
-        gF = subnet_bwd(blk.F, ws.fd, None, d1, -1.0, d2, True, n, t, h, w, want, pb.F, side, "F" + tag)
-        rt.call("selfc_coupling_bwd", 1, ws.x2.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel, sp)
-        gH, d1h = h_backward(keep)
-        gG = subnet_bwd(blk.G, ws.gd, keep, dx2, -1.0, d1, True, n, t, h, w, want, pb.G, side, "G" + tag)
-        if d1h is not None:
-            main.wait_event(ev_h[0])
-            d1.add_(d1h)
-    return d1, dx2, gF, gG, gH
+        gF = subnet_bwd(blk.F, ws.fd, None, d1, 1.0, dx2, True, n, t, h, w, want, pb.F, side, "F" + tag, dout_amax=amax_d1, dx_amax_out=A[2])
+        return d1, dx2, gF, gG, gH, A[2]                  # dx2 is the next block's d2
+    # y2 = (x2 - G(x1))*e^-s, s = s(H(x1)); y1 = x1 - F(y2).  keep = x1 (input), ws.x2 = y2 (also in fd)
+    gF = subnet_bwd(blk.F, ws.fd, None, d1, -1.0, d2, True, n, t, h, w, want, pb.F, side, "F" + tag, dout_amax=amax_in)
+    rt.call("selfc_coupling_bwd_x", 1, ws.x2.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel,
+            ptr(A[0]), ptr(A[1]), sp)
+    gH, d1h = h_backward(keep, A[1])
+    gG = subnet_bwd(blk.G, ws.gd, keep, dx2, -1.0, d1, True, n, t, h, w, want, pb.G, side, "G" + tag, dout_amax=A[0],
+                    dx_amax_out=A[2] if (fold and d1h is None) else None)
+    amax_d1 = A[2] if (fold and d1h is None) else None
+    if d1h is not None:
+        amax_d1 = join_d1(d1h, A[2])
+    return d1, dx2, gF, gG, gH, amax_d1                   # d1 is the next block's F dOut
 
 
 class InvStackFn(torch.autograd.Function):
@@ -681,8 +715,12 @@ class InvStackFn(torch.autograd.Function):
         else:
             rt.call("selfc_freq_inv_bwd", gy.data_ptr(), d1.data_ptr(), d2.data_ptr(), n, H, W, sp)
         grads = {}
+        # three max slots per block, zeroed by ONE fill (see _block_backward)
+        slots = torch.zeros(3 * len(ctx.saves), dtype=torch.float32, device=dev) if _FOLD_AMAX else None
+        amax = None
         for i, (blk, sv, keep, fd_intact) in enumerate(reversed(ctx.saves)):
-            d1, d2, gF, gG, gH = _block_backward(blk, sv, keep, rev, t, d1, d2, want, restore_fd=not fd_intact, tag=str(i))
+            d1, d2, gF, gG, gH, amax = _block_backward(blk, sv, keep, rev, t, d1, d2, want, restore_fd=not fd_intact, tag=str(i), amax_in=amax,
+                                                       amax_slots=None if slots is None else slots[3 * i:3 * i + 3])
             grads[id(blk)] = (*gF, *gG, *gH)
         dx = None
         if ctx.needs_input_grad[0]:

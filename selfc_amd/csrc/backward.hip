@@ -487,12 +487,24 @@ __global__ __launch_bounds__(256) void coupling_fwd_kernel(int rev, const float4
 
 // rev == 0 (y2 = x2*e^s + g, v = x2):   dx2 = dy2*e^s,   dh = dy2*x2*e^s * ds/dh,   dg = dy2
 // rev != 0 (y2 = (x2-g)*e^-s, v = y2):  dx2 = dy2*e^-s,  dh = -dy2*y2 * ds/dh,      dg = -dx2
+// max |value| of a float4 per lane -> one atomic per wave on the float bits (NaN -> 0x7fc00000: absmax_kernel's convention)
+__device__ __forceinline__ void wave_absmax(const float (&o)[4], unsigned* bits) {
+  float m = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+  const bool nan = (o[0] != o[0]) | (o[1] != o[1]) | (o[2] != o[2]) | (o[3] != o[3]);
+#pragma unroll
+  for (int k = 32; k > 0; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+  if (__any(nan)) { if ((threadIdx.x & 63) == 0) atomicMax(bits, 0x7fc00000u); }
+  else if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(bits, __float_as_uint(m));
+}
+
 __global__ __launch_bounds__(256) void coupling_bwd_kernel(int rev, const float4* __restrict__ v, const float4* __restrict__ s,
                                                            const float4* __restrict__ dy2, float4* __restrict__ dx2,
-                                                           float4* __restrict__ dh, float clamp, size_t n4) {
+                                                           float4* __restrict__ dh, float clamp, size_t n4,
+                                                           unsigned* __restrict__ dx2_amax, unsigned* __restrict__ dh_amax) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  const float4 vv = v[i], ss = s[i], dd = dy2[i];
+  const bool live = i < n4;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 vv = live ? v[i] : z4, ss = live ? s[i] : z4, dd = live ? dy2[i] : z4;
   const float va[4] = {vv.x, vv.y, vv.z, vv.w}, sa[4] = {ss.x, ss.y, ss.z, ss.w}, da[4] = {dd.x, dd.y, dd.z, dd.w};
   float ox[4], oh[4];
 #pragma unroll
@@ -503,8 +515,25 @@ __global__ __launch_bounds__(256) void coupling_bwd_kernel(int rev, const float4
     ox[j] = da[j] * e;
     oh[j] = (rev ? -da[j] * va[j] : ox[j] * va[j]) * dsdh;
   }
-  dx2[i] = make_float4(ox[0], ox[1], ox[2], ox[3]);
-  dh[i] = make_float4(oh[0], oh[1], oh[2], oh[3]);
+  if (live) {
+    dx2[i] = make_float4(ox[0], ox[1], ox[2], ox[3]);
+    dh[i] = make_float4(oh[0], oh[1], oh[2], oh[3]);
+  }
+  // max |dx2| / max |dh| where they are produced: the max|dOut| of G's (reverse) / H's backward without a separate pass
+  if (dx2_amax) wave_absmax(ox, dx2_amax);
+  if (dh_amax) wave_absmax(oh, dh_amax);
+}
+
+// a += b with max |a| of the result (the two halves of y1's gradient meet here; the sum is F's dOut)
+__global__ __launch_bounds__(256) void add_absmax_kernel(float4* __restrict__ a, const float4* __restrict__ b, size_t n4, unsigned* __restrict__ amax) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4) {
+    const float4 x = a[i], y = b[i];
+    o[0] = x.x + y.x; o[1] = x.y + y.y; o[2] = x.z + y.z; o[3] = x.w + y.w;
+    a[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  if (amax) wave_absmax(o, amax);
 }
 
 // FrequencyAnalyzer forward (lo = 4x4 mean, hi[(sy*4+sx)*3+c] = x - lo): adjoint on the latent layout
@@ -707,6 +736,14 @@ int selfc_subnet_bwd(const selfc_subnet_bw* bw, int kind, const void* dense, con
 int selfc_subnet_bwd_phase(int phases, const selfc_subnet_bw* bw, int kind, const void* dense, const float* xin, const float* dout,
                            float sign, float* dx, int accumulate_dx, float* const* wgrad, float* const* bgrad, float beta,
                            void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout, void* stream) {
+  return selfc_subnet_bwd_phase_x(phases, bw, kind, dense, xin, dout, sign, dx, accumulate_dx, wgrad, bgrad, beta, scratch, scratch_bytes,
+                                  N, T, H, W, cin, cout, nullptr, nullptr, stream);
+}
+
+int selfc_subnet_bwd_phase_x(int phases, const selfc_subnet_bw* bw, int kind, const void* dense, const float* xin, const float* dout,
+                             float sign, float* dx, int accumulate_dx, float* const* wgrad, float* const* bgrad, float beta,
+                             void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout,
+                             const float* dout_amax, float* dx_amax_out, void* stream) {
   if (!(phases & (SELFC_BWD_DATA | SELFC_BWD_WEIGHTS))) return SELFC_EINVAL;
   if (!bw || !dense || !dout || !scratch || !bw->wt5 || !bw->wtx || !bw->wtd[0] || !bw->wtd[1] || !bw->wtd[2]) return SELFC_EINVAL;
   if (N <= 0 || T <= 0 || N % T || H <= 0 || W <= 0 || cin < 1 || cin > 96 || cout < 1 || cout > 96) return SELFC_EINVAL;
@@ -731,8 +768,11 @@ int selfc_subnet_bwd_phase(int phases, const selfc_subnet_bw* bw, int kind, cons
   int rc;
   if (!(phases & SELFC_BWD_DATA)) goto weights;
 
-  // 1. scale + scaled f16 planes of dOut
-  if ((rc = bwd_absmax(dout, npix * coutp, amax, s))) return rc;
+  // 1. scale + scaled f16 planes of dOut.  dout_amax: the producer of dOut already took max|dOut| (selfc_coupling_bwd_x,
+  //    selfc_add_absmax, dx_amax_out of the call that wrote it): one 4-byte copy instead of a pass over dOut
+  if (dout_amax) {
+    if ((rc = hip_rc(hipMemcpyAsync(amax, dout_amax, sizeof(float), hipMemcpyDeviceToDevice, s)))) return rc;
+  } else if ((rc = bwd_absmax(dout, npix * coutp, amax, s))) return rc;
   if ((rc = bwd_to_planes(dout, gpl, npix, cout, coutp, L.ng, 0, sign, amax, s))) return rc;
   if (L.hasx && (rc = selfc_nhwc_to_planes(xin, xpl, npix, cin, stream))) return rc;
 
@@ -764,7 +804,7 @@ int selfc_subnet_bwd_phase(int phases, const selfc_subnet_bw* bw, int kind, cons
     BwdConv c{};
     c.in = gb; c.nplanes_in = 4; c.kt = 1; c.sp1 = 0; c.w = bw->wtx;
     c.ngroups = L.nx; c.add = t5; c.mask_z = -1;
-    c.plain = dx; c.coutp = cinp; c.accumulate = accumulate_dx; c.amax = amax;
+    c.plain = dx; c.coutp = cinp; c.accumulate = accumulate_dx; c.amax = amax; c.amax_out = dx_amax_out;
     if ((rc = bwd_conv_planes(c, N, T, H, W, s))) return rc;
   }
 weights:
@@ -810,11 +850,25 @@ int selfc_coupling_fwd(int rev, const float* x2, const float* g, const float* h,
 
 int selfc_coupling_bwd(int rev, const float* v, const float* s, const float* dy2, float* dx2, float* dh, float clamp,
                        size_t n, void* stream) {
+  return selfc_coupling_bwd_x(rev, v, s, dy2, dx2, dh, clamp, n, nullptr, nullptr, stream);
+}
+
+int selfc_coupling_bwd_x(int rev, const float* v, const float* s, const float* dy2, float* dx2, float* dh, float clamp,
+                         size_t n, float* dx2_amax, float* dh_amax, void* stream) {
   if (!v || !s || !dy2 || !dx2 || !dh || n == 0 || (n & 3) || clamp == 0.f) return SELFC_EINVAL;
   ProfScope prof(PROF_BWD, (hipStream_t)stream);
   const size_t n4 = n / 4;
   hipLaunchKernelGGL(coupling_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rev,
-                     (const float4*)v, (const float4*)s, (const float4*)dy2, (float4*)dx2, (float4*)dh, clamp, n4);
+                     (const float4*)v, (const float4*)s, (const float4*)dy2, (float4*)dx2, (float4*)dh, clamp, n4,
+                     (unsigned*)dx2_amax, (unsigned*)dh_amax);
+  return hip_rc(hipGetLastError());
+}
+
+int selfc_add_absmax(float* a, const float* b, size_t n, float* amax, void* stream) {
+  if (!a || !b || n == 0 || (n & 3)) return SELFC_EINVAL;
+  ProfScope prof(PROF_BWD, (hipStream_t)stream);
+  const size_t n4 = n / 4;
+  hipLaunchKernelGGL(add_absmax_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float4*)a, (const float4*)b, n4, (unsigned*)amax);
   return hip_rc(hipGetLastError());
 }
 

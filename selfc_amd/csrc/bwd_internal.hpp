@@ -25,6 +25,8 @@ struct BwdConv {
   float* plain;           // fp32 NHWC output (stride coutp) instead of planes: (acc + add) / S (+ old)
   int coutp, accumulate;
   const float* amax;      // device: max|dOut| of this subnet call (defines S)
+  float* amax_out;        // optional (plain output): atomic max |value| over everything this call stores - the max|dOut| of the
+                          // subnet call that consumes `plain` next, taken where the values are produced (no separate pass)
 };
 int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s);
 // conv5^T of a temporal dense block on the temporal-conv kernel (weights: packing.pack_t5_bwd)

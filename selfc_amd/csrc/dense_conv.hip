@@ -100,6 +100,7 @@ struct C3Args {
   const f16* bw_mask;
   f16* bw_alt;
   const float* bw_amax;
+  float* bw_amax_out;      // EPI_BWD plain output: atomic max |stored value| (float bits; NaN -> 0x7fc00000, see backward.hip absmax_kernel)
   int bw_mask_z, bw_acc;
   // coupling / plain epilogue (EPI != LRELU)
   float* x1io;           // EPI_F: y1 = x1 +- F: read here ...     [N][H][W][4]
@@ -398,6 +399,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
     if (keep == 123.456f) a.out[0][0] = (f16)keep;
     return;
   }
+  float bwmax = 0.f;           // EPI_BWD plain output with bw_amax_out: max |stored value| of this lane
+  bool bwnan = false;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int y = ty0 + py[m], x = tx0 + px[m];
@@ -467,6 +470,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
               o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
             }
             *dst = o;
+            bwmax = fmaxf(fmaxf(bwmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+            bwnan |= (o.x != o.x) | (o.y != o.y) | (o.z != o.z) | (o.w != o.w);
           }
         }
       } else {
@@ -531,6 +536,15 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
           }
         }
       }
+    }
+  }
+  if (EPI == EPI_BWD) {
+    if (a.plain && a.bw_amax_out) {        // one atomic per wave: the same max (and NaN convention) absmax_kernel would find in `plain`
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) bwmax = fmaxf(bwmax, __shfl_xor(bwmax, o));
+      unsigned* const bits = reinterpret_cast<unsigned*>(a.bw_amax_out);
+      if (__any(bwnan)) { if (lane == 0) atomicMax(bits, 0x7fc00000u); }
+      else if (lane == 0 && bwmax > 0.f) atomicMax(bits, __float_as_uint(bwmax));
     }
   }
 }
@@ -1021,7 +1035,7 @@ int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s)
   a.wz_stride = (size_t)a.nstages * (c.sp1 ? 2 : 18) * 512;
   a.out_coff = 0;
   a.bw_add = (const f16*)c.add; a.bw_mask = (const f16*)c.mask; a.bw_mask_z = c.mask_z; a.bw_alt = (f16*)c.alt;
-  a.bw_amax = c.amax; a.bw_acc = c.accumulate;
+  a.bw_amax = c.amax; a.bw_acc = c.accumulate; a.bw_amax_out = c.amax_out;
   a.plain = c.plain; a.coutp = c.coutp;
   return launch_conv3x3<EPI_BWD, true>(a, c.ngroups, s);
 }
@@ -1030,8 +1044,8 @@ int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s)
 
 extern "C" {
 
-const char* selfc_version(void) { return "selfc_hip gfx950 abi11 operands=" SELFC_OPERAND_NAME; }
-int selfc_abi_version(void) { return 11; }
+const char* selfc_version(void) { return "selfc_hip gfx950 abi12 operands=" SELFC_OPERAND_NAME; }
+int selfc_abi_version(void) { return 12; }
 
 int selfc_invblock_run(const selfc_invblock_w* blk, const selfc_latent* lat, int rev, void* stream) {
   if (!blk || !latent_ok(lat)) return SELFC_EINVAL;

@@ -323,3 +323,33 @@ def test_flat_optimizer_state_round_trips_through_the_reference_layout(dev):
         p.data = p.data.clone()
     with pytest.raises(RuntimeError, match="no longer alias"):
         tr.optimize_parameters(real_h, ref_l)
+
+
+def test_folded_gradient_maxima_change_nothing(dev):
+    """max|dOut| of every subnet backward is taken where dOut is produced (coupling gradient kernel, the y1-gradient add, F's dx
+    epilogue: selfc_coupling_bwd_x / selfc_add_absmax / dx_amax_out) instead of a pass over dOut per call.  Same maxima, same
+    power-of-two scales: the gradients of a step must be the ones of the unfolded path (SELFC_BWD_FOLD_AMAX=0) bit for bit -
+    with the third stream (H's chain beside G's) and without it."""
+    from selfc_amd import autograd as ag, train
+    x = load_golden("g8_large_stack")["x"]
+    gt = x.reshape(1, T, 3, 32, 48).transpose(1, 2).to(dev)
+    real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
+
+    def grads(fold, two_streams):
+        old = ag._FOLD_AMAX, ag._TWO_STREAMS
+        ag._FOLD_AMAX, ag._TWO_STREAMS = fold, two_streams
+        try:
+            net = _net(dev)
+            tr = train.RescaleTrainer(net, dict(train.TRAIN_OPT_LARGE), flat_params=False)
+            tr._zero_grad()
+            tr._forward_backward(real_h, ref_l)
+            torch.cuda.synchronize()
+            return {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+        finally:
+            ag._FOLD_AMAX, ag._TWO_STREAMS = old
+
+    for two in (True, False):
+        a, b = grads(False, two), grads(True, two)
+        assert a.keys() == b.keys() and len(a) > 300
+        bad = [n for n in a if not torch.equal(a[n], b[n])]
+        assert not bad, f"streams={two}: {len(bad)} gradients differ, e.g. {bad[:4]}"
