@@ -487,53 +487,71 @@ __global__ __launch_bounds__(256) void coupling_fwd_kernel(int rev, const float4
 
 // rev == 0 (y2 = x2*e^s + g, v = x2):   dx2 = dy2*e^s,   dh = dy2*x2*e^s * ds/dh,   dg = dy2
 // rev != 0 (y2 = (x2-g)*e^-s, v = y2):  dx2 = dy2*e^-s,  dh = -dy2*y2 * ds/dh,      dg = -dx2
-// max |value| of a float4 per lane -> one atomic per wave on the float bits (NaN -> 0x7fc00000: absmax_kernel's convention)
-__device__ __forceinline__ void wave_absmax(const float (&o)[4], unsigned* bits) {
-  float m = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
-  const bool nan = (o[0] != o[0]) | (o[1] != o[1]) | (o[2] != o[2]) | (o[3] != o[3]);
+// Block-wide max |value| -> ONE atomic per block on the float bits (NaN -> 0x7fc00000: absmax_kernel's convention).  Atomics on
+// one address serialise at the memory side (~90 per microsecond): the kernels below are grid-stride over <= 256 blocks, so a
+// maximum costs <= 256 of them, not one per wave of the whole tensor (13,600 for a 14 MB gradient: +3 ms per training step,
+// measured).  m: this thread's running max, nan: it saw a NaN; every thread of the block must call.
+__device__ __forceinline__ void block_absmax(float m, bool nan, unsigned* bits) {
+  __shared__ float red[8];
+  __shared__ int rednan;
+  if (threadIdx.x == 0) rednan = 0;
 #pragma unroll
   for (int k = 32; k > 0; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
-  if (__any(nan)) { if ((threadIdx.x & 63) == 0) atomicMax(bits, 0x7fc00000u); }
-  else if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(bits, __float_as_uint(m));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  if (__any(nan) && (threadIdx.x & 63) == 0) atomicOr(&rednan, 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float r = red[0];
+    for (int k = 1; k < (int)(blockDim.x >> 6); ++k) r = fmaxf(r, red[k]);
+    if (rednan) atomicMax(bits, 0x7fc00000u);
+    else if (r > 0.f) atomicMax(bits, __float_as_uint(r));
+  }
+}
+__device__ __forceinline__ void track4(const float (&o)[4], float& m, bool& nan) {
+  m = fmaxf(fmaxf(m, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+  nan |= (o[0] != o[0]) | (o[1] != o[1]) | (o[2] != o[2]) | (o[3] != o[3]);
 }
 
 __global__ __launch_bounds__(256) void coupling_bwd_kernel(int rev, const float4* __restrict__ v, const float4* __restrict__ s,
                                                            const float4* __restrict__ dy2, float4* __restrict__ dx2,
                                                            float4* __restrict__ dh, float clamp, size_t n4,
                                                            unsigned* __restrict__ dx2_amax, unsigned* __restrict__ dh_amax) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live = i < n4;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 vv = live ? v[i] : z4, ss = live ? s[i] : z4, dd = live ? dy2[i] : z4;
-  const float va[4] = {vv.x, vv.y, vv.z, vv.w}, sa[4] = {ss.x, ss.y, ss.z, ss.w}, da[4] = {dd.x, dd.y, dd.z, dd.w};
-  float ox[4], oh[4];
+  float mx = 0.f, mh = 0.f;
+  bool nx = false, nh = false;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 vv = v[i], ss = s[i], dd = dy2[i];
+    const float va[4] = {vv.x, vv.y, vv.z, vv.w}, sa[4] = {ss.x, ss.y, ss.z, ss.w}, da[4] = {dd.x, dd.y, dd.z, dd.w};
+    float ox[4], oh[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float u = sa[j] / clamp;
-    const float dsdh = clamp * (1.f - u * u) * 0.5f;
-    const float e = expf(rev ? -sa[j] : sa[j]);
-    ox[j] = da[j] * e;
-    oh[j] = (rev ? -da[j] * va[j] : ox[j] * va[j]) * dsdh;
-  }
-  if (live) {
+    for (int j = 0; j < 4; ++j) {
+      const float u = sa[j] / clamp;
+      const float dsdh = clamp * (1.f - u * u) * 0.5f;
+      const float e = expf(rev ? -sa[j] : sa[j]);
+      ox[j] = da[j] * e;
+      oh[j] = (rev ? -da[j] * va[j] : ox[j] * va[j]) * dsdh;
+    }
     dx2[i] = make_float4(ox[0], ox[1], ox[2], ox[3]);
     dh[i] = make_float4(oh[0], oh[1], oh[2], oh[3]);
+    track4(ox, mx, nx);
+    track4(oh, mh, nh);
   }
   // max |dx2| / max |dh| where they are produced: the max|dOut| of G's (reverse) / H's backward without a separate pass
-  if (dx2_amax) wave_absmax(ox, dx2_amax);
-  if (dh_amax) wave_absmax(oh, dh_amax);
+  if (dx2_amax) block_absmax(mx, nx, dx2_amax);
+  if (dh_amax) block_absmax(mh, nh, dh_amax);
 }
 
 // a += b with max |a| of the result (the two halves of y1's gradient meet here; the sum is F's dOut)
 __global__ __launch_bounds__(256) void add_absmax_kernel(float4* __restrict__ a, const float4* __restrict__ b, size_t n4, unsigned* __restrict__ amax) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  float o[4] = {0.f, 0.f, 0.f, 0.f};
-  if (i < n4) {
+  float m = 0.f;
+  bool nan = false;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     const float4 x = a[i], y = b[i];
-    o[0] = x.x + y.x; o[1] = x.y + y.y; o[2] = x.z + y.z; o[3] = x.w + y.w;
+    const float o[4] = {x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w};
     a[i] = make_float4(o[0], o[1], o[2], o[3]);
+    track4(o, m, nan);
   }
-  if (amax) wave_absmax(o, amax);
+  if (amax) block_absmax(m, nan, amax);
 }
 
 // FrequencyAnalyzer forward (lo = 4x4 mean, hi[(sy*4+sx)*3+c] = x - lo): adjoint on the latent layout
@@ -858,7 +876,9 @@ int selfc_coupling_bwd_x(int rev, const float* v, const float* s, const float* d
   if (!v || !s || !dy2 || !dx2 || !dh || n == 0 || (n & 3) || clamp == 0.f) return SELFC_EINVAL;
   ProfScope prof(PROF_BWD, (hipStream_t)stream);
   const size_t n4 = n / 4;
-  hipLaunchKernelGGL(coupling_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rev,
+  size_t nb = (n4 + 255) / 256;
+  if ((dx2_amax || dh_amax) && nb > 256) nb = 256;        // a maximum is one atomic per block (block_absmax)
+  hipLaunchKernelGGL(coupling_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, rev,
                      (const float4*)v, (const float4*)s, (const float4*)dy2, (float4*)dx2, (float4*)dh, clamp, n4,
                      (unsigned*)dx2_amax, (unsigned*)dh_amax);
   return hip_rc(hipGetLastError());
@@ -868,7 +888,9 @@ int selfc_add_absmax(float* a, const float* b, size_t n, float* amax, void* stre
   if (!a || !b || n == 0 || (n & 3)) return SELFC_EINVAL;
   ProfScope prof(PROF_BWD, (hipStream_t)stream);
   const size_t n4 = n / 4;
-  hipLaunchKernelGGL(add_absmax_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float4*)a, (const float4*)b, n4, (unsigned*)amax);
+  size_t nb = (n4 + 255) / 256;
+  if (amax && nb > 256) nb = 256;
+  hipLaunchKernelGGL(add_absmax_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (float4*)a, (const float4*)b, n4, (unsigned*)amax);
   return hip_rc(hipGetLastError());
 }
 
