@@ -324,10 +324,39 @@ def _frag16(w9: torch.Tensor, step, rb: int) -> torch.Tensor:
     return out.reshape(64, 8)
 
 
+_F16_GATHER: dict = {}
+
+
 def pack_fused_f16(weights: Sequence[torch.Tensor], cin: int = 48) -> torch.Tensor:
     """conv1..conv4 of a cin == 48 dense block -> the fragment stream of csrc/fused_f16.hip: per pair (conv a, conv b) the merged
-    steps [a rb0, a rb1, b rb0, b rb1] followed by the FM steps [b rb0, b rb1]: 74 + 146 fragments -> f16 [220, 64, 8]."""
+    steps [a rb0, a rb1, b rb0, b rb1] followed by the FM steps [b rb0, b rb1]: 74 + 146 fragments -> f16 [220, 64, 8].
+    The layout is a fixed gather of the four weight tensors: its index table is learnt once per process from index-valued
+    stand-ins (`_pack_fused_f16_steps`, a fragment-by-fragment construction) and applied as ONE gather afterwards."""
     assert cin == 48 and len(weights) == 4
+    ws = []
+    for k, w in enumerate(weights):
+        w = w.detach().float()
+        if w.dim() == 5:
+            w = w[:, :, 0]
+        assert w.shape == (32, cin + 32 * k, 3, 3), tuple(w.shape)
+        ws.append(w)
+    idx = _F16_GATHER.get("idx")
+    if idx is None:
+        fakes, off = [], 0
+        for w in ws:
+            fakes.append(torch.arange(off + 1, off + w.numel() + 1, dtype=torch.float64).reshape(w.shape))
+            off += w.numel()
+        idx = _pack_fused_f16_steps(fakes, cin).reshape(-1).round().long() - 1            # -1: zero padding
+        _F16_GATHER["idx"] = idx = torch.where(idx < 0, torch.full_like(idx, off), idx)   # -> the appended zero
+    dev = ws[0].device
+    if _F16_GATHER.get("dev") != dev:
+        _F16_GATHER["dev"], _F16_GATHER["idx_dev"] = dev, idx.to(dev)
+    flat = torch.cat([w.reshape(-1) for w in ws] + [torch.zeros(1, dtype=torch.float32, device=dev)])
+    return _operand(flat[_F16_GATHER["idx_dev"]].reshape(220, 64, 8))
+
+
+def _pack_fused_f16_steps(weights: Sequence[torch.Tensor], cin: int = 48) -> torch.Tensor:
+    """the layout of pack_fused_f16, built fragment by fragment (values of `weights` pass through unchanged) -> [220, 64, 8]"""
     out = []
     for pair in (0, 1):
         nin = cin + 64 * pair
@@ -345,7 +374,7 @@ def pack_fused_f16(weights: Sequence[torch.Tensor], cin: int = 48) -> torch.Tens
             out += [_frag16(ws[1], st, 0), _frag16(ws[1], st, 1)]
     res = torch.stack(out)
     assert res.shape[0] == 220
-    return _operand(res)
+    return res
 
 
 def pack_f5_partial16(w5: torch.Tensor, cin: int = 48) -> torch.Tensor:

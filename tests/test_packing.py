@@ -481,3 +481,81 @@ def test_gagg_row_perm_keeps_a_lanes_channels():
             assert rows == list(range(rows[0], rows[0] + 4)) and rows[0] % 4 == 0
             held = {32 * ks + 8 * kq + j for ks in (0, 1) for j in range(8)}        # the lane's input channels
             assert set(rows) <= held
+
+
+def _unpack_a16(frags):
+    """16x16x32 A fragments [n, 64, 8] -> (n, 16 rows, 32 k): lane l = (q = l >> 4, i = l & 15) holds row i, k = 8 q + j"""
+    return frags.float().reshape(-1, 4, 16, 8).permute(0, 2, 1, 3).reshape(-1, 16, 32)
+
+
+@pytest.mark.parametrize("pair", [0, 1])
+def test_pack_fused_f16_stream(pair):
+    """fragment stream of csrc/fused_f16.hip (v_mfma_f32_16x16x32): per pair [merged k32 steps: a rb0, a rb1, b rb0, b rb1]
+    [9 FM steps: b rb0, b rb1]; row r of block rb = output channel 8 (r >> 2) + 4 rb + (r & 3); the k-octets of a step follow
+    packing.f16_steps - the kernel's step_off / step_kind decode is restated here with BYTE offsets on an image whose pixel
+    holds [x2 48 | f1 32 | f2 32] f16 channels (96 / 224 bytes, no padding)."""
+    g = torch.Generator().manual_seed(170 + pair)
+    ws = [torch.randn(32, 48 + 32 * i, 1, 3, 3, generator=g) * 0.1 for i in range(4)]
+    stream = P.pack_fused_f16(ws, 48)
+    assert stream.shape == (220, 64, 8)
+    nin = 48 + 64 * pair
+    nm = 14 + 18 * pair
+    base = 0 if pair == 0 else 74
+    merged = _unpack_a16(stream[base: base + 4 * nm]).reshape(nm, 4, 16, 32)        # [step][a0 a1 b0 b1][row][k]
+    fmw = _unpack_a16(stream[base + 4 * nm: base + 4 * nm + 18]).reshape(9, 2, 16, 32)
+    n, h, w = 2, 5, 6
+    img = torch.randn(n, nin, h, w, generator=g)
+    fm = torch.randn(n, 32, h, w, generator=g)
+    ip = F.pad(img.permute(0, 2, 3, 1), (0, 0, 1, 1, 1, 1))            # [n][h+2][w+2][nin]: channel c at byte 2 c of the pixel
+    pitch = 2 * nin
+
+    def octet(y0, x0, byte):          # 8 channels starting at `byte` bytes from pixel (y0, x0)'s first byte, for every output pixel
+        dx, c = divmod(byte // 2, nin) if byte >= 0 else (0, 0)
+        return ip[:, y0:y0 + h, x0 + dx:x0 + dx + w, c:c + 8]
+
+    def step_bytes(s, q):             # the kernel: lane pointer of kind(s) (relative to the top-left tap pixel) + step_off(s); rows are dy
+        if s < 9:
+            return s // 3, (s % 3) * pitch + 16 * q
+        if s < 12:
+            return s - 9, (q >> 1) * pitch + 64 + 16 * (q & 1)
+        if s == 12:
+            return (q >> 1), 2 * pitch + 64 + 16 * (q & 1)
+        if s == 13:
+            return 2, 2 * pitch + 64 + 16 * (q & 1)
+        t, f = (s - 14) % 9, (s - 14) // 9
+        return t // 3, (t % 3) * pitch + 96 + 64 * f + 16 * q
+
+    acc_a = torch.zeros(n, 32, h, w)
+    acc_b = torch.zeros(n, 32, h, w)
+    chan = torch.tensor([[8 * (r >> 2) + 4 * rb + (r & 3) for r in range(16)] for rb in range(2)])
+    for s in range(nm):
+        k = torch.cat([octet(*((lambda dy, b: (dy, 0, b))(*step_bytes(s, q)))) for q in range(4)], -1)      # [n][h][w][32 k]
+        for rb in range(2):
+            acc_a[:, chan[rb]] += torch.einsum("rk,nhwk->nrhw", merged[s, rb], k)
+            acc_b[:, chan[rb]] += torch.einsum("rk,nhwk->nrhw", merged[s, 2 + rb], k)
+    fp = F.pad(fm.permute(0, 2, 3, 1), (0, 0, 1, 1, 1, 1))
+    for t in range(9):
+        k = fp[:, t // 3:t // 3 + h, t % 3:t % 3 + w, :]
+        for rb in range(2):
+            acc_b[:, chan[rb]] += torch.einsum("rk,nhwk->nrhw", fmw[t, rb], k)
+    ref_a = F.conv2d(img, ws[2 * pair][:, :, 0].half().float(), None, 1, 1)
+    ref_b = F.conv2d(torch.cat((img, fm), 1), ws[2 * pair + 1][:, :, 0].half().float(), None, 1, 1)
+    assert torch.allclose(acc_a, ref_a, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(acc_b, ref_b, atol=1e-4, rtol=1e-4)
+
+
+def test_pack_f5_partial16():
+    """conv5 partial-product fragments of the 16x16x32 kernels: row 4 tap + oc, K = 32 channels of one feature (x2[32:48] in the
+    lower half of a fragment whose upper half is zero): summed over the six fragments they are F's temporal conv5 per tap."""
+    g = torch.Generator().manual_seed(171)
+    w5 = torch.randn(3, 176, 3, 1, 1, generator=g) * 0.1
+    fr = _unpack_a16(P.pack_f5_partial16(w5, 48))                  # (6, 16, 32)
+    assert fr.shape == (6, 16, 32)
+    d = torch.randn(176, generator=g)
+    parts = [d[0:32], torch.cat((d[32:48], torch.zeros(16))), d[48:80], d[80:112], d[112:144], d[144:176]]
+    p = sum(fr[j] @ parts[j] for j in range(6))                    # 16 rows
+    for tap in range(3):
+        ref = w5[:, :, tap, 0, 0].half().float() @ d
+        assert torch.allclose(p[4 * tap:4 * tap + 3], ref, atol=1e-4, rtol=1e-4)
+        assert float(p[4 * tap + 3].abs()) == 0.0
+    assert float(p[12:].abs().max()) == 0.0
