@@ -42,6 +42,9 @@ struct F16Args {
   const f16* w5p;           // optional: conv5 partial-product fragments of this pair (packing.pack_f5_partial16)
   float* pf;                // optional: partial products of this pair, fp32 [3 taps][N][H][W][4]
   int store_feat;           // 1: the pair's two feature planes go to HBM; 0: nothing reads them afterwards
+#ifdef SELFC_STAMPS
+  unsigned long long* stamps;   // diagnostic build: per wave 7 phase sums + lifetime
+#endif
 };
 
 namespace {
@@ -51,6 +54,14 @@ constexpr int NWAVE = 8, NTHR = NWAVE * 64;
 constexpr int FPIX = 96;                          // FM pixel pitch: 64 B of features + 32 B (6 slots: see the header)
 constexpr int FROW = FS * FPIX;                   // 1728
 constexpr int FM_BYTES = FS * FROW;               // 31104
+
+#ifdef SELFC_STAMPS
+#define STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#define STAMP_ADD(k, a, b) phase[k] += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(k, a, b)
+#endif
 
 template <int PAIR>
 struct Geo {
@@ -136,6 +147,10 @@ __global__ __launch_bounds__(NTHR) void fused_f16_kernel(const F16Args a) {
   const int stile = blockIdx.x % a.ntiles, f0 = blockIdx.x / a.ntiles, gf = gridDim.x / a.ntiles;
   if (f0 >= a.N) return;
   const int ty0 = (stile / a.tiles_x) * TS, tx0 = (stile % a.tiles_x) * TS;
+#ifdef SELFC_STAMPS
+  unsigned long long phase[7] = {0, 0, 0, 0, 0, 0, 0};   // 0 tile setup, 1 merged steps, 2 epilogue 1 (+ P), 3 mid barrier, 4 FM steps, 5 epilogue 2 (+ P store), 6 end barrier
+  STAMP(tk0);
+#endif
 
   // ---- ring pixel of this lane (region coordinates 0..17): block 0 top row, 1 bottom row, 2 left column, 3 right column,
   // 4 the four corner-side leftovers (0,16) (0,17) (17,16) (17,17) - its other lanes re-read pixel (0,16) and store nothing
@@ -375,6 +390,7 @@ __global__ __launch_bounds__(NTHR) void fused_f16_kernel(const F16Args a) {
 
     for (int n = f0; n < a.N; n += gf) {
       const bool more = n + gf < a.N;
+      STAMP(ts0);
       if (more) lframe = (size_t)(n + gf) * frame_bytes;
       f32x4 acc1c[2][2], acc1r[2], acc2[2][2];
 #pragma unroll
@@ -383,6 +399,8 @@ __global__ __launch_bounds__(NTHR) void fused_f16_kernel(const F16Args a) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) { acc1c[rb][cb] = bias4(0, rb); acc2[rb][cb] = bias4(1, rb); }
       }
+      STAMP(ts1);
+      STAMP_ADD(0, ts0, ts1);
       auto merged = [&](auto ring_tag) __attribute__((always_inline)) {
         constexpr bool RING = decltype(ring_tag)::value;
         Ops ops[2];
@@ -414,6 +432,8 @@ __global__ __launch_bounds__(NTHR) void fused_f16_kernel(const F16Args a) {
       };
       if (ring) merged(std::true_type{});
       else merged(std::false_type{});
+      STAMP(ts2);
+      STAMP_ADD(1, ts1, ts2);
 
       u32x4 vc[2];
       epilogue1(acc1c, acc1r, n, vc);
@@ -429,7 +449,11 @@ __global__ __launch_bounds__(NTHR) void fused_f16_kernel(const F16Args a) {
         }
         p_feat(accp, 2, vc);
       }
+      STAMP(ts3);
+      STAMP_ADD(2, ts2, ts3);
       __syncthreads();                                // FM complete; every wave is done with the input image
+      STAMP(ts4);
+      STAMP_ADD(3, ts3, ts4);
       {
         const unsigned char* const wf = wl + G::NM * 4096;
         FOps fo[2];
@@ -443,12 +467,18 @@ __global__ __launch_bounds__(NTHR) void fused_f16_kernel(const F16Args a) {
           if constexpr (t < 6) { if (more) x_store_item(0, t); }      // the image is dead: the next tile-frame's halo goes in
         });
       }
+      STAMP(ts5);
+      STAMP_ADD(4, ts4, ts5);
       epilogue2(acc2, n, vc);
       if (do_p) {
         p_feat(accp, 3, vc);                          // f2
         p_store(accp, n);
       }
+      STAMP(ts6);
+      STAMP_ADD(5, ts5, ts6);
       __syncthreads();                                // image of the next tile-frame visible; FM free again
+      STAMP(ts7);
+      STAMP_ADD(6, ts6, ts7);
     }
   } else {
     // =====================================================================================================
@@ -499,6 +529,7 @@ __global__ __launch_bounds__(NTHR) void fused_f16_kernel(const F16Args a) {
 
     for (int n = f0; n < a.N; n += gf) {
       const bool more = n + gf < a.N;
+      STAMP(ts0);
       if (more) lframe = (size_t)(n + gf) * frame_bytes;
       f32x4 acc1c[2][2], acc1r[2], acc2[2][2];
 #pragma unroll
@@ -507,6 +538,8 @@ __global__ __launch_bounds__(NTHR) void fused_f16_kernel(const F16Args a) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) { acc1c[rb][cb] = bias4(0, rb); acc2[rb][cb] = bias4(1, rb); }
       }
+      STAMP(ts1);
+      STAMP_ADD(0, ts0, ts1);
       u32x4 vc[2];
       f32x4 accp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
       // LDS address of merged step s / FM step t: chunk, position inside the chunk
@@ -564,10 +597,16 @@ __global__ __launch_bounds__(NTHR) void fused_f16_kernel(const F16Args a) {
       };
       if (ring) merged(std::true_type{});
       else merged(std::false_type{});
+      STAMP(ts2);
+      STAMP_ADD(1, ts1, ts2);
 
       epilogue1(acc1c, acc1r, n, vc);
       if (do_p) p_feat(accp, 0, vc);                          // f3
+      STAMP(ts3);
+      STAMP_ADD(2, ts2, ts3);
       __syncthreads();                                        // barrier 11: FM complete, f2 dead, chunk 10 left
+      STAMP(ts4);
+      STAMP_ADD(3, ts3, ts4);
       {
         FOps fo[2];
         load_f(0, wl_f(0), fo[0]);
@@ -589,16 +628,29 @@ __global__ __launch_bounds__(NTHR) void fused_f16_kernel(const F16Args a) {
           if constexpr (t < 4) { if (more) x_store_item(2, t); }                   // f2 died at barrier 11
         });
       }
+      STAMP(ts5);
+      STAMP_ADD(4, ts4, ts5);
       epilogue2(acc2, n, vc);
       if (do_p) {
         p_feat(accp, 1, vc);                          // f4
         p_store(accp, n);
       }
+      STAMP(ts6);
+      STAMP_ADD(5, ts5, ts6);
       // the next tile-frame's chunk c uses the buffer this one's chunk c + 2 used (14 = 2 mod 3)
       const unsigned t0 = wb3[0], t1 = wb3[1];
       wb3[0] = wb3[2]; wb3[1] = t0; wb3[2] = t1;
     }
   }
+#ifdef SELFC_STAMPS
+  STAMP(tk1);
+  if (a.stamps && lane == 0) {
+    unsigned long long* o = a.stamps + ((size_t)blockIdx.x * NWAVE + wave) * 8;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) o[k] = phase[k];
+    o[7] = tk1 - tk0;
+  }
+#endif
 }
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 1000; }
@@ -620,6 +672,27 @@ int launch_pair16(F16Args& a, int maxwg, hipStream_t s) {
   if (rounds < minrounds) rounds = a.N < minrounds ? a.N : minrounds;
   const int gfr = (a.N + rounds - 1) / rounds;
   const int gx = gfr * a.ntiles;
+#ifdef SELFC_STAMPS
+  static unsigned long long* dbg = nullptr;
+  constexpr int DBG_WG = 1024;
+  if (!dbg) { (void)hipMalloc(&dbg, DBG_WG * NWAVE * 8 * sizeof(unsigned long long)); (void)hipMemset(dbg, 0, DBG_WG * NWAVE * 8 * sizeof(unsigned long long)); }
+  a.stamps = gx <= DBG_WG ? dbg : nullptr;
+  if (getenv("SELFC_STAMP_DUMP_F")) {      // diagnostic: dump the previous launch's sums (of this pair), then continue
+    static unsigned long long host[DBG_WG * NWAVE * 8];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
+    char fn[512];
+    snprintf(fn, sizeof(fn), "%s.%d", getenv("SELFC_STAMP_DUMP_F"), PAIR);
+    FILE* f = fopen(fn, "w");
+    if (f) {
+      for (int i = 0; i < DBG_WG * NWAVE; ++i) {
+        for (int j = 0; j < 8; ++j) fprintf(f, "%llu ", host[8 * i + j]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
+#endif
   if (big) hipLaunchKernelGGL((fused_f16_kernel<PAIR, false>), dim3((unsigned)gx), dim3(NTHR), G::LDS, s, a);
   else hipLaunchKernelGGL((fused_f16_kernel<PAIR, true>), dim3((unsigned)gx), dim3(NTHR), G::LDS, s, a);
   return hip_rc(hipGetLastError());

@@ -1,5 +1,5 @@
 """Diagnostic: per-phase time shares of the pairwise-fused F kernels (build with -DSELFC_STAMPS).
-Usage on the GPU box:  SELFC_LIB=$PWD/diag/libselfc_stamps.so SELFC_STAMP_DUMP_F=/tmp/stf python tools/stamp_report_f.py"""
+Usage on the GPU box:  make -C selfc_amd/csrc diag DIAG=-DSELFC_STAMPS && SELFC_LIB=$PWD/selfc_amd/libselfc_diag.so SELFC_STAMP_DUMP_F=/tmp/stf python tools/stamp_report_f.py"""
 import os
 import sys
 
@@ -18,8 +18,8 @@ with torch.no_grad():
     for _ in range(2):
         rt.run(x)          # every launch dumps the previous launch's sums of its own pair
 torch.cuda.synchronize()
-names = ["tile setup", "merged MFMA", "epilogue 1", "mid barrier", "FM MFMA", "epilogue 2 + image store", "end barrier", "kernel total"]
-names1 = ["tile setup", "merged + FM steps incl. hooks", "epilogue 1 (hook 10)", "barrier waits (12 hooks)", "(FM steps incl. hook 11)", "prefetch issue + image parts + epilogue 2", "weight commits", "kernel total"]
+names = ["tile setup", "merged k32 steps", "epilogue 1 + P", "mid barrier", "FM steps (+ halo stores)", "epilogue 2 + P store", "end barrier", "kernel total"]
+names1 = ["tile setup", "merged steps incl. chunk barriers", "epilogue 1 + P", "mid barrier", "FM steps (+ halo stores)", "epilogue 2 + P store", "(in the steps)", "kernel total"]
 for pair in (0, 1):
     d = np.loadtxt(os.environ["SELFC_STAMP_DUMP_F"] + f".{pair}")
     d = d[d[:, 7] > 0]
@@ -27,7 +27,7 @@ for pair in (0, 1):
     tot = d[:, 7].mean()
     w = np.arange(len(d)) % 8  # rows are (workgroup, wave)
     for i, n in enumerate((names1 if pair else names)[:7]):
-        ring = d[w < 3, i].mean()
-        rest = d[w >= 3, i].mean()
+        ring = d[w < 5, i].mean()      # fused_f16: the ring blocks sit on waves 0..4
+        rest = d[w >= 5, i].mean()
         print(f"  {n:26s} {100 * d[:, i].mean() / tot:5.1f} %   (ring waves {100 * ring / tot:5.1f} %, others {100 * rest / tot:5.1f} %)")
     print("  unaccounted: %.1f %%" % (100 * (1 - d[:, :7].sum(1).mean() / tot)))
