@@ -431,8 +431,16 @@ __device__ __forceinline__ void wgrad_finish_body(const FinArgs& a, const size_t
     ci = a.cin + 32 * (qq - a.nx) + c;
   }
   if (o >= a.O || ci >= Ctot) return;
+  // the partials are nW strided reads per thread: sixteen in flight (the loop is latency-bound, not bandwidth-bound)
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int w = 0;
+  for (; w + 16 <= a.nW; w += 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = a.part[(size_t)(w + j) * per + e];
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) { s0 += v[j]; s1 += v[j + 1]; s2 += v[j + 2]; s3 += v[j + 3]; }
+  }
   for (; w + 4 <= a.nW; w += 4) {
     s0 += a.part[(size_t)w * per + e];
     s1 += a.part[(size_t)(w + 1) * per + e];
@@ -627,7 +635,7 @@ BwdLayout bwd_layout(int N, int H, int W, int cin, int cout) {
 // by 12 MiB of partials (written once, read once by the finish pass)
 int wgrad_nsplit(int N, int H, int W, int npairs, int ttot) {
   const long ntiles = (long)N * ((H + 15) / 16) * ((W + 15) / 16);
-  long ns = (768 + (long)npairs - 1) / (long)npairs;
+  long ns = (768 + (long)npairs - 1) / (long)npairs;           // 512 / 1024 / 1536 / 2048 measured: all slower (profiles/r4/ab_experiments.txt)
   const long cap = 3072 / ((long)npairs * ttot);
   if (ns > cap) ns = cap;
   if (ns > ntiles) ns = ntiles;

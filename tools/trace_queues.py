@@ -1,5 +1,5 @@
 """Per-queue view of a rocprofv3 kernel trace (the multi-stream training step):
-  python tools/trace_queues.py <dir> [steps] [skip_steps]
+  python tools/trace_queues.py <dir> [steps] [skip_steps] [kernels listed per queue, default 8]
 For the steady-state steps: wall span per step, and per HIP queue the busy time, the number of launches, the idle time
 inside its own active window and its five heaviest kernels - i.e. which stream is the critical path and how full it is."""
 import csv
@@ -19,6 +19,7 @@ def main():
     d = sys.argv[1]
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 7
     skip = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    top = int(sys.argv[4]) if len(sys.argv) > 4 else 8
     rows = []
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -48,7 +49,7 @@ def main():
         for s, e, k, _ in rs:
             agg[k][0] += 1
             agg[k][1] += e - s
-        for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]:
+        for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
             print(f"    {k:56s} {n / nst:6.1f} x {t / n / 1e3:7.2f} us = {t / nst / 1e6:6.3f} ms/step")
 
 
