@@ -123,7 +123,7 @@ typedef struct {
 typedef struct {
   int kind;              /* SELFC_SUBNET_D2DT / SELFC_SUBNET_DB2D */
   int N, T, H, W;        /* frames (B*T), temporal length, latent height/width */
-  int c1, c2;            /* channel split (c1 <= 3, c2 <= 96 for D2DT, c2 <= 32 for DB2D) */
+  int c1, c2;            /* channel split (c1 <= 3, c2 <= 48 for D2DT, c2 <= 32 for DB2D; wider: composed from selfc_subnet_run) */
   float* x1;             /* latent state, updated in place */
   float* x2;
   void* fd;              /* workspaces (see layout above) */

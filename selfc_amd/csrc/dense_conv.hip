@@ -35,7 +35,7 @@ struct FGArgs {
   int ablate;
   unsigned long long* stamps;
 };
-int launch_fused_gh(FGArgs& a, hipStream_t s);
+int launch_fused_gh(FGArgs& a, hipStream_t s, int nets);
 // csrc/fused_f.hip
 int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, int H, int W, hipStream_t s,
                    const void* w5p, float* pf, const float* b5, const float* x1, float* x1out, int T, int rev, int keep_features);
@@ -878,8 +878,9 @@ int launch_t5(const T5Args& a, hipStream_t s) {
 
 // dispatch over the compiled (outch tiles, dense k-steps) combinations.  Only what a caller can reach is instantiated: F's
 // conv5 (one net, no fp32 x input) has one outch tile and 5..7 dense k-steps (c2 <= 32 / 64 / 96); the G/H pair always has the
-// four feature planes and 1..4 outch tiles (c2 <= 64); stand-alone subnets (EPI_PLAIN) keep the full table.  (The unreachable
-// G/H combinations with 5 or 6 k-steps spilled.)
+// four feature planes and 1..3 outch tiles (c2 <= 48: every shipped net; the four-tile instance spilled 18 VGPRs and is not built -
+// a block with a wider x2 runs composed from stand-alone subnets, modules/Inv_arch.py); stand-alone subnets (EPI_PLAIN) keep the
+// full table.
 template <int NETS, int HASX, int EPI>
 int dispatch_t5(const T5Args& a, int ot, int kd, hipStream_t s) {
 #define SELFC_T5_CASE(OT_, KD_) \
@@ -892,7 +893,7 @@ int dispatch_t5(const T5Args& a, int ot, int kd, hipStream_t s) {
       SELFC_T5_CASE(4, 4) SELFC_T5_CASE(4, 5) SELFC_T5_CASE(4, 6)
     }
   } else {
-    SELFC_T5_CASE(1, 4) SELFC_T5_CASE(2, 4) SELFC_T5_CASE(3, 4) SELFC_T5_CASE(4, 4)
+    SELFC_T5_CASE(1, 4) SELFC_T5_CASE(2, 4) SELFC_T5_CASE(3, 4)
   }
 #undef SELFC_T5_CASE
   return SELFC_EINVAL;
@@ -902,7 +903,7 @@ bool latent_ok(const selfc_latent* l) {
   if (!l || !l->x1 || !l->x2 || !l->fd || !l->gd || !l->hd) return false;
   if (l->N <= 0 || l->T <= 0 || l->N % l->T || l->H <= 0 || l->W <= 0) return false;
   if (l->c1 < 1 || l->c1 > 3 || l->c2 < 4) return false;
-  if (l->kind == SELFC_SUBNET_D2DT) return l->c2 <= 96;
+  if (l->kind == SELFC_SUBNET_D2DT) return l->c2 <= 48;
   if (l->kind == SELFC_SUBNET_DB2D) return l->c2 <= 32;
   return false;
 }
@@ -974,7 +975,7 @@ int run_GH(const selfc_invblock_w* blk, const selfc_latent* l, int rev, const fl
     for (int i = 0; i < 4; ++i) { fa.bias[0][i] = blk->G.b3[i]; fa.bias[1][i] = blk->H.b3[i]; }
     fa.dense[0] = (f16*)l->gd; fa.dense[1] = (f16*)l->hd;
     fa.N = l->N; fa.H = l->H; fa.W = l->W;
-    rc = launch_fused_gh(fa, s);
+    rc = launch_fused_gh(fa, s, 2);
   } else {
     rc = run_conv1to4(&blk->G, &blk->H, l->gd, l->hd, x1, l->c1, l->N, l->H, l->W, s);
   }
@@ -1089,7 +1090,18 @@ int selfc_subnet_run(const selfc_subnet_w* w, int kind, const float* xin, float*
     int rc = hip_rc(hipGetLastError());
     if (rc) return rc;
   }
-  int rc = run_conv1to4(w, nullptr, dense, nullptr, cin <= 3 ? xin : nullptr, cin, N, H, W, s);
+  int rc;
+  static const bool no_fuse = getenv("SELFC_NO_FUSE") != nullptr;     // developer A/B switch
+  if (cin == 3 && w->wfused && !no_fuse) {        // conv1..4 as ONE persistent launch (the G / H kernel on a single net)
+    FGArgs fa{};
+    fa.x1 = xin;
+    fa.w[0] = fa.w[1] = (const f16*)w->wfused;
+    for (int i = 0; i < 4; ++i) fa.bias[0][i] = fa.bias[1][i] = w->b3[i];
+    fa.dense[0] = fa.dense[1] = (f16*)dense;
+    fa.N = N; fa.H = H; fa.W = W;
+    rc = launch_fused_gh(fa, s, 1);
+  } else
+    rc = run_conv1to4(w, nullptr, dense, nullptr, cin <= 3 ? xin : nullptr, cin, N, H, W, s);
   if (rc) return rc;
   if (kind == SELFC_SUBNET_D2DT) {
     if (cout > 64) return SELFC_EINVAL;

@@ -516,8 +516,9 @@ inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 
 
 }  // namespace
 
-// Called from dense_conv.hip (run_GH) when the block carries fused fragment streams.
-int launch_fused_gh(FGArgs& a, hipStream_t s) {
+// Called from dense_conv.hip when the block carries fused fragment streams: run_GH with nets = 2 (G and H of a coupling block),
+// selfc_subnet_run with nets = 1 (a stand-alone 3-channel subnet: the first subnet of the STP chain, SelfC_GMM_arch_inv.py:305).
+int launch_fused_gh(FGArgs& a, hipStream_t s, int nets) {
   static std::atomic<unsigned long long> optin{0};
   if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&fused_gh_kernel), FG_LDS, optin); e != hipSuccess) return hip_rc(e);
   a.tiles_x = (a.W + TS - 1) / TS;
@@ -527,7 +528,8 @@ int launch_fused_gh(FGArgs& a, hipStream_t s) {
   // persistent workgroups, about 128 per net (one per CU overall): gfr workgroups per spatial tile, each walking
   // frames f0, f0 + gfr, ... - sized so that every workgroup walks (nearly) the same number of frames (no straggler
   // round) and unused CUs stay free for kernels of other streams
-  static const int maxwg = getenv("SELFC_FUSEDGH_MAXWG") ? atoi(getenv("SELFC_FUSEDGH_MAXWG")) : 128;
+  static const int maxwg2 = getenv("SELFC_FUSEDGH_MAXWG") ? atoi(getenv("SELFC_FUSEDGH_MAXWG")) : 128;
+  const int maxwg = nets == 2 ? maxwg2 : 2 * maxwg2;
   const int gmax = a.ntiles >= maxwg ? 1 : (maxwg / a.ntiles < a.N ? maxwg / a.ntiles : a.N);
   static const int minrounds = getenv("SELFC_FUSEDGH_MINROUNDS") ? atoi(getenv("SELFC_FUSEDGH_MINROUNDS")) : 2;
   int rounds = (a.N + gmax - 1) / gmax;
@@ -537,7 +539,7 @@ int launch_fused_gh(FGArgs& a, hipStream_t s) {
 #ifdef SELFC_STAMPS
   static unsigned long long* dbg = nullptr;
   if (!dbg) (void)hipMalloc(&dbg, 256 * NWAVE * 5 * sizeof(unsigned long long));
-  a.stamps = 2 * gx <= 256 ? dbg : nullptr;
+  a.stamps = nets * gx <= 256 ? dbg : nullptr;
   if (getenv("SELFC_STAMP_DUMP")) {      // diagnostic: dump the previous launch's sums, then continue
     static unsigned long long host[256 * NWAVE * 5];
     (void)hipDeviceSynchronize();
@@ -554,7 +556,7 @@ int launch_fused_gh(FGArgs& a, hipStream_t s) {
   a.stamps = clock_probe_slot(2);
 #endif
   ProfScope prof(PROF_FUSED_GH, s);
-  hipLaunchKernelGGL(fused_gh_kernel, dim3((unsigned)gx, 2), dim3(NTHR), FG_LDS, s, a);
+  hipLaunchKernelGGL(fused_gh_kernel, dim3((unsigned)gx, (unsigned)nets), dim3(NTHR), FG_LDS, s, a);
   return hip_rc(hipGetLastError());
 }
 

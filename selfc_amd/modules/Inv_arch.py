@@ -70,7 +70,7 @@ class InvBlockExp(nn.Module):
         if n % t:
             raise RuntimeError(f"{n} frames are not a multiple of the temporal length {t}")
         from .. import autograd as ag
-        if self.split_len1 > 3:
+        if self.split_len1 > 3 or (self.F.kind == rt.SUBNET_D2DT and self.split_len2 > 48):
             return self._forward_composed(x, bool(rev))
         if ag.module_needs_grad(x, self):          # training: buffers kept for the HIP backward (autograd.py)
             return ag.InvBlockFn.apply(x, self, bool(rev), t, *ag.block_params(self))
@@ -83,7 +83,8 @@ class InvBlockExp(nn.Module):
         return rt.latent_to_nchw(ws)
 
     def _forward_composed(self, x, rev):
-        """channel_split_num > 3 (Inv_arch.py:12-13 accepts any split): the fused block kernels keep x1 in a 4-float pixel, so a
+        """channel_split_num > 3 (Inv_arch.py:12-13 accepts any split), or a D2DTNet block whose x2 is wider than the 48 channels
+        the fused temporal conv5 + coupling kernel is built for: the fused block kernels keep x1 in a 4-float pixel, so a
         wider split runs as the reference composes it - F, G, H as stand-alone subnets (selfc_subnet_run, HIP backward through
         their autograd Functions) and the affine coupling as its own elementwise HIP pass (autograd.CouplingFn)."""
         from .. import autograd as ag

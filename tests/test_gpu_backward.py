@@ -737,10 +737,10 @@ def test_stp_v1_gmm_head_trains(dev):
     assert torch.isfinite(stp.neg_llh(stp.sample().detach())).all()
 
 
-@pytest.mark.parametrize("kind,cnum,split", [("DBNet", 12, 6), ("D2DTNet", 20, 8), ("D2DTNet", 51, 4)])
+@pytest.mark.parametrize("kind,cnum,split", [("DBNet", 12, 6), ("D2DTNet", 20, 8), ("D2DTNet", 51, 4), ("D2DTNet", 67, 3)])
 @pytest.mark.parametrize("rev", [False, True])
 def test_invblock_wide_split(dev, kind, cnum, split, rev):
-    """InvBlockExp with channel_split_num > 3 (Inv_arch.py:12-13 takes any split): composed from stand-alone subnets and the
+    """InvBlockExp with channel_split_num > 3 (Inv_arch.py:12-13 takes any split) or, for D2DTNet, an x2 wider than 48: composed from stand-alone subnets and the
     stand-alone coupling pass - output, s, jacobian, exact-inverse property and every gradient against the oracle."""
     from selfc_amd.modules.Inv_arch import InvBlockExp
     from selfc_amd.modules.Subnet_constructor import subnet
