@@ -766,12 +766,15 @@ int launch_fused_f(void* dense, const void* w, const float* const* bias, int N, 
   a.ntiles = a.tiles_x * a.tiles_y;
   a.plane = (size_t)N * H * W * 32;
   static const bool mfma32 = getenv("SELFC_F_MFMA32") != nullptr;
-  if (!mfma32) {
+  bool use32 = mfma32;
+  if (!use32) {
     ProfScope prof(PROF_CONV3X3, s);
     const int rc = launch_fused_f16_pairs(dense, (const f16*)w + (size_t)(Geo<0>::NFRAG + Geo<1>::NFRAG) * 512, bias, N, H, W, s,
                                           with_p ? (const f16*)w5p + (size_t)(Geo<0>::NP + Geo<1>::NP) * 512 : nullptr, with_p ? pf : nullptr, keep_features);
-    if (rc || !with_p) return rc;
-  } else {
+    if (rc == 2) use32 = true;         // SELFC_F16_TOO_BIG: beyond the 16x16x32 kernels' 2-GiB buffer addressing, nothing launched
+    else if (rc || !with_p) return rc;
+  }
+  if (use32) {
     ProfScope prof(PROF_CONV3X3, s);
     a.w = (const f16*)w;
     a.bias[0] = bias[0]; a.bias[1] = bias[1];

@@ -32,6 +32,8 @@ using namespace selfc;
 
 namespace selfc {
 
+constexpr int SELFC_F16_TOO_BIG = 2;      // launch_fused_f16_pairs: not launched, the caller falls back (same value in csrc/fused_f.hip)
+
 struct F16Args {
   f16* dense;               // F dense buffer, plane-blocked [6][N][H][W][32]: x2 (2 planes), f1..f4
   const f16* w;             // fragment stream of this pair (packing.pack_fused_f16)
@@ -133,7 +135,7 @@ __device__ __forceinline__ u32x4 lrelu_pack8(const f32x4& a0, const f32x4& a1, c
   return v;
 }
 
-template <int PAIR, bool BUF>
+template <int PAIR>
 __global__ __launch_bounds__(NTHR) void fused_f16_kernel(const F16Args a) {
   using G = Geo<PAIR>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(NTHR) void fused_f16_kernel(const F16Args a) {
     }
   }
   const size_t frame_bytes = (size_t)a.H * a.W * 64, plane_bytes = (size_t)a.plane * 2;
-  const buf_rsrc drs = make_rsrc(a.dense, BUF ? (unsigned)(plane_bytes * (G::NPLANE_IN + 2)) : 0u);
+  const buf_rsrc drs = make_rsrc(a.dense, (unsigned)(plane_bytes * (G::NPLANE_IN + 2)));   // < 2 GiB: launch_fused_f16_pairs checks
   constexpr int XMAX = 6;
   u32x4 xv[XMAX];
   size_t lframe = 0;                 // byte offset of the frame the next x_load_item reads (plane 0)
@@ -205,8 +207,7 @@ __global__ __launch_bounds__(NTHR) void fused_f16_kernel(const F16Args a) {
     const bool mb = part == 0 && it >= 4;
     const int pl = mb ? 1 : part == 0 ? 0 : part + 1;
     const unsigned go = mb ? goffB[it - 4] : goffA[it];
-    if (BUF) v[it] = buffer_load_b128(drs, go, (unsigned)(lframe + pl * plane_bytes));
-    else v[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.dense) + lframe + pl * plane_bytes + go);
+    v[it] = buffer_load_b128(drs, go, (unsigned)(lframe + pl * plane_bytes));
   };
   // fill = the workgroup's first fill: every existing piece is written, zeros where the frame ends (the convs' zero padding);
   // later fills leave the out-of-frame pieces alone
@@ -252,23 +253,20 @@ __global__ __launch_bounds__(NTHR) void fused_f16_kernel(const F16Args a) {
 
   // ---- output geometry (per-workgroup constants)
   bool cin_frame[2];
-  unsigned coff[2], poff[2], ppix[2];
+  unsigned coff[2], poff[2];
   const size_t tap_bytes = (size_t)a.N * a.H * a.W * 16;
-  constexpr bool pbuf = BUF;         // the launcher takes the flat instantiation when pf (or the dense buffer) is beyond 2 GiB
-  const buf_rsrc prs = make_rsrc(a.pf, pbuf ? (unsigned)(3 * tap_bytes) : 0u);
+  const buf_rsrc prs = make_rsrc(a.pf, (unsigned)(3 * tap_bytes));
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int y = ty0 + py + cb, x = tx0 + pos;
     cin_frame[cb] = (y < a.H) & (x < a.W);
     coff[cb] = (cin_frame[cb] & (a.store_feat != 0)) ? (unsigned)((y * a.W + x) * 64 + 16 * q) : BUF_OOB;
-    ppix[cb] = (unsigned)((y * a.W + x) * 16);                 // (flat instantiation only)
-    poff[cb] = (cin_frame[cb] & (q < 3)) ? ppix[cb] + (unsigned)q * (unsigned)tap_bytes : BUF_OOB;   // lane group q = tap q
+    poff[cb] = (cin_frame[cb] & (q < 3)) ? (unsigned)((y * a.W + x) * 16) + (unsigned)q * (unsigned)tap_bytes : BUF_OOB;   // lane group q = tap q
   }
   const bool rin = rvalid & (ty0 + rr - 1 >= 0) & (ty0 + rr - 1 < a.H) & (tx0 + rc - 1 >= 0) & (tx0 + rc - 1 < a.W);
   auto crop_store = [&](const int plane_idx, const int n, const int cb, const u32x4 v) __attribute__((always_inline)) {
     const size_t so = (size_t)plane_idx * plane_bytes + (size_t)n * frame_bytes;
-    if (BUF) buffer_store_b128(v, drs, coff[cb], (unsigned)so);
-    else if (coff[cb] != BUF_OOB) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.dense) + so + coff[cb]) = v;
+    buffer_store_b128(v, drs, coff[cb], (unsigned)so);
   };
   // epilogue of the pair's first conv: FM image (zero outside the frame) + centre crop to HBM; vc[cb] = the pixel's 8 channels
   // of octet q = the B fragment of the conv5 partial products
@@ -306,9 +304,7 @@ __global__ __launch_bounds__(NTHR) void fused_f16_kernel(const F16Args a) {
     const size_t so = (size_t)n * a.H * a.W * 16;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-      if (pbuf) buffer_store_b128(__builtin_bit_cast(u32x4, accp[cb]), prs, poff[cb], (unsigned)so);
-      else if (cin_frame[cb] & (q < 3))
-        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.pf) + so + ppix[cb] + (size_t)q * tap_bytes) = accp[cb];
+      buffer_store_b128(__builtin_bit_cast(u32x4, accp[cb]), prs, poff[cb], (unsigned)so);
     }
   };
   if (do_p && tid < G::NP * 64) *reinterpret_cast<u32x4*>(smem + G::OFF_P + tid * 16) = reinterpret_cast<const u32x4*>(a.w5p)[tid];
@@ -658,12 +654,8 @@ inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 
 template <int PAIR>
 int launch_pair16(F16Args& a, int maxwg, hipStream_t s) {
   using G = Geo<PAIR>;
-  static const bool force_flat = getenv("SELFC_F16_FLAT") != nullptr;                 // developer / test switch
-  const bool big = force_flat || (size_t)a.plane * 2 * (G::NPLANE_IN + 2) >= 0x7fff0000ull ||      // beyond what the buffer-resource path addresses
-                   (size_t)a.N * a.H * a.W * 48 >= 0x7fff0000ull;
-  static std::atomic<unsigned long long> optin{0}, optin_flat{0};
-  if (hipError_t e = big ? lds_optin(reinterpret_cast<const void*>(&fused_f16_kernel<PAIR, false>), G::LDS, optin_flat)
-                         : lds_optin(reinterpret_cast<const void*>(&fused_f16_kernel<PAIR, true>), G::LDS, optin); e != hipSuccess) return hip_rc(e);
+  static std::atomic<unsigned long long> optin{0};
+  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&fused_f16_kernel<PAIR>), G::LDS, optin); e != hipSuccess) return hip_rc(e);
   // frame walk: the launch geometry of csrc/fused_f.hip (gf workgroups per spatial tile), with at least TWO frames per workgroup
   // when there are (the 32x32x16 kernels wanted three; measured on the headline: 2 -> +1 %, 4 -> -1 % against 3)
   const int gmax = a.ntiles >= maxwg ? 1 : (maxwg / a.ntiles < a.N ? maxwg / a.ntiles : a.N);
@@ -693,17 +685,20 @@ int launch_pair16(F16Args& a, int maxwg, hipStream_t s) {
     }
   }
 #endif
-  if (big) hipLaunchKernelGGL((fused_f16_kernel<PAIR, false>), dim3((unsigned)gx), dim3(NTHR), G::LDS, s, a);
-  else hipLaunchKernelGGL((fused_f16_kernel<PAIR, true>), dim3((unsigned)gx), dim3(NTHR), G::LDS, s, a);
+  hipLaunchKernelGGL(fused_f16_kernel<PAIR>, dim3((unsigned)gx), dim3(NTHR), G::LDS, s, a);
   return hip_rc(hipGetLastError());
 }
 
 }  // namespace
 
 // The two pair launches of launch_fused_f (csrc/fused_f.hip) on the 16x16x32 kernels.  w16 = [pair 0: 74 fragments][pair 1: 146],
-// w5p16 = [pair 0: 4][pair 1: 2] (or null), pf = [2 pairs][3 taps][N][H][W][4] (or null).  Returns 0 or an error code.
+// w5p16 = [pair 0: 4][pair 1: 2] (or null), pf = [2 pairs][3 taps][N][H][W][4] (or null).  Returns 0, an error code, or
+// SELFC_F16_TOO_BIG (nothing launched): the kernels address the dense buffer and pf through 32-bit buffer-resource offsets, so
+// six planes (resp. the three taps of pf) must stay below 2 GiB - about 5.5 M pixel-frames, 43 1080p frames in one call; beyond
+// that launch_fused_f takes the flat-addressed 32x32x16 kernels of csrc/fused_f.hip.
 int launch_fused_f16_pairs(void* dense, const void* w16, const float* const* bias, int N, int H, int W, hipStream_t s,
                            const void* w5p16, float* pf, int keep_features) {
+  if ((size_t)N * H * W * 64 * (Geo<1>::NPLANE_IN + 2) >= 0x7fff0000ull || (size_t)N * H * W * 48 >= 0x7fff0000ull) return SELFC_F16_TOO_BIG;
   static const int maxwg = getenv("SELFC_FUSEDF_MAXWG") ? atoi(getenv("SELFC_FUSEDF_MAXWG")) : 256;
   F16Args a{};
   a.dense = (f16*)dense;

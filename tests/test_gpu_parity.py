@@ -304,12 +304,12 @@ np.savez(sys.argv[2], z=z.cpu().numpy(), xr=xr.cpu().numpy())
 """
 
 
-@pytest.mark.parametrize("switch", ["SELFC_NO_FUSE_F=1", "SELFC_NO_F5P=1", "SELFC_NO_FUSE=1", "SELFC_F_MFMA32=1", "SELFC_F16_FLAT=1"])
+@pytest.mark.parametrize("switch", ["SELFC_NO_FUSE_F=1", "SELFC_NO_F5P=1", "SELFC_NO_FUSE=1", "SELFC_F_MFMA32=1"])
 def test_fused_paths_agree_with_alternative_paths(dev, tmp_path, switch):
     """The default kernels (F's conv1-4 as two pairwise-fused 16x16x32 launches with conv5 as partial products, G/H's conv1-4 as
     one depth-4 fused launch) against the alternative paths of the library - layer-wise conv3x3 / temporal-conv5 kernels, the
-    32x32x16 pair kernels of F (SELFC_F_MFMA32), the flat-address instantiation of the 16x16x32 kernels that buffers beyond 2 GiB
-    take (SELFC_F16_FLAT) - run in a child process with the developer switch set: same f16 operands,
+    32x32x16 pair kernels of F (SELFC_F_MFMA32: also what a dense buffer beyond the 16x16x32 kernels' 2-GiB buffer addressing
+    takes) - run in a child process with the developer switch set: same f16 operands,
     different fp32 summation order (which flips some f16 roundings of the features): the two paths are each within
     ~3.5e-4 of the fp32 oracle and must agree with each other inside the parity tolerance.  Ragged size (18 x 25 latent)."""
     import os
@@ -329,6 +329,38 @@ def test_fused_paths_agree_with_alternative_paths(dev, tmp_path, switch):
     with np.load(out) as c:
         assert rel_err(z.cpu(), torch.from_numpy(c["z"])) < 6e-4
         assert rel_err(xr.cpu(), torch.from_numpy(c["xr"])) < TOL
+
+
+def test_dense_buffers_beyond_2gib_take_the_flat_kernels(dev):
+    """The 16x16x32 kernels of F address the dense buffer through 32-bit buffer-resource offsets (six planes below 2 GiB);
+    a call beyond that - 44 frames at the 1080p latent size, 5.7 M pixel-frames - must fall back to the flat-addressed
+    32x32x16 kernels inside the library (csrc/fused_f.hip launch_fused_f).  One coupling block (Inv_arch.py:20-31) over the
+    whole batch against the same block over its two halves (clips of 2 frames, so the halves are whole clips): different
+    kernels, same f16 operands - inside the parity tolerance, and the second half proves no offset wrapped."""
+    from selfc_amd import GlobalVar
+    from selfc_amd.modules.Inv_arch import InvBlockExp
+    from selfc_amd.modules.Subnet_constructor import subnet
+    torch.manual_seed(23)
+    blk = InvBlockExp(subnet("D2DTNet", "xavier"), 51, 3).to(dev).eval()
+    with torch.no_grad():
+        for sub in (blk.F, blk.G, blk.H):
+            sub.conv5.weight.normal_(0, 0.02)
+    n, h, w = 44, 270, 480
+    assert n * h * w * 64 * 6 >= 0x7fff0000
+    x = torch.randn(n, 51, h, w, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) * 0.5
+    try:
+        GlobalVar.set_Temporal_LEN(2)
+        with torch.no_grad():
+            for rev in (False, True):
+                whole = blk(x, rev=rev)
+                for lo in (0, n // 2):
+                    part = blk(x[lo:lo + n // 2].contiguous(), rev=rev)
+                    assert rel_err(whole[lo:lo + n // 2], part) < TOL, (rev, lo)
+                    del part
+                del whole
+    finally:
+        GlobalVar.set_Temporal_LEN(T)
+    torch.cuda.empty_cache()
 
 
 def test_temporal_len_one_and_clip_isolation(dev):
