@@ -47,6 +47,32 @@ def build_net(device):
     return net.to(device)
 
 
+def weights_checksum(net):
+    """sum of |w| over every parameter, in float64 on the host (a change of any weight by any leg would show)"""
+    return float(sum(v.detach().double().abs().sum().item() for v in net.state_dict().values() if v.is_floating_point()))
+
+
+def host_weights(net):
+    """The oracle's copy of the weights, each tensor verified by copying it back and comparing on the device (bit-exact); a
+    tensor that fails is copied again.  Why: on one box of the pool 9 of 45 runs of this script got ONE 3456-byte weight tensor
+    wrong in its device -> host copy (device content intact, every device path agreeing with an oracle fed a second copy;
+    profiles/r4/parity_leg_host_copy.txt) - a reference computed from such a copy reads as a parity failure of the kernels."""
+    params, recopied = {}, []
+    for k, v in net.state_dict().items():
+        if not k.startswith("operations."):
+            continue
+        v = v.detach()
+        for attempt in range(4):
+            c = v.cpu()
+            if not v.is_cuda or torch.equal(c.to(v.device), v):
+                break
+            recopied.append(k)
+        else:
+            raise RuntimeError(f"bench: the host copy of {k} does not match the device tensor after 4 attempts")
+        params[k] = c
+    return params, recopied
+
+
 def cpu_baseline(net, x_cpu, budget_s=20.0):
     """Oracle (port of the reference's torch path) on one septuplet of the same workload.
 
@@ -54,7 +80,7 @@ def cpu_baseline(net, x_cpu, budget_s=20.0):
     the thread count is calibrated on a 128x224 crop first and the one used is
     reported as `cores`."""
     from oracle import selfc_oracle as O      # checker / baseline only
-    params = {k: v.detach().cpu() for k, v in net.state_dict().items() if k.startswith("operations.")}
+    params, recopied = host_weights(net)
     ncpu = os.cpu_count() or 1
     small = x_cpu[:, :, :128, :224].contiguous()
     best_t, best_n = None, 1
@@ -79,7 +105,13 @@ def cpu_baseline(net, x_cpu, budget_s=20.0):
             times.append(time.perf_counter() - t0)
     timed = times[1:] if len(times) > 1 else times
     med = sorted(timed)[len(timed) // 2]
-    return {"value": 1.0 / med, "unit": "septuplets/s", "cores": best_n, "kind": "port",
+    try:
+        cpu_model = next(ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name"))
+    except Exception:  # noqa: BLE001
+        cpu_model = None
+    cpu_baseline.params = params                  # kept for the parity leg's self-diagnosis
+    return {"value": 1.0 / med, "unit": "septuplets/s", "cores": best_n, "kind": "port", "cpu_model": cpu_model,
+            "weights_recopied_after_a_failed_copy_check": recopied,
             "sample": f"1 septuplet 7x3x{H}x{W}, fwd+quant+inv through the CPU oracle (torch fp32), {len(timed)} timed run(s), median; "
                       f"{best_n} threads (calibrated) of {ncpu} host CPUs"}, z, zq, xr
 
@@ -120,6 +152,7 @@ def main():
     from selfc_amd.pipeline import MultiStreamRoundTrip, RescaleRoundTrip
     L = _lib.lib()
     net = build_net(dev)
+    w_sum0 = weights_checksum(net)
     n_frames = B_PER_GPU * T
     g = torch.Generator().manual_seed(launch.rank_seed(1234, rank))
     x_cpu = torch.rand(n_frames, 3, H, W, generator=g)
@@ -426,6 +459,31 @@ def main():
                          "fwd_lr_rel_err": mx(z[:, :3], z_ref[:, :3]), "fwd_hf_rel_err": mx(z[:, 3:], z_ref[:, 3:]),
                          "fwd_lr_rel_l2": l2(z[:, :3], z_ref[:, :3]), "fwd_hf_rel_l2": l2(z[:, 3:], z_ref[:, 3:]),
                          "tolerance": 1e-3, "metric": "max|a-b|/max|b| (rel_err), ||a-b||/||b|| (rel_l2)", "against": "CPU oracle, septuplet 0"}
+        if max(out["parity"]["fwd_latent_rel_err"], out["parity"]["inv_rel_err"]) > 1e-3:
+            # never expected: say which side moved (device result repeated, a freshly packed runner, the drop-in module call,
+            # the oracle recomputed on one thread, the weights' checksum against the one taken when the net was built)
+            dbg = {}
+            try:
+                from oracle import selfc_oracle as O      # checker only
+                with torch.no_grad():
+                    dbg["fwd_again"] = mx(rt.forward_latent(x)[:T].cpu(), z_ref)
+                    rt2 = RescaleRoundTrip(net, T, H, W, dev)
+                    dbg["fwd_fresh_runner_one_septuplet"] = mx(rt2.forward_latent(x[:T].contiguous()).cpu(), z_ref)
+                    zm, _ = net(x=x[:T].contiguous(), rev=False)
+                    dbg["fwd_module_call"] = mx(zm.cpu(), z_ref)
+                    p0 = cpu_baseline.params
+                    dbg["oracle_again_same_threads_same_params_vs_first"] = mx(O.large_fwd(p0, x_cpu[:T], T), z_ref)
+                    params, _ = host_weights(net)
+                    dbg["params_of_the_first_pass_differ_in"] = [k for k in params if not torch.equal(params[k], p0[k])][:8]
+                    dbg["oracle_again_same_threads_new_params_vs_first"] = mx(O.large_fwd(params, x_cpu[:T], T), z_ref)
+                    torch.set_num_threads(1)
+                    dbg["oracle_one_thread_vs_first"] = mx(O.large_fwd(params, x_cpu[:T], T), z_ref)
+                dbg["weights_checksum_now"] = weights_checksum(net)
+                dbg["weights_checksum_at_build"] = w_sum0
+                dbg["torch_threads_of_the_reference"] = cb["cores"]
+            except Exception as e:  # noqa: BLE001
+                dbg["error"] = repr(e)[:300]
+            out["parity"]["debug"] = dbg
     if rank == 0:
         print(json.dumps(out), flush=True)
     ranks.close()
