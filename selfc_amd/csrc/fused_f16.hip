@@ -146,7 +146,10 @@ __global__ __launch_bounds__(NTHR) void fused_f16_kernel(const F16Args a) {
   const int pos = i < 4 ? i : (i < 12 ? i + 4 : i - 8);
   const bool ring = wave < 5;                    // waves 0..4 own one of the five ring blocks (68 ring pixels)
 
-  const int stile = blockIdx.x % a.ntiles, f0 = blockIdx.x / a.ntiles, gf = gridDim.x / a.ntiles;
+  // workgroups go to the XCDs round robin: the swizzle gives each XCD a contiguous run of (frame group, tile) pairs, so the tiles
+  // that share halo pixels of one frame read them through the same L2
+  const int lbid = xcd_swizzle((int)blockIdx.x, (int)gridDim.x);          // (-23 % FETCH_SIZE on the headline's launches)
+  const int stile = lbid % a.ntiles, f0 = lbid / a.ntiles, gf = gridDim.x / a.ntiles;
   if (f0 >= a.N) return;
   const int ty0 = (stile / a.tiles_x) * TS, tx0 = (stile % a.tiles_x) * TS;
 #ifdef SELFC_STAMPS
