@@ -140,12 +140,15 @@ def main():
         sys.exit(rc)
     if args.dry_run:
         return dry_run(args)
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # SELFC_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box, tests): every rank runs on cuda:0 and the protocol's collectives go over
+    # gloo - the N-rank launch, sharding, barrier and max-over-ranks timing on real kernels, everything except RCCL.  The line says so.
+    share_gpu = os.environ.get("SELFC_BENCH_SHARE_GPU") == "1" and args.gpus > 1
+    local = 0 if share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if local >= torch.cuda.device_count():       # device_count() does not initialise HIP
         raise SystemExit(f"rank with LOCAL_RANK={local} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    ranks = launch.Ranks(args.gpus, "nccl", dev)
+    ranks = launch.Ranks(args.gpus, "gloo" if share_gpu else "nccl", dev)
     world, rank = ranks.world, ranks.rank
 
     from selfc_amd import _lib
@@ -316,7 +319,8 @@ def main():
                    "septuplets_per_gpu": B_PER_GPU, "launch": (f"hipGraph replay ({graph_form})" if args.streams > 1 else "hipGraph replay") if use_graph else "eager", "streams": args.streams,
                    "graph_form_probe": graph_probe,
                    "prewarm": f"untimed, before the W warm-up steps: the eager roofline leg ({args.steps} steps) + {n_pw} steps over {args.prewarm_s} s of wall time",
-                   "sharding": f"{world} rank(s) x {B_PER_GPU} independent septuplets, no data-path collective"},
+                   "sharding": f"{world} rank(s) x {B_PER_GPU} independent septuplets, no data-path collective"
+                               + (" - REHEARSAL: all ranks share ONE GPU (SELFC_BENCH_SHARE_GPU=1), collectives over gloo; not a scaling figure" if share_gpu else "")},
         "rccl_ranks": rccl_ranks,
         "box_calibration": {"shader_clock_GHz_under_the_workload": None if clk_ghz is None else round(clk_ghz, 3),
                             "mfma_f16_loop_TFLOPs": round(cal_m.value, 1) or None, "device_copy_GBps": round(cal_c.value, 1) or None, "error": cal_err,

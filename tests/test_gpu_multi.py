@@ -49,6 +49,22 @@ def _train2(*extra):
     return d
 
 
+def test_bench_two_ranks_share_one_gpu():
+    """`bench.py --gpus 2` on the ONE visible MI355X (SELFC_BENCH_SHARE_GPU=1: both ranks on cuda:0, the protocol's collectives over
+    gloo): self-launch of the child ranks, per-rank synthetic septuplets, capture + replay on real kernels in two processes at
+    once, barrier + max-over-ranks timing, one JSON line from rank 0 that says what it is.  Everything of the N-rank bench
+    except RCCL; the figure is two ranks SHARING a GPU, so it must not exceed what one rank reaches alone by much."""
+    env = dict(_clean_env(), SELFC_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    d = _json_line(p)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "REHEARSAL" in d["config"]["sharding"]
+    assert "full_test_path" not in d and "train_step" not in d and "cpu_baseline" not in d      # the one-rank legs stay off
+    assert d["value"] < 2500, d["value"]        # two ranks share one chip: the whole-job rate cannot be twice the one-GPU rate
+    print("two ranks on one GPU:", d["value"], "septuplets/s,", d["ms_per_step"], "ms per step (each rank 4 septuplets)")
+
+
 def test_ddp_two_ranks_keep_equal_parameters():
     """config 3 (train.py under torch.distributed.launch, README.md:85): after optimisation steps on DIFFERENT data the
     ranks' parameters must be identical - the gradient all-reduce over RCCL is the only thing that makes them so.  Three
