@@ -68,9 +68,13 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g
 }
 
 // item = (pixel, 8-channel chunk of the padded planes): 16-byte stores
+// amax_copy (optional): the scale's source is handed on to the phase's own slot by this kernel (one lane) - the kernels that follow
+// read the slot, this one reads the source, so no separate 4-byte copy node sits in front of it
 __global__ __launch_bounds__(256) void grad_to_planes_kernel(const float* __restrict__ g, f16* __restrict__ planes, size_t npix,
-                                                             int c, int cs, int nplanes, int lrelu, float sign, const float* __restrict__ amax) {
+                                                             int c, int cs, int nplanes, int lrelu, float sign, const float* __restrict__ amax,
+                                                             float* __restrict__ amax_copy) {
   const float sc = amax ? sign * grad_scale(*amax) : sign;
+  if (amax_copy && blockIdx.x == 0 && threadIdx.x == 0) *amax_copy = *amax;
   const size_t total = npix * (size_t)nplanes * 4;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -655,10 +659,10 @@ int bwd_absmax(const float* g, size_t n, float* amax, hipStream_t s) {
 }
 
 int bwd_to_planes(const float* x, void* planes, size_t npix, int c, int cs, int nplanes, int lrelu, float sign,
-                  const float* amax, hipStream_t s) {
+                  const float* amax, hipStream_t s, float* amax_copy) {
   const size_t items = npix * (size_t)nplanes * 4;
   hipLaunchKernelGGL(grad_to_planes_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
-                     x, (f16*)planes, npix, c, cs, nplanes, lrelu, sign, amax);
+                     x, (f16*)planes, npix, c, cs, nplanes, lrelu, sign, amax, amax_copy);
   return hip_rc(hipGetLastError());
 }
 
@@ -795,12 +799,11 @@ int selfc_subnet_bwd_phase_x(int phases, const selfc_subnet_bw* bw, int kind, co
   if (!(phases & SELFC_BWD_DATA)) goto weights;
 
   // 1. scale + scaled f16 planes of dOut.  dout_amax: the producer of dOut already took max|dOut| (selfc_coupling_bwd_x,
-  //    selfc_add_absmax, dx_amax_out of the call that wrote it): one 4-byte copy instead of a pass over dOut
-  if (dout_amax) {
-    if ((rc = hip_rc(hipMemcpyAsync(amax, dout_amax, sizeof(float), hipMemcpyDeviceToDevice, s)))) return rc;
-  } else if ((rc = bwd_absmax(dout, npix * coutp, amax, s))) return rc;
-  if ((rc = bwd_to_planes(dout, gpl, npix, cout, coutp, L.ng, 0, sign, amax, s))) return rc;
-  if (L.hasx && (rc = selfc_nhwc_to_planes(xin, xpl, npix, cin, stream))) return rc;
+  //    selfc_add_absmax, dx_amax_out of the call that wrote it): no pass over dOut, and the to-planes kernel hands the value on
+  //    to this phase's slot (a 4-byte copy node in front of every subnet cost 0.06 - 0.17 ms of the captured step)
+  if (!dout_amax && (rc = bwd_absmax(dout, npix * coutp, amax, s))) return rc;
+  if ((rc = bwd_to_planes(dout, gpl, npix, cout, coutp, L.ng, 0, sign, dout_amax ? dout_amax : amax, s, dout_amax ? amax : nullptr))) return rc;
+  if (L.hasx && (rc = selfc_nhwc_to_planes(xin, xpl, npix, cin, stream))) return rc;      // (stays in the data phase: xin may be rewritten before the weight phase runs on its side stream)
 
   // 2. conv5^T(dOut): x-groups and f1..f3 as addend planes, f4 masked straight into dpre4.  Temporal conv5 (D2DTInput):
   //    the frame-walking temporal-conv kernel, one 32-channel output plane per blockIdx.y; 3x3 conv5 (DenseBlock): the

@@ -38,7 +38,7 @@ int bwd_absmax(const float* g, size_t n, float* amax, hipStream_t s);    // *ama
 // fp32 rows (stride cs, c valid channels) -> f16 planes [nplanes][npix][32]: sign * S(*amax) * (lrelu ? LeakyReLU(x) : x);
 // amax == nullptr: no scaling (activations)
 int bwd_to_planes(const float* x, void* planes, size_t npix, int c, int cs, int nplanes, int lrelu, float sign,
-                  const float* amax, hipStream_t s);
+                  const float* amax, hipStream_t s, float* amax_copy = nullptr);
 
 struct WgradJob {
   const void* P; int Pn;            // gradient planes (scaled f16)
