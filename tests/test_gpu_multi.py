@@ -65,6 +65,18 @@ def test_bench_two_ranks_share_one_gpu():
     print("two ranks on one GPU:", d["value"], "septuplets/s,", d["ms_per_step"], "ms per step (each rank 4 septuplets)")
 
 
+def test_uvg_shard_by_clip_two_ranks_share_one_gpu():
+    """config 5's launcher (`tools/bench_uvg.py --gpus 2`: clips round-robin over the ranks, no data-path collective) with both
+    ranks on the ONE visible MI355X: 3 clips of 21 frames at 256x448 -> rank 0 owns clips 0 and 2, rank 1 clip 1; the line counts
+    every clip and both ranks."""
+    env = dict(_clean_env(), SELFC_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_uvg.py"), "--gpus", "2", "--clips", "3", "--frames", "21",
+                        "--height", "256", "--width", "448"], env=env, capture_output=True, text=True, timeout=900)
+    d = _json_line(p)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["clips"] == 3 and d["gops_per_clip"] == 3 and d["frames_per_s"] > 0
+    assert "REHEARSAL" in d["sharding"]
+
+
 def test_ddp_two_ranks_keep_equal_parameters():
     """config 3 (train.py under torch.distributed.launch, README.md:85): after optimisation steps on DIFFERENT data the
     ranks' parameters must be identical - the gradient all-reduce over RCCL is the only thing that makes them so.  Three

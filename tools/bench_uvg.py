@@ -70,10 +70,12 @@ def main():
     rc = launch.self_launch(a.gpus, os.path.abspath(__file__), sys.argv[1:])      # before anything touches the GPU
     if rc is not None:
         sys.exit(rc)
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # SELFC_BENCH_SHARE_GPU=1: rehearsal on a one-GPU box - every rank on cuda:0, the protocol's collectives over gloo (as bench.py)
+    share_gpu = os.environ.get("SELFC_BENCH_SHARE_GPU") == "1" and a.gpus > 1
+    local = 0 if share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    ranks = launch.Ranks(a.gpus, "nccl", dev)
+    ranks = launch.Ranks(a.gpus, "gloo" if share_gpu else "nccl", dev)
     rank, world = ranks.rank, ranks.world
     from selfc_amd import GlobalVar, _lib
     from selfc_amd.modules.SelfC_GMM_arch_inv import SelfCInvNet
@@ -93,7 +95,7 @@ def main():
                           "gops_per_s": round(ngop / sec, 2), "unit": "7x3x%dx%d septuplets/s" % (H, W), "n_gpus": world, "clips": a.clips,
                           "frames_per_clip": a.frames, "gops_per_clip": ngops_clip, "seconds": round(sec, 3), "dtype": _lib.OPERAND,
                           "stack_roofline_per_gpu": roofline_fracs(ngop, world, sec, H, W),
-                          "streams_per_gpu": S, "sharding": f"{world} rank(s), clips round-robin, no data-path collective", "rccl_ranks": nranks, "data": "synthetic"}))
+                          "streams_per_gpu": S, "sharding": f"{world} rank(s), clips round-robin, no data-path collective" + (" - REHEARSAL: all ranks share ONE GPU, collectives over gloo" if share_gpu else ""), "rccl_ranks": nranks, "data": "synthetic"}))
     ranks.close()
 
 
