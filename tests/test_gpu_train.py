@@ -353,3 +353,38 @@ def test_folded_gradient_maxima_change_nothing(dev):
         assert a.keys() == b.keys() and len(a) > 300
         bad = [n for n in a if not torch.equal(a[n], b[n])]
         assert not bad, f"streams={two}: {len(bad)} gradients differ, e.g. {bad[:4]}"
+
+
+def test_backward_is_linear_in_the_output_gradient_at_chain_level(dev):
+    """A bar the LeakyReLU kinks cannot loosen: with the forward fixed (same input, same weights -> the same f16 features and
+    the same masks), the backward of the WHOLE stack (FrequencyAnalyzer + 8 InvBlockExp, selfc_amd.autograd.InvStackFn) is a
+    linear map of the output gradient.  grad(a u + b v) must equal a grad(u) + b grad(v) for the input and for every parameter,
+    up to the f16 rounding of the gradient planes (each call scales them by its own max|dOut|): relative L2 below 2e-3, ten
+    times tighter than the comparisons with autograd through the fp32 oracle can be (Inv_arch.py:20-31, Subnet_constructor.py:
+    98-133, SelfC_GMM_arch_inv.py:62-82 are what is differentiated)."""
+    net = _net(dev)
+    gen = torch.Generator().manual_seed(41)
+    x = torch.rand(T, 3, 64, 80, generator=gen).to(dev)
+    u = torch.randn(T, 51, 16, 20, generator=gen).to(dev) * 1e-2
+    v = torch.randn(T, 51, 16, 20, generator=gen).to(dev) * 1e-2
+    a, b = 0.7, -1.9
+    names = [n for n, p in net.named_parameters() if n.startswith("operations.") and p.requires_grad]
+
+    def grads(w):
+        net.zero_grad(set_to_none=True)
+        xd = x.clone().requires_grad_(True)
+        z, _ = net(x=xd, rev=False)
+        z.backward(w)
+        ps = dict(net.named_parameters())
+        return xd.grad.detach().clone(), torch.cat([ps[n].grad.detach().reshape(-1) for n in names])
+
+    gx_u, gp_u = grads(u)
+    gx_v, gp_v = grads(v)
+    gx_w, gp_w = grads(a * u + b * v)
+    from conftest import rel_l2
+    ex = rel_l2(gx_w, a * gx_u + b * gx_v)
+    ep = rel_l2(gp_w, a * gp_u + b * gp_v)
+    print("linearity of the stack's backward: input gradient", ex, "parameter gradients", ep)
+    assert ex < 2e-3 and ep < 2e-3
+    gx_u2, gp_u2 = grads(u)                       # and it is a function: the same call twice, bit for bit
+    assert torch.equal(gx_u, gx_u2) and torch.equal(gp_u, gp_u2)
