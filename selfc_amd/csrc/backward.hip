@@ -818,6 +818,20 @@ int selfc_subnet_bwd_phase_x(int phases, const selfc_subnet_bw* bw, int kind, co
     c.amax = amax;
     if ((rc = bwd_conv_planes(c, N, T, H, W, s))) return rc;
   }
+  // 3 + 4 as ONE launch (csrc/dgrad_chain.hip: the chain in LDS, bit-identical values) while its workgroups - one per 12x16
+  // tile and frame, one per CU - fit the chip in a single round: training crops at 1..4 septuplets per rank (63..252 tiles;
+  // captured step 8.4 -> 7.8, 9.0 -> 8.3, 10.3 -> 9.85 ms).  Beyond that the layer-wise launches win (3-wave workgroups, four
+  // per CU, G's and H's chains side by side: 13.8 against 14.6 ms at 8 septuplets; the chain for F alone: 13.95).
+  // SELFC_BWD_CHAIN=0 / 1: never / always (tests).
+  {
+    static const int chain_env = getenv("SELFC_BWD_CHAIN") ? atoi(getenv("SELFC_BWD_CHAIN")) : -1;
+    const long chain_wgs = (long)N * ((H + 11) / 12) * ((W + 15) / 16);
+    if (chain_env == 1 || (chain_env < 0 && chain_wgs <= 256)) {
+      const void* wtd[3] = {bw->wtd[0], bw->wtd[1], bw->wtd[2]};
+      if ((rc = bwd_dgrad_chain(gb, t5, feat, wtd, bw->wtx, dx, L.nx, cinp, accumulate_dx, amax, dx_amax_out, N, H, W, s))) return rc;
+      goto weights;
+    }
+  }
   // 3. dpre3, dpre2, dpre1
   for (int j = 3; j >= 1; --j) {
     BwdConv c{};

@@ -33,6 +33,10 @@ int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s)
 int bwd_tconv5T(const void* g, int ng, const void* w, int nplanes_out, void* out_planes, const void* mask, int mask_z, void* alt,
                 int N, int T, int H, int W, hipStream_t s);
 
+// csrc/dgrad_chain.hip: dpre3, dpre2, dpre1 (planes 1..3 of gb, plane 0 = dpre4) and, with dx, the input gradient as ONE launch
+int bwd_dgrad_chain(void* gb, const void* add, const void* feat, const void* const* wtd, const void* wtx, float* dx, int nx, int cinp,
+                    int accumulate_dx, const float* amax, float* amax_out, int N, int H, int W, hipStream_t s);
+
 // csrc/backward.hip building blocks (also used by the STP gradients in csrc/stp.hip)
 int bwd_absmax(const float* g, size_t n, float* amax, hipStream_t s);    // *amax = max|g| (zeroed first)
 // fp32 rows (stride cs, c valid channels) -> f16 planes [nplanes][npix][32]: sign * S(*amax) * (lrelu ? LeakyReLU(x) : x);

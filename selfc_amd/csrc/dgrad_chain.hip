@@ -1,0 +1,293 @@
+// The data-gradient chain of one dense block as ONE launch (backward of Subnet_constructor.py:27-30 / :126-129, the four 3x3
+// convs with their concats and LeakyReLUs), for gfx950.
+//
+// csrc/backward.hip runs the chain layer by layer on the generic plane conv (csrc/dense_conv.hip, EPI_BWD):
+//     dpre3 = m3 (t3 + W4^T[f3] dpre4)
+//     dpre2 = m2 (t2 + W4^T[f2] dpre4 + W3^T[f2] dpre3)
+//     dpre1 = m1 (t1 + W4^T[f1] dpre4 + W3^T[f1] dpre3 + W2^T[f1] dpre2)
+//     dx    =     tx + W4^T[x ] dpre4 + W3^T[x ] dpre3 + W2^T[x ] dpre2 + W1^T[x] dpre1
+// (t = conv5^T(dOut), m = LeakyReLU'(saved feature)) - four or five launches of ~4 us of MFMA work each on the 36x36 latents of a
+// training crop, in series, 32 subnets in series per step.  Here one workgroup owns a 12x16 output tile of one frame and keeps
+// the chain in LDS (halo recompute: dpre_j on the tile grown by j pixels; dpre4 comes in with a 4-pixel halo), the same
+// decomposition as csrc/fused_gh.hip forward.  Same fragments (packing.pack_subnet_bwd), same stage / tap / k order and the same
+// MFMA as the layer-wise path, so every value it stores is BIT-IDENTICAL to that path's (tests/test_gpu_train.py).
+//
+// LDS: images G4 (20x24), G3 (18x22), G2 (16x20), G1 (14x18) of 32 f16 channels at the conv kernels' 80-byte pixel pitch and
+// 256-byte-multiple row pitches (40 + 31.5 + 28 + 21 KiB) + one 18-KiB weight stage = 138.5 KiB: one workgroup of 8 waves per CU.
+// M-tiles are 2 rows x 16 columns (dense_conv.hip's): a region 22 / 20 / 18 columns wide takes two column blocks, the lanes of
+// the second block beyond the region multiply whatever the image row holds there (their results are not stored; an MFMA's
+// output column depends on its own input column only).
+#include <stdio.h>
+#include <stdlib.h>
+#include <atomic>
+#include <type_traits>
+#include "common.hpp"
+#include "prof.hpp"
+#include "bwd_internal.hpp"
+#include "../../include/selfc_hip.h"
+
+using namespace selfc;
+
+namespace selfc {
+
+struct DgArgs {
+  const f16* g4;          // dpre4: plane 0 of the chain buffer [N][H][W][32]
+  f16* gb;                // the chain buffer: dpre_j is written to plane 4 - j
+  const f16* add;         // conv5^T(dOut): planes [nx x-groups][f1][f2][f3]
+  const f16* feat;        // saved features f1, f2, f3 (the masks)
+  const f16* wtd[3];      // fragments of dpre3, dpre2, dpre1 (stages: dpre4, dpre3, ..; 18 fragments each)
+  const f16* wtx;         // fragments of dx: nx groups x 4 stages x 18
+  float* dx;              // fp32 NHWC rows of stride cinp, or null (no input gradient wanted)
+  const float* amax;      // max|dOut| of the call: dx is stored as value / grad_scale(*amax)
+  float* amax_out;        // optional: atomic max |stored dx|
+  size_t plane;           // halfs per plane
+  int N, H, W, tiles_x, tiles_y;
+  int nx, cinp, acc_dx;
+};
+
+namespace {
+
+constexpr int TH = 12, TW = 16;
+constexpr int NWAVE = 8, NT = NWAVE * 64;
+template <int K>
+struct Img {
+  static constexpr int rows = TH + 2 * K, cols = TW + 2 * K;
+  static constexpr int rowb = (cols * PS + 255) / 256 * 256;
+  static constexpr int bytes = rows * rowb;
+};
+constexpr int OFF4 = 0, OFF3 = OFF4 + Img<4>::bytes, OFF2 = OFF3 + Img<3>::bytes, OFF1 = OFF2 + Img<2>::bytes;
+constexpr int OFFW = OFF1 + Img<1>::bytes;
+constexpr int DG_LDS = OFFW + 18 * 1024;
+static_assert(DG_LDS <= 160 * 1024, "LDS budget");
+template <int K> constexpr int img_off() { return K == 4 ? OFF4 : K == 3 ? OFF3 : K == 2 ? OFF2 : OFF1; }
+constexpr int WITER = (18 * 64 + NT - 1) / NT;      // 3
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+__global__ __launch_bounds__(NT) void dgrad_chain_kernel(const DgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const lw = smem + OFFW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int wg = xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+  const int tx = wg % a.tiles_x, ty = (wg / a.tiles_x) % a.tiles_y, n = wg / (a.tiles_x * a.tiles_y);
+  const int tx0 = tx * TW, ty0 = ty * TH;
+  const int H = a.H, W = a.W;
+
+  // flat list of the weight stages: dpre3 (1), dpre2 (2), dpre1 (3), dx (4 per x-group)
+  const int nstage_all = 6 + (a.dx ? 4 * a.nx : 0);
+  auto wsrc_of = [&](const int g) __attribute__((always_inline)) -> const u32x4* {
+    const f16* p;
+    if (g < 1) p = a.wtd[0];
+    else if (g < 3) p = a.wtd[1] + (size_t)(g - 1) * 18 * 512;
+    else if (g < 6) p = a.wtd[2] + (size_t)(g - 3) * 18 * 512;
+    else p = a.wtx + (size_t)(g - 6) * 18 * 512;          // group z = (g - 6) / 4 follows group z - 1 (stride 4 x 18 fragments)
+    return reinterpret_cast<const u32x4*>(p);
+  };
+  u32x4 wreg[WITER];
+  auto load_w = [&](const int g) __attribute__((always_inline)) {
+    const u32x4* __restrict__ src = wsrc_of(g);
+#pragma unroll
+    for (int it = 0; it < WITER; ++it) wreg[it] = src[min(tid + it * NT, 18 * 64 - 1)];
+  };
+  auto store_w = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < WITER; ++it) {
+      const int i = tid + it * NT;
+      if (i < 18 * 64) *reinterpret_cast<u32x4*>(lw + i * 16) = wreg[it];
+    }
+  };
+
+  load_w(0);
+  // ---- dpre4 with its 4-pixel halo -> G4 (zero outside the frame: the convs' zero padding)
+  {
+    constexpr int NITEM = Img<4>::rows * Img<4>::cols * 4;
+    constexpr int AITER = (NITEM + NT - 1) / NT;
+    u32x4 v[AITER];
+    bool ok[AITER];
+#pragma unroll
+    for (int it = 0; it < AITER; ++it) {
+      const int i = min(tid + it * NT, NITEM - 1);
+      const int p = i >> 2, q = i & 3;
+      const int hy = p / Img<4>::cols, hx = p - hy * Img<4>::cols;
+      const int y = ty0 + hy - 4, x = tx0 + hx - 4;
+      ok[it] = (y >= 0) & (y < H) & (x >= 0) & (x < W);
+      const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+      v[it] = *reinterpret_cast<const u32x4*>(a.g4 + ((size_t)(n * H + yc) * W + xc) * 32 + q * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < AITER; ++it) {
+      const int i = tid + it * NT;
+      if (i < NITEM) {
+        const int p = i >> 2, q = i & 3;
+        const int hy = p / Img<4>::cols, hx = p - hy * Img<4>::cols;
+        *reinterpret_cast<u32x4*>(smem + OFF4 + hy * Img<4>::rowb + hx * PS + q * 16) = ok[it] ? v[it] : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  }
+  store_w();
+  __syncthreads();
+
+  int gstage = 0;        // the stage whose fragments are in LDS
+  float bwmax = 0.f;
+  bool bwnan = false;
+
+  // one layer: J = 3, 2, 1 -> dpre_J on the tile grown by J; J = 0 -> one 32-channel group of dx on the tile
+  auto layer = [&](auto jtag, const int zg) __attribute__((always_inline)) {
+    constexpr int J = decltype(jtag)::value;
+    constexpr int RH = TH + 2 * J, RW = TW + 2 * J, NBX = (RW + 15) / 16, NMT = (RH / 2) * NBX, MT = (NMT + NWAVE - 1) / NWAVE;
+    constexpr int NST = 4 - J;
+    f32x16 acc[MT];
+    int rr[MT], cc[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const int m = min(wave + NWAVE * mi, NMT - 1);
+      const int by = m / NBX, bx = m - by * NBX;
+      rr[mi] = 2 * by + ((lane & 31) >> 4);
+      cc[mi] = 16 * bx + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+    }
+    // the epilogue's operands (conv5^T addend, saved feature = the mask; for dx the addend and, when accumulating, the old value)
+    // are fetched BEFORE the MFMA stages: out-of-frame and out-of-region lanes read pixel 0 and ignore it
+    bool inimg[MT];
+    size_t pixv[MT];
+    f16x4 tadd[MT][4], tmask[J > 0 ? MT : 1][4];
+    float4 told[J == 0 ? MT : 1][4];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const int y = ty0 + rr[mi] - J, x = tx0 + cc[mi] - J;
+      inimg[mi] = (cc[mi] < RW) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
+      pixv[mi] = inimg[mi] ? (size_t)(n * H + y) * W + x : 0;
+      const f16* __restrict__ ad = a.add + (size_t)(J > 0 ? a.nx + J - 1 : zg) * a.plane + pixv[mi] * 32 + 4 * half;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) tadd[mi][g] = *reinterpret_cast<const f16x4*>(ad + 8 * g);
+      if constexpr (J > 0) {
+        const f16* __restrict__ mk = a.feat + (size_t)(J - 1) * a.plane + pixv[mi] * 32 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) tmask[mi][g] = *reinterpret_cast<const f16x4*>(mk + 8 * g);
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int oc = min(32 * zg + 8 * g + 4 * half, a.cinp - 4);
+          told[mi][g] = a.acc_dx ? *reinterpret_cast<const float4*>(a.dx + pixv[mi] * a.cinp + oc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+    static_for<0, NST>([&](auto stag) __attribute__((always_inline)) {
+      constexpr int S = decltype(stag)::value, K = 4 - S, SH = K - J - 1;
+      constexpr int ROWB = Img<K>::rowb;
+      if (gstage + 1 < nstage_all) load_w(gstage + 1);
+      const unsigned char* const img = smem + img_off<K>();
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const f16x8 af = *reinterpret_cast<const f16x8*>(lw + (tap * 2 + ks) * 1024 + lane * 16);
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi) {
+            if (wave + NWAVE * mi < NMT) {       // wave-uniform
+              const f16x8 bf = *reinterpret_cast<const f16x8*>(img + (rr[mi] + SH + tap / 3) * ROWB + (cc[mi] + SH + tap % 3) * PS + half * 16 + ks * 32);
+              acc[mi] = mfma_32x32x16(af, bf, acc[mi]);
+            }
+          }
+        }
+      }
+      ++gstage;
+      __syncthreads();                           // every wave is done with this stage's fragments
+      if (gstage < nstage_all) store_w();
+      if constexpr (S + 1 < NST) __syncthreads();
+    });
+    // ---- epilogue (the next stage's fragments are already in LDS; the barrier after it also publishes G_J)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      if (wave + NWAVE * mi >= NMT) continue;
+      const int r = rr[mi], c = cc[mi];
+      if (c >= RW) continue;
+      const bool in_img = inimg[mi];
+      const size_t pix = pixv[mi];
+      float v[4][4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[g][j] = acc[mi][4 * g + j] + (float)tadd[mi][g][j];
+      if constexpr (J > 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[g][j] *= ((float)tmask[mi][g][j] > 0.f) ? 1.f : 0.2f;
+        const bool centre = in_img & (r >= J) & (r < J + TH) & (c >= J) & (c < J + TW);
+        unsigned char* const lp = smem + img_off<(J > 0 ? J : 1)>() + r * Img<(J > 0 ? J : 1)>::rowb + c * PS + 8 * half;
+        f16* const gp = a.gb + (size_t)(4 - J) * a.plane + pix * 32 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 u;
+          u.x = in_img ? pack2(v[g][0], v[g][1]) : 0u;
+          u.y = in_img ? pack2(v[g][2], v[g][3]) : 0u;
+          *reinterpret_cast<uint2*>(lp + 16 * g) = u;
+          if (centre) *reinterpret_cast<uint2*>(gp + 8 * g) = u;
+        }
+      } else {
+        if (!in_img) continue;
+        const float inv = 1.f / grad_scale(*a.amax);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int oc = 32 * zg + 8 * g + 4 * half;
+          if (oc < a.cinp) {
+            float4* dst = reinterpret_cast<float4*>(a.dx + pix * a.cinp + oc);
+            float4 o = make_float4(v[g][0] * inv, v[g][1] * inv, v[g][2] * inv, v[g][3] * inv);
+            const float4 old = told[mi][g];
+            o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            *dst = o;
+            bwmax = fmaxf(fmaxf(bwmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+            bwnan |= (o.x != o.x) | (o.y != o.y) | (o.z != o.z) | (o.w != o.w);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  };
+
+  layer(std::integral_constant<int, 3>{}, 0);
+  layer(std::integral_constant<int, 2>{}, 0);
+  layer(std::integral_constant<int, 1>{}, 0);
+  if (a.dx) {
+    for (int z = 0; z < a.nx; ++z) layer(std::integral_constant<int, 0>{}, z);
+    if (a.amax_out) {        // one atomic per wave, the convention of dense_conv.hip's EPI_BWD (NaN -> 0x7fc00000)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) bwmax = fmaxf(bwmax, __shfl_xor(bwmax, o));
+      unsigned* const bits = reinterpret_cast<unsigned*>(a.amax_out);
+      if (__any(bwnan)) { if (lane == 0) atomicMax(bits, 0x7fc00000u); }
+      else if (lane == 0 && bwmax > 0.f) atomicMax(bits, __float_as_uint(bwmax));
+    }
+  }
+}
+
+inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 1000; }
+
+}  // namespace
+
+// dpre3, dpre2, dpre1 (planes 1..3 of gb) and, with dx, the input gradient - steps 3 and 4 of selfc_subnet_bwd_phase_x as one launch
+int bwd_dgrad_chain(void* gb, const void* add, const void* feat, const void* const* wtd, const void* wtx, float* dx, int nx, int cinp,
+                    int accumulate_dx, const float* amax, float* amax_out, int N, int H, int W, hipStream_t s) {
+  static std::atomic<unsigned long long> optin{0};
+  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&dgrad_chain_kernel), DG_LDS, optin); e != hipSuccess) return hip_rc(e);
+  DgArgs a{};
+  a.g4 = (const f16*)gb; a.gb = (f16*)gb; a.add = (const f16*)add; a.feat = (const f16*)feat;
+  for (int i = 0; i < 3; ++i) a.wtd[i] = (const f16*)wtd[i];
+  a.wtx = (const f16*)wtx; a.dx = dx; a.amax = amax; a.amax_out = amax_out;
+  a.plane = (size_t)N * H * W * 32;
+  a.N = N; a.H = H; a.W = W;
+  a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
+  a.nx = nx; a.cinp = cinp; a.acc_dx = accumulate_dx;
+  ProfScope prof(-1, s);
+  hipLaunchKernelGGL(dgrad_chain_kernel, dim3((unsigned)(a.tiles_x * a.tiles_y * N)), dim3(NT), DG_LDS, s, a);
+  return hip_rc(hipGetLastError());
+}
+
+}  // namespace selfc

@@ -388,3 +388,51 @@ def test_backward_is_linear_in_the_output_gradient_at_chain_level(dev):
     assert ex < 2e-3 and ep < 2e-3
     gx_u2, gp_u2 = grads(u)                       # and it is a function: the same call twice, bit for bit
     assert torch.equal(gx_u, gx_u2) and torch.equal(gp_u, gp_u2)
+
+
+_CHILD_GRADS = r"""
+import sys
+import numpy as np
+import torch
+root, out = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root)
+sys.path.insert(0, root + "/tests")
+import test_gpu_train as tg
+from selfc_amd import GlobalVar, _lib, train
+_lib.lib()
+GlobalVar.set_Temporal_LEN(tg.T)
+dev = torch.device("cuda:0")
+np.savez(out, **{k: v.cpu().numpy() for k, v in tg._chain_case_grads(dev).items()})
+"""
+
+
+def _chain_case_grads(dev):
+    """every gradient of one training forward + backward on a ragged clip (latent 19 x 37: tiles with 7 / 5 valid rows, 5 valid columns)"""
+    from selfc_amd import train
+    gt = torch.rand(1, 3, T, 76, 148, generator=torch.Generator().manual_seed(77)).to(dev)
+    real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
+    net = _net(dev)
+    tr = train.RescaleTrainer(net, dict(train.TRAIN_OPT_LARGE), flat_params=False)
+    tr._zero_grad()
+    tr._forward_backward(real_h, ref_l)
+    torch.cuda.synchronize()
+    return {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+
+
+def test_fused_data_gradient_chain_is_bit_identical_to_the_layer_wise_launches(dev, tmp_path):
+    """csrc/dgrad_chain.hip (dpre3, dpre2, dpre1 and dx of a dense block as ONE launch, the chain kept in LDS with halo recompute;
+    taken while its workgroups fit the chip in one round) against the four or five launches of the generic plane conv it
+    replaces (SELFC_BWD_CHAIN=0, in a child process): same fragments, same stage / tap / k order, same MFMA - every gradient of
+    a training step must be the same bit for bit, on a ragged frame (backward of Subnet_constructor.py:27-30,126-129)."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "grads.npz")
+    subprocess.run([sys.executable, "-c", _CHILD_GRADS, root, out], check=True, env=dict(os.environ, SELFC_BWD_CHAIN="0"), timeout=600)
+    mine = _chain_case_grads(dev)                                    # this process: the default (one launch at this size)
+    with np.load(out) as ref:
+        assert set(ref.files) == set(mine) and len(mine) > 300
+        bad = [n for n in mine if not np.array_equal(mine[n].cpu().numpy(), ref[n])]
+    assert not bad, f"{len(bad)} gradients differ, e.g. {bad[:4]}"
