@@ -594,8 +594,18 @@ __global__ __launch_bounds__(t5_waves<EPI>() * 64) void tconv5_kernel(const T5Ar
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   {
+    // every load of a thread's share is issued before the first LDS store: as a rolled loop (load, wait, store, branch) the
+    // up-to-twelve 16-byte pieces per thread were twelve serial L2 round trips at the head of EVERY workgroup of every launch
     const uint4* __restrict__ wsrc = reinterpret_cast<const uint4*>(a.w + (EPI == EPI_T5B ? (size_t)blockIdx.y * a.wz_stride : 0));
-    for (int i = tid; i < NFRAG * 64; i += NTH) *reinterpret_cast<uint4*>(smem + (size_t)i * 16) = wsrc[i];
+    constexpr int WIT = (NFRAG * 64 + NTH - 1) / NTH;
+    uint4 wv[WIT];
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) wv[it] = wsrc[min(tid + it * NTH, NFRAG * 64 - 1)];
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+      const int i = tid + it * NTH;
+      if (i < NFRAG * 64) *reinterpret_cast<uint4*>(smem + (size_t)i * 16) = wv[it];
+    }
   }
   __syncthreads();
 
