@@ -664,7 +664,9 @@ int launch_pair16(F16Args& a, int maxwg, hipStream_t s) {
   const int gmax = a.ntiles >= maxwg ? 1 : (maxwg / a.ntiles < a.N ? maxwg / a.ntiles : a.N);
   static const int minrounds = getenv("SELFC_FUSEDF_MINROUNDS") ? atoi(getenv("SELFC_FUSEDF_MINROUNDS")) : 2;
   int rounds = (a.N + gmax - 1) / gmax;
-  if (rounds < minrounds) rounds = a.N < minrounds ? a.N : minrounds;
+  // (not when every tile-frame gets a workgroup of its own in ONE round - training crops at 1..4 septuplets per rank: there the
+  // launch is latency, and one tile-frame per workgroup halves it: captured training step 7.75 -> 7.43 ms at one septuplet)
+  if (rounds < minrounds && (long)a.N * a.ntiles > maxwg) rounds = a.N < minrounds ? a.N : minrounds;
   const int gfr = (a.N + rounds - 1) / rounds;
   const int gx = gfr * a.ntiles;
 #ifdef SELFC_STAMPS

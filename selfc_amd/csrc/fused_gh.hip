@@ -533,7 +533,7 @@ int launch_fused_gh(FGArgs& a, hipStream_t s, int nets) {
   const int gmax = a.ntiles >= maxwg ? 1 : (maxwg / a.ntiles < a.N ? maxwg / a.ntiles : a.N);
   static const int minrounds = getenv("SELFC_FUSEDGH_MINROUNDS") ? atoi(getenv("SELFC_FUSEDGH_MINROUNDS")) : 2;
   int rounds = (a.N + gmax - 1) / gmax;
-  if (rounds < minrounds) rounds = a.N < minrounds ? a.N : minrounds;
+  if (rounds < minrounds && (long)a.N * a.ntiles > maxwg) rounds = a.N < minrounds ? a.N : minrounds;   // (one round of single tile-frames stays: see fused_f16.hip)
   const int gfr = (a.N + rounds - 1) / rounds;
   const int gx = gfr * a.ntiles;
 #ifdef SELFC_STAMPS
