@@ -47,19 +47,22 @@ struct DgArgs {
 
 namespace {
 
-constexpr int TH = 12, TW = 16;
+constexpr int TW = 16;
 constexpr int NWAVE = 8, NT = NWAVE * 64;
-template <int K>
+// TH = tile rows: 12 (three tiles down a 36-row training latent), or 6 where that still fits one round - twice the workgroups,
+// each with less serial work (launches of 63 / 126 tile-frames at 12 rows are all latency)
+template <int TH, int K>
 struct Img {
   static constexpr int rows = TH + 2 * K, cols = TW + 2 * K;
   static constexpr int rowb = (cols * PS + 255) / 256 * 256;
   static constexpr int bytes = rows * rowb;
 };
-constexpr int OFF4 = 0, OFF3 = OFF4 + Img<4>::bytes, OFF2 = OFF3 + Img<3>::bytes, OFF1 = OFF2 + Img<2>::bytes;
-constexpr int OFFW = OFF1 + Img<1>::bytes;
-constexpr int DG_LDS = OFFW + 18 * 1024;
-static_assert(DG_LDS <= 160 * 1024, "LDS budget");
-template <int K> constexpr int img_off() { return K == 4 ? OFF4 : K == 3 ? OFF3 : K == 2 ? OFF2 : OFF1; }
+template <int TH, int K> constexpr int img_off() {
+  return K == 4 ? 0 : K == 3 ? Img<TH, 4>::bytes : K == 2 ? Img<TH, 4>::bytes + Img<TH, 3>::bytes : Img<TH, 4>::bytes + Img<TH, 3>::bytes + Img<TH, 2>::bytes;
+}
+template <int TH> constexpr int off_w() { return img_off<TH, 1>() + Img<TH, 1>::bytes; }
+template <int TH> constexpr int dg_lds() { return off_w<TH>() + 18 * 1024; }
+static_assert(dg_lds<12>() <= 160 * 1024, "LDS budget");
 constexpr int WITER = (18 * 64 + NT - 1) / NT;      // 3
 
 template <int I, int N, class F>
@@ -70,9 +73,10 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+template <int TH>
 __global__ __launch_bounds__(NT) void dgrad_chain_kernel(const DgArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const lw = smem + OFFW;
+  unsigned char* const lw = smem + off_w<TH>();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int wg = xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
   const int tx = wg % a.tiles_x, ty = (wg / a.tiles_x) % a.tiles_y, n = wg / (a.tiles_x * a.tiles_y);
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(NT) void dgrad_chain_kernel(const DgArgs a) {
   load_w(0);
   // ---- dpre4 with its 4-pixel halo -> G4 (zero outside the frame: the convs' zero padding)
   {
-    constexpr int NITEM = Img<4>::rows * Img<4>::cols * 4;
+    constexpr int NITEM = Img<TH, 4>::rows * Img<TH, 4>::cols * 4;
     constexpr int AITER = (NITEM + NT - 1) / NT;
     u32x4 v[AITER];
     bool ok[AITER];
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(NT) void dgrad_chain_kernel(const DgArgs a) {
     for (int it = 0; it < AITER; ++it) {
       const int i = min(tid + it * NT, NITEM - 1);
       const int p = i >> 2, q = i & 3;
-      const int hy = p / Img<4>::cols, hx = p - hy * Img<4>::cols;
+      const int hy = p / Img<TH, 4>::cols, hx = p - hy * Img<TH, 4>::cols;
       const int y = ty0 + hy - 4, x = tx0 + hx - 4;
       ok[it] = (y >= 0) & (y < H) & (x >= 0) & (x < W);
       const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
@@ -125,8 +129,8 @@ __global__ __launch_bounds__(NT) void dgrad_chain_kernel(const DgArgs a) {
       const int i = tid + it * NT;
       if (i < NITEM) {
         const int p = i >> 2, q = i & 3;
-        const int hy = p / Img<4>::cols, hx = p - hy * Img<4>::cols;
-        *reinterpret_cast<u32x4*>(smem + OFF4 + hy * Img<4>::rowb + hx * PS + q * 16) = ok[it] ? v[it] : u32x4{0u, 0u, 0u, 0u};
+        const int hy = p / Img<TH, 4>::cols, hx = p - hy * Img<TH, 4>::cols;
+        *reinterpret_cast<u32x4*>(smem + hy * Img<TH, 4>::rowb + hx * PS + q * 16) = ok[it] ? v[it] : u32x4{0u, 0u, 0u, 0u};
       }
     }
   }
@@ -181,9 +185,9 @@ __global__ __launch_bounds__(NT) void dgrad_chain_kernel(const DgArgs a) {
     }
     static_for<0, NST>([&](auto stag) __attribute__((always_inline)) {
       constexpr int S = decltype(stag)::value, K = 4 - S, SH = K - J - 1;
-      constexpr int ROWB = Img<K>::rowb;
+      constexpr int ROWB = Img<TH, K>::rowb;
       if (gstage + 1 < nstage_all) load_w(gstage + 1);
-      const unsigned char* const img = smem + img_off<K>();
+      const unsigned char* const img = smem + img_off<TH, K>();
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(NT) void dgrad_chain_kernel(const DgArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[g][j] *= ((float)tmask[mi][g][j] > 0.f) ? 1.f : 0.2f;
         const bool centre = in_img & (r >= J) & (r < J + TH) & (c >= J) & (c < J + TW);
-        unsigned char* const lp = smem + img_off<(J > 0 ? J : 1)>() + r * Img<(J > 0 ? J : 1)>::rowb + c * PS + 8 * half;
+        unsigned char* const lp = smem + img_off<TH, (J > 0 ? J : 1)>() + r * Img<TH, (J > 0 ? J : 1)>::rowb + c * PS + 8 * half;
         f16* const gp = a.gb + (size_t)(4 - J) * a.plane + pix * 32 + 4 * half;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -275,18 +279,28 @@ inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 
 // dpre3, dpre2, dpre1 (planes 1..3 of gb) and, with dx, the input gradient - steps 3 and 4 of selfc_subnet_bwd_phase_x as one launch
 int bwd_dgrad_chain(void* gb, const void* add, const void* feat, const void* const* wtd, const void* wtx, float* dx, int nx, int cinp,
                     int accumulate_dx, const float* amax, float* amax_out, int N, int H, int W, hipStream_t s) {
-  static std::atomic<unsigned long long> optin{0};
-  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&dgrad_chain_kernel), DG_LDS, optin); e != hipSuccess) return hip_rc(e);
   DgArgs a{};
   a.g4 = (const f16*)gb; a.gb = (f16*)gb; a.add = (const f16*)add; a.feat = (const f16*)feat;
   for (int i = 0; i < 3; ++i) a.wtd[i] = (const f16*)wtd[i];
   a.wtx = (const f16*)wtx; a.dx = dx; a.amax = amax; a.amax_out = amax_out;
   a.plane = (size_t)N * H * W * 32;
   a.N = N; a.H = H; a.W = W;
-  a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
+  a.tiles_x = (W + TW - 1) / TW;
   a.nx = nx; a.cinp = cinp; a.acc_dx = accumulate_dx;
+  static const int th_env = getenv("SELFC_BWD_CHAIN_TH") ? atoi(getenv("SELFC_BWD_CHAIN_TH")) : 0;
+  const bool th6 = th_env ? th_env == 6 : (long)N * a.tiles_x * ((H + 5) / 6) <= 256;
+  static std::atomic<unsigned long long> optin12{0}, optin6{0};
+  if (th6) {
+    if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&dgrad_chain_kernel<6>), dg_lds<6>(), optin6); e != hipSuccess) return hip_rc(e);
+    a.tiles_y = (H + 5) / 6;
+    ProfScope prof(-1, s);
+    hipLaunchKernelGGL(dgrad_chain_kernel<6>, dim3((unsigned)(a.tiles_x * a.tiles_y * N)), dim3(NT), dg_lds<6>(), s, a);
+    return hip_rc(hipGetLastError());
+  }
+  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&dgrad_chain_kernel<12>), dg_lds<12>(), optin12); e != hipSuccess) return hip_rc(e);
+  a.tiles_y = (H + 11) / 12;
   ProfScope prof(-1, s);
-  hipLaunchKernelGGL(dgrad_chain_kernel, dim3((unsigned)(a.tiles_x * a.tiles_y * N)), dim3(NT), DG_LDS, s, a);
+  hipLaunchKernelGGL(dgrad_chain_kernel<12>, dim3((unsigned)(a.tiles_x * a.tiles_y * N)), dim3(NT), dg_lds<12>(), s, a);
   return hip_rc(hipGetLastError());
 }
 
