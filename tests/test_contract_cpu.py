@@ -133,3 +133,26 @@ def test_module_with_published_head_output_pickles():
     got = m2.__dict__["parameters"]
     assert type(got) is torch.Tensor and not got.requires_grad and torch.equal(got, m.parameters.detach())
     assert pickle.loads(pickle.dumps(m.parameters)).shape == (3, 2)
+
+
+def test_bench_host_weights_checks_its_copies():
+    """bench.py feeds the CPU oracle a host copy of the weights that it verifies against the source tensor (a reference computed
+    from a wrong copy reads as a parity failure of the kernels: profiles/r4/parity_leg_host_copy.txt).  On host tensors the
+    check is the identity: every `operations.*` tensor comes back equal, nothing is re-copied; other keys are not taken."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.operations = torch.nn.ModuleList([torch.nn.Conv2d(3, 4, 3), torch.nn.Conv2d(4, 2, 1)])
+            self.stp_net = torch.nn.Linear(2, 2)
+
+    net = Net()
+    params, recopied = bench.host_weights(net)
+    assert recopied == []
+    assert set(params) == {k for k in net.state_dict() if k.startswith("operations.")} and len(params) == 4
+    assert all(torch.equal(params[k], net.state_dict()[k]) for k in params)
+    assert bench.weights_checksum(net) == bench.weights_checksum(net) > 0
