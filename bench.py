@@ -47,40 +47,118 @@ def build_net(device):
     return net.to(device)
 
 
-def weights_checksum(net):
-    """sum of |w| over every parameter, in float64 on the host (a change of any weight by any leg would show)"""
-    return float(sum(v.detach().double().abs().sum().item() for v in net.state_dict().values() if v.is_floating_point()))
+_HASH_MUL = 0x9E3779B97F4A7C15 - (1 << 64)          # odd 64-bit multiplier (as a signed int64)
 
 
-def host_weights(net):
-    """The oracle's copy of the weights, each tensor verified by copying it back and comparing on the device (bit-exact); a
-    tensor that fails is copied again.  Why: on one box of the pool 9 of 45 runs of this script got ONE 3456-byte weight tensor
-    wrong in its device -> host copy (device content intact, every device path agreeing with an oracle fed a second copy;
-    profiles/r4/parity_leg_host_copy.txt) - a reference computed from such a copy reads as a parity failure of the kernels."""
-    params, recopied = {}, []
+def tensor_hash(t: torch.Tensor) -> int:
+    """Position-dependent 64-bit hash of a float32 tensor's BITS, computed where the tensor lives (device tensors: on the device,
+    only the 8-byte result crosses PCIe): sum over i of (bits[i] + 1) * (2 i + 1) * M, wrapping in int64.  Unlike a sum of |w| it
+    moves with a permutation, a sign flip or a swapped pair of elements; the same function on a host copy must give the same value."""
+    b = t.detach().contiguous().view(torch.int32).flatten().to(torch.int64)
+    i = torch.arange(b.numel(), dtype=torch.int64, device=b.device)
+    return int((((b + 1) * (2 * i + 1)) * _HASH_MUL).sum().item())
+
+
+def weights_hash(net) -> dict:
+    """tensor name -> tensor_hash of the device tensor, for every floating-point entry of the state dict"""
+    return {k: tensor_hash(v) for k, v in net.state_dict().items() if v.is_floating_point()}
+
+
+def box_identity() -> dict:
+    """Which physical card / host this run landed on (sysfs only - no HIP call): makes "one box" a testable statement when a
+    fault is seen on some runs of a pool and not on others (profiles/r5/host_copy_*.txt)."""
+    out = {}
+    try:
+        import glob
+        import socket
+        out["host"] = socket.gethostname()
+        for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+            try:
+                if open(os.path.join(d, "vendor")).read().strip() != "0x1002":
+                    continue
+                uid = os.path.join(d, "unique_id")
+                out.setdefault("gpus", []).append({"pci": os.path.basename(os.path.realpath(d)),
+                                                   "unique_id": open(uid).read().strip() if os.path.exists(uid) else None})
+            except OSError:
+                continue
+        out["boot_id"] = open("/proc/sys/kernel/random/boot_id").read().strip()
+    except Exception as e:  # noqa: BLE001
+        out["error"] = repr(e)[:100]
+    return out
+
+
+def describe_bad_copy(name, wrong: torch.Tensor, dev_t: torch.Tensor, others: dict) -> dict:
+    """A host copy that does not match its device tensor: WHERE it differs (byte ranges), WHAT the wrong bytes are (hex sample,
+    all zero?), and whether they equal the same region of any other buffer we can still name (`others`: name -> host tensor of
+    the same shape, e.g. the training leg's final / initial weights).  The pair is also saved under gpurun_out/ for offline study."""
+    import numpy as np
+    right = dev_t.detach().cpu()
+    w8 = wrong.contiguous().view(torch.uint8).flatten().numpy()
+    r8 = right.contiguous().view(torch.uint8).flatten().numpy()
+    bad = np.flatnonzero(w8 != r8)
+    info = {"tensor": name, "nbytes": int(w8.size), "bad_bytes": int(bad.size), "second_copy_matches_the_device": bool(torch.equal(right.to(dev_t.device), dev_t))}
+    if bad.size:
+        cuts = np.flatnonzero(np.diff(bad) > 1)
+        runs = [(int(bad[a]), int(bad[b]) + 1) for a, b in zip(np.r_[0, cuts + 1], np.r_[cuts, bad.size - 1])]
+        lo, hi = int(bad[0]), int(bad[-1]) + 1
+        info.update({"first_bad_byte": lo, "last_bad_byte": hi - 1, "bad_runs": runs[:16], "n_bad_runs": len(runs),
+                     "span_aligned_64": [lo % 64, hi % 64], "wrong_bytes_all_zero": bool((w8[lo:hi] == 0).all()),
+                     "wrong_hex_first_32": w8[lo:lo + 32].tobytes().hex(), "right_hex_first_32": r8[lo:lo + 32].tobytes().hex()})
+        same = []
+        for oname, o in others.items():
+            try:
+                o8 = o.detach().cpu().contiguous().view(torch.uint8).flatten().numpy()
+                if o8.size == w8.size and (o8[lo:hi] == w8[lo:hi]).all():
+                    same.append(oname)
+            except Exception:  # noqa: BLE001
+                continue
+        info["wrong_bytes_equal_the_same_region_of"] = same
+        # is the wrong span a shifted piece of the right tensor (a copy that landed at the wrong offset)?
+        span = w8[lo:hi].tobytes()
+        at = r8.tobytes().find(span) if hi - lo >= 16 else -1
+        info["wrong_span_found_in_the_right_tensor_at_byte"] = at
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        fn = os.path.join(ROOT, "gpurun_out", f"host_copy_mismatch_{int(time.time())}_{name.replace('.', '_')}.npz")
+        np.savez(fn, wrong=w8, right=r8)
+        info["dump"] = os.path.relpath(fn, ROOT)
+    except Exception as e:  # noqa: BLE001
+        info["dump_error"] = repr(e)[:100]
+    return info
+
+
+def host_weights(net, others=None):
+    """The oracle's copy of the weights.  Every host copy is checked against the device tensor two ways - copied back and compared
+    on the device bit for bit, and tensor_hash(host copy) against tensor_hash taken on the device - and a copy that fails is NOT
+    silently replaced: it is described (describe_bad_copy: offsets, contents, what else the bytes equal), dumped, and returned in
+    `errors`, which the caller puts into the bench line as an error field.  The oracle is then fed a second, verified copy so that
+    the parity figures stay a statement about the kernels.  Why this exists: profiles/r4/parity_leg_host_copy.txt (9 of 45 runs on
+    one day got one 3456-byte weight wrong in this copy); deliberately NO device synchronize in front of the copies - `v.cpu()`
+    orders against the current stream only, and a missing join with some other stream is exactly what this is meant to expose."""
+    params, errors = {}, []
     for k, v in net.state_dict().items():
         if not k.startswith("operations."):
             continue
         v = v.detach()
-        for attempt in range(4):
+        c = v.cpu()
+        if v.is_cuda and not (torch.equal(c.to(v.device), v) and tensor_hash(c) == tensor_hash(v)):
+            errors.append(describe_bad_copy(k, c, v, {f"{n}:{kk}": o[kk] for n, o in (others or {}).items() for kk in o
+                                                      if kk != k and o[kk].numel() == v.numel()}))
             c = v.cpu()
-            if not v.is_cuda or torch.equal(c.to(v.device), v):
-                break
-            recopied.append(k)
-        else:
-            raise RuntimeError(f"bench: the host copy of {k} does not match the device tensor after 4 attempts")
+            if not torch.equal(c.to(v.device), v):
+                raise RuntimeError(f"bench: the host copy of {k} does not match the device tensor twice in a row")
         params[k] = c
-    return params, recopied
+    return params, errors
 
 
-def cpu_baseline(net, x_cpu, budget_s=20.0):
+def cpu_baseline(net, x_cpu, budget_s=20.0, others=None):
     """Oracle (port of the reference's torch path) on one septuplet of the same workload.
 
     torch's CPU convs scale badly past a few dozen threads on a many-core host, so
     the thread count is calibrated on a 128x224 crop first and the one used is
     reported as `cores`."""
     from oracle import selfc_oracle as O      # checker / baseline only
-    params, recopied = host_weights(net)
+    params, copy_errors = host_weights(net, others)
     ncpu = os.cpu_count() or 1
     small = x_cpu[:, :, :128, :224].contiguous()
     best_t, best_n = None, 1
@@ -111,7 +189,7 @@ def cpu_baseline(net, x_cpu, budget_s=20.0):
         cpu_model = None
     cpu_baseline.params = params                  # kept for the parity leg's self-diagnosis
     return {"value": 1.0 / med, "unit": "septuplets/s", "cores": best_n, "kind": "port", "cpu_model": cpu_model,
-            "weights_recopied_after_a_failed_copy_check": recopied,
+            "host_copy_errors": copy_errors,      # [] = every device -> host weight copy was bit-exact at the first attempt
             "sample": f"1 septuplet 7x3x{H}x{W}, fwd+quant+inv through the CPU oracle (torch fp32), {len(timed)} timed run(s), median; "
                       f"{best_n} threads (calibrated) of {ncpu} host CPUs"}, z, zq, xr
 
@@ -155,7 +233,7 @@ def main():
     from selfc_amd.pipeline import MultiStreamRoundTrip, RescaleRoundTrip
     L = _lib.lib()
     net = build_net(dev)
-    w_sum0 = weights_checksum(net)
+    w_hash0 = weights_hash(net)
     n_frames = B_PER_GPU * T
     g = torch.Generator().manual_seed(launch.rank_seed(1234, rank))
     x_cpu = torch.rand(n_frames, 3, H, W, generator=g)
@@ -322,6 +400,7 @@ def main():
                    "sharding": f"{world} rank(s) x {B_PER_GPU} independent septuplets, no data-path collective"
                                + (" - REHEARSAL: all ranks share ONE GPU (SELFC_BENCH_SHARE_GPU=1), collectives over gloo; not a scaling figure" if share_gpu else "")},
         "rccl_ranks": rccl_ranks,
+        "box_identity": box_identity(),
         "box_calibration": {"shader_clock_GHz_under_the_workload": None if clk_ghz is None else round(clk_ghz, 3),
                             "mfma_f16_loop_TFLOPs": round(cal_m.value, 1) or None, "device_copy_GBps": round(cal_c.value, 1) or None, "error": cal_err,
                             "what": "rank 0, right after the timed region: shader clock sampled by one wave on a side stream over more steps of the same workload "
@@ -443,7 +522,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["train_step"] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb, z_ref, zq_ref, xr_ref = cpu_baseline(net, x_cpu[:T])
+        cb, z_ref, zq_ref, xr_ref = cpu_baseline(net, x_cpu[:T], others={"this_net": net.state_dict()})
         out["cpu_baseline"] = cb
         with torch.no_grad():
             z = rt.forward_latent(x)[:T].cpu()
@@ -463,6 +542,13 @@ def main():
                          "fwd_lr_rel_err": mx(z[:, :3], z_ref[:, :3]), "fwd_hf_rel_err": mx(z[:, 3:], z_ref[:, 3:]),
                          "fwd_lr_rel_l2": l2(z[:, :3], z_ref[:, :3]), "fwd_hf_rel_l2": l2(z[:, 3:], z_ref[:, 3:]),
                          "tolerance": 1e-3, "metric": "max|a-b|/max|b| (rel_err), ||a-b||/||b|| (rel_l2)", "against": "CPU oracle, septuplet 0"}
+        # the device weights must still be the ones the net was built with (per-tensor position-dependent hash taken on the device)
+        changed = [k for k, h_ in weights_hash(net).items() if w_hash0.get(k) != h_]
+        out["parity"]["device_weights_changed_since_build"] = changed[:8]
+        if cb["host_copy_errors"] or changed:
+            out["parity"]["error"] = ("a device -> host weight copy did not match its device tensor at the first attempt (cpu_baseline.host_copy_errors: "
+                                      "offsets, contents, dump); the oracle was fed a second, verified copy" if cb["host_copy_errors"] else
+                                      "device weights changed during the run")
         if max(out["parity"]["fwd_latent_rel_err"], out["parity"]["inv_rel_err"]) > 1e-3:
             # never expected: say which side moved (device result repeated, a freshly packed runner, the drop-in module call,
             # the oracle recomputed on one thread, the weights' checksum against the one taken when the net was built)
@@ -482,8 +568,6 @@ def main():
                     dbg["oracle_again_same_threads_new_params_vs_first"] = mx(O.large_fwd(params, x_cpu[:T], T), z_ref)
                     torch.set_num_threads(1)
                     dbg["oracle_one_thread_vs_first"] = mx(O.large_fwd(params, x_cpu[:T], T), z_ref)
-                dbg["weights_checksum_now"] = weights_checksum(net)
-                dbg["weights_checksum_at_build"] = w_sum0
                 dbg["torch_threads_of_the_reference"] = cb["cores"]
             except Exception as e:  # noqa: BLE001
                 dbg["error"] = repr(e)[:300]

@@ -31,7 +31,6 @@ class RescaleRoundTrip:
         self.h, self.w = H // self.k, W // self.k
         blk = net._blocks()[0]
         self.ws = rt.Workspace(device, blk.F.kind, n_frames, t, self.h, self.w, blk.split_len1, blk.split_len2)
-        self._params = [p for b in net._blocks() for p in rt.plist(b)] + self._extra_params()
         self._bind()
         self.lat = self.ws.latent()
         self.out = torch.empty((n_frames, 3, H, W), dtype=torch.float32, device=device)
@@ -41,6 +40,13 @@ class RescaleRoundTrip:
 
     def _extra_params(self):
         return []
+
+    @property
+    def _params(self):
+        """The net's CURRENT Parameter objects, re-derived per check (rt.plist notices re-registered parameters -
+        load_state_dict(assign=True), parametrize, `block.F.conv1.weight = nn.Parameter(...)` - by identity): a list taken once
+        at construction would keep stamping objects the net no longer uses and never see such a change."""
+        return [p for b in self.net._blocks() for p in rt.plist(b)] + self._extra_params()
 
     def _bind(self):
         """(Re)pack the blocks' weights and remember which weights that was."""
@@ -99,6 +105,7 @@ class RescaleRoundTrip:
             self.run(x)                    # warm-up outside capture (lazy function attributes etc.)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        self.graph = None                  # a stale exec dies BEFORE the new one is instantiated (rt.new_graph's docstring)
         g = rt.new_graph()
         with rt.graph_capture(g, x.device):
             self.run(x)
@@ -257,10 +264,8 @@ class ModuleGraph:
         self.lat = [ws.latent() for ws in self.ws]
         self._own_streams = [rt.OwnStream(device) for _ in range(nstreams)] if nstreams > 1 else []
         self.streams = [o.stream for o in self._own_streams]
-        self._params = [p for b in net._blocks() for p in rt.plist(b)]
         if mode == "rev":
             stp = net.stp_net
-            self._params = self._params + rt.plist(stp)
             self.stp_scratch = [{} for _ in range(nstreams)]
             self.eps = [torch.empty((per * h * w, stp.hf_dim * stp.K), dtype=torch.float32, device=device)
                         if stp.fh_loss != "l2" else None for _ in range(nstreams)]
@@ -280,6 +285,14 @@ class ModuleGraph:
     @property
     def net(self):
         return self._net()
+
+    @property
+    def _params(self):
+        """The Parameter objects the net holds NOW (per call, as the eager path derives them: rt.plist is keyed on identity) -
+        parameters re-registered on the net (load_state_dict(assign=True), parametrize) must change the stamp and re-capture."""
+        net = self.net
+        ps = [p for b in net._blocks() for p in rt.plist(b)]
+        return ps + rt.plist(net.stp_net) if self.mode == "rev" else ps
 
     # -- the captured call ------------------------------------------------------------------------------------------------
     # slots: 0 = the caller's input tensor, 1 = the first output, 2 = recon_hf (mode 'rev')
@@ -345,6 +358,7 @@ class ModuleGraph:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize(self.device)
         del warm
+        self.graph = None                  # a stale exec dies BEFORE the new one is instantiated (rt.new_graph's docstring)
         g = rt.new_graph()
         with rt.graph_capture(g, self.device):
             self._run_parts()

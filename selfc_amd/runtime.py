@@ -257,25 +257,45 @@ class graph_capture:
         self.own, self.ctx, self.swapped = None, None, None
 
     def __enter__(self):
-        self.own = OwnStream(self.device)
-        if self.fresh_side is not None:       # dict of module-level side streams to replace for the duration of the capture
-            self.swapped = dict(self.fresh_side)
-            self.side_own = {k: OwnStream(self.device) for k in self.fresh_side}
-            for k, o in self.side_own.items():
-                self.fresh_side[k] = o.stream
+        dev = torch.device("cuda", torch.cuda.current_device()) if self.device is None else torch.device(self.device)
+        with torch.cuda.device(dev):           # streams are created on the CURRENT device: make that the one they are labelled with
+            self.own = OwnStream(dev)
+            if self.fresh_side is not None:       # dict of module-level side streams to replace for the duration of the capture
+                self.swapped = dict(self.fresh_side)
+                self.side_own = {k: OwnStream(dev) for k in self.fresh_side}
+                for k, o in self.side_own.items():
+                    self.fresh_side[k] = o.stream
         kw = {} if self.pool is None else {"pool": self.pool}
-        self.ctx = torch.cuda.graph(self.g, stream=self.own.stream, **kw)
-        return self.ctx.__enter__()
+        try:
+            self.ctx = torch.cuda.graph(self.g, stream=self.own.stream, **kw)
+            return self.ctx.__enter__()
+        except BaseException:
+            self._restore()                    # nothing was captured: undo the swap, drop the streams
+            raise
+
+    def _restore(self):
+        """Put the module-level side streams back and destroy this capture's own streams - on every way out of the capture, also
+        when the captured body (or capture_end) raised: the temporary streams die with this object, and a later backward must
+        not launch on destroyed handles."""
+        try:
+            torch.cuda.synchronize()
+        finally:
+            try:
+                if self.swapped is not None:
+                    self.fresh_side.update(self.swapped)
+                    self.swapped = None
+                    for o in self.side_own.values():
+                        o.close()
+            finally:
+                if self.own is not None:
+                    self.own.close()
+                    self.own = None
 
     def __exit__(self, *exc):
-        r = self.ctx.__exit__(*exc)
-        torch.cuda.synchronize()
-        if self.swapped is not None:
-            self.fresh_side.update(self.swapped)
-            for o in self.side_own.values():
-                o.close()
-        self.own.close()
-        return r
+        try:
+            return self.ctx.__exit__(*exc)
+        finally:
+            self._restore()
 
 
 def warmup_stream(device=None) -> "torch.cuda.Stream":

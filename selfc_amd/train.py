@@ -273,9 +273,21 @@ class RescaleTrainer:
     def load_optimizer_state_dict(self, sd: dict):
         """Inverse of `optimizer_state_dict`: accepts a per-parameter Adam state (a reference `.state` file's 'optimizers' entry,
         or one saved here).  With the flat optimizer the per-parameter moments are merged into the flat tensor's; that needs one
-        common `step` - if the file's steps differ between parameters the trainer falls back to the per-tensor optimizer."""
-        if not self.flat_optimizer:
-            return self.optimizer_G.load_state_dict(sd)
+        common `step` - if the file's steps differ between parameters the trainer falls back to the per-tensor optimizer.
+
+        The file's hyper-parameter VALUES are adopted (lr, betas, eps, weight_decay, initial_lr); the flags that select the
+        step's implementation (capturable, foreach, fused, differentiable) stay the trainer's own, the learning rate of a
+        capturable trainer stays the device tensor the captured step reads (the value is written into it), and state tensors
+        that already exist are overwritten IN PLACE - a captured step keeps updating the tensors it was recorded on.  A file
+        written by torch 1.7 (float lr, integer `step`, no capturable key: what the reference saves) therefore loads into a
+        capturable trainer, before or after capture()."""
+        if self.flat_optimizer:
+            sd = self._merge_state_for_flat(sd)
+        self._load_state_keeping_own_groups(sd)
+
+    def _merge_state_for_flat(self, sd: dict) -> dict:
+        """The per-parameter state `sd` in the layout of the ONE-tensor Adam (param id 0); falls back to the per-tensor optimizer
+        (and returns `sd` unchanged) when the parameters' steps differ or some parameter has no state."""
         n_par = len(self.sink.params)
         ids = [i for g_ in sd["param_groups"] for i in g_["params"]]
         if len(ids) != n_par:
@@ -284,9 +296,8 @@ class RescaleTrainer:
         steps = {float(state[i]["step"]) for i in ids if i in state}
         if state and (len(steps) != 1 or any(i not in state for i in ids)):
             self._per_tensor_optimizer()
-            return self.optimizer_G.load_state_dict(sd)
-        flat_sd = self.optimizer_G.state_dict()
-        flat_sd["param_groups"] = [dict(g_, params=[0]) for g_ in sd["param_groups"][:1]]
+            return sd
+        out = {"param_groups": [dict(g_, params=[0]) for g_ in sd["param_groups"][:1]], "state": {}}
         if state:
             dev, first = self.sink.flat.device, state[ids[0]]
             merged = {}
@@ -299,10 +310,52 @@ class RescaleTrainer:
                     merged[k_] = buf
                 else:
                     merged[k_] = val.clone() if torch.is_tensor(val) else val
-            flat_sd["state"] = {0: merged}
-        else:
-            flat_sd["state"] = {}
-        return self.optimizer_G.load_state_dict(flat_sd)
+            out["state"] = {0: merged}
+        return out
+
+    _IMPL_FLAGS = ("capturable", "foreach", "fused", "differentiable")
+
+    def _load_state_keeping_own_groups(self, sd: dict):
+        opt = self.optimizer_G
+        if len(sd["param_groups"]) != len(opt.param_groups):
+            raise ValueError(f"optimizer state has {len(sd['param_groups'])} parameter groups, the trainer's optimizer {len(opt.param_groups)}")
+        state = sd.get("state", {})
+        for own, saved in zip(opt.param_groups, sd["param_groups"]):
+            if len(saved["params"]) != len(own["params"]):
+                raise ValueError(f"optimizer state group holds {len(saved['params'])} parameters, the trainer's group {len(own['params'])}")
+            for k_, val in saved.items():
+                if k_ == "params" or k_ in self._IMPL_FLAGS:
+                    continue
+                if k_ == "lr" and torch.is_tensor(own.get("lr")):
+                    own["lr"].fill_(float(val))                       # the tensor a captured step reads: same object, new value
+                else:
+                    own[k_] = float(val) if torch.is_tensor(val) and val.numel() == 1 and k_ in ("lr", "initial_lr") else val
+            for pid, p_ in zip(saved["params"], own["params"]):
+                new, cur = state.get(pid), opt.state.get(p_)
+                if new is None:
+                    if cur:
+                        if self.graph is not None:
+                            raise RuntimeError("the loaded optimizer state has no entry for a parameter the captured step updates: capture again")
+                        del opt.state[p_]
+                    continue
+                if cur and set(cur) == set(new):
+                    for k_, val in new.items():                          # in place: a captured step keeps its tensors
+                        if torch.is_tensor(cur[k_]):
+                            cur[k_].copy_(torch.as_tensor(val).to(device=cur[k_].device, dtype=cur[k_].dtype))
+                        else:
+                            cur[k_] = val
+                    continue
+                if self.graph is not None:
+                    raise RuntimeError("the loaded optimizer state does not match the tensors the captured step updates: capture again")
+                fresh = {}
+                for k_, val in new.items():
+                    if k_ == "step":          # torch.optim.Adam._init_group: a device float32 scalar when capturable, a host one otherwise
+                        fresh[k_] = torch.tensor(float(val), dtype=torch.float32, device=p_.device if own.get("capturable") or own.get("fused") else "cpu")
+                    elif torch.is_tensor(val):
+                        fresh[k_] = val.to(device=p_.device, dtype=p_.dtype).clone()
+                    else:
+                        fresh[k_] = val
+                opt.state[p_] = fresh
 
     def _sync_grads(self):
         """The data-parallel step's one collective: all-reduce (SUM, / world) of the flat gradient buffer."""
@@ -370,6 +423,7 @@ class RescaleTrainer:
         torch.cuda.synchronize()
         if self.sink is None:
             self.optimizer_G.zero_grad(set_to_none=True)
+        self.graph, self.graph_tail = None, None      # a re-capture: the old execs die BEFORE the new one is instantiated (rt.new_graph)
         g = rt.new_graph()
         # every capture of the step: own capture stream, own side streams for its duration (runtime.graph_capture)
         if not self.data_parallel:

@@ -135,10 +135,12 @@ def test_module_with_published_head_output_pickles():
     assert pickle.loads(pickle.dumps(m.parameters)).shape == (3, 2)
 
 
-def test_bench_host_weights_checks_its_copies():
+def test_bench_host_weights_checks_its_copies(tmp_path, monkeypatch):
     """bench.py feeds the CPU oracle a host copy of the weights that it verifies against the source tensor (a reference computed
     from a wrong copy reads as a parity failure of the kernels: profiles/r4/parity_leg_host_copy.txt).  On host tensors the
-    check is the identity: every `operations.*` tensor comes back equal, nothing is re-copied; other keys are not taken."""
+    check is the identity: every `operations.*` tensor comes back equal, no error is recorded; other keys are not taken.  The
+    per-tensor hash must move with what a sum of |w| cannot see (a swapped pair, a sign flip), and a wrong copy must be described
+    (where, what, what else holds those bytes) rather than silently replaced."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -151,8 +153,25 @@ def test_bench_host_weights_checks_its_copies():
             self.stp_net = torch.nn.Linear(2, 2)
 
     net = Net()
-    params, recopied = bench.host_weights(net)
-    assert recopied == []
+    params, errors = bench.host_weights(net)
+    assert errors == []
     assert set(params) == {k for k in net.state_dict() if k.startswith("operations.")} and len(params) == 4
     assert all(torch.equal(params[k], net.state_dict()[k]) for k in params)
-    assert bench.weights_checksum(net) == bench.weights_checksum(net) > 0
+    h0 = bench.weights_hash(net)
+    assert h0 == bench.weights_hash(net) and len(h0) == 6
+    w = net.operations[0].weight.detach()
+    sw = w.clone()
+    sw.view(-1)[[0, 1]] = w.view(-1)[[1, 0]]
+    assert bench.tensor_hash(sw) != bench.tensor_hash(w) and bench.tensor_hash(-w) != bench.tensor_hash(w)
+    assert float(sw.abs().sum()) == float(w.abs().sum())             # what the old checksum saw: nothing
+    # a wrong copy: bytes 64..127 replaced by the bytes of another buffer
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    other = torch.randn_like(w)
+    wrong = w.clone()
+    wrong.view(-1)[16:32] = other.view(-1)[16:32]
+    info = bench.describe_bad_copy("operations.0.weight", wrong, w, {"other": other, "unrelated": torch.zeros_like(w)})
+    assert info["first_bad_byte"] >= 64 and info["last_bad_byte"] <= 127 and info["bad_bytes"] >= 56     # (a byte may coincide)
+    assert all(64 <= a < b <= 128 for a, b in info["bad_runs"])
+    assert info["wrong_bytes_equal_the_same_region_of"] == ["other"] and not info["wrong_bytes_all_zero"]
+    assert info["second_copy_matches_the_device"] and os.path.exists(os.path.join(str(tmp_path), info["dump"]))
+    assert "host" in bench.box_identity()

@@ -862,3 +862,39 @@ def test_module_call_is_the_cached_graph_and_stays_a_drop_in(dev):
     # (5)
     net2 = copy.deepcopy(net)
     assert net2 not in pipeline._MODULE_GRAPHS
+
+
+def test_module_graph_follows_re_registered_parameters(dev):
+    """load_state_dict(assign=True) (and parametrize, or `conv.weight = nn.Parameter(...)`) puts NEW Parameter objects
+    on the net; the old ones keep their version counters and addresses.  A cached ModuleGraph / pre-bound pipeline that stamped
+    the objects it saw at construction would replay the old packed weights for ever - the eager path re-derives its list per call
+    and is safe.  The graph paths must re-capture: third call == eager on the new weights, for the module API and for
+    RescaleRoundTrip (eager run and refused stale replay)."""
+    from selfc_amd import pipeline
+    g = load_golden("g8_large_stack")
+    net = _large_net(dev, g, "l2", load_golden("g7_stp_l2_full_rev"))
+    x = torch.rand(2 * T, 3, 32, 48, generator=torch.Generator().manual_seed(5)).to(dev)
+    with torch.no_grad():
+        z1, _ = net(x=x, rev=False)            # seen once
+        z2, _ = net(x=x, rev=False)            # captured
+        assert torch.equal(z1, z2)
+        rtp = pipeline.RescaleRoundTrip(net, 2 * T, 32, 48, dev)
+        y_old = rtp.run(x).clone()
+        rtp.capture(x)
+        new_sd = {k: (v * 1.1 if k.startswith("operations.3.") and v.is_floating_point() else v.clone()) for k, v in net.state_dict().items()}
+        old_first = net.operations[3].F.conv1.weight
+        net.load_state_dict(new_sd, assign=True)
+        assert net.operations[3].F.conv1.weight is not old_first            # re-registered, not copied into
+        z3, _ = net(x=x, rev=False)            # must notice and re-capture
+        pipeline.MODULE_GRAPH = False
+        try:
+            z_eager, _ = net(x=x, rev=False)
+        finally:
+            pipeline.MODULE_GRAPH = True
+        assert torch.equal(z3, z_eager) and not torch.equal(z3, z2)
+        with pytest.raises(RuntimeError, match="capture\\(\\) again"):
+            rtp.replay()
+        y_new = rtp.run(x)
+        assert not torch.equal(y_new, y_old)
+        z_or = O.large_fwd({k: v.cpu() for k, v in new_sd.items()}, x.cpu(), T)
+        assert rel_err(z3.cpu(), z_or) < TOL

@@ -325,6 +325,72 @@ def test_flat_optimizer_state_round_trips_through_the_reference_layout(dev):
         tr.optimize_parameters(real_h, ref_l)
 
 
+def _reference_layout(sd):
+    """An optimizer state as torch 1.7 (the reference's pin) writes it: host tensors, integer `step`, float lr, no capturable /
+    foreach / fused keys - what `base_model.save_training_state` leaves in a `.state` file."""
+    keep = ("lr", "betas", "eps", "weight_decay", "amsgrad", "initial_lr", "params")
+    groups = [{k: (float(v) if torch.is_tensor(v) else v) for k, v in g.items() if k in keep} for g in sd["param_groups"]]
+    state = {i: {k: (int(float(v)) if k == "step" else v.detach().cpu().clone()) for k, v in st.items()} for i, st in sd["state"].items()}
+    return {"state": state, "param_groups": groups}
+
+
+def test_reference_optimizer_state_loads_into_a_capturable_trainer(dev):
+    """a reference `.state` file (float lr, integer step, no capturable flag) loaded into RescaleTrainer(capturable=True)
+    must not replace the device-tensor learning rate or the capturable flag (Adam's step.item() would then fail inside the capture),
+    and loaded AFTER capture() it must land in the tensors the captured step updates.  Both orders against an eager trainer that
+    simply kept training."""
+    from selfc_amd import train
+    x = load_golden("g8_large_stack")["x"]
+    gt = x.reshape(1, T, 3, 32, 48).transpose(1, 2).to(dev)
+    real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
+    net_a = _net(dev)
+    tr_a = train.RescaleTrainer(net_a, dict(train.TRAIN_OPT_LARGE))
+    tr_a.optimize_parameters(real_h, ref_l)
+    tr_a.optimize_parameters(real_h, ref_l)
+    weights2 = {k: v.detach().clone() for k, v in net_a.state_dict().items()}
+    sd2 = _reference_layout(tr_a.optimizer_state_dict())
+    sd2["param_groups"][0]["lr"] = 5e-5                     # a value the fresh trainer does not have: it must be adopted
+    tr_a.optimizer_G.param_groups[0]["lr"] = 5e-5
+    tr_a.optimize_parameters(real_h, ref_l)
+    tr_a.optimize_parameters(real_h, ref_l)                 # A is at step 4
+
+    def worst(n1, n2):
+        return max(float((a - b).abs().max()) for a, b in zip(n1.state_dict().values(), n2.state_dict().values()))
+
+    # (a) load, then capture (one warm-up step = step 3), then one replay = step 4
+    net_b = _net(dev)
+    net_b.load_state_dict(weights2)
+    tr_b = train.RescaleTrainer(net_b, dict(train.TRAIN_OPT_LARGE), capturable=True)
+    lr_tensor = tr_b.optimizer_G.param_groups[0]["lr"]
+    assert torch.is_tensor(lr_tensor)
+    tr_b.load_optimizer_state_dict(sd2)
+    grp = tr_b.optimizer_G.param_groups[0]
+    assert grp["lr"] is lr_tensor and abs(float(lr_tensor) - 5e-5) < 1e-12 and grp["capturable"] is True
+    st = tr_b.optimizer_G.state[grp["params"][0]]
+    assert st["step"].is_cuda and float(st["step"]) == 2.0
+    tr_b.capture(real_h, ref_l, warmup=1)
+    tr_b.optimize_parameters(real_h, ref_l)
+    torch.cuda.synchronize()
+    assert worst(net_a, net_b) < 1e-6, worst(net_a, net_b)
+    # (b) load AFTER capture: same tensors, new contents; two replays bring B to A's step 4 again
+    ids_before = {k: v.data_ptr() for k, v in st.items() if torch.is_tensor(v)}
+    with torch.no_grad():
+        for k, v in net_b.state_dict().items():
+            v.copy_(weights2[k])
+    tr_b.load_optimizer_state_dict(sd2)
+    st = tr_b.optimizer_G.state[tr_b.optimizer_G.param_groups[0]["params"][0]]
+    assert {k: v.data_ptr() for k, v in st.items() if torch.is_tensor(v)} == ids_before
+    assert tr_b.optimizer_G.param_groups[0]["lr"] is lr_tensor
+    tr_b.optimize_parameters(real_h, ref_l)
+    tr_b.optimize_parameters(real_h, ref_l)
+    torch.cuda.synchronize()
+    assert worst(net_a, net_b) < 1e-6, worst(net_a, net_b)
+    # (c) a state that does not cover the captured step's tensors is refused, not half-applied
+    bad = {"state": {}, "param_groups": sd2["param_groups"]}
+    with pytest.raises(RuntimeError, match="capture again"):
+        tr_b.load_optimizer_state_dict(bad)
+
+
 def test_folded_gradient_maxima_change_nothing(dev):
     """max|dOut| of every subnet backward is taken where dOut is produced (coupling gradient kernel, the y1-gradient add, F's dx
     epilogue: selfc_coupling_bwd_x / selfc_add_absmax / dx_amax_out) instead of a pass over dOut per call.  Same maxima, same
@@ -436,3 +502,46 @@ def test_fused_data_gradient_chain_is_bit_identical_to_the_layer_wise_launches(d
         assert set(ref.files) == set(mine) and len(mine) > 300
         bad = [n for n in mine if not np.array_equal(mine[n].cpu().numpy(), ref[n])]
     assert not bad, f"{len(bad)} gradients differ, e.g. {bad[:4]}"
+
+
+def test_host_copies_of_weights_after_a_captured_training_leg(dev):
+    """on one day 9 of 45 runs of bench.py got ONE 3456-byte weight (`operations.{1,2}.{G,H}.conv1.weight`)
+    wrong in the device -> host copy its oracle was fed, always right after the training legs of the same process
+    (profiles/r4/parity_leg_host_copy.txt).  The failing sequence, in one process: build the inference net, run it, run captured
+    training legs on OTHER nets (graphs, own streams and trainers die when each leg returns), then - with NO device synchronize in
+    between, exactly as bench.py's parity leg does - copy the 3456-byte tensors of the first net to the host 200 times, each copy
+    checked against the device tensor (copied back, compared on the device) and against a hash taken on the device.  Zero
+    mismatches; a mismatch is described (offsets, contents) in the assertion message."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tools")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    import bench_train
+    from selfc_amd.pipeline import RescaleRoundTrip
+    net = bench.build_net(dev)
+    x = torch.rand(7, 3, 64, 96, device=dev)
+    rtp = RescaleRoundTrip(net, 7, 64, 96, dev)
+    with torch.no_grad():
+        rtp.run(x)
+    small = {k: v for k, v in net.state_dict().items() if k.startswith("operations.") and v.numel() * 4 == 3456}
+    assert len(small) == 16                                      # G.conv1 and H.conv1 of the eight blocks
+    hashes = None
+    bad, copies = [], 0
+    for leg, lb in enumerate((2, 1)):
+        bench_train.run(batch=lb, size=144, steps=6, warmup=1, fh_loss="gmm", profile=False, graph=True)
+        # no torch.cuda.synchronize() here on purpose
+        for rep in range(100 // len(small) + 1):
+            for k, v in small.items():
+                c = v.detach().cpu()
+                copies += 1
+                if not torch.equal(c.to(dev), v):
+                    bad.append(bench.describe_bad_copy(k, c, v, {}))
+        if hashes is None:
+            hashes = {k: bench.tensor_hash(v) for k, v in small.items()}
+        for k, v in small.items():                               # and the device tensors themselves never move
+            assert bench.tensor_hash(v) == hashes[k] == bench.tensor_hash(v.detach().cpu()), k
+    assert copies >= 200
+    assert not bad, f"{len(bad)} of {copies} device -> host copies were wrong: {bad[:3]}"

@@ -1,8 +1,12 @@
 #!/bin/bash
-# repeat the driver's command and print the parity leg of every run (looking for a run-to-run drift of the parity figures)
+# Repeat the driver's command and print, per run: the headline, the parity leg, the box identity (PCI id / unique id of the card,
+# boot id of the host: "one box" as a testable statement) and any device -> host weight copy that failed its check (bench.py
+# host_weights: offsets, contents and a dump under gpurun_out/ - no silent retry).  profiles/r5/host_copy_*.txt collects the output.
 N=${1:-6}
 for i in $(seq 1 $N); do
   python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.readlines()[-1]); p=d['parity']; print('run $i', d['value'], d['cpu_baseline']['cores'], round(d['cpu_baseline']['value'],3), d['cpu_baseline'].get('cpu_model'), round(p['fwd_latent_rel_err'],6), round(p['inv_rel_err'],6), p.get('debug'), 'recopied', d['cpu_baseline'].get('weights_recopied_after_a_failed_copy_check'), flush=True)" || exit 1
+d=json.loads(sys.stdin.readlines()[-1]); p=d['parity']; b=d.get('box_identity',{}); g=(b.get('gpus') or [{}])[0]
+print('run $i', d['value'], 'clk', d['box_calibration']['shader_clock_GHz_under_the_workload'], 'box', b.get('host'), g.get('pci'), g.get('unique_id'), b.get('boot_id','')[:8],
+      'parity', round(p['fwd_latent_rel_err'],6), round(p['inv_rel_err'],6), 'error', p.get('error'), 'host_copy_errors', d['cpu_baseline'].get('host_copy_errors'), p.get('debug'), flush=True)" || exit 1
 done
