@@ -357,6 +357,14 @@ def test_dense_buffers_beyond_2gib_take_the_flat_kernels(dev):
                     part = blk(x[lo:lo + n // 2].contiguous(), rev=rev)
                     assert rel_err(whole[lo:lo + n // 2], part) < TOL, (rev, lo)
                     del part
+                # ... and against the ORACLE (not only against itself): the LAST clip - the far end of every plane - on a crop that
+                # holds the frame's bottom-right corner (rows 256..269 are the partial tile row).  One block sees 8 pixels per
+                # direction (four 3x3 convs of F, then four of G / H), so the crop's interior beyond 8 pixels of its cut edges is exact.
+                r0, c0, m = h - 80, w - 80, 8
+                p_or = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+                want = O.invblock("D2DTNet", p_or, x[n - 2:n, :, r0:, c0:].cpu(), 3, 2, rev=rev)[0]
+                got = whole[n - 2:n, :, r0:, c0:].cpu()
+                assert rel_err(got[:, :, m:, m:], want[:, :, m:, m:]) < TOL, ("oracle crop", rev)
                 del whole
     finally:
         GlobalVar.set_Temporal_LEN(T)
@@ -602,6 +610,46 @@ def test_1080p_tile_invertibility(dev):
         z0 = rt.latent_to_nchw(ws)
         fa = net.operations[0](x)
     assert rel_err(z0.cpu(), fa.cpu()) < TOL
+
+
+def test_1080p_against_the_oracle_on_corner_crops(dev):
+    """VERDICT r4 item 3 - config 5's size held against the ORACLE, not against the stack's own inverse (a tile-edge or addressing
+    bug applied symmetrically in both directions passes test_1080p_tile_invertibility).  The HIP path runs the whole frame
+    (7x3x1080x1920, latent 270x480 = 16.9 x 30 tiles: the bottom tile row is 14 rows); the oracle runs four 640x640 HR crops
+    that each hold one true corner of the frame.  A block's output depends on its input within 8 latent pixels (four 3x3 convs
+    of F, then four of G / H; the temporal conv5 is pointwise in space), the eight blocks on 64: inside a crop, everything
+    further than 64 latent pixels from the two CUT edges is exactly what the full frame gives - a 96x96 latent corner per crop,
+    incl. the frame border on two sides, the partial tile row and the last tile column.  Forward latent and inverse
+    reconstruction (the same quantised latent into both sides), 1e-3 (SelfC_model.py:199-250 is the caller of this size)."""
+    g = load_golden("g8_large_stack")
+    net = _large_net(dev, g)
+    Hh, Ww, C, M = 1080, 1920, 160, 64                      # latent crop side, dependency radius of the stack
+    h, w = Hh // 4, Ww // 4
+    x = torch.rand(T, 3, Hh, Ww, generator=torch.Generator().manual_seed(1080))
+    with torch.no_grad():
+        z, _ = net(x=x.to(dev), rev=False)
+        z = z.cpu()
+        zq = torch.cat((O.quantize(z[:, :3]), z[:, 3:]), 1)             # the latent both inverses start from
+        xr = net.inverse_from_latent(zq.to(dev)).cpu()
+    worst = {}
+    for name, r0, c0 in (("top-left", 0, 0), ("top-right", 0, w - C), ("bottom-left", h - C, 0), ("bottom-right", h - C, w - C)):
+        # valid interior in crop coordinates: away from the cut edges (the frame's own edges are real borders)
+        rs = slice(0, C - M) if r0 == 0 else slice(M, C)
+        cs = slice(0, C - M) if c0 == 0 else slice(M, C)
+        xc = x[:, :, 4 * r0:4 * (r0 + C), 4 * c0:4 * (c0 + C)].contiguous()
+        z_or = O.large_fwd(g, xc, T)
+        e_f = rel_err(z[:, :, r0:r0 + C, c0:c0 + C][:, :, rs, cs], z_or[:, :, rs, cs])
+        e_g = group_err(z[:, :, r0:r0 + C, c0:c0 + C][:, :, rs, cs], z_or[:, :, rs, cs])
+        x_or = O.large_inv_from_latent(g, zq[:, :, r0:r0 + C, c0:c0 + C].contiguous(), T)
+        hrs = slice(4 * rs.start, 4 * rs.stop)
+        hcs = slice(4 * cs.start, 4 * cs.stop)
+        e_i = rel_err(xr[:, :, 4 * r0:4 * (r0 + C), 4 * c0:4 * (c0 + C)][:, :, hrs, hcs], x_or[:, :, hrs, hcs])
+        worst[name] = (e_f, e_g, e_i)
+        # the method's own check: INSIDE the cut margin the crop must differ from the frame (else the margin proves nothing)
+        if name == "bottom-right":
+            cut = rel_err(z[:, :, r0:r0 + C, c0:c0 + C][:, :, :8, :], z_or[:, :, :8, :])
+            assert cut > 10 * TOL, cut
+    assert all(max(v) < TOL for v in worst.values()), worst
 
 
 def test_freq_k2_and_clip_len_3(dev):
