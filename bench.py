@@ -463,6 +463,8 @@ def main():
                 fp[name] = round(ms.value / 5, 3)
             L.selfc_profile_reset()
         out["full_test_path"] = {"septuplets_per_s": round(B_PER_GPU / tf, 1), "ms_per_batch": round(tf * 1e3, 3),
+                                 # stack + STP algorithmic FLOPs (546.4 GFLOP per septuplet) over the measured time
+                                 "mfma_frac_whole_path": round((2.0 * MAC_BLOCK_PX * 16 + 2331776.0) * npx / tf / 1e12 / PEAK_F16_TFLOPS, 4),
                                  "note": "module API: netG(x=x) -> Quantization -> netG(x=LR, rev=True), fresh NCHW tensors in and out, fh_loss gmm with device RNG; "
                                          "each call replays its cached two-stream hipGraph (pipeline.ModuleGraph), 40 timed batches after 5",
                                  "eager": {"septuplets_per_s": round(B_PER_GPU / te, 1), "ms_per_batch": round(te * 1e3, 3), "kernel_ms": fp,
@@ -512,8 +514,13 @@ def main():
                 r_ = bench_train.run(batch=lb, size=144, steps=20, warmup=2, fh_loss="gmm", profile=False, graph=True)
                 by_batch[str(lb)] = round(r_["ms_per_step"], 2)
             by_batch["8"] = round(tg["ms_per_step"], 2)
+            # algorithmic work of a training step: forward + data gradient + weight gradient of the whole test path (stack fwd + rev,
+            # STP) = 3 x 10.89 MFLOP per LR pixel-frame, 36x36 latent pixels x 7 frames per septuplet
+            step_flop = lambda lb: 3.0 * (2.0 * MAC_BLOCK_PX * 16 + 2331776.0) * lb * T * 36 * 36      # noqa: E731
             out["train_step"] = {"septuplets_per_s": round(tg["value"], 1), "ms_per_step": round(tg["ms_per_step"], 2),
                                  "captured_ms_per_step_by_local_batch": by_batch,
+                                 "mfma_frac_by_local_batch": {k_: round(step_flop(int(k_)) / (v_ * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4) for k_, v_ in by_batch.items()},
+                                 "mfma_frac": round(step_flop(8) / (tg["ms_per_step"] * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
                                  "launch": "RescaleTrainer.capture(): the whole optimisation step replayed as one hipGraph",
                                  "eager_ms_per_step": round(te["ms_per_step"], 2), "eager_septuplets_per_s": round(te["value"], 1),
                                  "config": "8 x 7x3x144x144 crops, fh_loss gmm, l2 + l1 losses, clip 10, Adam (one flat tensor); 3 streams",

@@ -11,9 +11,9 @@
 //   the net's dense buffer) because the temporal conv5 reads all four features.
 //   Features outside the image are stored as ZERO (they are the next conv's zero padding).
 //
-// MFMA 32x32x16 f16, D[outch][pixel]; M-tiles are 32 consecutive pixels of the conv's region in
-// row-major order (region widths 22/20/18 need not be multiples of 16; with the LDS row pitch a
-// multiple of 256 B the 16-lane groups of ds_read_b128 still hit 16 distinct slots).
+// MFMA 32x32x16 f16, D[outch][pixel]; an M-tile is 32 pixels of the conv's region laid out so that every
+// ds_read_b128 lane group hits 16 distinct 16-byte slots in EVERY feature image it reads (mtile_geom:
+// two-row checkerboard tiles + column strips for region widths 20 / 18 / 16; conv1: 32 consecutive pixels).
 // The 3-channel input enters as an "im2col48" stage: K = 12 taps x 4 (c0 c1 c2 0), so a lane's 8
 // K-entries are two whole pixels of X = two ds_read_b64, no repacking (3 MFMAs instead of 2).
 // Weights: the packed fragment stream of the four convs (120 KiB per net) is read in chunks of
@@ -51,17 +51,22 @@ constexpr int TS = 16;
 constexpr int XS = TS + 2 * DEPTH;         // X halo side (24 / 22)
 constexpr int XPITCH = XS * 8;             // bytes
 constexpr int X_BYTES = XS * XPITCH;       // 4608
-// LDS row pitch of F1..F3 (bytes): pitch/16 = 5 R (mod 16) for the region width R of the image's busiest reader (the next
-// conv), so a linearly enumerated M-tile stays on distinct 16-byte slots across a row wrap
-constexpr int feat_pitch(const int rows_img, const int r_reader) {
-  int s = 5 * rows_img;
-  while (s % 16 != (5 * r_reader) % 16) ++s;
-  return s * 16;
-}
-constexpr int P1 = feat_pitch(TS + 2 * (DEPTH - 1), TS + 2 * (DEPTH - 2));
-constexpr int P2 = feat_pitch(TS + 2 * (DEPTH - 2), TS + 2 * (DEPTH - 3));
-constexpr int P3 = DEPTH == 4 ? feat_pitch(TS + 2, TS) : 16;
-static_assert(DEPTH != 4 || (P1 == 1856 && P2 == 1696 && P3 == 1536), "depth-4 pitches");
+// LDS row pitches of F1..F3 (bytes).  A ds_read_b128 is served in lane groups G0 = {0-3, 12-15, 20-27}, G1 = {4-11, 16-19, 28-31}
+// (and the same + 32): 16 lanes that must hit 16 different 16-byte slots (mod 16).  With the 80-byte pixel a pixel (r, c) of an
+// image of pitch p slots sits on slot p r + 5 c.  Round 5: M-tiles are no longer 32 consecutive pixels of the region (which is
+// conflict-free for ONE reader per image only: F1's conv3 / conv4 reads and F2's conv4 reads took 8 LDS cycles instead of 4 -
+// 44 % more B-read cycles per tile, SQ_LDS_BANK_CONFLICT 19 % of the LDS cycles) but (mtile_geom):
+//   * main tiles = two image rows x 16 columns, each lane group a CHECKERBOARD of them (G0: odd columns of the first row + even
+//     columns of the second; G1 the opposite): 5 c takes every residue once over 16 columns, so the second row's eight slots
+//     avoid the first row's eight for EVERY even p;
+//   * the region's columns 16.. (20x20: 4 columns, 18x18: 2) = strip tiles of 4 columns x 8 rows (a lane group = the even or the
+//     odd rows of it: slots 2 p k + {0, 5, 10, 15}) or 2 columns x 16 rows (a group = 8 consecutive rows: p k + {0, 5}).
+// p1 = 2 (mod 16) serves conv2's 4-column strips and conv3's 2-column strips, p2 = 2 (mod 4) conv3's strips, p3 is even:
+// tools/lds_conflicts_fused_gh.py replays every B read of a tile - 4.0 LDS cycles per read everywhere but conv2's last strip
+// tile (clamped rows: 4.15), 6,120 -> 4,284 cycles per tile and net.
+constexpr int P1 = 1824, P2 = 1632, P3 = DEPTH == 4 ? 1440 : 16;
+static_assert(DEPTH != 4 || (P1 >= (TS + 6) * 80 && (P1 / 16) % 16 == 2 && P2 >= (TS + 4) * 80 && (P2 / 16) % 4 == 2 && P3 >= (TS + 2) * 80 && (P3 / 16) % 2 == 0),
+              "pitches: see above");
 constexpr int F1_BYTES = (TS + 2 * (DEPTH - 1)) * P1, F2_BYTES = (TS + 2 * (DEPTH - 2)) * P2, F3_BYTES = DEPTH == 4 ? (TS + 2) * P3 : 0;
 constexpr int WCH = 21;                    // fragments per weight chunk buffer
 constexpr int W_BYTES = WCH * 1024;
@@ -172,11 +177,36 @@ __device__ __forceinline__ void mtile_geom(const Ctx& c, const int m, int& r, in
   constexpr int W0 = second_tile_first_wave<K>();
   static_assert(G::NTL - NWAVE <= NWAVE - W0, "second tiles fit the waves from W0 on");
   const int mt = m == 0 ? c.wave : NWAVE + c.wave - W0;
-  const int q = mt * 32 + (c.lane & 31);
-  valid = (m == 0 || c.wave >= W0) & (mt < G::NTL) & (q < G::NPX);
-  const int qc = min(q, G::NPX - 1);
-  r = qc / G::R;
-  cc = qc - r * G::R;
+  const bool own = (m == 0 || c.wave >= W0) & (mt < G::NTL);
+  if constexpr (K == 1 || DEPTH != 4) {
+    // conv1 reads only the X halo (ds_read_b64): 32 consecutive pixels of the 22x22 region per M-tile
+    const int q = mt * 32 + (c.lane & 31);
+    valid = own & (q < G::NPX);
+    const int qc = min(q, G::NPX - 1);
+    r = qc / G::R;
+    cc = qc - r * G::R;
+  } else {
+  // conv2..4 (regions 20 / 18 / 16 wide): checkerboard main tiles + column-strip tiles, see the pitch comment above.
+  // lane -> (group, index in the group's hardware order): lanes {0-3, 12-15, 20-27} are group 0
+  constexpr int NMAIN = G::R / 2, LW = G::R - 16;
+  static_assert(NMAIN + (LW * G::R + 31) / 32 == G::NTL && (LW == 0 || LW == 2 || LW == 4), "tile count of the region");
+  const int l = c.lane & 31;
+  const int g = (0x96 >> (l >> 2)) & 1, idx = ((l >> 3) << 2) | (l & 3);
+  int rr;
+  if (mt < NMAIN) {
+    const int hi = idx >> 3;                    // first / second row of the pair
+    rr = 2 * mt + hi;
+    cc = 2 * (idx & 7) + (g ^ hi ^ 1);
+  } else if (LW == 4) {
+    rr = 8 * (mt - NMAIN) + 2 * (idx >> 2) + g;
+    cc = 16 + (idx & 3);
+  } else {
+    rr = 16 * (mt - NMAIN) + 8 * g + (idx >> 1);
+    cc = 16 + (idx & 1);
+  }
+  valid = own & (rr < G::R);
+  r = min(rr, G::R - 1);
+  }
 }
 template <int K, int MT>
 __device__ __forceinline__ void epi_piece(const Ctx& c, const FGArgs& a, const int net, const size_t fofs, const int ty0, const int tx0,
@@ -487,7 +517,7 @@ __global__ __launch_bounds__(NTHR) void fused_gh_kernel(const FGArgs a) {
       conv_fused<(DEPTH == 4 ? 4 : 3), true, TWO3>(c, a, net, xbuf, fofs, ty0, tx0, &acc3, nullptr);
     }
     STAMP(tt0);
-    __syncthreads();
+    __syncthreads();            // (round 5: a build without this barrier - no hazard needs it, conv1's own barrier follows - measured 0: ab_experiments.txt)
     c.par ^= 1;
     c.first = false;
     xbuf ^= 1;

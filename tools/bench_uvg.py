@@ -49,11 +49,20 @@ def measure(net, dev, clips, frames, H, W, S, ranks, rank=0, world=1):
     return sec, len(gops)
 
 
+STACK_FLOP_PX = 2.0 * 267408 * 16          # InvBlock stack fwd + inv per LR pixel-frame
+STP_FLOP_PX = 2331776.0                     # STP-large (D2DT subnets, GlobalAgg, GMM head) per LR pixel-frame
+
+
 def roofline_fracs(ngop, world, sec, H, W):
+    """The leg's time against the MFMA peak and the layer-granular HBM model.  `mfma_frac` counts the STACK's FLOPs only (the
+    figure rounds 2-4 reported; the STP's time is in the denominator, its work is not in the numerator - which is why it read
+    20 % under the 256x448 figure that counted both: VERDICT r4 weak 7); `mfma_frac_whole_path` counts what the leg really
+    executes, stack + STP (9,878 GFLOP per 1080p GOP), and is the one to compare with bench.py's full_test_path at 256x448."""
     npx = 7 * (H // 4) * (W // 4)
-    flops = 2.0 * 267408 * npx * 16                                              # InvBlock stack fwd + inv per GOP (STP not counted)
-    return {"mfma_frac": round(flops * ngop / world / sec / 1e12 / 2500.0, 4),
-            "hbm_frac_layer_granular": round(2 * 8 * 1815 * 2 * npx * ngop / world / sec / 8.0e12, 4)}
+    per = ngop / world / sec
+    return {"mfma_frac": round(STACK_FLOP_PX * npx * per / 1e12 / 2500.0, 4),
+            "mfma_frac_whole_path": round((STACK_FLOP_PX + STP_FLOP_PX) * npx * per / 1e12 / 2500.0, 4),
+            "hbm_frac_layer_granular": round(2 * 8 * 1815 * 2 * npx * per / 8.0e12, 4)}
 
 
 def main():
