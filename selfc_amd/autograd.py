@@ -855,6 +855,17 @@ def _buf(cache: Dict, name: str, nbytes: int, device) -> torch.Tensor:
 _STP_CACHE: Dict = {}
 
 
+def _sink_add(param, grad: torch.Tensor) -> Optional[torch.Tensor]:
+    """A parameter gradient computed with torch ops: with a gradient sink it is ADDED into the parameter's view of the flat buffer
+    here, on the calling stream, and autograd sees None (no AccumulateGrad node, no copy); without a sink it is returned unchanged."""
+    if _SINK is not None:
+        v = _SINK.view_of(param)
+        if v is not None:
+            v.add_(grad.reshape(v.shape))
+            return None
+    return grad
+
+
 def globalagg_bwd(m, x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, n: int, t: int, h: int, w: int, defer_fc: Optional[list] = None) -> Dict[str, torch.Tensor]:
     """Backward of GlobalAgg.run_nhwc: x, dy, dx fp32 [n][h*w][64]; returns {parameter name: gradient}."""
     pk = m._packed(h, w)
@@ -898,7 +909,7 @@ def globalagg_bwd(m, x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, n: int
         defer_fc.append((m, dwmap))
         g = {"fc.weight": None}
     else:
-        g = {"fc.weight": pool_weight_map_grad(dwmap, h, w)}
+        g = {"fc.weight": _sink_add(m.fc.weight, pool_weight_map_grad(dwmap, h, w))}
     for nm, o, p_shape in zip(names, outs, [(64, 64, 1, 1), (64,), (64, 64), (64,), (64, 64), (64,), (1,)]):
         g[nm] = None if sunk is not None else o.reshape(p_shape)
     return g
@@ -1099,7 +1110,7 @@ class STPSampleFn(torch.autograd.Function):
         if fc_maps:                   # d fc.weight of every GlobalAgg: ONE batched fold (packing.pool_weight_map_grad_batch)
             folded = pool_weight_map_grad_batch(torch.stack([dm for _, dm in fc_maps]), h, w)
             for i, (m, _) in enumerate(fc_maps):
-                grads[id(m.fc.weight)] = folded[i].reshape(1, 32 * 32)
+                grads[id(m.fc.weight)] = _sink_add(m.fc.weight, folded[i].reshape(1, 32 * 32))
         dlr = None
         if ctx.needs_input_grad[0]:
             dlr = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)

@@ -553,3 +553,4 @@ def test_host_copies_of_weights_after_a_captured_training_leg(dev):
             assert bench.tensor_hash(v) == hashes[k] == bench.tensor_hash(v.detach().cpu()), k
     assert copies >= 200
     assert not bad, f"{len(bad)} of {copies} device -> host copies were wrong: {bad[:3]}"
+
