@@ -154,6 +154,23 @@ class GradSink:
         self.touched.clear()
         self.attach()
 
+    def norm(self) -> torch.Tensor:
+        """L2 norm of the whole buffer (gradient clipping) as THREE staged reductions - rows of 256, rows of 64, the rest - instead
+        of one `vector_norm(flat)`.  Why: 3.4 M elements into ONE output is torch's multi-block "global reduce" (per-block partials
+        plus a semaphore that a memset in front of the kernel zeroes); inside a captured step such a reduction was seen to leave its
+        output unwritten on this stack (the loss scalars of a one-stream capture at 8 septuplets: train.ReconstructionLoss,
+        tools/experiments/loss_alias_probe.py).  Every stage here has either thousands of outputs or a few hundred inputs, i.e. no
+        cross-block stage; the value is the same norm (norm of row norms), deterministic, a handful of small launches."""
+        n = self.flat.numel()
+        main = n - n % (256 * 64)
+        parts = []
+        if main:
+            r1 = torch.linalg.vector_norm(self.flat[:main].view(-1, 256), dim=1)
+            parts.append(torch.linalg.vector_norm(r1.view(-1, 64), dim=1))
+        if n > main:
+            parts.append(torch.linalg.vector_norm(self.flat[main:].view(-1, 64), dim=1))     # < 16,384 elements (slices are 64-float aligned)
+        return torch.linalg.vector_norm(torch.cat(parts) if len(parts) > 1 else parts[0])
+
     def view_of(self, p_) -> Optional[torch.Tensor]:
         """The view a kernel may accumulate into (marks the parameter as having received a gradient this step)."""
         v = self.index.get(id(p_))

@@ -53,8 +53,16 @@ class ReconstructionLoss(nn.Module):
         else:
             print("reconstruction loss type error!")
             return 0
-        # the reference's v.mean(-1).mean(-1).mean(-1).mean(-1) (loss.py): means of equal-sized groups = one mean over the four axes
-        return v.mean(dim=(-4, -3, -2, -1))
+        # the reference's v.mean(-1).mean(-1).mean(-1).mean(-1) (loss.py), as written there.  (Rounds 3-4 folded it into ONE mean over
+        # the four axes: equal-sized groups, same value - but a single reduction of 3.5 M elements to one output is torch's multi-block
+        # "global reduce" (partials + a semaphore zeroed by a memset in front of the kernel), and inside a captured step on ONE stream at
+        # 8 septuplets per rank that kernel left its output unwritten: the step then REPORTED l_back_rec = l_forw_fit, the value the
+        # recycled output block still held (tools/experiments/loss_alias_probe.py; the gradients - and so the training - were never
+        # affected, they do not read the scalar).  Each stage of the chained form has either many outputs or a short inner dimension:
+        # no cross-block stage, nothing for a graph replay to get wrong.)
+        if os.environ.get("SELFC_LOSS_ONE_MEAN") == "1":
+            return v.mean(dim=(-4, -3, -2, -1))
+        return v.mean(-1).mean(-1).mean(-1).mean(-1)
 
 
 class MultiStepLR_Restart(_LRScheduler):
@@ -369,7 +377,7 @@ class RescaleTrainer:
         max_norm = self.train_opt.get("gradient_clipping")
         if max_norm and self.sink is not None:
             # clip_grad_norm_ on the flat buffer (pads are zero): three launches instead of a foreach over 350 views
-            self.grad_norm = torch.linalg.vector_norm(self.sink.flat)
+            self.grad_norm = self.sink.norm()              # staged: no multi-block reduction inside a captured step (GradSink.norm)
             self.sink.flat.mul_(torch.clamp(max_norm / (self.grad_norm + 1e-6), max=1.0))
         elif max_norm:
             self.grad_norm = nn.utils.clip_grad_norm_(self.optim_params, max_norm)

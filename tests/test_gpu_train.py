@@ -81,29 +81,43 @@ def test_train_step_matches_reference_step(dev):
 def test_flat_gradient_sink_equals_autograd_accumulation(dev):
     """RescaleTrainer(flat_grads=True): gradients accumulated by the kernels into one buffer (beta = 1) and clipped there -
     the same step as stock autograd accumulation + clip_grad_norm_ (two calls per block and step: the sums differ only in
-    the order of two fp32 additions)."""
+    the order of two fp32 additions).  Two steps (the second checks the re-zeroing of the buffer); the two trainers start the
+    second step from the SAME weights: their clip coefficients differ in the last bit (a staged norm of one buffer against
+    clip_grad_norm_ over 350 tensors), and a 1e-8 weight difference moves the f16 kernels' next gradients by up to 0.5 % (LeakyReLU
+    kinks) - equivalence of the two accumulation paths is a statement about equal weights."""
     from selfc_amd import train
     x = load_golden("g8_large_stack")["x"]
     gt = x.reshape(1, T, 3, 32, 48).transpose(1, 2).to(dev)
     real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
-    out = {}
+    nets, trs, got = {}, {}, {}
     for flat in (False, True):
-        net = _net(dev)
-        tr = train.RescaleTrainer(net, dict(train.TRAIN_OPT_LARGE), flat_grads=flat)
-        assert (tr.sink is not None) == flat
-        got = {}
-        tr.before_clip = lambda t_, net=net, got=got: got.update({n: p.grad.detach().clone() for n, p in net.named_parameters()})
-        logs = [tr.optimize_parameters(real_h, ref_l)["loss"] for _ in range(2)]      # the second step checks the re-zeroing
-        out[flat] = (got, float(tr.grad_norm), logs, {n: p.detach().clone() for n, p in net.named_parameters()})
-    ga, na, la, pa = out[False]
-    gb, nb, lb, pb = out[True]
-    assert set(ga) == set(gb) and all(v is not None for v in gb.values())
-    worst = max(float((ga[n] - gb[n]).norm() / (ga[n].norm() + 1e-12)) for n in ga)
+        nets[flat] = _net(dev)
+        trs[flat] = train.RescaleTrainer(nets[flat], dict(train.TRAIN_OPT_LARGE), flat_grads=flat)
+        assert (trs[flat].sink is not None) == flat
+        got[flat] = {}
+        trs[flat].before_clip = lambda t_, net=nets[flat], g_=got[flat]: g_.update({n: p.grad.detach().clone() for n, p in net.named_parameters()})
     from conftest import record
-    record("flat gradient sink vs autograd accumulation, worst per-tensor relative L2 (second step)", worst)
-    assert worst < 1e-4, worst                    # second-step gradients: also covers the first step's identical update
-    assert abs(na - nb) < 1e-4 * na and abs(la[1] - lb[1]) < 1e-5 * abs(la[1])
-    assert max(float((pa[n] - pb[n]).abs().max()) for n in pa) < 2e-6
+    for step in range(2):
+        logs = {flat: trs[flat].optimize_parameters(real_h, ref_l)["loss"] for flat in (False, True)}
+        ga, gb = got[False], got[True]
+        assert set(ga) == set(gb) and all(v is not None for v in gb.values())
+        # per-tensor relative L2, against a floor of 1e-7 of the whole gradient's norm: the proj3 biases of the GlobalAgg blocks have
+        # a gradient that is ZERO in exact arithmetic (a bias in front of a softmax over its own axis shifts every logit alike) - what
+        # the kernels deliver for them is cancellation noise at 1e-13 of the gradient's norm
+        g_all = float(torch.sqrt(sum((v.double() ** 2).sum() for v in ga.values())))
+        worst = max(float((ga[n] - gb[n]).norm() / (ga[n].norm() + 1e-7 * g_all)) for n in ga)
+        record(f"flat gradient sink vs autograd accumulation, worst per-tensor relative L2 (step {step + 1})", worst)
+        assert worst < 1e-4, (step, worst)
+        na, nb = float(trs[False].grad_norm), float(trs[True].grad_norm)
+        assert abs(na - nb) < 1e-5 * na and abs(logs[False] - logs[True]) < 1e-5 * abs(logs[False])
+        pd = max(float((a - b).abs().max()) for a, b in zip(nets[False].state_dict().values(), nets[True].state_dict().values()))
+        assert pd < 2e-6, (step, pd)                            # the same update
+        if step == 0:                                           # same weights into the second step (docstring)
+            with torch.no_grad():
+                for a, b in zip(nets[False].state_dict().values(), nets[True].state_dict().values()):
+                    b.copy_(a)
+            from selfc_amd import runtime as rt
+            rt.invalidate_weights()
 
 
 def test_gmm_training_reduces_loss(dev):
@@ -554,3 +568,46 @@ def test_host_copies_of_weights_after_a_captured_training_leg(dev):
     assert copies >= 200
     assert not bad, f"{len(bad)} of {copies} device -> host copies were wrong: {bad[:3]}"
 
+
+
+@pytest.mark.parametrize("two_streams", [True, False])
+def test_captured_step_reports_the_eager_steps_scalars(dev, two_streams):
+    """Round 5: inside a captured step on ONE stream at 8 septuplets per rank the reported l_back_rec came out EQUAL to l_forw_fit
+    (loss 987 where 15,909 was due; the gradients, and so the training, were right): the loss was ONE torch mean over 3.5 M elements,
+    i.e. torch's multi-block "global reduce" (partials + a semaphore zeroed by a memset in front of the kernel), and on replay that
+    kernel left its output block unwritten (tools/experiments/loss_alias_probe.py; SELFC_LOSS_ONE_MEAN=1 brings it back).  The loss
+    is now the reference's chained means and the clip's norm is staged (GradSink.norm): no reduction of the captured step has a
+    cross-block stage.  Held here at the failing size, with and without the side streams: the scalars a captured step reports
+    (both losses, their sum, the gradient norm) are the eager step's - same kernels, same arithmetic, l2 head (no device RNG)."""
+    from selfc_amd import GlobalVar, autograd as ag, train
+    from selfc_amd.modules.SelfC_GMM_arch_inv import SelfCInvNet
+    old = ag._TWO_STREAMS
+    ag._TWO_STREAMS = two_streams
+    try:
+        def make():
+            torch.manual_seed(10)
+            net = SelfCInvNet(dict(OPT, fh_loss="l2"), 3, 3, "D2DTNet", [4, 4], 2).to(dev)
+            return net, train.RescaleTrainer(net, dict(train.TRAIN_OPT_LARGE), capturable=True)
+        gt = torch.rand(8, 3, T, 144, 144, generator=torch.Generator().manual_seed(1234)).to(dev)
+        real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
+        (net_e, tr_e), (net_g, tr_g) = make(), make()
+        logs_e, logs_g, norms_e, norms_g = [], [], [], []
+        for _ in range(2):
+            tr_e.optimize_parameters(real_h, ref_l)
+            tr_g.optimize_parameters(real_h, ref_l)
+        tr_g.capture(real_h, ref_l, warmup=0)
+        for _ in range(4):
+            logs_e.append(dict(tr_e.optimize_parameters(real_h, ref_l)))
+            norms_e.append(float(tr_e.grad_norm))
+            logs_g.append(dict(tr_g.optimize_parameters(real_h, ref_l)))
+            norms_g.append(float(tr_g.grad_norm))
+        for le, lg, ne, ng in zip(logs_e, logs_g, norms_e, norms_g):
+            assert le["l_back_rec"] > 3 * le["l_forw_fit"] > 0                       # the two losses are nowhere near each other here
+            for k in ("l_forw_fit", "l_back_rec", "loss"):
+                assert abs(le[k] - lg[k]) <= 1e-6 * abs(le[k]), (k, le, lg)
+            assert abs(ne - ng) <= 1e-6 * ne, (ne, ng)
+            assert abs(le["loss"] - (le["l_forw_fit"] + le["l_back_rec"]) * 144 * 144 * 3) <= 1e-4 * le["loss"]
+        # the staged norm is the norm
+        assert abs(float(tr_e.sink.norm()) - float(torch.linalg.vector_norm(tr_e.sink.flat.double()))) <= 1e-5 * float(tr_e.sink.norm())
+    finally:
+        ag._TWO_STREAMS = old

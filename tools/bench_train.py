@@ -34,6 +34,8 @@ def run(batch=8, size=144, steps=10, warmup=3, fh_loss="gmm", profile=False, gra
         tr.optimize_parameters(real_h, ref_l)
     if a.graph:
         tr.capture(real_h, ref_l)
+        if os.environ.get("SELFC_BT_TRACE"):
+            print("static loss tensors", [(t_.data_ptr(), tuple(t_.shape), t_.dtype) for t_ in tr._static_losses], file=sys.stderr, flush=True)
         tr.optimize_parameters(real_h, ref_l)
     torch.cuda.synchronize()
     L = _lib.lib()
@@ -43,6 +45,8 @@ def run(batch=8, size=144, steps=10, warmup=3, fh_loss="gmm", profile=False, gra
     t0 = time.perf_counter()
     for _ in range(a.steps):
         log = tr.optimize_parameters(real_h, ref_l)
+        if os.environ.get("SELFC_BT_TRACE"):
+            print("step loss", log["loss"], log["l_forw_fit"], log["l_back_rec"], file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     out = {"metric": "training septuplets/s (optimize_parameters, 7x3x%dx%d crops)" % (a.size, a.size), "value": a.batch / dt,
