@@ -499,6 +499,13 @@ def main():
                                      "sample": f"{ngop} GOPs of 7x3x1080x1920 (one synthetic {frames}-frame clip), whole test path (fwd stack, Quantization, STP sample, rev stack), "
                                                "2 GOPs per hipGraph replay on 2 streams, incl. the device copies of each GOP into the graph's input"},
                                     **bench_uvg.roofline_fracs(ngop, 1, sec, 1080, 1920))
+            try:        # per-kernel counters of this leg's workload (committed passes of tools/profile_uvg.sh, one GOP eager on one stream)
+                with open(os.path.join(ROOT, "profiles", "r5", "uvg1080p_pmc.json")) as fh:
+                    ref = json.load(fh)
+                out["uvg_1080p"]["pmc_reference"] = dict({k: v for k, v in ref.items() if k != "_meta"},
+                                                         meta=dict(ref.get("_meta", {}), file="profiles/r5/uvg1080p_pmc.json", kernel_sources_unchanged_since=same_sources))
+            except (OSError, ValueError):
+                pass
             torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001
             out["uvg_1080p"] = {"error": repr(e)[:300]}
