@@ -533,6 +533,13 @@ def main():
                                  "config": "8 x 7x3x144x144 crops, fh_loss gmm, l2 + l1 losses, clip 10, Adam (one flat tensor); 3 streams",
                                  "note": "every forward / reverse / gradient kernel is HIP (selfc_amd/autograd.py); losses, clip and Adam are torch; "
                                          "the eager figure is host-bound and moves with the box's CPU"}
+            try:        # counters of this leg's largest kernels (committed passes of tools/pmc_train.sh over the eager step at 8 septuplets)
+                with open(os.path.join(ROOT, "profiles", "r5", "train_step_pmc.json")) as fh:
+                    ref = json.load(fh)
+                out["train_step"]["pmc_reference"] = dict({k: v for k, v in list(ref.items())[:6] if k != "_meta"},
+                                                          meta=dict(ref.get("_meta", {}), file="profiles/r5/train_step_pmc.json", kernel_sources_unchanged_since=same_sources))
+            except (OSError, ValueError):
+                pass
         except Exception as e:  # noqa: BLE001
             out["train_step"] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
