@@ -82,6 +82,9 @@ def box_identity() -> dict:
             except OSError:
                 continue
         out["boot_id"] = open("/proc/sys/kernel/random/boot_id").read().strip()
+        if torch.cuda.is_initialized():       # which of the host's cards this process runs on (sysfs lists all of them)
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+            out["device"] = {k: (str(getattr(pr, k)) if k == "uuid" else getattr(pr, k)) for k in ("name", "pci_domain_id", "pci_bus_id", "pci_device_id", "uuid") if hasattr(pr, k)}
     except Exception as e:  # noqa: BLE001
         out["error"] = repr(e)[:100]
     return out
