@@ -197,7 +197,14 @@ def cpu_baseline(net, x_cpu, budget_s=20.0, others=None):
                       f"{best_n} threads (calibrated) of {ncpu} host CPUs"}, z, zq, xr
 
 
+def mark(what: str):
+    """progress marker on stderr (never stdout: the line is the only thing printed there): where a run was when it died"""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {what}", file=sys.stderr, flush=True)
+
+
 def main():
+    import faulthandler
+    faulthandler.enable()          # a crash inside a native call (HIP runtime, a kernel launch) leaves the Python stack on stderr
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed steps (2.8 ms each: the rate keeps rising until ~100 steps - clocks, caches - so short runs under-report the steady state by ~4 %%)")
@@ -324,6 +331,7 @@ def main():
             cal_err = str(e)[:200]
             torch.cuda.synchronize()
 
+    mark("headline timed, calibration done")
     npx = n_frames * (H // 4) * (W // 4)
     # per-kernel rooflines: algorithmic FLOPs per launch / live HIP-event duration of that launch
     kern = {}
@@ -489,6 +497,7 @@ def main():
             del ftp
         except Exception as e:  # noqa: BLE001
             out["full_test_path"]["pipeline"] = {"error": repr(e)[:300]}
+    mark("full test path leg done")
     if not args.no_uvg and world == 1:
         # config 5 of BASELINE.json, bounded sample: 1080p GOPs (7x3x1080x1920) through the whole test path, two GOPs per hipGraph
         # replay on two streams (tools/bench_uvg.py measure(); the full 100-frame clips / --gpus N live there).  Secondary leg.
@@ -512,6 +521,7 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001
             out["uvg_1080p"] = {"error": repr(e)[:300]}
+    mark("1080p leg done")
     if not args.no_train_step and world == 1:
         # config 3 of BASELINE.json: one optimize_parameters step (fwd, quantise, STP sample, reverse, backward, clip, Adam)
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
@@ -545,6 +555,7 @@ def main():
                 pass
         except Exception as e:  # noqa: BLE001
             out["train_step"] = {"error": repr(e)[:300]}
+    mark("training leg done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, z_ref, zq_ref, xr_ref = cpu_baseline(net, x_cpu[:T], others={"this_net": net.state_dict()})
         out["cpu_baseline"] = cb
@@ -596,9 +607,18 @@ def main():
             except Exception as e:  # noqa: BLE001
                 dbg["error"] = repr(e)[:300]
             out["parity"]["debug"] = dbg
+    mark("cpu baseline / parity leg done")
     if rank == 0:
         print(json.dumps(out), flush=True)
+    mark("line printed")
     ranks.close()
+    # leave nothing to interpreter finalisation: the training legs' trainers die inside reference cycles (optimizer <-> scheduler), and a
+    # hipGraph destroyed by the FINAL garbage collection segfaulted in 2 of 14 runs after the line was printed (runtime._shutdown)
+    import gc
+    del runner, rt, net
+    gc.collect()
+    torch.cuda.synchronize()
+    mark("main() returns")
 
 
 def dry_run(args):

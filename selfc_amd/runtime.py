@@ -2,7 +2,9 @@
 cache, and thin wrappers over the C ABI (include/selfc_hip.h)."""
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import weakref
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -215,14 +217,41 @@ def new_graph() -> "torch.cuda.CUDAGraph":
     return torch.cuda.CUDAGraph()
 
 
+#: every live OwnStream (weak): closed by _shutdown() at interpreter exit, while the HIP runtime is still there
+_LIVE_STREAMS: "weakref.WeakSet" = weakref.WeakSet()
+
+
+def _shutdown():
+    """atexit: destroy what must not be left to interpreter finalisation.  A hipGraph that died inside a reference cycle (a trainer:
+    optimizer <-> LR scheduler) is only destroyed by the cyclic collector - if that is the FINAL collection, torch's CUDAGraph and this
+    package's stream destructors run while the interpreter (and with it torch's CUDA state) is being torn down: bench.py then
+    segfaulted AFTER printing its line and returning from main(), in 2 of every 14 runs (faulthandler: "Garbage-collecting, <no Python
+    frame>"; profiles/r5/host_copy_repeats.txt).  atexit handlers run before that tear-down: collect now, wait for the device, close
+    the package's own streams."""
+    try:
+        import gc
+        gc.collect()
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+        for s_ in list(_LIVE_STREAMS):
+            s_.close()
+        gc.collect()
+    except Exception:      # noqa: BLE001  (never turn an exit into a traceback)
+        pass
+
+
+atexit.register(_shutdown)
+
+
 class OwnStream:
     """A non-blocking HIP stream of the package's own (selfc_stream_create), outside torch's 32-entry round-robin pool,
-    wrapped as a torch.cuda.ExternalStream (`.stream`); destroyed with `close()` / when the object dies."""
+    wrapped as a torch.cuda.ExternalStream (`.stream`); destroyed with `close()` / when the object dies / at interpreter exit."""
 
     def __init__(self, device=None):
         p = C.c_void_p()
         _lib.check(_lib.lib().selfc_stream_create(C.byref(p)), "selfc_stream_create")
         self.handle = p.value
+        _LIVE_STREAMS.add(self)
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.stream = torch.cuda.ExternalStream(self.handle, device=dev)
 

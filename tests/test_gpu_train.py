@@ -603,9 +603,10 @@ def test_captured_step_reports_the_eager_steps_scalars(dev, two_streams):
             norms_g.append(float(tr_g.grad_norm))
         for le, lg, ne, ng in zip(logs_e, logs_g, norms_e, norms_g):
             assert le["l_back_rec"] > 3 * le["l_forw_fit"] > 0                       # the two losses are nowhere near each other here
+            # two trainers stepping side by side agree to ~1e-6 (not always bit for bit); the fault this guards reported a loss 5 x off
             for k in ("l_forw_fit", "l_back_rec", "loss"):
-                assert abs(le[k] - lg[k]) <= 1e-6 * abs(le[k]), (k, le, lg)
-            assert abs(ne - ng) <= 1e-6 * ne, (ne, ng)
+                assert abs(le[k] - lg[k]) <= 1e-4 * abs(le[k]), (k, le, lg)
+            assert abs(ne - ng) <= 1e-4 * ne, (ne, ng)
             assert abs(le["loss"] - (le["l_forw_fit"] + le["l_back_rec"]) * 144 * 144 * 3) <= 1e-4 * le["loss"]
         # the staged norm is the norm
         assert abs(float(tr_e.sink.norm()) - float(torch.linalg.vector_norm(tr_e.sink.flat.double()))) <= 1e-5 * float(tr_e.sink.norm())

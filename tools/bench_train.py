@@ -61,6 +61,13 @@ def run(batch=8, size=144, steps=10, warmup=3, fh_loss="gmm", profile=False, gra
             L.selfc_profile_read(cls, C.byref(ms), C.byref(n))
             km[name] = {"ms_per_step": ms.value / a.steps, "launches_per_step": n.value / a.steps}
         out["kernel_ms"] = km
+    # the trainer dies inside a reference cycle (optimizer <-> LR scheduler): drop its hipGraphs and collect NOW, while the runtime is
+    # there - left to the interpreter's final collection their destructors crashed at exit (selfc_amd/runtime.py _shutdown)
+    import gc
+    tr.graph = tr.graph_tail = None
+    del tr, net
+    gc.collect()
+    torch.cuda.synchronize()
     return out
 
 
