@@ -393,7 +393,21 @@ def test_reference_optimizer_state_loads_into_a_capturable_trainer(dev):
     assert worst(net_b, weights3) < 1e-6, ("after the warm-up step of capture()", worst(net_b, weights3), worst(net_b, weights2))
     tr_b.optimize_parameters(real_h, ref_l)
     torch.cuda.synchronize()
-    assert worst(net_a, net_b) < 1e-6, ("after the first replay", worst(net_a, net_b), worst(net_b, weights3))
+    weights4 = {k: v.detach().clone() for k, v in net_a.state_dict().items()}
+
+    def update_err(net, before, ref_before, ref_after):
+        """relative L2 distance between the net's UPDATE (its weights minus `before`) and the reference update: a replayed step and
+        an eager step are the same kernels but not bit for bit the same sums, and Adam turns the rounding noise of a gradient that
+        is zero in exact arithmetic (proj3 biases) into +-0.1 lr - a per-element bound on the weights would be a lottery; a wrong
+        learning rate, step count or moment buffer shows here as an error of order one"""
+        num = den = 0.0
+        for k, v in net.state_dict().items():
+            ref = (ref_after[k] - ref_before[k]).double()
+            num += float(((v.detach() - before[k]).double() - ref).pow(2).sum())
+            den += float(ref.pow(2).sum())
+        return (num / den) ** 0.5
+    e4 = update_err(net_b, weights3, weights3, weights4)
+    assert e4 < 2e-2, ("after the first replay", e4)
     # (b) load AFTER capture: same tensors, new contents; two replays bring B to A's step 4 again
     ids_before = {k: v.data_ptr() for k, v in st.items() if torch.is_tensor(v)}
     with torch.no_grad():
@@ -406,7 +420,8 @@ def test_reference_optimizer_state_loads_into_a_capturable_trainer(dev):
     tr_b.optimize_parameters(real_h, ref_l)
     tr_b.optimize_parameters(real_h, ref_l)
     torch.cuda.synchronize()
-    assert worst(net_a, net_b) < 1e-6, worst(net_a, net_b)
+    e24 = update_err(net_b, weights2, weights2, weights4)          # two replayed steps from the reloaded state against A's steps 3 and 4
+    assert e24 < 2e-2, e24
     # (c) a state that does not cover the captured step's tensors is refused, not half-applied
     bad = {"state": {}, "param_groups": sd2["param_groups"]}
     with pytest.raises(RuntimeError, match="capture again"):
