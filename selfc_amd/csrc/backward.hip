@@ -650,8 +650,17 @@ int wgrad_nsplit(int N, int H, int W, int npairs, int ttot) {
 
 namespace selfc {
 
+// *amax = 0 as a KERNEL, not hipMemsetAsync (round 5).  Inside a captured step a memset NODE in front of the atomic-max kernel was not
+// ordered with the kernels around it when the capture ran on ONE stream: the maximum kept its previous value (or was zeroed late), the
+// power-of-two gradient scale came out wrong and the replayed step's gradient norm differed from the eager step's by 1.5 % at 8 septuplets
+// (tools/experiments/graph_vs_eager_bits.py: with this kernel the replayed and the eager steps are bit-identical on one stream and on
+// three; the three-stream capture happened to be right with the memset too).  The same mechanism left torch's multi-block reductions
+// (a semaphore zeroed by a memset) without output.  No memset node is left in any graph of the package.
+__global__ void zero1_kernel(float* p) { *p = 0.f; }
+
 int bwd_absmax(const float* g, size_t n, float* amax, hipStream_t s) {
-  int rc = hip_rc(hipMemsetAsync(amax, 0, sizeof(float), s));
+  hipLaunchKernelGGL(zero1_kernel, dim3(1), dim3(1), 0, s, amax);
+  int rc = hip_rc(hipGetLastError());
   if (rc) return rc;
   const size_t nb = (n + 256 * 32 - 1) / (256 * 32);
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(nb < 1 ? 1 : (nb > 256 ? 256 : nb))), dim3(256), 0, s, g, n, (unsigned*)amax);
