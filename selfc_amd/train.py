@@ -398,6 +398,9 @@ class RescaleTrainer:
         self.log_dict["l_back_rec"] = l_back_rec.item()
         self.log_dict["loss_c"] = float(loss_c)
         self.log_dict["loss"] = loss.item()
+        gn = getattr(self, "grad_norm", None)
+        if gn is not None:
+            self.log_dict["grad_norm"] = float(gn)         # the total norm BEFORE clipping (clip_grad_norm_'s return value)
         return self.log_dict
 
     def optimize_parameters(self, real_H: torch.Tensor, ref_L: torch.Tensor, step: int = 0):
@@ -423,12 +426,18 @@ class RescaleTrainer:
         self._static_h, self._static_l = real_H.clone(), ref_L.clone()
         s = rt.warmup_stream()
         s.wait_stream(torch.cuda.current_stream())
+        warm = []
         with torch.cuda.stream(s):
             for _ in range(warmup):
                 self._zero_grad()
-                self._step(self._static_h, self._static_l)
+                warm.append(self._step(self._static_h, self._static_l) + (getattr(self, "grad_norm", None),))
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        #: the warm-up steps are real optimisation steps: their log entries (read after the synchronize, not between the steps)
+        self.warmup_logs = []
+        for *losses, gn in warm:
+            self.grad_norm = gn
+            self.warmup_logs.append(dict(self._log(tuple(losses))))
         if self.sink is None:
             self.optimizer_G.zero_grad(set_to_none=True)
         self.graph, self.graph_tail = None, None      # a re-capture: the old execs die BEFORE the new one is instantiated (rt.new_graph)

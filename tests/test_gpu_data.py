@@ -65,6 +65,96 @@ def test_folder_of_groups_through_the_hip_path(dev, tmp_path):
         assert r["max_psnr_diff_vs_oracle_dB"] < 0.02, r          # BASELINE: PSNR within 0.02 dB of the reference path
 
 
+#: Vid4's four sequences: HR frame size and clip length (README.md:36-58 of the reference names the set; 576x720 / 576x704 / 480x720,
+#: 41 / 34 / 49 / 47 frames) - the frames and selfc_large_pretrain.pth themselves are not available (.MISSING_LARGE_BLOBS)
+VID4_GEOMETRY = {"calendar": (576, 720, 41), "city": (576, 704, 34), "foliage": (480, 720, 49), "walk": (480, 720, 47)}
+
+
+def _synthetic_clip(h, w, n, seed):
+    """n frames (n,3,h,w) of a drifting low-frequency pattern with light texture, in [0,1]"""
+    gen = torch.Generator().manual_seed(seed)
+    low = torch.rand(1, 3, h // 16, w // 16, generator=gen)
+    base = torch.nn.functional.interpolate(low, size=(h, w), mode="bicubic", align_corners=False)[0]
+    return torch.stack([(torch.roll(base, shifts=(i, 2 * i), dims=(1, 2)) + 0.04 * torch.randn(3, h, w, generator=gen)).clamp(0, 1)
+                        for i in range(n)])
+
+
+@pytest.mark.parametrize("seq", sorted(VID4_GEOMETRY))
+def test_vid4_geometry_and_clip_lengths_against_the_oracle(dev, seq):
+    """Config 4's WORKLOAD SHAPE without its assets: synthetic clips at Vid4's exact frame sizes and clip
+    lengths through the restated test loop (SelfC_model.py:185-250, test_rescaling.py:65-153) - the whole clip cut into GOPs
+    of 7 with the last GOP padded by repeating the final frame (harness.rescale_video), and one 7-frame group through
+    harness.rescale_test incl. the reference's redundant tail pass.  Against the oracle: the TAIL GOP (the padded one) on
+    the WHOLE frame - LR, HF (l2 STP head: no noise) and reconstruction at 1e-3, Y-PSNR of every frame within 0.02 dB of the
+    oracle's (north star) - and the first GOP on the four corner crops (the :615 method of test_gpu_parity.py: dependency
+    radius 64 latent pixels).  Latents are 144x180 / 144x176 / 120x180: partial tile rows and columns in both kernel tilings."""
+    from conftest import rel_err, record, subdict
+    from oracle import selfc_oracle as O
+    from selfc_amd import GlobalVar, harness
+    from selfc_amd.modules.SelfC_GMM_arch_inv import SelfCInvNet
+    GlobalVar.set_Temporal_LEN(7)
+    H, W, n = VID4_GEOMETRY[seq]
+    g, s = load_golden("g8_large_stack"), load_golden("g7_stp_l2_full_rev")
+    net = SelfCInvNet({"global_module": "nonlocal", "stp_blk_num": 6, "fh_loss": "l2", "scale": 4, "gmm_k": 5}, 3, 3, "D2DTNet", [4, 4], 2)
+    sd = {k: v for k, v in g.items() if k.startswith("operations.")}
+    sd.update({k: v for k, v in s.items() if k.startswith("stp_net.")})
+    net.load_state_dict(sd, strict=True)
+    net.to(dev).eval()
+    clip = _synthetic_clip(H, W, n, seed=len(seq) + n)
+    out = harness.rescale_video(net, clip.to(dev), gops_per_call=2)
+    assert out["frames"] == list(range(n)) and out["lr"].shape == (n, 3, H // 4, W // 4) and out["rec"].shape == (n, 3, H, W)
+    slices = harness.gop_slices(n)
+    assert len(slices) == -(-n // 7) and slices[-1][-1] == n - 1 and len(slices[-1]) == 7
+    # --- tail GOP (n % 7 real frames + repeats of the last one), whole frame, against the oracle
+    tail = slices[-1]
+    keep = n - tail[0]
+    x = clip[tail]
+    with torch.no_grad():
+        z, _ = net(x=x.to(dev), rev=False)
+        from selfc_amd.modules.Quantization import Quantization
+        lrq = Quantization()(z[:, :3])
+        xr, hf = net(x=lrq, rev=True)
+    # the video loop's tail frames ARE this GOP's first `keep` frames
+    assert torch.equal(out["lr"][tail[0]:].cpu(), lrq[:keep].cpu()) and torch.equal(out["rec"][tail[0]:].cpu(), xr[:keep, :3].cpu())
+    z_or = O.large_fwd(g, x, 7)
+    e_z = rel_err(z.cpu(), z_or)
+    lr_or = O.quantize(z_or[:, :3])
+    # quantisation ties: a latent value within 1e-3 relative of a rounding boundary may land on the other 1/255 step; compare the
+    # HIP path's reverse on the HIP path's OWN quantised LR (what the caller feeds it) against the oracle on the same LR
+    flips = float((lrq.cpu() != lr_or).float().mean())
+    record(f"Vid4 geometry {seq}: fraction of LR pixels on the other quantisation step", flips)
+    assert flips < 2e-3 and float((lrq.cpu() - lr_or).abs().max()) <= 1.0 / 255 + 1e-6
+    hf_or = O.stp_v2_parameters(subdict(s, "stp_net"), lrq.cpu(), 7)
+    e_hf = rel_err(hf.cpu(), hf_or)
+    x_or = O.large_inv_from_latent(g, torch.cat((lrq.cpu(), hf_or), 1), 7)
+    e_x = rel_err(xr.cpu(), x_or)
+    assert max(e_z, e_hf, e_x) < 1e-3, (e_z, e_hf, e_x)
+    p_hip = harness.psnr_y(xr[:, :3], x.to(dev))
+    p_or = O.psnr_per_frame(x_or[:, :3], x)
+    d_psnr = record(f"Vid4 geometry {seq}: max per-frame |Y-PSNR(HIP) - Y-PSNR(oracle)| dB", max(abs(a - b) for a, b in zip(p_hip, p_or)))
+    assert d_psnr < 0.02, (p_hip, p_or)
+    # --- first GOP: the four corners of the frame against the oracle on crops (forward latent and inverse)
+    x0 = clip[slices[0]]
+    h, w, C, M = H // 4, W // 4, 112, 64
+    with torch.no_grad():
+        z0, _ = net(x=x0.to(dev), rev=False)
+        z0 = z0.cpu()
+        zq = torch.cat((O.quantize(z0[:, :3]), z0[:, 3:]), 1)
+        xr0 = net.inverse_from_latent(zq.to(dev)).cpu()
+    for r0, c0 in ((0, 0), (0, w - C), (h - C, 0), (h - C, w - C)):
+        rs = slice(0, C - M) if r0 == 0 else slice(M, C)
+        cs = slice(0, C - M) if c0 == 0 else slice(M, C)
+        xc = x0[:, :, 4 * r0:4 * (r0 + C), 4 * c0:4 * (c0 + C)].contiguous()
+        zc = O.large_fwd(g, xc, 7)
+        assert rel_err(z0[:, :, r0:r0 + C, c0:c0 + C][:, :, rs, cs], zc[:, :, rs, cs]) < 1e-3
+        xo = O.large_inv_from_latent(g, zq[:, :, r0:r0 + C, c0:c0 + C].contiguous(), 7)
+        hrs, hcs = slice(4 * rs.start, 4 * rs.stop), slice(4 * cs.start, 4 * cs.stop)
+        assert rel_err(xr0[:, :, 4 * r0:4 * (r0 + C), 4 * c0:4 * (c0 + C)][:, :, hrs, hcs], xo[:, :, hrs, hcs]) < 1e-3
+    # --- the reference's own loop on one 7-frame group, with its discarded extra pass (SelfC_model.py:203-209): same outputs
+    fl, fh = harness.rescale_test(net, x0.to(dev), reference_tail_pass=True)
+    assert torch.equal(fl.cpu(), out["lr"][:7].cpu()) and torch.equal(fh.cpu(), out["rec"][:7].cpu())
+
+
 def test_vid4_config4_if_assets_present(dev):
     root, ckpt = os.environ.get("SELFC_VID4_ROOT"), os.environ.get("SELFC_PRETRAIN")
     if not (root and ckpt and os.path.isdir(root) and os.path.isfile(ckpt)):

@@ -78,6 +78,51 @@ def test_train_step_matches_reference_step(dev):
     assert float(agree) > 0.98
 
 
+@pytest.mark.parametrize("mode", ["eager", "captured"])
+def test_k20_training_trajectory_tracks_the_reference(dev, mode):
+    """K = 20 consecutive optimisation steps on one fixed 32x48 clip against fixture g18 (tools/make_golden_r6.py: the SAME 20
+    steps on the imported reference modules, fp32 CPU, stock autograd, torch Adam; SelfC_model.py:148-183): every step's
+    l_forw_fit / l_back_rec within 1 % of the reference trajectory's, and the accumulated weight update (final - initial over
+    the 350 trainable tensors) compared as ONE vector.  The f16-operand steps do not drift: each step's losses are forward
+    quantities of the weights the previous 1..k-1 f16-gradient steps produced."""
+    from conftest import record
+    from selfc_amd import train
+    g = load_golden("g18_train_trajectory")
+    x = load_golden("g8_large_stack")["x"]
+    net = _net(dev)
+    names = [n for n, p in net.named_parameters() if p.requires_grad]
+    assert names == g["names"]
+    before = [p.detach().clone() for n, p in net.named_parameters() if p.requires_grad]
+    cap = mode == "captured"
+    tr = train.RescaleTrainer(net, dict(train.TRAIN_OPT_LARGE), capturable=cap)
+    gt = x.reshape(1, T, 3, 32, 48).transpose(1, 2).to(dev)
+    real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
+    K = len(g["loss"])
+    logs = []
+    if cap:
+        tr.capture(real_h, ref_l, warmup=3)                         # 3 real (eager, capturable-Adam) steps, then replays
+        logs += tr.warmup_logs
+    while len(logs) < K:
+        logs.append(dict(tr.optimize_parameters(real_h, ref_l)))
+    worst_fit = max(abs(l["l_forw_fit"] - float(r)) / float(r) for l, r in zip(logs, g["l_forw_fit"]))
+    worst_rec = max(abs(l["l_back_rec"] - float(r)) / float(r) for l, r in zip(logs, g["l_back_rec"]))
+    worst_gn = max(abs(l["grad_norm"] - float(r)) / float(r) for l, r in zip(logs, g["grad_norm"]))
+    record(f"K=20 trajectory ({mode}): worst per-step l_forw_fit relative error", worst_fit)
+    record(f"K=20 trajectory ({mode}): worst per-step l_back_rec relative error", worst_rec)
+    record(f"K=20 trajectory ({mode}): worst per-step total-gradient-norm relative error", worst_gn)
+    assert worst_fit < 1e-2 and worst_rec < 1e-2, (worst_fit, worst_rec)
+    # the update vector.  Adam's per-element step is lr * m / (sqrt(v) + eps): elements whose gradient is noise-sized (sign flips from
+    # one step to the next) move by +-lr whatever the size of the gradient, so the vector's relative L2 error is far above a gradient's;
+    # measured on the MI355X: see profiles/r6/parity_report_gpu.json
+    ref = g["update_q"].float() * float(g["update_scale"])
+    after = [p.detach() for n, p in net.named_parameters() if p.requires_grad]
+    upd = torch.cat([(a - b).flatten() for a, b in zip(after, before)]).cpu()
+    e_all = record(f"K=20 trajectory ({mode}): ||update - ref|| / ||ref|| over all 3.37 M weights", (upd - ref).norm() / ref.norm())
+    cos = record(f"K=20 trajectory ({mode}): cosine(update, ref)", torch.dot(upd, ref) / (upd.norm() * ref.norm()))
+    record(f"K=20 trajectory ({mode}): ||update|| / ||ref||", upd.norm() / ref.norm())
+    assert e_all < 0.15 and cos > 0.99, (e_all, cos)
+
+
 def test_flat_gradient_sink_equals_autograd_accumulation(dev):
     """RescaleTrainer(flat_grads=True): gradients accumulated by the kernels into one buffer (beta = 1) and clipped there -
     the same step as stock autograd accumulation + clip_grad_norm_ (two calls per block and step: the sums differ only in

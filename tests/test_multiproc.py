@@ -69,7 +69,7 @@ def _run_bench(extra, env=None):
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *extra], env=e, capture_output=True, text=True, timeout=300)
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 8])
 def test_bench_self_launches_its_ranks(n):
     """`python bench.py --gpus N` from a clean environment (what the driver runs) must start its own N ranks, print ONE
     JSON line from rank 0 and exit 0.  --dry-run: gloo, no HIP call, so this runs in the CPU container."""
@@ -222,9 +222,11 @@ def _sink_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_grad_sink_all_reduce_averages_fake_gradients():
+@pytest.mark.parametrize("world", [2, 8])
+def test_grad_sink_all_reduce_averages_fake_gradients(world):
+    """world 8 = the reference's training launch (train.py:19-27, README.md:85: eight ranks, one septuplet each)"""
     from selfc_amd import launch
-    world, port = 2, launch.free_port()
+    port = launch.free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_sink_worker, args=(r, world, port, q)) for r in range(world)]
@@ -234,11 +236,12 @@ def test_grad_sink_all_reduce_averages_fake_gradients():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    mean = (world + 1) / 2.0                                                    # mean of 1..world: 1.5 / 4.5, exact in fp32
     for rank, w, nd, flat, none1, nones in res:
         flat = torch.tensor(flat)
-        assert w == 2 and nd == 1 and none1 and nones == [False, True, False]
+        assert w == world and nd == 1 and none1 and nones == [False, True, False]
         assert flat.numel() == 64 + 64 + 128                                   # 256-byte aligned slices
-        assert torch.equal(flat[:35], torch.full((35,), 1.5))                   # mean of 1 and 2
+        assert torch.equal(flat[:35], torch.full((35,), mean))
         assert torch.equal(flat[35:128], torch.zeros(93))                       # pad + the untouched parameter + its pad
-        assert torch.allclose(flat[128:198], torch.arange(70.0) * 1.5)
-    assert res[0][3] == res[1][3]
+        assert torch.allclose(flat[128:198], torch.arange(70.0) * mean)
+    assert all(r[3] == res[0][3] for r in res)                                  # every rank holds the same averaged buffer, bit for bit
