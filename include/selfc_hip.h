@@ -227,6 +227,29 @@ int selfc_subnet_bwd_phase_x(int phases, const selfc_subnet_bw* bw, int kind, co
                              float sign, float* dx, int accumulate_dx, float* const* wgrad, float* const* bgrad, float beta,
                              void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout,
                              const float* dout_amax, float* dx_amax_out, void* stream);
+/* (abi 13) Fewer, fatter launches for the training backward (the reference's autograd launches one ATen op per layer and tensor,
+ * models/SelfC_model.py:148-183; here a replayed step is made of graph nodes, and on a 36x36 training latent every node is latency).
+ * - `selfc_subnet_bwd_phase_d` = `selfc_subnet_bwd_phase_x` with deferred weight-gradient finishes: with `fin_jobs` (room for 2 jobs of
+ *   `selfc_fin_job_bytes()` each, HOST memory) the weights phase leaves its two partial-sum reductions as job descriptors instead
+ *   of launching them; `selfc_wgrad_finish_jobs` runs any number of collected jobs (24 per launch), in order.  The scratch buffers of
+ *   the deferred calls must stay untouched until that launch has run.  fin_jobs NULL: as before.
+ * - `selfc_gh_bwd_pair`: G and H of ONE InvBlockExp (Inv_arch.py:18-20,26-30: same input, same shapes, input gradients add up) in one
+ *   call: every step of the subnet backward runs once for both nets (a grid dimension), under one power-of-two gradient scale taken
+ *   from max(max|dOut_G|, max|dOut_H|) (`amax_g` / `amax_h`: the finished maxima, NULL = taken here), and dx (+= when accumulate_dx)
+ *   is a single conv over both nets' gradient planes.  cin <= 3, D2DTInput subnets.  `fin_jobs`: room for 4 jobs, or NULL.
+ *   Scratch: `selfc_gh_bwd_pair_scratch_bytes`. */
+size_t selfc_fin_job_bytes(void);
+int selfc_wgrad_finish_jobs(const void* jobs, int njobs, void* stream);
+int selfc_subnet_bwd_phase_d(int phases, const selfc_subnet_bw* bw, int kind, const void* dense, const float* xin, const float* dout,
+                             float sign, float* dx, int accumulate_dx, float* const* wgrad, float* const* bgrad, float beta,
+                             void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout,
+                             const float* dout_amax, float* dx_amax_out, void* fin_jobs, void* stream);
+size_t selfc_gh_bwd_pair_scratch_bytes(int N, int H, int W, int cin, int cout);
+int selfc_gh_bwd_pair(int phases, const selfc_subnet_bw* bw_g, const selfc_subnet_bw* bw_h, const void* dense_g, const void* dense_h,
+                      const float* xin, const float* dout_g, const float* dout_h, float sign_g, float sign_h,
+                      float* dx, int accumulate_dx, float* const* wgrad_g, float* const* bgrad_g, float* const* wgrad_h, float* const* bgrad_h,
+                      float beta, void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout,
+                      const float* amax_g, const float* amax_h, float* dx_amax_out, void* fin_jobs, void* stream);
 /* Adjoint of selfc_freq_fwd (latent grads d1 [N][h][w][4], d2 [N][h][w][48] -> dx NCHW (N,3,H,W)) and of selfc_freq_inv
  * (dout NCHW -> d1, d2). */
 int selfc_freq_fwd_bwd(const float* d1, const float* d2, float* dx, int N, int H, int W, void* stream);
@@ -321,6 +344,9 @@ int selfc_profile_clock_sample(unsigned long long* out2, int micros, void* strea
  * hipGraphs on, and forks onto, streams of its own rather than streams of torch's shared 32-entry pool (runtime.own_stream). */
 int selfc_stream_create(void** out);
 int selfc_stream_destroy(void* stream);
+/* (abi 13) Node census of a captured hipGraph_t: counts[5] = {all, kernel, memset, memcpy, other}.  Host-only.  No reference counterpart
+ * (the reference launches eagerly); used by the tests ("no memset node in any graph of the package") and by bench.py (nodes per step). */
+int selfc_graph_stats(void* graph, long long* counts);
 
 /* ---- indirect tensor addresses (abi 10): the module API as ONE replayed hipGraph ----
  * The reference's callers pass a new input tensor to every netG(x=..., rev=...) call and own the tensors it returns

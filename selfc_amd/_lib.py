@@ -25,7 +25,7 @@ def operand_dtype():
 SUBNET_D2DT = 0
 SUBNET_DB2D = 1
 LAT_KEEP_FEATURES = 1      # selfc_latent.flags (SELFC_LAT_KEEP_FEATURES)
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 #: every symbol include/selfc_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -42,7 +42,8 @@ SYMBOLS = [
     "selfc_bwd_wgrad_scratch_bytes", "selfc_bwd_wgrad", "selfc_gmm_sample_bwd", "selfc_gmm_sample_generic_bwd", "selfc_lrelu_bwd",
     "selfc_globalagg_bwd_scratch_bytes", "selfc_globalagg_bwd", "selfc_rowsum_accum",
     "selfc_coupling_bwd_x", "selfc_add_absmax", "selfc_subnet_bwd_phase_x", "selfc_stream_create", "selfc_stream_destroy", "selfc_set_pointers", "selfc_freq_fwd_ind", "selfc_freq_inv_ind", "selfc_nchw_to_latent_ind", "selfc_latent_to_nchw_ind",
-    "selfc_nchw_to_nhwc4_ind", "selfc_nhwc4_to_nchw_ind",
+    "selfc_nchw_to_nhwc4_ind", "selfc_nhwc4_to_nchw_ind", "selfc_graph_stats",
+    "selfc_fin_job_bytes", "selfc_wgrad_finish_jobs", "selfc_subnet_bwd_phase_d", "selfc_gh_bwd_pair_scratch_bytes", "selfc_gh_bwd_pair",
 ]
 
 
@@ -129,6 +130,11 @@ def lib():
                                        vp, sz, i, i, i, i, i, i, vp],
             "selfc_subnet_bwd_phase_x": [i, C.POINTER(SubnetBW), i, vp, vp, vp, f, vp, i, C.POINTER(vp), C.POINTER(vp), f,
                                          vp, sz, i, i, i, i, i, i, vp, vp, vp],
+            "selfc_subnet_bwd_phase_d": [i, C.POINTER(SubnetBW), i, vp, vp, vp, f, vp, i, C.POINTER(vp), C.POINTER(vp), f,
+                                         vp, sz, i, i, i, i, i, i, vp, vp, vp, vp],
+            "selfc_gh_bwd_pair": [i, C.POINTER(SubnetBW), C.POINTER(SubnetBW), vp, vp, vp, vp, vp, f, f, vp, i,
+                                  C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), f, vp, sz, i, i, i, i, i, i, vp, vp, vp, vp, vp],
+            "selfc_wgrad_finish_jobs": [vp, i, vp],
             "selfc_coupling_bwd_x": [i, vp, vp, vp, vp, vp, f, sz, vp, vp, vp],
             "selfc_add_absmax": [vp, vp, sz, vp, vp],
             "selfc_coupling_fwd": [i, vp, vp, vp, vp, vp, f, sz, vp],
@@ -146,6 +152,7 @@ def lib():
             "selfc_rowsum_accum": [C.POINTER(RowSum), vp],
             "selfc_stream_create": [C.POINTER(vp)],
             "selfc_stream_destroy": [vp],
+            "selfc_graph_stats": [vp, C.POINTER(C.c_longlong)],
             "selfc_set_pointers": [vp, i, vp, vp, vp, vp, vp],
             "selfc_freq_fwd_ind": [vp, sz, vp, vp, vp, i, i, i, i, i, vp],
             "selfc_freq_inv_ind": [vp, vp, vp, sz, i, i, i, i, vp],
@@ -164,6 +171,10 @@ def lib():
         L.selfc_bwd_wgrad_scratch_bytes.argtypes = [i, i, i, i, i, i]
         L.selfc_globalagg_bwd_scratch_bytes.restype = sz
         L.selfc_globalagg_bwd_scratch_bytes.argtypes = [i, i, i, i]
+        L.selfc_gh_bwd_pair_scratch_bytes.restype = sz
+        L.selfc_gh_bwd_pair_scratch_bytes.argtypes = [i, i, i, i, i]
+        L.selfc_fin_job_bytes.restype = sz
+        L.selfc_fin_job_bytes.argtypes = []
         L.selfc_subnet_bwd_scratch_bytes.restype = sz
         L.selfc_subnet_bwd_scratch_bytes.argtypes = [i, i, i, i, i]
         L.selfc_globalagg_partial_floats.restype = sz

@@ -23,10 +23,10 @@ _SCRATCH: Dict[Tuple, torch.Tensor] = {}
 _SLOT_BUSY: Dict[Tuple, "torch.cuda.Event"] = {}
 
 
-def _scratch(device, n, h, w, cin, cout, slot="") -> torch.Tensor:
-    """Scratch of one subnet backward.  `slot` separates calls whose weight-gradient phase may still be running on the side
-    stream while the next call's data phase starts."""
-    need = _lib.lib().selfc_subnet_bwd_scratch_bytes(n, h, w, cin, cout)
+def _scratch(device, n, h, w, cin, cout, slot="", pair: bool = False) -> torch.Tensor:
+    """Scratch of one subnet backward (pair: of a G/H pair's, selfc_gh_bwd_pair).  `slot` separates calls whose weight-gradient
+    phase may still be running on the side stream while the next call's data phase starts."""
+    need = (_lib.lib().selfc_gh_bwd_pair_scratch_bytes if pair else _lib.lib().selfc_subnet_bwd_scratch_bytes)(n, h, w, cin, cout)
     if need == 0:
         raise RuntimeError("selfc_subnet_bwd_scratch_bytes: invalid shape")
     key = (str(device), slot)
@@ -34,6 +34,36 @@ def _scratch(device, n, h, w, cin, cout, slot="") -> torch.Tensor:
     if buf is None or buf.numel() < need:
         buf = _SCRATCH[key] = torch.empty(need, dtype=torch.uint8, device=device)
     return buf
+
+
+#: SELFC_BWD_PAIR=0: G and H of a coupling block run their backward as two subnet calls on two streams again (round 5) instead of
+#: ONE paired call (selfc_gh_bwd_pair: every launch covers both nets, one gradient scale, one input-gradient conv)
+_PAIR = os.environ.get("SELFC_BWD_PAIR", "1") != "0"
+#: SELFC_BWD_DEFER_FIN=0: every subnet call reduces its weight-gradient partials itself (one finish launch per subnet) instead of
+#: leaving them to ONE launch per 24 jobs at the end of the block stack's backward (FinJobs)
+_DEFER_FIN = os.environ.get("SELFC_BWD_DEFER_FIN", "1") != "0"
+
+
+class FinJobs:
+    """Deferred weight-gradient finishes of a block stack's backward (selfc_subnet_bwd_phase_d / selfc_gh_bwd_pair leave job
+    descriptors here, host memory; flush() reduces all of them with one launch per 24 jobs, in the order they were left)."""
+
+    def __init__(self, capacity: int):
+        self.size = int(_lib.lib().selfc_fin_job_bytes())
+        self.buf = (C.c_ubyte * (self.size * capacity))()
+        self.cap, self.n = capacity, 0
+
+    def take(self, k: int):
+        if self.n + k > self.cap:
+            raise RuntimeError("FinJobs: capacity exceeded")
+        p_ = C.c_void_p(C.addressof(self.buf) + self.n * self.size)
+        self.n += k
+        return p_
+
+    def flush(self):
+        if self.n:
+            rt.call("selfc_wgrad_finish_jobs", C.c_void_p(C.addressof(self.buf)), self.n, _lib.stream_ptr())
+            self.n = 0
 
 
 #: weight gradients run on a second HIP stream, overlapping the (latency-bound) data-gradient chain of the next subnet;
@@ -257,7 +287,8 @@ def subnet_params(mod) -> List[torch.Tensor]:
 def subnet_bwd(mod, dense: torch.Tensor, xin: Optional[torch.Tensor], dout: torch.Tensor, sign: float,
                dx: Optional[torch.Tensor], accumulate_dx: bool, n: int, t: int, h: int, w: int,
                want_params: bool = True, pk=None, side=None, slot: str = "", on_data_done=None,
-               dout_amax: Optional[torch.Tensor] = None, dx_amax_out: Optional[torch.Tensor] = None) -> List[Optional[torch.Tensor]]:
+               dout_amax: Optional[torch.Tensor] = None, dx_amax_out: Optional[torch.Tensor] = None,
+               fin: Optional["FinJobs"] = None) -> List[Optional[torch.Tensor]]:
     """Backward of one DenseBlock / D2DTInput on kernel-layout buffers; returns the 10 parameter gradients
     (reference layouts) or Nones.  With `side` (a stream) the weight-gradient phase is enqueued there, ordered after the
     data phase; the caller joins the streams before it hands the gradients on and must not reuse `slot` before that.
@@ -304,22 +335,83 @@ def subnet_bwd(mod, dense: torch.Tensor, xin: Optional[torch.Tensor], dout: torc
             wg if want_params else None, bg if want_params else None, beta,
             scratch.data_ptr(), scratch.numel(), n, t, h, w, cin, cout,
             None if dout_amax is None else dout_amax.data_ptr(), None if dx_amax_out is None else dx_amax_out.data_ptr())
+    jobs = fin.take(2) if (fin is not None and want_params) else None      # deferred finish: the caller flushes (FinJobs)
     if (side is None or not want_params) and on_data_done is None:
-        rt.call("selfc_subnet_bwd_phase_x", 3, *args, _lib.stream_ptr())
+        rt.call("selfc_subnet_bwd_phase_d", 3, *args, jobs, _lib.stream_ptr())
         return grads
-    rt.call("selfc_subnet_bwd_phase_x", 1, *args, _lib.stream_ptr())
+    rt.call("selfc_subnet_bwd_phase_d", 1, *args, None, _lib.stream_ptr())
     if on_data_done is not None:
         on_data_done()
     if not want_params:
         return grads
     if side is None:
-        rt.call("selfc_subnet_bwd_phase_x", 2, *args, _lib.stream_ptr())
+        rt.call("selfc_subnet_bwd_phase_d", 2, *args, jobs, _lib.stream_ptr())
         return grads
     side.wait_event(torch.cuda.current_stream().record_event())
     with torch.cuda.stream(side):
-        rt.call("selfc_subnet_bwd_phase_x", 2, *args, _lib.stream_ptr())
+        rt.call("selfc_subnet_bwd_phase_d", 2, *args, jobs, _lib.stream_ptr())
         _SLOT_BUSY[(str(dev), slot)] = side.record_event()
     return grads
+
+
+def _grad_targets(mod, want_params: bool, dev):
+    """(grads list for autograd, wg array, bg array, beta) of one subnet: views of the trainer's flat buffer (beta = 1, autograd gets
+    None) or one fresh allocation handed out as views."""
+    grads: List[Optional[torch.Tensor]] = [None] * 10
+    wg = (C.c_void_p * 5)()
+    bg = (C.c_void_p * 5)()
+    if not want_params:
+        return grads, None, None, 0.0
+    prm = subnet_params(mod)
+    if _SINK is not None:
+        sunk = [_SINK.view_of(p_) for p_ in prm]
+        if all(v is not None for v in sunk):
+            for i, v in enumerate(sunk):
+                (wg if i % 2 == 0 else bg)[i // 2] = v.data_ptr()
+            return grads, wg, bg, 1.0
+    offs, total = [], 0
+    for p_ in prm:
+        offs.append(total)
+        total += (p_.numel() + 63) & ~63
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    base = flat.data_ptr()
+    for i, p_ in enumerate(prm):
+        grads[i] = flat[offs[i]:offs[i] + p_.numel()].view(p_.shape)
+        (wg if i % 2 == 0 else bg)[i // 2] = base + 4 * offs[i]
+    return grads, wg, bg, 0.0
+
+
+def gh_pair_bwd(blk, pb, gd: torch.Tensor, hd: torch.Tensor, xin: torch.Tensor, dout_g: torch.Tensor, dout_h: torch.Tensor,
+                sign_g: float, sign_h: float, dx: torch.Tensor, n: int, t: int, h: int, w: int, want_params: bool, side=None,
+                slot: str = "", amax_g: Optional[torch.Tensor] = None, amax_h: Optional[torch.Tensor] = None,
+                dx_amax_out: Optional[torch.Tensor] = None, fin: Optional["FinJobs"] = None):
+    """Backward of G and H of one InvBlockExp as ONE call (selfc_gh_bwd_pair): both read `xin`, dx += both input gradients.
+    Returns (gG, gH): the two lists of 10 parameter gradients (or Nones).  `side`: stream of the weight-gradient phase."""
+    G, H = blk.G, blk.H
+    cin, cout = G.channel_in, G.channel_out
+    dev = dout_g.device
+    gG, wgG, bgG, betaG = _grad_targets(G, want_params, dev)
+    gH, wgH, bgH, betaH = _grad_targets(H, want_params, dev)
+    if want_params and betaG != betaH:
+        raise RuntimeError("gh_pair_bwd: G and H must both (or neither) accumulate into the flat gradient buffer")
+    scratch = _scratch(dev, n, h, w, cin, cout, slot, pair=True)
+    busy = _SLOT_BUSY.pop((str(dev), slot), None)
+    if busy is not None:
+        torch.cuda.current_stream().wait_event(busy)
+    ptr = lambda t_: None if t_ is None else t_.data_ptr()      # noqa: E731
+    args = (pb.G.bwd_struct(), pb.H.bwd_struct(), gd.data_ptr(), hd.data_ptr(), xin.data_ptr(), dout_g.data_ptr(), dout_h.data_ptr(),
+            float(sign_g), float(sign_h), dx.data_ptr(), 1, wgG, bgG, wgH, bgH, betaG,
+            scratch.data_ptr(), scratch.numel(), n, t, h, w, cin, cout, ptr(amax_g), ptr(amax_h), ptr(dx_amax_out))
+    jobs = fin.take(4) if (fin is not None and want_params) else None
+    if side is None or not want_params:
+        rt.call("selfc_gh_bwd_pair", 3 if want_params else 1, *args, jobs, _lib.stream_ptr())
+        return gG, gH
+    rt.call("selfc_gh_bwd_pair", 1, *args, None, _lib.stream_ptr())
+    side.wait_event(torch.cuda.current_stream().record_event())
+    with torch.cuda.stream(side):
+        rt.call("selfc_gh_bwd_pair", 2, *args, jobs, _lib.stream_ptr())
+        _SLOT_BUSY[(str(dev), slot)] = side.record_event()
+    return gG, gH
 
 
 def _dense_buffer(cin: int, n: int, h: int, w: int, dev) -> torch.Tensor:
@@ -558,7 +650,7 @@ def _join_side_streams(dev, want: bool):
 _FOLD_AMAX = os.environ.get("SELFC_BWD_FOLD_AMAX", "1") != "0"
 
 
-def _block_backward(blk, ws, keep, rev, t, d1, d2, want, restore_fd, tag="", amax_in=None, amax_slots=None):
+def _block_backward(blk, ws, keep, rev, t, d1, d2, want, restore_fd, tag="", amax_in=None, amax_slots=None, fin=None):
     """Gradient of one InvBlockExp call on the latent layout.  d1 / d2: gradients w.r.t. the block's outputs (y1, y2) as fp32
     [n][h][w][4] / [n][h][w][c2p] (d1 is updated in place); ws: what the forward left - fd / gd / hd (dense features), s, and
     the OUTPUT side the formulas need (forward: ws.x1 = y1; reverse: ws.x2 = y2); keep: the INPUT side the kernels overwrote
@@ -589,6 +681,24 @@ def _block_backward(blk, ws, keep, rev, t, d1, d2, want, restore_fd, tag="", ama
     fold = amax_slots is not None
     A = [amax_slots[i:i + 1] for i in range(3)] if fold else [None, None, None]
     ptr = lambda t_: None if t_ is None else t_.data_ptr()      # noqa: E731
+
+    if _PAIR and blk.G.kind == rt.SUBNET_D2DT and blk.G.channel_in <= 3:
+        # G and H as ONE call: no third stream, no d1 += d1h; the pair's dx conv is the last writer of d1 and leaves its max
+        if not rev:
+            rt.call("selfc_coupling_bwd_x", 0, keep.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel,
+                    None, ptr(A[0]), sp)
+            gG, gH = gh_pair_bwd(blk, pb, ws.gd, ws.hd, ws.x1, d2, dh, 1.0, 1.0, d1, n, t, h, w, want, side, "GH" + tag,
+                                 amax_g=amax_in, amax_h=A[0], dx_amax_out=A[1], fin=fin)
+            if restore_fd:
+                rt.call("selfc_nhwc_to_planes", keep.data_ptr(), ws.fd.data_ptr(), n * h * w, c2, sp)
+            gF = subnet_bwd(blk.F, ws.fd, None, d1, 1.0, dx2, True, n, t, h, w, want, pb.F, side, "F" + tag, dout_amax=A[1], dx_amax_out=A[2], fin=fin)
+            return d1, dx2, gF, gG, gH, A[2]
+        gF = subnet_bwd(blk.F, ws.fd, None, d1, -1.0, d2, True, n, t, h, w, want, pb.F, side, "F" + tag, dout_amax=amax_in, fin=fin)
+        rt.call("selfc_coupling_bwd_x", 1, ws.x2.data_ptr(), ws.s.data_ptr(), d2.data_ptr(), dx2.data_ptr(), dh.data_ptr(), clamp, nel,
+                ptr(A[0]), ptr(A[1]), sp)
+        gG, gH = gh_pair_bwd(blk, pb, ws.gd, ws.hd, keep, dx2, dh, -1.0, 1.0, d1, n, t, h, w, want, side, "GH" + tag,
+                             amax_g=A[0], amax_h=A[1], dx_amax_out=A[2], fin=fin)
+        return d1, dx2, gF, gG, gH, A[2]
 
     def h_backward(xin_gh, amax_dh, dx_amax=None):
         """H's whole backward (data chain, then its weight gradients) next to G's: own stream, own dx buffer."""
@@ -735,10 +845,24 @@ class InvStackFn(torch.autograd.Function):
         # three max slots per block, zeroed by ONE fill (see _block_backward)
         slots = torch.zeros(3 * len(ctx.saves), dtype=torch.float32, device=dev) if _FOLD_AMAX else None
         amax = None
+        # the weight-gradient partials of every subnet are reduced by ONE launch per 24 jobs behind the last block (FinJobs); each block
+        # has its own scratch set (tag), so nothing is overwritten before that
+        fin = FinJobs(6 * len(ctx.saves)) if (want and _DEFER_FIN) else None
         for i, (blk, sv, keep, fd_intact) in enumerate(reversed(ctx.saves)):
             d1, d2, gF, gG, gH, amax = _block_backward(blk, sv, keep, rev, t, d1, d2, want, restore_fd=not fd_intact, tag=str(i), amax_in=amax,
-                                                       amax_slots=None if slots is None else slots[3 * i:3 * i + 3])
+                                                       amax_slots=None if slots is None else slots[3 * i:3 * i + 3], fin=fin)
             grads[id(blk)] = (*gF, *gG, *gH)
+        if fin is not None and fin.n:
+            side = side_stream(dev)
+            if side is None:
+                fin.flush()
+            else:
+                # behind every weight-gradient phase (the side stream is in order; H's non-paired phases, stream 1, are joined first)
+                if side_stream(dev, 1) is not None:
+                    side.wait_stream(side_stream(dev, 1))
+                side.wait_event(torch.cuda.current_stream().record_event())
+                with torch.cuda.stream(side):
+                    fin.flush()
         dx = None
         if ctx.needs_input_grad[0]:
             if not rev:

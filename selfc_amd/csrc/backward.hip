@@ -92,6 +92,36 @@ __global__ __launch_bounds__(256) void grad_to_planes_kernel(const float* __rest
   *reinterpret_cast<f16x8*>(planes + (size_t)(ch0 >> 5) * npix * 32 + pix * 32 + (ch0 & 31)) = o;
 }
 
+// The same for the two dOut tensors of a G/H pair (blockIdx.y) under ONE scale: S from max(max|dOut_G|, max|dOut_H|), written to
+// *amax_common for every kernel that follows.  A power-of-two scale is exact, and with the common maximum at (128, 256] the smaller
+// tensor keeps f16's full mantissa while its own maximum is within 2^-22 of the larger one's - so the pair's input gradient can be ONE
+// accumulation over both nets' planes (and one launch).
+__global__ __launch_bounds__(256) void grad_to_planes2_kernel(const float* __restrict__ g0, const float* __restrict__ g1, f16* __restrict__ planes0,
+                                                              f16* __restrict__ planes1, size_t npix, int c, int cs, int nplanes, float sign0, float sign1,
+                                                              const float* __restrict__ amax0, const float* __restrict__ amax1, float* __restrict__ amax_common) {
+  const float m0 = *amax0, m1 = *amax1;
+  const float am = (m0 != m0) ? m0 : (m1 != m1) ? m1 : fmaxf(m0, m1);       // a NaN in either poisons the call (absmax_kernel's convention)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *amax_common = am;
+  const bool second = blockIdx.y != 0;
+  const float* __restrict__ g = second ? g1 : g0;
+  f16* __restrict__ planes = second ? planes1 : planes0;
+  const float sc = (second ? sign1 : sign0) * grad_scale(am);
+  const size_t total = npix * (size_t)nplanes * 4;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int chunk = (int)(i % ((size_t)nplanes * 4));
+  const size_t pix = i / ((size_t)nplanes * 4);
+  const int ch0 = chunk * 8;
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = ch0 + e;
+    const float v = (ch < c) ? g[pix * cs + ch] : 0.f;
+    o[e] = (f16)(v * sc);
+  }
+  *reinterpret_cast<f16x8*>(planes + (size_t)(ch0 >> 5) * npix * 32 + pix * 32 + (ch0 & 31)) = o;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // weight gradients
 // ---------------------------------------------------------------------------------------------------------
@@ -132,7 +162,7 @@ __device__ __forceinline__ f16x8 tr_frag(const unsigned char* lds, const int off
 // fetched into registers while the current one is multiplied (the launches are short: exposed load latency per tile
 // was most of their time).
 template <int TAPS>
-__global__ __launch_bounds__((TAPS == 1 ? 4 : 3) * 64) void wgrad_kernel(const WgArgs a) {
+__device__ __forceinline__ void wgrad_body(const WgArgs& a) {
   constexpr int NW = TAPS == 1 ? 4 : 3, NT = NW * 64;
   constexpr int TPW = TAPS == 9 ? 3 : 1;                    // taps per wave
   constexpr int HALO = TAPS == 9 ? 1 : 0;
@@ -282,17 +312,29 @@ __global__ __launch_bounds__((TAPS == 1 ? 4 : 3) * 64) void wgrad_kernel(const W
   }
 }
 
+template <int TAPS>
+__global__ __launch_bounds__((TAPS == 1 ? 4 : 3) * 64) void wgrad_kernel(const WgArgs a) {
+  wgrad_body<TAPS>(a);
+}
+
+// multi mode only (conv1..4 of a dense block, grid.z unused by the body): the jobs of two nets of one geometry in one launch
+__global__ __launch_bounds__(192) void wgrad_pair_kernel(const WgArgs a, const WgArgs b) {
+  if (blockIdx.z) wgrad_body<9>(b);
+  else wgrad_body<9>(a);
+}
+
 // Temporal weight gradient (conv5 of D2DTInput: dW[o][c][tap] = sum_px g[n][px][o] * in[n + tap - 1][px][c] inside each clip).
 // A workgroup owns (clip, 16x16 spatial tile) units and walks the clip's frames in order with a three-slot ring of
 // activation tiles in LDS, so every frame's tile is loaded once (the generic kernel loaded three per frame) while the next
 // frame's two tiles are prefetched into registers; wave w multiplies with the ring slot of frame t + w - 1.
-__global__ __launch_bounds__(192) void wgrad_temporal_kernel(const WgArgs a) {
+// bz / nz: this workgroup's gradient plane and the number of gradient planes of its net (blockIdx.z / gridDim.z of a one-net launch)
+__device__ __forceinline__ void wgrad_temporal_body(const WgArgs& a, const int bz, const int nz) {
   constexpr int NT = 192, PI = (1024 + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) unsigned char lp[256 * 64];
   __shared__ __attribute__((aligned(16))) unsigned char lq[3 * 256 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qi = blockIdx.y;
-  const f16* __restrict__ P = a.P + (size_t)blockIdx.z * a.plane;
+  const f16* __restrict__ P = a.P + (size_t)bz * a.plane;
   const f16* __restrict__ Q = qi < a.nq0 ? a.Q0 + (size_t)qi * a.plane : a.Q1 + (size_t)(qi - a.nq0) * a.plane;
   const int H = a.H, W = a.W, T = a.T;
   const bool want_bias = a.bpart != nullptr && qi == 0;
@@ -366,8 +408,8 @@ __global__ __launch_bounds__(192) void wgrad_temporal_kernel(const WgArgs a) {
       }
     }
   }
-  const int npairs = (int)(gridDim.y * gridDim.z);
-  const int pair = (int)(blockIdx.z * gridDim.y + blockIdx.y);
+  const int npairs = (int)gridDim.y * nz;
+  const int pair = bz * (int)gridDim.y + (int)blockIdx.y;
   float* __restrict__ base = a.part + ((((size_t)blockIdx.x * npairs + pair) * 3 + wave) << 10);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -375,10 +417,21 @@ __global__ __launch_bounds__(192) void wgrad_temporal_kernel(const WgArgs a) {
     base[o * 32 + (lane & 31)] = acc[r];
   }
   if (want_bias && wave == 0 && (lane & 31) == 0) {
-    float* __restrict__ bb = a.bpart + ((size_t)blockIdx.x * gridDim.z + blockIdx.z) * 32;
+    float* __restrict__ bb = a.bpart + ((size_t)blockIdx.x * nz + bz) * 32;
 #pragma unroll
     for (int r = 0; r < 16; ++r) bb[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = accb[r];
   }
+}
+
+__global__ __launch_bounds__(192) void wgrad_temporal_kernel(const WgArgs a) {
+  wgrad_temporal_body(a, (int)blockIdx.z, (int)gridDim.z);
+}
+
+// two nets of one geometry: blockIdx.z in [0, 2 Pn)
+__global__ __launch_bounds__(192) void wgrad_temporal_pair_kernel(const WgArgs a, const WgArgs b) {
+  const int nz = (int)gridDim.z >> 1;
+  if ((int)blockIdx.z >= nz) wgrad_temporal_body(b, (int)blockIdx.z - nz, nz);
+  else wgrad_temporal_body(a, (int)blockIdx.z, nz);
 }
 
 struct FinArgs {
@@ -465,6 +518,22 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const FinArgs a) {
 __global__ __launch_bounds__(256) void wgrad_finish2_kernel(const FinArgs a, const FinArgs b, const unsigned nblk_a) {
   if (blockIdx.x < nblk_a) wgrad_finish_body(a, (size_t)blockIdx.x * 256 + threadIdx.x);
   else wgrad_finish_body(b, (size_t)(blockIdx.x - nblk_a) * 256 + threadIdx.x);
+}
+
+// Up to FIN_TABLE finish jobs in one launch (the deferred finishes of a whole block stack's weight gradients: one launch per
+// 24 jobs instead of one per subnet - 54 launches of 11..26 us per training step, 0.74 TB/s).  Blocks [start[j], start[j+1]) do job j.
+constexpr int FIN_TABLE = 24;
+struct FinTable {
+  int n;
+  unsigned start[FIN_TABLE + 1];
+  FinArgs job[FIN_TABLE];
+};
+static_assert(sizeof(FinTable) <= 4096, "kernel argument limit");
+
+__global__ __launch_bounds__(256) void wgrad_finish_table_kernel(const FinTable t) {
+  int j = 0;
+  while (j + 1 < t.n && blockIdx.x >= t.start[j + 1]) ++j;               // workgroup-uniform
+  wgrad_finish_body(t.job[j], (size_t)(blockIdx.x - t.start[j]) * 256 + threadIdx.x);
 }
 
 inline unsigned fin_blocks(const FinArgs& f) {
@@ -732,28 +801,52 @@ int bwd_wgrad(const WgradJob& j, const float* amax, void* scratch, int N, int T,
 
 // conv1..conv4 of one dense block in one launch + one finish.  dpre: the four gradient planes [dpre4 dpre3 dpre2 dpre1];
 // inputs of conv k = the first (nqc1 + k - 1) planes of the run Q0 (nq0 planes) followed by Q1.
-int bwd_wgrad14(const void* dpre, const void* Q0, int nq0, const void* Q1, int nqc1, int cin, int nx,
-                float* const* wout, float* const* bout, float beta, const float* amax, void* scratch,
-                int N, int T, int H, int W, hipStream_t s, FinArgs* defer) {
+// arguments of the conv1..4 job (one launch) and of its finish
+static void wgrad14_args(const void* dpre, const void* Q0, int nq0, const void* Q1, int nqc1, int cin, int nx,
+                         float* const* wout, float* const* bout, float beta, const float* amax, void* scratch,
+                         int N, int T, int H, int W, WgArgs& a, FinArgs& f, int& nsplit, int& npairs) {
   const size_t npix = (size_t)N * H * W, plane = npix * 32;
-  const int npairs = 4 * nqc1 + 6;
-  const int nsplit = wgrad_nsplit(N, H, W, npairs, 9);
+  npairs = 4 * nqc1 + 6;
+  nsplit = wgrad_nsplit(N, H, W, npairs, 9);
   float* bpart = (float*)scratch;
   float* part = (float*)((unsigned char*)scratch + up256((size_t)nsplit * 4 * 32 * sizeof(float)));
-  WgArgs a{};
+  a = WgArgs{};
   a.P = (const f16*)dpre; a.Q0 = (const f16*)Q0; a.nq0 = nq0; a.Q1 = (const f16*)Q1;
   a.part = part; a.bpart = bout ? bpart : nullptr; a.plane = plane;
   a.N = N; a.T = T; a.H = H; a.W = W; a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16; a.ntiles = N * a.tiles_x * a.tiles_y;
   a.multi = 1; a.nqc1 = nqc1;
-  int rc = launch_wgrad_any<9>(a, nsplit, npairs, 1, s);
-  if (rc) return rc;
-  FinArgs f{};
+  f = FinArgs{};
   f.part = part; f.bpart = bpart; f.nW = nsplit; f.Pn = 4; f.ttot = 9; f.O = 32; f.cin = cin; f.nx = nx;
   f.multi = 1; f.nqc1 = nqc1; f.npairs = npairs; f.amax = amax; f.beta = beta;
   for (int k = 0; k < 4; ++k) { f.out[k] = wout ? wout[k] : nullptr; f.bout[k] = bout ? bout[k] : nullptr; }
+}
+
+int bwd_wgrad14(const void* dpre, const void* Q0, int nq0, const void* Q1, int nqc1, int cin, int nx,
+                float* const* wout, float* const* bout, float beta, const float* amax, void* scratch,
+                int N, int T, int H, int W, hipStream_t s, FinArgs* defer) {
+  WgArgs a; FinArgs f; int nsplit, npairs;
+  wgrad14_args(dpre, Q0, nq0, Q1, nqc1, cin, nx, wout, bout, beta, amax, scratch, N, T, H, W, a, f, nsplit, npairs);
+  int rc = launch_wgrad_any<9>(a, nsplit, npairs, 1, s);
+  if (rc) return rc;
   if (defer) { *defer = f; return SELFC_OK; }
   hipLaunchKernelGGL(wgrad_finish_kernel, dim3(fin_blocks(f)), dim3(256), 0, s, f);
   return hip_rc(hipGetLastError());
+}
+
+// launch up to FIN_TABLE deferred finish jobs per kernel
+static int launch_fin_jobs(const FinArgs* jobs, int njobs, hipStream_t s) {
+  for (int j0 = 0; j0 < njobs; j0 += FIN_TABLE) {
+    FinTable t{};
+    t.n = njobs - j0 < FIN_TABLE ? njobs - j0 : FIN_TABLE;
+    unsigned nb = 0;
+    for (int j = 0; j < t.n; ++j) { t.job[j] = jobs[j0 + j]; t.start[j] = nb; nb += fin_blocks(jobs[j0 + j]); }
+    t.start[t.n] = nb;
+    if (!nb) continue;
+    hipLaunchKernelGGL(wgrad_finish_table_kernel, dim3(nb), dim3(256), 0, s, t);
+    const int rc = hip_rc(hipGetLastError());
+    if (rc) return rc;
+  }
+  return SELFC_OK;
 }
 
 }  // namespace selfc
@@ -783,6 +876,21 @@ int selfc_subnet_bwd_phase_x(int phases, const selfc_subnet_bw* bw, int kind, co
                              float sign, float* dx, int accumulate_dx, float* const* wgrad, float* const* bgrad, float beta,
                              void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout,
                              const float* dout_amax, float* dx_amax_out, void* stream) {
+  return selfc_subnet_bwd_phase_d(phases, bw, kind, dense, xin, dout, sign, dx, accumulate_dx, wgrad, bgrad, beta, scratch, scratch_bytes,
+                                  N, T, H, W, cin, cout, dout_amax, dx_amax_out, nullptr, stream);
+}
+
+size_t selfc_fin_job_bytes(void) { return sizeof(FinArgs); }
+
+int selfc_wgrad_finish_jobs(const void* jobs, int njobs, void* stream) {
+  if (!jobs || njobs < 0) return SELFC_EINVAL;
+  return launch_fin_jobs((const FinArgs*)jobs, njobs, (hipStream_t)stream);
+}
+
+int selfc_subnet_bwd_phase_d(int phases, const selfc_subnet_bw* bw, int kind, const void* dense, const float* xin, const float* dout,
+                             float sign, float* dx, int accumulate_dx, float* const* wgrad, float* const* bgrad, float beta,
+                             void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout,
+                             const float* dout_amax, float* dx_amax_out, void* fin_jobs, void* stream) {
   if (!(phases & (SELFC_BWD_DATA | SELFC_BWD_WEIGHTS))) return SELFC_EINVAL;
   if (!bw || !dense || !dout || !scratch || !bw->wt5 || !bw->wtx || !bw->wtd[0] || !bw->wtd[1] || !bw->wtd[2]) return SELFC_EINVAL;
   if (N <= 0 || T <= 0 || N % T || H <= 0 || W <= 0 || cin < 1 || cin > 96 || cout < 1 || cout > 96) return SELFC_EINVAL;
@@ -880,6 +988,12 @@ weights:
     j.O = cout; j.Ctot = cin + 128; j.cin = cin; j.nx = L.nx; j.beta = beta;
     const bool has5 = j.wout || j.bout;
     if ((rc = bwd_wgrad_impl(j, amax, sb + L.off_wg5, N, T, H, W, s, &fb))) return rc;
+    if (fin_jobs) {          // deferred: the caller finishes many subnets' jobs in one launch (selfc_wgrad_finish_jobs); a job without
+      FinArgs* out = (FinArgs*)fin_jobs;       // outputs has zero blocks there
+      out[0] = fa;
+      out[1] = has5 ? fb : FinArgs{};
+      return SELFC_OK;
+    }
     if (has5) {
       const unsigned na = fin_blocks(fa);
       hipLaunchKernelGGL(wgrad_finish2_kernel, dim3(na + fin_blocks(fb)), dim3(256), 0, s, fa, fb, na);
@@ -889,6 +1003,160 @@ weights:
     if ((rc = hip_rc(hipGetLastError()))) return rc;
   }
   return SELFC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// G and H of one InvBlockExp as ONE backward call (abi 13): the two subnets read the same input (y1 / x1), have the same
+// shapes, and their input gradients add up - every step of selfc_subnet_bwd_phase_x runs once for both (grid dimension = net),
+// under one gradient scale (grad_to_planes2_kernel), and the input gradient is a single conv over the eight dpre planes.
+// Against two calls on two streams: half the launches, no fork / join (a cross-queue dependency costs ~10 us inside a replayed
+// graph on this runtime), no d1 += d1h pass, and launches that fill the chip on a training crop.  D2DTInput subnets only.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct PairLayout {
+  int nx, ng;
+  size_t plane_b;
+  size_t off_gb, off_g, off_t5, off_xplane, off_amax, off_wg[2], off_wg5[2], total;
+};
+PairLayout pair_layout(int N, int H, int W, int cin, int cout) {
+  PairLayout L{};
+  L.nx = (cin + 31) / 32;
+  L.ng = (cout + 31) / 32;
+  L.plane_b = (size_t)N * H * W * 64;
+  L.off_gb = 0;                                             // 8 planes: G's dpre4..1, H's dpre4..1
+  L.off_g = 8 * L.plane_b;                                  // dOut planes: G's ng, H's ng
+  L.off_t5 = L.off_g + 2 * (size_t)L.ng * L.plane_b;        // conv5^T(dOut): (nx + 3) planes per net
+  L.off_xplane = L.off_t5 + 2 * (size_t)(L.nx + 3) * L.plane_b;
+  L.off_amax = L.off_xplane + L.plane_b;
+  size_t o = up256(L.off_amax + 256);
+  const size_t a4 = bwd_wgrad14_scratch_bytes(N, H, W, L.nx);
+  const size_t a5 = bwd_wgrad_scratch_bytes(N, H, W, L.ng, L.nx + 4, 3);
+  for (int q = 0; q < 2; ++q) {
+    L.off_wg[q] = o; o = up256(o + a4);
+    L.off_wg5[q] = o; o = up256(o + a5);
+  }
+  L.total = o;
+  return L;
+}
+}  // namespace
+
+size_t selfc_gh_bwd_pair_scratch_bytes(int N, int H, int W, int cin, int cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || cin < 1 || cin > 3 || cout < 1 || cout > 96) return 0;
+  return pair_layout(N, H, W, cin, cout).total;
+}
+
+int selfc_gh_bwd_pair(int phases, const selfc_subnet_bw* bw_g, const selfc_subnet_bw* bw_h, const void* dense_g, const void* dense_h,
+                      const float* xin, const float* dout_g, const float* dout_h, float sign_g, float sign_h,
+                      float* dx, int accumulate_dx, float* const* wgrad_g, float* const* bgrad_g, float* const* wgrad_h, float* const* bgrad_h,
+                      float beta, void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout,
+                      const float* amax_g, const float* amax_h, float* dx_amax_out, void* fin_jobs, void* stream) {
+  if (!(phases & (SELFC_BWD_DATA | SELFC_BWD_WEIGHTS))) return SELFC_EINVAL;
+  if (!bw_g || !bw_h || !dense_g || !dense_h || !xin || !dout_g || !dout_h || !scratch) return SELFC_EINVAL;
+  for (const selfc_subnet_bw* bw : {bw_g, bw_h})
+    if (!bw->wt5 || !bw->wtx || !bw->wtd[0] || !bw->wtd[1] || !bw->wtd[2]) return SELFC_EINVAL;
+  if (N <= 0 || T <= 0 || N % T || H <= 0 || W <= 0 || cin < 1 || cin > 3 || cout < 1 || cout > 96) return SELFC_EINVAL;
+  const PairLayout L = pair_layout(N, H, W, cin, cout);
+  if (scratch_bytes < L.total) return SELFC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(PROF_BWD, s);
+  unsigned char* sb = (unsigned char*)scratch;
+  const size_t npix = (size_t)N * H * W, plane = npix * 32;
+  f16* gb[2] = {(f16*)(sb + L.off_gb), (f16*)(sb + L.off_gb) + 4 * plane};
+  f16* gpl[2] = {(f16*)(sb + L.off_g), (f16*)(sb + L.off_g) + (size_t)L.ng * plane};
+  f16* t5[2] = {(f16*)(sb + L.off_t5), (f16*)(sb + L.off_t5) + (size_t)(L.nx + 3) * plane};
+  f16* xpl = (f16*)(sb + L.off_xplane);
+  float* amax = (float*)(sb + L.off_amax);                 // [0] the pair's common maximum, [1], [2] the nets' own when the caller has none
+  const f16* feat[2] = {(const f16*)dense_g, (const f16*)dense_h};       // cin <= 3: the dense buffers start at f1
+  const selfc_subnet_bw* bw[2] = {bw_g, bw_h};
+  const int coutp = (cout + 3) & ~3, cinp = (cin + 3) & ~3;
+  int rc;
+  if (phases & SELFC_BWD_DATA) {
+    // 1. both dOut tensors as scaled f16 planes under one scale
+    if (!amax_g) { if ((rc = bwd_absmax(dout_g, npix * coutp, amax + 1, s))) return rc; amax_g = amax + 1; }
+    if (!amax_h) { if ((rc = bwd_absmax(dout_h, npix * coutp, amax + 2, s))) return rc; amax_h = amax + 2; }
+    {
+      const size_t items = npix * (size_t)L.ng * 4;
+      hipLaunchKernelGGL(grad_to_planes2_kernel, dim3((unsigned)((items + 255) / 256), 2), dim3(256), 0, s, dout_g, dout_h, gpl[0], gpl[1], npix,
+                         cout, coutp, L.ng, sign_g, sign_h, amax_g, amax_h, amax);
+      if ((rc = hip_rc(hipGetLastError()))) return rc;
+    }
+    if ((rc = selfc_nhwc_to_planes(xin, xpl, npix, cin, stream))) return rc;
+    // 2. conv5^T(dOut) of both nets: x-groups and f1..f3 as addend planes, f4 masked straight into dpre4
+    if ((rc = bwd_tconv5T_pair(gpl[0], gpl[1], L.ng, bw_g->wt5, bw_h->wt5, L.nx + 4, t5[0], t5[1], feat[0] + 3 * plane, feat[1] + 3 * plane,
+                               L.nx + 3, gb[0], gb[1], N, T, H, W, s))) return rc;
+    // 3. dpre3, dpre2, dpre1 of both nets: the chain kernel while its workgroups fit the chip in one round, else layer by layer
+    static const int chain_env = getenv("SELFC_BWD_CHAIN") ? atoi(getenv("SELFC_BWD_CHAIN")) : -1;
+    const long chain_wgs = 2L * N * ((H + 11) / 12) * ((W + 15) / 16);
+    if (chain_env == 1 || (chain_env < 0 && chain_wgs <= 256)) {
+      const void* wtd0[3] = {bw_g->wtd[0], bw_g->wtd[1], bw_g->wtd[2]};
+      const void* wtd1[3] = {bw_h->wtd[0], bw_h->wtd[1], bw_h->wtd[2]};
+      if ((rc = bwd_dgrad_chain_pair(gb[0], gb[1], t5[0], t5[1], feat[0], feat[1], wtd0, wtd1, L.nx, amax, N, H, W, s))) return rc;
+    } else {
+      for (int j = 3; j >= 1; --j) {
+        BwdConv c[2];
+        for (int q = 0; q < 2; ++q) {
+          c[q] = BwdConv{};
+          c[q].in = gb[q]; c[q].nplanes_in = 4 - j; c[q].kt = 1; c[q].sp1 = 0; c[q].w = bw[q]->wtd[3 - j];
+          c[q].ngroups = 1; c[q].out_planes = gb[q] + (size_t)(4 - j) * plane;
+          c[q].add = t5[q] + (size_t)(L.nx + j - 1) * plane;
+          c[q].mask = feat[q] + (size_t)(j - 1) * plane; c[q].mask_z = 0;
+          c[q].amax = amax;
+        }
+        if ((rc = bwd_conv_planes_pair(c[0], c[1], N, T, H, W, s))) return rc;
+      }
+    }
+    // 4. dx: one conv over the eight dpre planes of both nets (+ both conv5^T x-parts)
+    if (dx) {
+      BwdConv c{};
+      c.in = gb[0]; c.nplanes_in = 4; c.kt = 1; c.sp1 = 0; c.w = bw_g->wtx;
+      c.in2 = gb[1]; c.nplanes_in2 = 4; c.w2 = bw_h->wtx; c.add2 = t5[1];
+      c.ngroups = L.nx; c.add = t5[0]; c.mask_z = -1;
+      c.plain = dx; c.coutp = cinp; c.accumulate = accumulate_dx; c.amax = amax; c.amax_out = dx_amax_out;
+      if ((rc = bwd_conv_planes(c, N, T, H, W, s))) return rc;
+    }
+  }
+  if (!(phases & SELFC_BWD_WEIGHTS) || (!wgrad_g && !bgrad_g && !wgrad_h && !bgrad_h)) return SELFC_OK;
+  // 5. weight / bias gradients: conv1..4 of both nets in one launch, the temporal conv5 of both in another
+  {
+    float* const* wg[2] = {wgrad_g, wgrad_h};
+    float* const* bg[2] = {bgrad_g, bgrad_h};
+    WgArgs a14[2], a5[2];
+    FinArgs f14[2], f5[2];
+    int nsplit14 = 0, npairs14 = 0, nsplit5 = 0;
+    const int qtot = 1 + 4;                                  // x plane (the scratch copy) + f1..f4
+    for (int q = 0; q < 2; ++q) {
+      wgrad14_args(gb[q], xpl, 1, feat[q], L.nx, cin, L.nx, wg[q], bg[q], beta, amax, sb + L.off_wg[q], N, T, H, W, a14[q], f14[q], nsplit14, npairs14);
+      // conv5 (temporal taps): P = the dOut planes, Q = [x | f1..f4]
+      nsplit5 = wgrad_nsplit(N, H, W, L.ng * qtot, 3);
+      const int nunits = (N / T) * ((W + 15) / 16) * ((H + 15) / 16);
+      if (nsplit5 > nunits) nsplit5 = nunits;
+      float* bpart = (float*)(sb + L.off_wg5[q]);
+      float* part = (float*)(sb + L.off_wg5[q] + up256((size_t)nsplit5 * (L.ng < 4 ? 4 : L.ng) * 32 * sizeof(float)));
+      float* wout = wg[q] ? wg[q][4] : nullptr;
+      float* bout = bg[q] ? bg[q][4] : nullptr;
+      WgArgs& a = a5[q];
+      a = WgArgs{};
+      a.P = gpl[q]; a.Q0 = xpl; a.nq0 = 1; a.Q1 = feat[q];
+      a.part = part; a.bpart = bout ? bpart : nullptr; a.plane = plane;
+      a.N = N; a.T = T; a.H = H; a.W = W; a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16; a.ntiles = N * a.tiles_x * a.tiles_y;
+      FinArgs& f = f5[q];
+      f = FinArgs{};
+      if (wout || bout) {
+        f.part = part; f.bpart = bpart; f.out[0] = wout; f.bout[0] = bout; f.nW = nsplit5; f.Pn = L.ng; f.qtot = qtot; f.ttot = 3;
+        f.O = cout; f.Ctot = cin + 128; f.cin = cin; f.nx = L.nx; f.npairs = L.ng * qtot; f.amax = amax; f.beta = beta;
+      }
+    }
+    hipLaunchKernelGGL(wgrad_pair_kernel, dim3((unsigned)nsplit14, (unsigned)npairs14, 2), dim3(192), 0, s, a14[0], a14[1]);
+    if ((rc = hip_rc(hipGetLastError()))) return rc;
+    hipLaunchKernelGGL(wgrad_temporal_pair_kernel, dim3((unsigned)nsplit5, (unsigned)qtot, (unsigned)(2 * L.ng)), dim3(192), 0, s, a5[0], a5[1]);
+    if ((rc = hip_rc(hipGetLastError()))) return rc;
+    const FinArgs jobs[4] = {f14[0], f5[0], f14[1], f5[1]};
+    if (fin_jobs) {
+      for (int j = 0; j < 4; ++j) ((FinArgs*)fin_jobs)[j] = jobs[j];
+      return SELFC_OK;
+    }
+    return launch_fin_jobs(jobs, 4, s);
+  }
 }
 
 int selfc_coupling_fwd(int rev, const float* x2, const float* g, const float* h, float* y2, float* s, float clamp, size_t n, void* stream) {

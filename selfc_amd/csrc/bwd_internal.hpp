@@ -27,8 +27,17 @@ struct BwdConv {
   const float* amax;      // device: max|dOut| of this subnet call (defines S)
   float* amax_out;        // optional (plain output): atomic max |value| over everything this call stores - the max|dOut| of the
                           // subnet call that consumes `plain` next, taken where the values are produced (no separate pass)
+  // optional second source (kt == 1, 3x3 taps): nplanes_in2 more input planes `in2` with the fragments `w2` (one output group's
+  // worth per group, as `w`) and a second addend `add2` - the input gradient of a G/H pair as ONE conv over both nets' planes
+  const void* in2;
+  int nplanes_in2;
+  const void* w2;
+  const void* add2;
 };
 int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s);
+int bwd_conv_planes_pair(const BwdConv& c0, const BwdConv& c1, int N, int T, int H, int W, hipStream_t s);
+int bwd_tconv5T_pair(const void* g0, const void* g1, int ng, const void* w0, const void* w1, int nplanes_out, void* out0, void* out1,
+                     const void* mask0, const void* mask1, int mask_z, void* alt0, void* alt1, int N, int T, int H, int W, hipStream_t s);
 // conv5^T of a temporal dense block on the temporal-conv kernel (weights: packing.pack_t5_bwd)
 int bwd_tconv5T(const void* g, int ng, const void* w, int nplanes_out, void* out_planes, const void* mask, int mask_z, void* alt,
                 int N, int T, int H, int W, hipStream_t s);
@@ -36,6 +45,9 @@ int bwd_tconv5T(const void* g, int ng, const void* w, int nplanes_out, void* out
 // csrc/dgrad_chain.hip: dpre3, dpre2, dpre1 (planes 1..3 of gb, plane 0 = dpre4) and, with dx, the input gradient as ONE launch
 int bwd_dgrad_chain(void* gb, const void* add, const void* feat, const void* const* wtd, const void* wtx, float* dx, int nx, int cinp,
                     int accumulate_dx, const float* amax, float* amax_out, int N, int H, int W, hipStream_t s);
+
+int bwd_dgrad_chain_pair(void* gb0, void* gb1, const void* add0, const void* add1, const void* feat0, const void* feat1,
+                         const void* const* wtd0, const void* const* wtd1, int nx, const float* amax, int N, int H, int W, hipStream_t s);
 
 // csrc/backward.hip building blocks (also used by the STP gradients in csrc/stp.hip)
 int bwd_absmax(const float* g, size_t n, float* amax, hipStream_t s);    // *amax = max|g| (zeroed first)

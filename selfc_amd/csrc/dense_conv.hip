@@ -61,7 +61,8 @@ enum { EPI_LRELU = 0, EPI_PLAIN = 1, EPI_F = 2, EPI_GH = 3, EPI_BWD = 4, EPI_T5B
 struct C3Stage {
   int coff;   // first channel of the stage in the dense buffer
   int width;  // 16 or 32 channels
-  int kind;   // 0: 9-tap stage of the dense buffer; 1: im2col stage built from x1 (K = 9*c1 <= 32)
+  int kind;   // 0: 9-tap stage of the dense buffer; 1: im2col stage built from x1 (K = 9*c1 <= 32); 2: generic mode, a plane of the
+              // SECOND source (C3Args::gen_split)
   int dt;     // generic mode: frame offset of a temporal tap (-1, 0, +1), 0 otherwise
 };
 
@@ -91,12 +92,18 @@ struct C3Args {
   int gen_planes, gen_tt, T;
   size_t wz_stride;
   int gen_sp1;           // generic mode: centre spatial tap only ((kt,1,1) kernels: 2 fragments per stage)
+  // generic mode, two sources (the input gradient of a G/H PAIR in one launch, csrc/backward.hip): stages [0, gen_split) read planes
+  // 0.. of dense[0] with the fragments of w[0], stages [gen_split, nstages) planes 0.. of dense[1] with w[1] (+ z*wz_stride2);
+  // gen_split == 0: one source.  No temporal taps in this mode.
+  int gen_split;
+  size_t wz_stride2;
   // EPI_BWD (generic mode, csrc/backward.hip): v = acc + add[z] (f16 plane, optional); group z == bw_mask_z is
   // multiplied by LeakyReLU'(bw_mask) (1 where the saved feature is > 0, else 0.2; bw_mask_z -2: every group against its own
   // mask plane, -3: the same with ReLU' = 0 where the feature is 0).  Output: f16 plane
   // out[0] + (out_coff/32 + z) planes (group bw_mask_z goes to bw_alt when that is set), or, with `plain`,
   // fp32 NHWC rows of stride coutp scaled by 1/grad_scale(*bw_amax), added to the old value when bw_acc.
   const f16* bw_add;
+  const f16* bw_add2;      // second addend planes (the pair's other net), or null
   const f16* bw_mask;
   f16* bw_alt;
   const float* bw_amax;
@@ -123,6 +130,7 @@ struct C3Args {
 template <bool GEN>
 __device__ __forceinline__ C3Stage stage_of(const C3Args& a, const int s) {
   if (GEN) {
+    if (a.gen_split && s >= a.gen_split) return C3Stage{32 * (s - a.gen_split), 32, 2, 0};
     const int ti = s / a.gen_planes;
     return C3Stage{32 * (s - ti * a.gen_planes), 32, 0, a.gen_tt == 3 ? ti - 1 : 0};
   }
@@ -134,7 +142,7 @@ __device__ __forceinline__ C3Stage stage_of(const C3Args& a, const int s) {
 // GEN: generic plane-list mode (temporal taps, output groups) as a template parameter so that the hot
 // non-generic instantiations keep their register budget (as a runtime flag it cost 21 VGPRs = one wave/SIMD).
 template <int TH, int TW, int NW, int MT, int EPI, bool GEN>
-__global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
+__device__ __forceinline__ void conv3x3_body(const C3Args& a) {
   static_assert(TH * TW == NW * MT * 32, "tile must be covered by the waves' M-tiles");
   static_assert(TW % 16 == 0 && TH % 2 == 0, "M-tiles are 2 rows x 16 cols");
   constexpr int HWD = TW + 2, NPIX = (TH + 2) * HWD;
@@ -226,16 +234,19 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
     auto load_stage = [&](const C3Stage st, const int fb) __attribute__((always_inline)) {
       if (ABL(a, 2)) return;
       const bool tv = (tclip + st.dt >= 0) & (tclip + st.dt < (gen ? a.T : 1 << 30));
-      const f16* __restrict__ src = dense + (size_t)(st.coff >> 5) * a.plane + (tv ? st.dt * frame_stride : 0);
+      const bool second = GEN && st.kind == 2;             // workgroup-uniform: the pair's other net (gen_split)
+      const f16* __restrict__ src = (second ? a.dense[1] : dense) + (size_t)(st.coff >> 5) * a.plane + (tv ? st.dt * frame_stride : 0);
       if (!ABL(a, 64))
 #pragma unroll
       for (int it = 0; it < AITER; ++it) areg[it] = *reinterpret_cast<const u32x4*>(src + gofs[it]);
       const int nfr = (GEN && a.gen_sp1) ? 2 : 9 * (st.width >> 4);
+      const u32x4* __restrict__ ws = second ? reinterpret_cast<const u32x4*>(a.w[1] + (size_t)blockIdx.z * a.wz_stride2) : wsrc;
+      const int fbb = second ? fb - 18 * a.gen_split : fb;
       if (!ABL(a, 32))
 #pragma unroll
       for (int it = 0; it < WITER; ++it) {
         const int i = min(tid + it * NT, nfr * 64 - 1);  // unconditional (clamped): keeps wreg in registers
-        wreg[it] = wsrc[(size_t)fb * 64 + i];
+        wreg[it] = ws[(size_t)fbb * 64 + i];
       }
     };
     auto store_stage = [&](const C3Stage st) __attribute__((always_inline)) {
@@ -447,6 +458,15 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
           for (int j = 0; j < 4; ++j) v[g][j] += (float)t[j];
         }
       }
+      if (a.bw_add2) {
+        const f16* __restrict__ ad = a.bw_add2 + (size_t)zg * a.plane + pix * 32 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f16x4 t = *reinterpret_cast<const f16x4*>(ad + 8 * g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[g][j] += (float)t[j];
+        }
+      }
       if (masked) {
         const f16* __restrict__ mk = a.bw_mask + (a.bw_mask_z <= -2 ? (size_t)zg * a.plane : 0) + pix * 32 + 4 * half;
 #pragma unroll
@@ -549,6 +569,20 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
   }
 }
 
+template <int TH, int TW, int NW, int MT, int EPI, bool GEN>
+__global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
+  conv3x3_body<TH, TW, NW, MT, EPI, GEN>(a);
+}
+
+// Two independent convs of the same geometry in ONE launch (blockIdx.y picks the argument set): the data-gradient layers of a G/H
+// pair (csrc/backward.hip).  On a training crop one net's launch is half a round of workgroups, and the two nets' launches used to
+// run side by side on two streams - with a cross-queue dependency (~10 us each on this runtime) at the fork and at the join.
+template <int TH, int TW, int NW, int MT, int EPI, bool GEN>
+__global__ __launch_bounds__(NW * 64) void conv3x3_pair_kernel(const C3Args a, const C3Args b) {
+  if (blockIdx.y) conv3x3_body<TH, TW, NW, MT, EPI, GEN>(b);
+  else conv3x3_body<TH, TW, NW, MT, EPI, GEN>(a);
+}
+
 // ---------------------------------------------------------------------------------
 // tconv5: out[t] = W0 d[t-1] + W1 d[t] + W2 d[t+1] (+bias), zero outside the clip.
 // Workgroup = 8 waves x 16 pixels of one clip; all weight fragments live in LDS for
@@ -579,6 +613,13 @@ struct T5Args {
   f16* altp;
   int mask_z;
   size_t wz_stride;
+  // EPI_T5B, two nets in one launch (the G/H pair of csrc/backward.hip): blockIdx.y in [pair_planes, 2 pair_planes) is output plane
+  // y - pair_planes of the SECOND net: input dense[1], weights w2, outputs outp2 / altp2, mask maskp2.  0: one net.
+  int pair_planes;
+  const f16* w2;
+  f16* outp2;
+  const f16* maskp2;
+  f16* altp2;
 };
 
 // Waves per workgroup.  Measured and dropped: 16 waves for the HBM-bound F conv5 (same bytes in flight on half the CUs,
@@ -596,7 +637,9 @@ __global__ __launch_bounds__(t5_waves<EPI>() * 64) void tconv5_kernel(const T5Ar
   {
     // every load of a thread's share is issued before the first LDS store: as a rolled loop (load, wait, store, branch) the
     // up-to-twelve 16-byte pieces per thread were twelve serial L2 round trips at the head of EVERY workgroup of every launch
-    const uint4* __restrict__ wsrc = reinterpret_cast<const uint4*>(a.w + (EPI == EPI_T5B ? (size_t)blockIdx.y * a.wz_stride : 0));
+    const bool net2w = EPI == EPI_T5B && a.pair_planes && (int)blockIdx.y >= a.pair_planes;
+    const uint4* __restrict__ wsrc = reinterpret_cast<const uint4*>((net2w ? a.w2 : a.w) +
+                                                                     (EPI == EPI_T5B ? (size_t)(blockIdx.y - (net2w ? a.pair_planes : 0)) * a.wz_stride : 0));
     constexpr int WIT = (NFRAG * 64 + NTH - 1) / NTH;
     uint4 wv[WIT];
 #pragma unroll
@@ -618,6 +661,7 @@ __global__ __launch_bounds__(t5_waves<EPI>() * 64) void tconv5_kernel(const T5Ar
   const int pc = pvalid ? pl : a.HW - 1;   // clamp loads of masked lanes to a valid pixel
   const int kq = lane >> 4;                // this lane's 8-channel group of a 32-wide k-step
   if (p0 >= a.HW) return;                  // whole wave outside (no barriers below)
+  const bool net2 = EPI == EPI_T5B && a.pair_planes && (int)blockIdx.y >= a.pair_planes;     // workgroup-uniform
 
   f32x4 accp[NETS][OT], accc[NETS][OT], accn[NETS][OT];
 #pragma unroll
@@ -638,7 +682,7 @@ __global__ __launch_bounds__(t5_waves<EPI>() * 64) void tconv5_kernel(const T5Ar
     for (int q = 0; q < NETS; ++q)
 #pragma unroll
       for (int ks = 0; ks < KD; ++ks)
-        dst[q][ks] = *reinterpret_cast<const u32x4*>((q ? a.dense[1] : a.dense[0]) + (size_t)ks * a.plane + pix * 32 + kq * 8);
+        dst[q][ks] = *reinterpret_cast<const u32x4*>(((q || net2) ? a.dense[1] : a.dense[0]) + (size_t)ks * a.plane + pix * 32 + kq * 8);
     if (HASX) xd = *reinterpret_cast<const float4*>(a.x1 + pix * 4);
   };
 
@@ -667,14 +711,16 @@ __global__ __launch_bounds__(t5_waves<EPI>() * 64) void tconv5_kernel(const T5Ar
     if (!pvalid) return;
     const size_t pix = (size_t)(b * a.T + t) * a.HW + pl;
     if (EPI == EPI_T5B) {
-      const int zg = blockIdx.y;
-      const bool masked = a.maskp != nullptr && zg == a.mask_z;
-      f16* __restrict__ dst = (masked && a.altp ? a.altp : a.outp + (size_t)zg * a.plane) + pix * 32 + kq * 4;
+      const int zg = (int)blockIdx.y - (net2 ? a.pair_planes : 0);
+      const f16* __restrict__ mkp = net2 ? a.maskp2 : a.maskp;
+      f16* const altp = net2 ? a.altp2 : a.altp;
+      const bool masked = mkp != nullptr && zg == a.mask_z;
+      f16* __restrict__ dst = (masked && altp ? altp : (net2 ? a.outp2 : a.outp) + (size_t)zg * a.plane) + pix * 32 + kq * 4;
 #pragma unroll
       for (int o = 0; o < OT; ++o) {
         float v[4] = {acc[0][o][0], acc[0][o][1], acc[0][o][2], acc[0][o][3]};
         if (masked) {
-          const f16x4 m = *reinterpret_cast<const f16x4*>(a.maskp + pix * 32 + o * 16 + kq * 4);
+          const f16x4 m = *reinterpret_cast<const f16x4*>(mkp + pix * 32 + o * 16 + kq * 4);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] *= ((float)m[j] > 0.f) ? 1.f : 0.2f;
         }
@@ -844,6 +890,24 @@ int launch_conv3x3_cfg(C3Args& a, int nets_z, hipStream_t s) {
   return hip_rc(hipGetLastError());
 }
 
+template <int TH, int TW, int NW, int MT, int EPI, bool GEN>
+int launch_conv3x3_pair_cfg(C3Args& a, C3Args& b, int nets_z, hipStream_t s) {
+  a.tiles_x = b.tiles_x = (a.W + TW - 1) / TW;
+  a.tiles_y = b.tiles_y = (a.H + TH - 1) / TH;
+  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), 2, (unsigned)nets_z);
+  ProfScope prof(-1, s);
+  hipLaunchKernelGGL((conv3x3_pair_kernel<TH, TW, NW, MT, EPI, GEN>), grid, dim3(NW * 64), (c3_lds<TH, TW>()), s, a, b);
+  return hip_rc(hipGetLastError());
+}
+
+// two convs of one geometry (same N, H, W, stage count) in one launch
+template <int EPI, bool GEN>
+int launch_conv3x3_pair(C3Args& a, C3Args& b, int nets_z, hipStream_t s) {
+  const int rows16 = (a.H + 15) / 16 * 16, rows12 = (a.H + 11) / 12 * 12;
+  if (rows12 < rows16) return launch_conv3x3_pair_cfg<12, 16, 3, 2, EPI, GEN>(a, b, nets_z, s);
+  return launch_conv3x3_pair_cfg<16, 16, 4, 2, EPI, GEN>(a, b, nets_z, s);
+}
+
 template <int EPI, bool GEN = false>
 int launch_conv3x3(C3Args& a, int nets_z, hipStream_t s) {
 #ifdef SELFC_DEV
@@ -882,7 +946,7 @@ int launch_t5(const T5Args& a, hipStream_t s) {
   constexpr int pxwg = t5_waves<EPI>() * 16;
   const int tiles = (a.HW + pxwg - 1) / pxwg;
   ProfScope prof(EPI == EPI_F ? PROF_CONV5_F : EPI == EPI_GH ? PROF_CONV5_GH : EPI == EPI_T5B ? -1 : PROF_CONV5_PLAIN, s);
-  hipLaunchKernelGGL((tconv5_kernel<NETS, OT, KD, HASX, EPI>), dim3((unsigned)(tiles * a.B), EPI == EPI_T5B ? (unsigned)a.coutp : 1u), dim3(t5_waves<EPI>() * 64), lds, s, a);
+  hipLaunchKernelGGL((tconv5_kernel<NETS, OT, KD, HASX, EPI>), dim3((unsigned)(tiles * a.B), EPI == EPI_T5B ? (unsigned)(a.pair_planes ? 2 * a.pair_planes : a.coutp) : 1u), dim3(t5_waves<EPI>() * 64), lds, s, a);
   return hip_rc(hipGetLastError());
 }
 
@@ -1033,10 +1097,26 @@ int bwd_tconv5T(const void* g, int ng, const void* w, int nplanes_out, void* out
   return SELFC_EINVAL;
 }
 
+// the same for two nets of one geometry in ONE launch (grid.y = 2 x nplanes_out)
+int bwd_tconv5T_pair(const void* g0, const void* g1, int ng, const void* w0, const void* w1, int nplanes_out, void* out0, void* out1,
+                     const void* mask0, const void* mask1, int mask_z, void* alt0, void* alt1, int N, int T, int H, int W, hipStream_t s) {
+  T5Args a{};
+  a.dense[0] = (const f16*)g0; a.dense[1] = (const f16*)g1; a.w = (const f16*)w0; a.w2 = (const f16*)w1;
+  a.B = N / T; a.T = T; a.HW = H * W; a.plane = (size_t)N * H * W * 32;
+  a.outp = (f16*)out0; a.outp2 = (f16*)out1; a.maskp = (const f16*)mask0; a.maskp2 = (const f16*)mask1;
+  a.altp = (f16*)alt0; a.altp2 = (f16*)alt1; a.mask_z = mask_z;
+  a.coutp = nplanes_out; a.pair_planes = nplanes_out;
+  a.wz_stride = (size_t)3 * ng * 2 * 512;
+  if (ng == 1) return launch_t5<1, 2, 1, 0, EPI_T5B>(a, s);
+  if (ng == 2) return launch_t5<1, 2, 2, 0, EPI_T5B>(a, s);
+  if (ng == 3) return launch_t5<1, 2, 3, 0, EPI_T5B>(a, s);
+  return SELFC_EINVAL;
+}
+
 // Generic plane-list conv with the EPI_BWD epilogue (see C3Args); used by csrc/backward.hip for the data
 // gradients of a dense block.  `in` = first of nplanes_in contiguous f16 planes; kt temporal taps (1 | 3);
 // sp1: (kt,1,1) kernel instead of (kt,3,3); ngroups 32-channel output groups.
-int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s) {
+static C3Args bwd_conv_args(const BwdConv& c, int N, int T, int H, int W) {
   C3Args a{};
   a.dense[0] = (const f16*)c.in; a.out[0] = (f16*)c.out_planes;
   a.w[0] = (const f16*)c.w;
@@ -1044,11 +1124,30 @@ int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s)
   a.gen_planes = c.nplanes_in; a.gen_tt = c.kt; a.T = T; a.gen_sp1 = c.sp1;
   a.nstages = c.nplanes_in * c.kt;
   a.wz_stride = (size_t)a.nstages * (c.sp1 ? 2 : 18) * 512;
+  if (c.in2) {             // second source: nplanes_in2 more stages (BwdConv::in2)
+    a.dense[1] = (const f16*)c.in2; a.w[1] = (const f16*)c.w2;
+    a.gen_split = a.nstages; a.nstages += c.nplanes_in2;
+    a.wz_stride2 = (size_t)c.nplanes_in2 * 18 * 512;
+    a.bw_add2 = (const f16*)c.add2;
+  }
   a.out_coff = 0;
   a.bw_add = (const f16*)c.add; a.bw_mask = (const f16*)c.mask; a.bw_mask_z = c.mask_z; a.bw_alt = (f16*)c.alt;
   a.bw_amax = c.amax; a.bw_acc = c.accumulate; a.bw_amax_out = c.amax_out;
   a.plain = c.plain; a.coutp = c.coutp;
+  return a;
+}
+
+int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s) {
+  if (c.in2 && (c.kt != 1 || c.sp1)) return SELFC_EINVAL;
+  C3Args a = bwd_conv_args(c, N, T, H, W);
   return launch_conv3x3<EPI_BWD, true>(a, c.ngroups, s);
+}
+
+// two data-gradient convs of one geometry (same plane counts, taps, groups) in one launch
+int bwd_conv_planes_pair(const BwdConv& c0, const BwdConv& c1, int N, int T, int H, int W, hipStream_t s) {
+  if (c0.nplanes_in != c1.nplanes_in || c0.kt != c1.kt || c0.sp1 != c1.sp1 || c0.ngroups != c1.ngroups || c0.in2 || c1.in2) return SELFC_EINVAL;
+  C3Args a = bwd_conv_args(c0, N, T, H, W), b = bwd_conv_args(c1, N, T, H, W);
+  return launch_conv3x3_pair<EPI_BWD, true>(a, b, c0.ngroups, s);
 }
 
 }  // namespace selfc
@@ -1056,7 +1155,7 @@ int bwd_conv_planes(const BwdConv& c, int N, int T, int H, int W, hipStream_t s)
 extern "C" {
 
 const char* selfc_version(void) { return "selfc_hip gfx950 abi12 operands=" SELFC_OPERAND_NAME; }
-int selfc_abi_version(void) { return 12; }
+int selfc_abi_version(void) { return 13; }
 
 int selfc_invblock_run(const selfc_invblock_w* blk, const selfc_latent* lat, int rev, void* stream) {
   if (!blk || !latent_ok(lat)) return SELFC_EINVAL;

@@ -74,7 +74,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 template <int TH>
-__global__ __launch_bounds__(NT) void dgrad_chain_kernel(const DgArgs a) {
+__device__ __forceinline__ void dgrad_chain_body(const DgArgs& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const lw = smem + off_w<TH>();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
@@ -272,9 +272,50 @@ __global__ __launch_bounds__(NT) void dgrad_chain_kernel(const DgArgs a) {
   }
 }
 
+template <int TH>
+__global__ __launch_bounds__(NT) void dgrad_chain_kernel(const DgArgs a) {
+  dgrad_chain_body<TH>(a);
+}
+
+// the chains of two nets of one geometry (a G/H pair) in one launch: blockIdx.y picks the argument set
+template <int TH>
+__global__ __launch_bounds__(NT) void dgrad_chain_pair_kernel(const DgArgs a, const DgArgs b) {
+  if (blockIdx.y) dgrad_chain_body<TH>(b);
+  else dgrad_chain_body<TH>(a);
+}
+
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 1000; }
 
 }  // namespace
+
+// dpre3, dpre2, dpre1 of TWO nets of one geometry in one launch (no input gradient: the pair's dx is one conv over both nets' planes,
+// bwd_conv_planes with a second source)
+int bwd_dgrad_chain_pair(void* gb0, void* gb1, const void* add0, const void* add1, const void* feat0, const void* feat1,
+                         const void* const* wtd0, const void* const* wtd1, int nx, const float* amax, int N, int H, int W, hipStream_t s) {
+  DgArgs a{}, b{};
+  a.g4 = (const f16*)gb0; a.gb = (f16*)gb0; a.add = (const f16*)add0; a.feat = (const f16*)feat0;
+  b.g4 = (const f16*)gb1; b.gb = (f16*)gb1; b.add = (const f16*)add1; b.feat = (const f16*)feat1;
+  for (int i = 0; i < 3; ++i) { a.wtd[i] = (const f16*)wtd0[i]; b.wtd[i] = (const f16*)wtd1[i]; }
+  a.amax = b.amax = amax;
+  a.plane = b.plane = (size_t)N * H * W * 32;
+  a.N = b.N = N; a.H = b.H = H; a.W = b.W = W;
+  a.tiles_x = b.tiles_x = (W + TW - 1) / TW;
+  a.nx = b.nx = nx;
+  static const int th_env = getenv("SELFC_BWD_CHAIN_TH") ? atoi(getenv("SELFC_BWD_CHAIN_TH")) : 0;
+  const bool th6 = th_env ? th_env == 6 : 2L * N * a.tiles_x * ((H + 5) / 6) <= 256;
+  static std::atomic<unsigned long long> optin12{0}, optin6{0};
+  ProfScope prof(-1, s);
+  if (th6) {
+    if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&dgrad_chain_pair_kernel<6>), dg_lds<6>(), optin6); e != hipSuccess) return hip_rc(e);
+    a.tiles_y = b.tiles_y = (H + 5) / 6;
+    hipLaunchKernelGGL(dgrad_chain_pair_kernel<6>, dim3((unsigned)(a.tiles_x * a.tiles_y * N), 2), dim3(NT), dg_lds<6>(), s, a, b);
+    return hip_rc(hipGetLastError());
+  }
+  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&dgrad_chain_pair_kernel<12>), dg_lds<12>(), optin12); e != hipSuccess) return hip_rc(e);
+  a.tiles_y = b.tiles_y = (H + 11) / 12;
+  hipLaunchKernelGGL(dgrad_chain_pair_kernel<12>, dim3((unsigned)(a.tiles_x * a.tiles_y * N), 2), dim3(NT), dg_lds<12>(), s, a, b);
+  return hip_rc(hipGetLastError());
+}
 
 // dpre3, dpre2, dpre1 (planes 1..3 of gb) and, with dx, the input gradient - steps 3 and 4 of selfc_subnet_bwd_phase_x as one launch
 int bwd_dgrad_chain(void* gb, const void* add, const void* feat, const void* const* wtd, const void* wtx, float* dx, int nx, int cinp,

@@ -130,6 +130,33 @@ int selfc_stream_destroy(void* stream) {
   return e == hipSuccess ? SELFC_OK : -(int)e - 1000;
 }
 
+// Node census of a captured hipGraph (abi 13): counts[0] = all nodes, [1] = kernel, [2] = memset, [3] = memcpy (any kind), [4] = every other
+// type.  `graph` is a hipGraph_t (torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()).  Host-only; the tests hold "no memset node in
+// any graph of the package" with it (a memset node is not ordered with its neighbours in a one-stream capture on this runtime),
+// bench.py reports the captured training step's node count.
+int selfc_graph_stats(void* graph, long long* counts) {
+  if (!graph || !counts) return SELFC_EINVAL;
+  size_t n = 0;
+  hipError_t e = hipGraphGetNodes((hipGraph_t)graph, nullptr, &n);
+  if (e != hipSuccess) return -(int)e - 1000;
+  for (int i = 0; i < 5; ++i) counts[i] = 0;
+  counts[0] = (long long)n;
+  if (!n) return SELFC_OK;
+  hipGraphNode_t* nodes = new hipGraphNode_t[n];
+  e = hipGraphGetNodes((hipGraph_t)graph, nodes, &n);
+  for (size_t i = 0; e == hipSuccess && i < n; ++i) {
+    hipGraphNodeType ty;
+    e = hipGraphNodeGetType(nodes[i], &ty);
+    if (e != hipSuccess) break;
+    if (ty == hipGraphNodeTypeKernel) ++counts[1];
+    else if (ty == hipGraphNodeTypeMemset) ++counts[2];
+    else if (ty == hipGraphNodeTypeMemcpy || ty == hipGraphNodeTypeMemcpyFromSymbol || ty == hipGraphNodeTypeMemcpyToSymbol) ++counts[3];
+    else ++counts[4];
+  }
+  delete[] nodes;
+  return e == hipSuccess ? SELFC_OK : -(int)e - 1000;
+}
+
 int selfc_profile_calibrate(double* mfma_tflops, double* copy_GBps, void* stream) {
   if (!mfma_tflops || !copy_GBps) return SELFC_EINVAL;
   hipStream_t s = (hipStream_t)stream;

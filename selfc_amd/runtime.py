@@ -3,6 +3,7 @@ cache, and thin wrappers over the C ABI (include/selfc_hip.h)."""
 from __future__ import annotations
 
 import atexit
+import os
 import ctypes as C
 import weakref
 from typing import Dict, Optional, Tuple
@@ -202,8 +203,15 @@ def params_key(*mods) -> Tuple:
     return (_WEIGHT_EPOCH,) + tuple((p.data_ptr(), p._version) for m in mods for p in plist(m))
 
 
-def new_graph() -> "torch.cuda.CUDAGraph":
-    """A fresh torch.cuda.CUDAGraph to capture into, behind a garbage collection and a device sync.
+#: SELFC_KEEP_GRAPHS=1 (or rt.KEEP_GRAPHS = True): every graph of the package is created with keep_graph and its node census is appended
+#: to GRAPH_LOG when its capture ends (graph_capture.__exit__) - tests ("no memset node"), bench.py (nodes per training step)
+KEEP_GRAPHS = os.environ.get("SELFC_KEEP_GRAPHS") == "1"
+GRAPH_LOG: list = []
+
+
+def new_graph(keep: bool = False) -> "torch.cuda.CUDAGraph":
+    """A fresh torch.cuda.CUDAGraph to capture into, behind a garbage collection and a device sync.  keep=True: the hipGraph_t
+    outlives instantiation (torch's keep_graph), so that graph_stats() can count its nodes.
 
     Why: on this stack (ROCm 7.0 runtime bundled with torch 2.10) replaying a just-instantiated hipGraph crashed inside
     hip::Graph::UpdateStreams (host segfault in hipGraphLaunch) when OTHER graph execs had been destroyed between its
@@ -214,7 +222,21 @@ def new_graph() -> "torch.cuda.CUDAGraph":
     import gc
     gc.collect()
     torch.cuda.synchronize()
+    if keep or KEEP_GRAPHS:
+        g = torch.cuda.CUDAGraph(keep_graph=True)
+        _KEPT.add(id(g))
+        return g
     return torch.cuda.CUDAGraph()
+
+
+_KEPT: set = set()
+
+
+def graph_stats(g) -> Dict[str, int]:
+    """{"nodes", "kernel", "memset", "memcpy", "other"} of a graph captured into new_graph(keep=True) (selfc_graph_stats)."""
+    counts = (C.c_longlong * 5)()
+    _lib.check(_lib.lib().selfc_graph_stats(C.c_void_p(int(g.raw_cuda_graph())), counts), "selfc_graph_stats")
+    return dict(zip(("nodes", "kernel", "memset", "memcpy", "other"), (int(v) for v in counts)))
 
 
 #: every live OwnStream (weak): closed by _shutdown() at interpreter exit, while the HIP runtime is still there
@@ -322,7 +344,11 @@ class graph_capture:
 
     def __exit__(self, *exc):
         try:
-            return self.ctx.__exit__(*exc)
+            r = self.ctx.__exit__(*exc)
+            if exc[0] is None and id(self.g) in _KEPT:
+                _KEPT.discard(id(self.g))
+                GRAPH_LOG.append(graph_stats(self.g))
+            return r
         finally:
             self._restore()
 

@@ -17,7 +17,7 @@ def test_exports_match_header():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _lib.lib().selfc_abi_version() == _lib.ABI_VERSION == 12
+    assert _lib.lib().selfc_abi_version() == _lib.ABI_VERSION == 13
     assert b"gfx950" in _lib.lib().selfc_version() and b"operands=f16" in _lib.lib().selfc_version()
     bf = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libselfc_hip_bf16.so"))     # the bf16-operand build
     bf.selfc_version.restype = ctypes.c_char_p

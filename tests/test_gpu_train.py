@@ -113,14 +113,14 @@ def test_k20_training_trajectory_tracks_the_reference(dev, mode):
     assert worst_fit < 1e-2 and worst_rec < 1e-2, (worst_fit, worst_rec)
     # the update vector.  Adam's per-element step is lr * m / (sqrt(v) + eps): elements whose gradient is noise-sized (sign flips from
     # one step to the next) move by +-lr whatever the size of the gradient, so the vector's relative L2 error is far above a gradient's;
-    # measured on the MI355X: see profiles/r6/parity_report_gpu.json
+    # measured on the MI355X (profiles/r6/parity_report_gpu.json): losses 7e-4 / 9e-5, gradient norm 1.1e-2 worst step, update 1.1e-2
     ref = g["update_q"].float() * float(g["update_scale"])
     after = [p.detach() for n, p in net.named_parameters() if p.requires_grad]
     upd = torch.cat([(a - b).flatten() for a, b in zip(after, before)]).cpu()
     e_all = record(f"K=20 trajectory ({mode}): ||update - ref|| / ||ref|| over all 3.37 M weights", (upd - ref).norm() / ref.norm())
     cos = record(f"K=20 trajectory ({mode}): cosine(update, ref)", torch.dot(upd, ref) / (upd.norm() * ref.norm()))
     record(f"K=20 trajectory ({mode}): ||update|| / ||ref||", upd.norm() / ref.norm())
-    assert e_all < 0.15 and cos > 0.99, (e_all, cos)
+    assert e_all < 0.035 and cos > 0.999, (e_all, cos)          # measured 1.08e-2 / 1.04e-2 (eager / captured), cosine 1.0000
 
 
 def test_flat_gradient_sink_equals_autograd_accumulation(dev):
@@ -451,8 +451,9 @@ def test_reference_optimizer_state_loads_into_a_capturable_trainer(dev):
             num += float(((v.detach() - before[k]).double() - ref).pow(2).sum())
             den += float(ref.pow(2).sum())
         return (num / den) ** 0.5
-    e4 = update_err(net_b, weights3, weights3, weights4)
-    assert e4 < 2e-2, ("after the first replay", e4)
+    from conftest import record
+    e4 = record("reference optimizer state -> capturable trainer: update error of the first replayed step", update_err(net_b, weights3, weights3, weights4))
+    assert e4 < E_UPDATE, ("after the first replay", e4)
     # (b) load AFTER capture: same tensors, new contents; two replays bring B to A's step 4 again
     ids_before = {k: v.data_ptr() for k, v in st.items() if torch.is_tensor(v)}
     with torch.no_grad():
@@ -465,12 +466,69 @@ def test_reference_optimizer_state_loads_into_a_capturable_trainer(dev):
     tr_b.optimize_parameters(real_h, ref_l)
     tr_b.optimize_parameters(real_h, ref_l)
     torch.cuda.synchronize()
-    e24 = update_err(net_b, weights2, weights2, weights4)          # two replayed steps from the reloaded state against A's steps 3 and 4
-    assert e24 < 2e-2, e24
+    e24 = record("reference optimizer state -> capturable trainer: update error of two replayed steps after a reload",
+                 update_err(net_b, weights2, weights2, weights4))          # two replayed steps from the reloaded state against A's steps 3 and 4
+    assert e24 < E_UPDATE, e24
     # (c) a state that does not cover the captured step's tensors is refused, not half-applied
     bad = {"state": {}, "param_groups": sd2["param_groups"]}
     with pytest.raises(RuntimeError, match="capture again"):
         tr_b.load_optimizer_state_dict(bad)
+
+
+#: bar of the two update errors above (an eager, non-capturable Adam against replayed capturable steps of the same kernels): measured
+#: 0.0 and 0.0 since replayed and eager steps are bit-identical (round 5); a wrong lr, step count or moment buffer is an error of order one
+E_UPDATE = 1e-6
+
+
+def test_no_graph_of_the_package_contains_a_memset_node(dev):
+    """A memset NODE is not ordered with the kernel nodes around it in a one-stream capture on this runtime (DESIGN 4b, round 5:
+    the gradient scale's maximum zeroed late, torch's multi-block reductions left without output).  Every capture of the package -
+    the pre-bound round trip, the two-stream whole test path with the STP sampler, the module API's cached graph, the training step
+    on one and on three streams - is censused node by node (selfc_graph_stats): kernels and nothing else but the copy nodes of
+    the captured tensor copies; zero memsets."""
+    from selfc_amd import autograd as ag, pipeline as PL, runtime as rt, train
+    from selfc_amd.pipeline import FullTestPath, MultiStreamRoundTrip, RescaleRoundTrip
+    x = load_golden("g8_large_stack")["x"]
+    gt = x.reshape(1, T, 3, 32, 48).transpose(1, 2).to(dev)
+    real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
+    old_keep, old_two = rt.KEEP_GRAPHS, ag._TWO_STREAMS
+    rt.KEEP_GRAPHS = True
+    del rt.GRAPH_LOG[:]
+    labels = []
+    try:
+        net = _net(dev, "gmm").eval()
+        xx = torch.cat((real_h, real_h)).contiguous()                      # two clips
+        with torch.no_grad():
+            r1 = RescaleRoundTrip(net, 14, 32, 48, dev)
+            r1.capture(xx)
+            r1.replay()
+            labels.append("RescaleRoundTrip")
+            r2 = MultiStreamRoundTrip(net, 14, 32, 48, dev, 2, part_cls=FullTestPath)
+            r2.capture(xx)
+            r2.replay()
+            labels.append("MultiStreamRoundTrip(FullTestPath) x 2 streams")
+            n0 = len(rt.GRAPH_LOG)
+            for _ in range(3):                                             # the module API: cached graphs from the second call on
+                z, _ = net(x=xx, rev=False)
+                net(x=z[:, :3].contiguous(), rev=True)
+            labels += ["ModuleGraph"] * (len(rt.GRAPH_LOG) - n0)
+            assert len(rt.GRAPH_LOG) > n0 or not PL.MODULE_GRAPH
+        for two in (True, False):
+            ag._TWO_STREAMS = two
+            tr = train.RescaleTrainer(_net(dev, "gmm"), dict(train.TRAIN_OPT_LARGE), capturable=True)
+            tr.capture(real_h, ref_l, warmup=2)
+            tr.optimize_parameters(real_h, ref_l)
+            labels.append("RescaleTrainer.capture, " + ("three streams" if two else "one stream"))
+            del tr
+        torch.cuda.synchronize()
+        assert len(rt.GRAPH_LOG) == len(labels) >= 5, (labels, rt.GRAPH_LOG)
+        from conftest import record
+        for lab, st in zip(labels, rt.GRAPH_LOG):
+            record(f"graph nodes: {lab}", st["nodes"])
+            assert st["memset"] == 0 and st["kernel"] > 0 and st["kernel"] + st["memcpy"] + st["other"] == st["nodes"], (lab, st)
+    finally:
+        rt.KEEP_GRAPHS, ag._TWO_STREAMS = old_keep, old_two
+        del rt.GRAPH_LOG[:]
 
 
 def test_folded_gradient_maxima_change_nothing(dev):
@@ -501,6 +559,42 @@ def test_folded_gradient_maxima_change_nothing(dev):
         assert a.keys() == b.keys() and len(a) > 300
         bad = [n for n in a if not torch.equal(a[n], b[n])]
         assert not bad, f"streams={two}: {len(bad)} gradients differ, e.g. {bad[:4]}"
+
+
+@pytest.mark.parametrize("defer", [True, False])
+def test_paired_gh_backward_equals_the_two_subnet_calls(dev, defer):
+    """Round 6: G and H of a coupling block run their backward as ONE call (selfc_gh_bwd_pair: every launch covers both nets, one
+    power-of-two gradient scale from the larger of the two maxima, the input gradient one conv over both nets' planes) and the
+    weight-gradient partials of the whole stack are reduced by one launch per 24 jobs (FinJobs).  Against round 5's two subnet calls on
+    two streams (SELFC_BWD_PAIR=0, finishes per subnet): the same f16 operands up to the exact power-of-two scale, the same fp32 sums
+    up to the order of two additions in y1's gradient - which the next subnet rounds to f16 again, so a last-bit difference there is
+    a 1e-3 difference of single elements further down the 16 block calls.  Measured: 1.6e-4 worst per-tensor relative L2 (floor: 1e-7
+    of the whole gradient); a wrong plane, weight or scale anywhere in the paired path is an error of order one."""
+    from conftest import record
+    from selfc_amd import autograd as ag, train
+    x = load_golden("g8_large_stack")["x"]
+    gt = x.reshape(1, T, 3, 32, 48).transpose(1, 2).to(dev)
+    real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
+
+    def grads(pair, defer_):
+        old = ag._PAIR, ag._DEFER_FIN
+        ag._PAIR, ag._DEFER_FIN = pair, defer_
+        try:
+            net = _net(dev)
+            tr = train.RescaleTrainer(net, dict(train.TRAIN_OPT_LARGE), flat_params=False)
+            tr._zero_grad()
+            losses = tr._forward_backward(real_h, ref_l)
+            torch.cuda.synchronize()
+            return {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}, [float(v) for v in losses[:2]]
+        finally:
+            ag._PAIR, ag._DEFER_FIN = old
+
+    (a, la), (b, lb) = grads(False, False), grads(True, defer)
+    assert set(a) == set(b) and la == lb
+    g_all = float(torch.sqrt(sum((v.double() ** 2).sum() for v in a.values())))
+    worst = max(float((a[n] - b[n]).norm() / (a[n].norm() + 1e-7 * g_all)) for n in a)
+    record(f"paired G/H backward (deferred finishes: {defer}) vs two subnet calls: worst per-tensor relative L2", worst)
+    assert worst < 6e-4, worst
 
 
 def test_backward_is_linear_in_the_output_gradient_at_chain_level(dev):
