@@ -198,8 +198,82 @@ def cpu_baseline(net, x_cpu, budget_s=20.0, others=None):
 
 
 def mark(what: str):
-    """progress marker on stderr (never stdout: the line is the only thing printed there): where a run was when it died"""
-    print(f"[bench {time.strftime('%H:%M:%S')}] {what}", file=sys.stderr, flush=True)
+    """progress marker on stderr (never stdout: the line is the only thing printed there): where a run was when it died.
+    SELFC_BENCH_MARKS=1 only: the driver keeps the last 2,000 characters of stdout + stderr, and they belong to the line."""
+    if os.environ.get("SELFC_BENCH_MARKS") == "1":
+        print(f"[bench {time.strftime('%H:%M:%S')}] {what}", file=sys.stderr, flush=True)
+
+
+def short(text, n=118):
+    """the driver's record truncates strings at 120 characters"""
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + "..."
+
+
+def rocprof_reference(kernel_key: str, csrc_sha16: str):
+    """avg launch duration of `kernel_key` in the TRACKED rocprofv3 kernel trace of this round (profiles/r6/rocprof_kernel_avgs.json,
+    written by tools/rocprof_avgs.py from the committed trace of this same command) - next to the live HIP-event figure."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r6", "rocprof_kernel_avgs.json")) as fh:
+            ref = json.load(fh)
+        k = ref.get(kernel_key)
+        meta = ref.get("_meta", {})
+        if not k:
+            return None
+        return {"avg_us": k["avg_us"], "file": "profiles/r6/rocprof_kernel_avgs.json", "same_sources": meta.get("csrc_sha16") == csrc_sha16}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def compact_line(out: dict) -> dict:
+    """The ONE line the driver records: its standard keys, `config`, `roofline` and `cpu_baseline` - scalars only (the record keeps
+    no nested objects and no other top-level key: BENCH_r05.parsed.extra_keys), strings under 120 characters.  The secondary legs
+    travel as flat scalars inside `roofline`; the verbose form is `--full-line` (and gpurun_out/bench_full_line.json)."""
+    keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: out.get(k) for k in keys}
+    cfg = out.get("config", {})
+    cal = out.get("box_calibration") or {}
+    line["config"] = {"workload": "SelfC-large FreqAnalyzer + 8 InvBlockExp(D2DTNet) fwd, Quantization, 8 rev, FreqAnalyzer rev; 4 x 7x3x256x448 in HBM",
+                      "septuplets_per_gpu": cfg.get("septuplets_per_gpu"), "launch": short(cfg.get("launch")), "streams": cfg.get("streams"),
+                      "sharding": short(cfg.get("sharding")), "prewarm": short(cfg.get("prewarm")),
+                      "rccl_ranks": out.get("rccl_ranks"), "shader_clock_GHz": cal.get("shader_clock_GHz_under_the_workload"),
+                      "box_mfma_f16_loop_TFLOPs": cal.get("mfma_f16_loop_TFLOPs"), "box_device_copy_GBps": cal.get("device_copy_GBps")}
+    rf = out.get("roofline")
+    if rf is not None:
+        r = {k: (short(v) if isinstance(v, str) else v) for k, v in rf.items() if not isinstance(v, (dict, list))}
+        sr = out.get("stack_roofline") or {}
+        r["stack_mfma_frac"] = sr.get("mfma_frac")
+        r["stack_hbm_frac_layer_granular"] = sr.get("hbm_frac_layer_granular")
+        c5 = (out.get("roofline_other") or {}).get("conv5_GH") or {}
+        r["conv5_GH_hbm_GBps"], r["conv5_GH_hbm_frac"] = c5.get("achieved"), c5.get("frac")
+        ff = (out.get("roofline_other") or {}).get("conv3x3") or {}
+        r["fused_f_mfma_frac"] = ff.get("frac")
+        ts = out.get("train_step") or {}
+        by = ts.get("captured_ms_per_step_by_local_batch") or {}
+        r["train_step_ms_b8"], r["train_step_ms_b4"], r["train_step_ms_b2"], r["train_step_ms_b1"] = by.get("8"), by.get("4"), by.get("2"), by.get("1")
+        r["train_step_mfma_frac"], r["train_step_graph_nodes"] = ts.get("mfma_frac"), ts.get("graph_nodes")
+        r["train_step_graph_nodes_b1"], r["train_step_eager_ms"] = ts.get("graph_nodes_b1"), ts.get("eager_ms_per_step")
+        uv = out.get("uvg_1080p") or {}
+        r["uvg_1080p_frames_per_s"], r["uvg_1080p_mfma_frac_whole_path"] = uv.get("frames_per_s"), uv.get("mfma_frac_whole_path")
+        fp = out.get("full_test_path") or {}
+        r["full_test_path_septuplets_per_s"] = fp.get("septuplets_per_s")
+        r["full_test_path_mfma_frac_whole_path"] = fp.get("mfma_frac_whole_path")
+        r["headline_through_module_api_septuplets_per_s"] = (out.get("headline_through_module_api") or {}).get("septuplets_per_s")
+        pa = out.get("parity") or {}
+        r["parity_fwd_rel_err"], r["parity_inv_rel_err"] = pa.get("fwd_latent_rel_err"), pa.get("inv_rel_err")
+        r["parity_fwd_rel_l2"], r["parity_inv_rel_l2"], r["parity_error"] = pa.get("fwd_latent_rel_l2"), pa.get("inv_rel_l2"), short(pa.get("error")) if pa.get("error") else None
+        for leg in ("train_step", "uvg_1080p", "full_test_path"):
+            if isinstance(out.get(leg), dict) and out[leg].get("error"):
+                r[leg + "_error"] = short(out[leg]["error"])
+        line["roofline"] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in r.items()}
+    else:
+        line["roofline"] = None
+    cb = out.get("cpu_baseline")
+    if cb is not None:
+        line["cpu_baseline"] = {"value": round(cb["value"], 4), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "cpu_model": short(cb.get("cpu_model")), "host_copy_errors": len(cb.get("host_copy_errors") or []),
+                                "sample": "1 septuplet 7x3x256x448 fwd+quant+inv, CPU oracle (torch fp32), median of the timed runs, calibrated threads"}
+    return line
 
 
 def main():
@@ -219,6 +293,7 @@ def main():
     ap.add_argument("--no-uvg", action="store_true", help="skip the 1080p leg (config 5, bounded sample: 6 GOPs through the whole test path)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the extra training-step timing (config 3: 8 x 7x3x144x144)")
     ap.add_argument("--no-roofline-leg", action="store_true", help="profiling runs only (tools/profile_gpu.sh): skip the eager one-stream leg that times every launch, so that a trace holds the timed configuration alone; `roofline` is then null")
+    ap.add_argument("--full-line", action="store_true", help="print the verbose dict (every leg's details, per-kernel rooflines, box identity) instead of the compact line the driver records")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo rehearsal of launch, sharding and the timing protocol: no HIP call, value is null")
     args = ap.parse_args()
 
@@ -372,6 +447,20 @@ def main():
     same_sources = bool(pmc_meta.get("csrc_sha16")) and pmc_meta.get("csrc_sha16") == hsh.hexdigest()[:16]
     pmc_meta["kernel_sources_unchanged_since"] = same_sources
 
+    def pmc_file_of(name):
+        """path of the newest tracked counter file of that name + whether ITS OWN source hash (its _meta.csrc_sha16) is the current one
+        (the flag used to compare against pmc_traffic.json's hash whatever file was meant)"""
+        for rnd in ("r6", "r5"):
+            path = os.path.join(ROOT, "profiles", rnd, name)
+            try:
+                with open(path) as fh:
+                    meta = json.load(fh).get("_meta", {})
+                own = meta.get("csrc_sha16")
+                return {"file": f"profiles/{rnd}/{name}", "same_sources": (own == hsh.hexdigest()[:16]) if own else None}
+            except (OSError, ValueError):
+                continue
+        return None
+
     def add_pmc(entry, key):
         t = traffic_all.get(key)
         if t:
@@ -380,7 +469,8 @@ def main():
             scale = n_frames / float(pmc_meta.get("frames_per_launch") or n_frames)
             if same_sources:
                 entry["traffic"] = t["hbm_bytes_per_launch"] * scale
-            entry["pmc_reference"] = dict({k: v for k, v in t.items() if k != "source"}, **{"meta": pmc_meta})
+            entry["pmc_reference_file"] = pmc_meta.get("file")
+            entry["pmc_reference_same_sources"] = same_sources
     if f_scopes == 1 and "fused_f" in traffic_all:
         traffic_all["conv3x3"] = traffic_all["fused_f"]
     for k in kern:
@@ -397,6 +487,13 @@ def main():
         add_pmc(kern["conv5_GH"], "conv5_GH")
     dominant = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
     roofline = kern[dominant] if kern else None
+    if roofline is not None:
+        ref_ = rocprof_reference({"fused_gh": "fused_gh_kernel", "conv3x3": "fused_f16_kernel<1>", "conv5_GH": "tconv5_kernel<2, 3, 4, 1, 3>"}.get(dominant, ""),
+                                 hsh.hexdigest()[:16])
+        # the same kernel's average in the tracked rocprofv3 trace of this command (another card, under the profiler): README explains gaps > 5 %
+        roofline["rocprof_avg_us"] = ref_["avg_us"] if ref_ else None
+        roofline["rocprof_file"] = ref_["file"] if ref_ else None
+        roofline["rocprof_same_sources"] = ref_["same_sources"] if ref_ else None
     value = launch.whole_job_rate(B_PER_GPU, world, args.steps, dt)
     whole_flops = 2.0 * MAC_BLOCK_PX * npx * 16
     out = {
@@ -511,13 +608,7 @@ def main():
                                      "sample": f"{ngop} GOPs of 7x3x1080x1920 (one synthetic {frames}-frame clip), whole test path (fwd stack, Quantization, STP sample, rev stack), "
                                                "2 GOPs per hipGraph replay on 2 streams, incl. the device copies of each GOP into the graph's input"},
                                     **bench_uvg.roofline_fracs(ngop, 1, sec, 1080, 1920))
-            try:        # per-kernel counters of this leg's workload (committed passes of tools/profile_uvg.sh, one GOP eager on one stream)
-                with open(os.path.join(ROOT, "profiles", "r5", "uvg1080p_pmc.json")) as fh:
-                    ref = json.load(fh)
-                out["uvg_1080p"]["pmc_reference"] = dict({k: v for k, v in ref.items() if k != "_meta"},
-                                                         meta=dict(ref.get("_meta", {}), file="profiles/r5/uvg1080p_pmc.json", kernel_sources_unchanged_since=same_sources))
-            except (OSError, ValueError):
-                pass
+            out["uvg_1080p"]["pmc_reference_file"] = pmc_file_of("uvg1080p_pmc.json")
             torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001
             out["uvg_1080p"] = {"error": repr(e)[:300]}
@@ -529,16 +620,19 @@ def main():
             import bench_train
             tg = bench_train.run(batch=8, size=144, steps=20, warmup=3, fh_loss="gmm", profile=False, graph=True)
             te = bench_train.run(batch=8, size=144, steps=20, warmup=3, fh_loss="gmm", profile=False)
-            by_batch = {}
+            by_batch, nodes_b1 = {}, None
             for lb in (1, 2, 4):       # the reference's global batch 8 split over 8 / 4 / 2 ranks (train_rescaling_selfc_large.yml:12,26: 2 GPUs x 4)
                 r_ = bench_train.run(batch=lb, size=144, steps=20, warmup=2, fh_loss="gmm", profile=False, graph=True)
                 by_batch[str(lb)] = round(r_["ms_per_step"], 2)
+                if lb == 1:
+                    nodes_b1 = (r_.get("graph_nodes") or {}).get("nodes")
             by_batch["8"] = round(tg["ms_per_step"], 2)
             # algorithmic work of a training step: forward + data gradient + weight gradient of the whole test path (stack fwd + rev,
             # STP) = 3 x 10.89 MFLOP per LR pixel-frame, 36x36 latent pixels x 7 frames per septuplet
             step_flop = lambda lb: 3.0 * (2.0 * MAC_BLOCK_PX * 16 + 2331776.0) * lb * T * 36 * 36      # noqa: E731
             out["train_step"] = {"septuplets_per_s": round(tg["value"], 1), "ms_per_step": round(tg["ms_per_step"], 2),
                                  "captured_ms_per_step_by_local_batch": by_batch,
+                                 "graph_nodes": (tg.get("graph_nodes") or {}).get("nodes"), "graph_nodes_b1": nodes_b1,
                                  "mfma_frac_by_local_batch": {k_: round(step_flop(int(k_)) / (v_ * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4) for k_, v_ in by_batch.items()},
                                  "mfma_frac": round(step_flop(8) / (tg["ms_per_step"] * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
                                  "launch": "RescaleTrainer.capture(): the whole optimisation step replayed as one hipGraph",
@@ -546,13 +640,7 @@ def main():
                                  "config": "8 x 7x3x144x144 crops, fh_loss gmm, l2 + l1 losses, clip 10, Adam (one flat tensor); 3 streams",
                                  "note": "every forward / reverse / gradient kernel is HIP (selfc_amd/autograd.py); losses, clip and Adam are torch; "
                                          "the eager figure is host-bound and moves with the box's CPU"}
-            try:        # counters of this leg's largest kernels (committed passes of tools/pmc_train.sh over the eager step at 8 septuplets)
-                with open(os.path.join(ROOT, "profiles", "r5", "train_step_pmc.json")) as fh:
-                    ref = json.load(fh)
-                out["train_step"]["pmc_reference"] = dict({k: v for k, v in list(ref.items())[:6] if k != "_meta"},
-                                                          meta=dict(ref.get("_meta", {}), file="profiles/r5/train_step_pmc.json", kernel_sources_unchanged_since=same_sources))
-            except (OSError, ValueError):
-                pass
+            out["train_step"]["pmc_reference_file"] = pmc_file_of("train_step_pmc.json")
         except Exception as e:  # noqa: BLE001
             out["train_step"] = {"error": repr(e)[:300]}
     mark("training leg done")
@@ -609,7 +697,13 @@ def main():
             out["parity"]["debug"] = dbg
     mark("cpu baseline / parity leg done")
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out if args.full_line else compact_line(out)), flush=True)
+        try:                                   # the verbose record, best effort (scratch on the GPU box, merged back by gpurun)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_full_line.json"), "w") as fh:
+                json.dump(out, fh)
+        except OSError:
+            pass
     mark("line printed")
     ranks.close()
     # leave nothing to interpreter finalisation: the training legs' trainers die inside reference cycles (optimizer <-> scheduler), and a

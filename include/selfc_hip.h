@@ -240,16 +240,31 @@ int selfc_subnet_bwd_phase_x(int phases, const selfc_subnet_bw* bw, int kind, co
  *   Scratch: `selfc_gh_bwd_pair_scratch_bytes`. */
 size_t selfc_fin_job_bytes(void);
 int selfc_wgrad_finish_jobs(const void* jobs, int njobs, void* stream);
+/* - `wg_jobs` (with fin_jobs; room for 2 - pair: 4 - jobs of `selfc_wg_job_bytes()` each, HOST memory): the weights phase launches
+ *   NOTHING and leaves its weight-gradient launches as job descriptors too; `selfc_wgrad_run_jobs` runs any number of them as ONE launch
+ *   per kind (conv1..4 / temporal conv5) and 32 jobs - the weight gradients of a whole block stack behind its data-gradient chain: on a
+ *   training crop each such launch under-fills the chip, and inside a replayed graph side streams buy no overlap on this runtime.
+ *   Call order: selfc_wgrad_run_jobs, then selfc_wgrad_finish_jobs; every scratch / saved-feature buffer of the deferred calls stays
+ *   untouched until then. */
+size_t selfc_wg_job_bytes(void);
+int selfc_wgrad_run_jobs(const void* jobs, int njobs, void* stream);
 int selfc_subnet_bwd_phase_d(int phases, const selfc_subnet_bw* bw, int kind, const void* dense, const float* xin, const float* dout,
                              float sign, float* dx, int accumulate_dx, float* const* wgrad, float* const* bgrad, float beta,
                              void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout,
-                             const float* dout_amax, float* dx_amax_out, void* fin_jobs, void* stream);
+                             const float* dout_amax, float* dx_amax_out, void* fin_jobs, void* wg_jobs, void* stream);
 size_t selfc_gh_bwd_pair_scratch_bytes(int N, int H, int W, int cin, int cout);
 int selfc_gh_bwd_pair(int phases, const selfc_subnet_bw* bw_g, const selfc_subnet_bw* bw_h, const void* dense_g, const void* dense_h,
                       const float* xin, const float* dout_g, const float* dout_h, float sign_g, float sign_h,
                       float* dx, int accumulate_dx, float* const* wgrad_g, float* const* bgrad_g, float* const* wgrad_h, float* const* bgrad_h,
                       float beta, void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout,
-                      const float* amax_g, const float* amax_h, float* dx_amax_out, void* fin_jobs, void* stream);
+                      const float* amax_g, const float* amax_h, float* dx_amax_out, void* fin_jobs, void* wg_jobs, void* stream);
+/* (abi 13) ReconstructionLoss (models/modules/loss.py:5-21) and its gradient in two launches: *out = weight * mean(v), v = (x-t)^2
+ * (l1 == 0) or sqrt((x-t)^2 + eps) (l1 != 0); grad (dense [n_outer][inner], or NULL) = weight / count * dv/dx (the gradient w.r.t. t is
+ * its negative).  x / t: n_outer rows of `inner` contiguous floats at row strides stride_x / stride_t (elements).  partial: scratch of
+ * selfc_recon_loss_blocks() doubles.  Deterministic, no atomics, capturable. */
+int selfc_recon_loss_blocks(void);
+int selfc_recon_loss(const float* x, size_t stride_x, const float* t, size_t stride_t, size_t n_outer, size_t inner, int l1, float eps,
+                     float weight, float* grad, double* partial, float* out, void* stream);
 /* Adjoint of selfc_freq_fwd (latent grads d1 [N][h][w][4], d2 [N][h][w][48] -> dx NCHW (N,3,H,W)) and of selfc_freq_inv
  * (dout NCHW -> d1, d2). */
 int selfc_freq_fwd_bwd(const float* d1, const float* d2, float* dx, int N, int H, int W, void* stream);

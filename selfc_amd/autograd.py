@@ -42,16 +42,33 @@ _PAIR = os.environ.get("SELFC_BWD_PAIR", "1") != "0"
 #: SELFC_BWD_DEFER_FIN=0: every subnet call reduces its weight-gradient partials itself (one finish launch per subnet) instead of
 #: leaving them to ONE launch per 24 jobs at the end of the block stack's backward (FinJobs)
 _DEFER_FIN = os.environ.get("SELFC_BWD_DEFER_FIN", "1") != "0"
+#: SELFC_BWD_DEFER_WG=0: the weight-gradient launches of a block stack run per subnet on the side stream again instead of as ONE launch
+#: per kind (conv1..4 / temporal conv5) behind the stack's data-gradient chain.  Inside a replayed graph one stream and three streams
+#: take the same time on this runtime (the executor maps the branches onto hardware queues its own way: the "side" work ends up in front
+#: of the main chain on the same queue), and every per-subnet launch under-fills the chip - 24 subnets' jobs in one launch do not.
+_DEFER_WG = os.environ.get("SELFC_BWD_DEFER_WG", "1") != "0"
 
 
 class FinJobs:
     """Deferred weight-gradient finishes of a block stack's backward (selfc_subnet_bwd_phase_d / selfc_gh_bwd_pair leave job
     descriptors here, host memory; flush() reduces all of them with one launch per 24 jobs, in the order they were left)."""
 
-    def __init__(self, capacity: int):
+    def __init__(self, capacity: int, defer_wg: bool = False):
         self.size = int(_lib.lib().selfc_fin_job_bytes())
         self.buf = (C.c_ubyte * (self.size * capacity))()
         self.cap, self.n = capacity, 0
+        # defer_wg: the weight-gradient LAUNCHES are left as jobs too (selfc_wgrad_run_jobs); one per finish job
+        self.defer_wg = defer_wg
+        self.wsize = int(_lib.lib().selfc_wg_job_bytes())
+        self.wbuf = (C.c_ubyte * (self.wsize * capacity))() if defer_wg else None
+        self.wn = 0
+
+    def take_wg(self, k: int):
+        if not self.defer_wg:
+            return None
+        p_ = C.c_void_p(C.addressof(self.wbuf) + self.wn * self.wsize)
+        self.wn += k
+        return p_
 
     def take(self, k: int):
         if self.n + k > self.cap:
@@ -61,6 +78,9 @@ class FinJobs:
         return p_
 
     def flush(self):
+        if self.wn:
+            rt.call("selfc_wgrad_run_jobs", C.c_void_p(C.addressof(self.wbuf)), self.wn, _lib.stream_ptr())
+            self.wn = 0
         if self.n:
             rt.call("selfc_wgrad_finish_jobs", C.c_void_p(C.addressof(self.buf)), self.n, _lib.stream_ptr())
             self.n = 0
@@ -336,20 +356,27 @@ def subnet_bwd(mod, dense: torch.Tensor, xin: Optional[torch.Tensor], dout: torc
             scratch.data_ptr(), scratch.numel(), n, t, h, w, cin, cout,
             None if dout_amax is None else dout_amax.data_ptr(), None if dx_amax_out is None else dx_amax_out.data_ptr())
     jobs = fin.take(2) if (fin is not None and want_params) else None      # deferred finish: the caller flushes (FinJobs)
-    if (side is None or not want_params) and on_data_done is None:
-        rt.call("selfc_subnet_bwd_phase_d", 3, *args, jobs, _lib.stream_ptr())
+    wjobs = fin.take_wg(2) if (jobs is not None and mod.kind == rt.SUBNET_D2DT) else None
+    if wjobs is not None:
+        # the weight-gradient launches are deferred as well: nothing of this call runs beside the data chain
+        rt.call("selfc_subnet_bwd_phase_d", 3, *args, jobs, wjobs, _lib.stream_ptr())
+        if on_data_done is not None:
+            on_data_done()
         return grads
-    rt.call("selfc_subnet_bwd_phase_d", 1, *args, None, _lib.stream_ptr())
+    if (side is None or not want_params) and on_data_done is None:
+        rt.call("selfc_subnet_bwd_phase_d", 3, *args, jobs, None, _lib.stream_ptr())
+        return grads
+    rt.call("selfc_subnet_bwd_phase_d", 1, *args, None, None, _lib.stream_ptr())
     if on_data_done is not None:
         on_data_done()
     if not want_params:
         return grads
     if side is None:
-        rt.call("selfc_subnet_bwd_phase_d", 2, *args, jobs, _lib.stream_ptr())
+        rt.call("selfc_subnet_bwd_phase_d", 2, *args, jobs, None, _lib.stream_ptr())
         return grads
     side.wait_event(torch.cuda.current_stream().record_event())
     with torch.cuda.stream(side):
-        rt.call("selfc_subnet_bwd_phase_d", 2, *args, jobs, _lib.stream_ptr())
+        rt.call("selfc_subnet_bwd_phase_d", 2, *args, jobs, None, _lib.stream_ptr())
         _SLOT_BUSY[(str(dev), slot)] = side.record_event()
     return grads
 
@@ -403,13 +430,14 @@ def gh_pair_bwd(blk, pb, gd: torch.Tensor, hd: torch.Tensor, xin: torch.Tensor, 
             float(sign_g), float(sign_h), dx.data_ptr(), 1, wgG, bgG, wgH, bgH, betaG,
             scratch.data_ptr(), scratch.numel(), n, t, h, w, cin, cout, ptr(amax_g), ptr(amax_h), ptr(dx_amax_out))
     jobs = fin.take(4) if (fin is not None and want_params) else None
-    if side is None or not want_params:
-        rt.call("selfc_gh_bwd_pair", 3 if want_params else 1, *args, jobs, _lib.stream_ptr())
+    wjobs = fin.take_wg(4) if jobs is not None else None
+    if side is None or not want_params or wjobs is not None:
+        rt.call("selfc_gh_bwd_pair", 3 if want_params else 1, *args, jobs, wjobs, _lib.stream_ptr())
         return gG, gH
-    rt.call("selfc_gh_bwd_pair", 1, *args, None, _lib.stream_ptr())
+    rt.call("selfc_gh_bwd_pair", 1, *args, None, None, _lib.stream_ptr())
     side.wait_event(torch.cuda.current_stream().record_event())
     with torch.cuda.stream(side):
-        rt.call("selfc_gh_bwd_pair", 2, *args, jobs, _lib.stream_ptr())
+        rt.call("selfc_gh_bwd_pair", 2, *args, jobs, None, _lib.stream_ptr())
         _SLOT_BUSY[(str(dev), slot)] = side.record_event()
     return gG, gH
 
@@ -847,15 +875,17 @@ class InvStackFn(torch.autograd.Function):
         amax = None
         # the weight-gradient partials of every subnet are reduced by ONE launch per 24 jobs behind the last block (FinJobs); each block
         # has its own scratch set (tag), so nothing is overwritten before that
-        fin = FinJobs(6 * len(ctx.saves)) if (want and _DEFER_FIN) else None
+        fin = FinJobs(6 * len(ctx.saves), defer_wg=_DEFER_WG and _PAIR) if (want and _DEFER_FIN) else None
         for i, (blk, sv, keep, fd_intact) in enumerate(reversed(ctx.saves)):
             d1, d2, gF, gG, gH, amax = _block_backward(blk, sv, keep, rev, t, d1, d2, want, restore_fd=not fd_intact, tag=str(i), amax_in=amax,
                                                        amax_slots=None if slots is None else slots[3 * i:3 * i + 3], fin=fin)
             grads[id(blk)] = (*gF, *gG, *gH)
         if fin is not None and fin.n:
             side = side_stream(dev)
-            if side is None:
-                fin.flush()
+            if side is None or fin.defer_wg:
+                if side is not None:         # (a subnet kind whose launches cannot be deferred ran its weight phase there)
+                    torch.cuda.current_stream().wait_stream(side)
+                fin.flush()                  # the stack's weight gradients: two fat launches + the finishes, behind the data chain
             else:
                 # behind every weight-gradient phase (the side stream is in order; H's non-paired phases, stream 1, are joined first)
                 if side_stream(dev, 1) is not None:

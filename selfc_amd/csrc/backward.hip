@@ -161,8 +161,9 @@ __device__ __forceinline__ f16x8 tr_frag(const unsigned char* lds, const int off
 // Every workgroup writes ONE partial per tap, so the finish pass reads nsplit blocks.  The next tile's operands are
 // fetched into registers while the current one is multiplied (the launches are short: exposed load latency per tile
 // was most of their time).
+// gx / gy: the launch's extent in x (pixel splits) and y (pairs) for THIS job (gridDim.x / gridDim.y of a one-job launch)
 template <int TAPS>
-__device__ __forceinline__ void wgrad_body(const WgArgs& a) {
+__device__ __forceinline__ void wgrad_body(const WgArgs& a, const int gx, const int gy) {
   constexpr int NW = TAPS == 1 ? 4 : 3, NT = NW * 64;
   constexpr int TPW = TAPS == 9 ? 3 : 1;                    // taps per wave
   constexpr int HALO = TAPS == 9 ? 1 : 0;
@@ -230,7 +231,7 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a) {
 
   int tile = blockIdx.x;
   if (tile < a.ntiles) fetch(tile);
-  for (; tile < a.ntiles; tile += gridDim.x) {
+  for (; tile < a.ntiles; tile += gx) {
     const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y;
     const int tx0 = tx * 16, ty0 = ty * 16;
     __syncthreads();                       // the previous tile's fragments have been read
@@ -245,7 +246,7 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a) {
       if (i < QF * QPIX * 4) *reinterpret_cast<u32x4*>(lq + (size_t)(i >> 2) * 64 + (i & 3) * 16) = ((okq >> it) & 1u) ? qreg[it] : u32x4{0u, 0u, 0u, 0u};
     }
     __syncthreads();
-    if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
+    if (tile + gx < a.ntiles) fetch(tile + gx);
     // 16 patches of 4x4 pixels; patches wholly outside the image are skipped (wave-uniform: the transposing
     // read needs EXEC all ones).  TAPS == 1: each wave takes 4 of them; otherwise each wave takes all 16 for its taps.
     for (int pi = (TAPS == 1 ? wave : 0); pi < 16; pi += (TAPS == 1 ? 4 : 1)) {
@@ -266,8 +267,8 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a) {
     }
   }
   // D[o][c]: lane owns column c = lane & 31, rows o = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int npairs = a.multi ? (int)gridDim.y : (int)(gridDim.y * gridDim.z);
-  const int pair = a.multi ? (int)blockIdx.y : (int)(blockIdx.z * gridDim.y + blockIdx.y);
+  const int npairs = a.multi ? gy : (int)(gy * gridDim.z);
+  const int pair = a.multi ? (int)blockIdx.y : (int)(blockIdx.z * gy + blockIdx.y);
   const size_t blk = (size_t)blockIdx.x * npairs + pair;
   if (TAPS == 1) {
     // reduce the 4 waves' accumulators (and bias sums) through LDS, wave 0 writes
@@ -314,13 +315,30 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a) {
 
 template <int TAPS>
 __global__ __launch_bounds__((TAPS == 1 ? 4 : 3) * 64) void wgrad_kernel(const WgArgs a) {
-  wgrad_body<TAPS>(a);
+  wgrad_body<TAPS>(a, (int)gridDim.x, (int)gridDim.y);
 }
 
 // multi mode only (conv1..4 of a dense block, grid.z unused by the body): the jobs of two nets of one geometry in one launch
 __global__ __launch_bounds__(192) void wgrad_pair_kernel(const WgArgs a, const WgArgs b) {
-  if (blockIdx.z) wgrad_body<9>(b);
-  else wgrad_body<9>(a);
+  if (blockIdx.z) wgrad_body<9>(b, (int)gridDim.x, (int)gridDim.y);
+  else wgrad_body<9>(a, (int)gridDim.x, (int)gridDim.y);
+}
+
+// Up to WG_TABLE conv1..4 jobs (multi mode) in ONE launch: blockIdx.z = job, whose own extent is gx[z] x gy[z] (the rest of the grid
+// returns at once).  A training step is a serial chain of launches that each under-fill the chip (one stream and three streams take
+// the same time inside a replayed graph on this runtime): the weight gradients of a whole block stack - independent of everything
+// behind them - are therefore ONE fat launch at the end of the stack's data-gradient chain instead of 24 thin ones beside it.
+constexpr int WG_TABLE = 32;
+struct WgTable {
+  int n;
+  int gx[WG_TABLE], gy[WG_TABLE];
+  WgArgs job[WG_TABLE];
+};
+static_assert(sizeof(WgTable) <= 4096, "kernel argument limit");
+__global__ __launch_bounds__(192) void wgrad_table_kernel(const WgTable t) {
+  const int z = blockIdx.z;
+  if ((int)blockIdx.x >= t.gx[z] || (int)blockIdx.y >= t.gy[z]) return;          // workgroup-uniform
+  wgrad_body<9>(t.job[z], t.gx[z], t.gy[z]);
 }
 
 // Temporal weight gradient (conv5 of D2DTInput: dW[o][c][tap] = sum_px g[n][px][o] * in[n + tap - 1][px][c] inside each clip).
@@ -328,7 +346,7 @@ __global__ __launch_bounds__(192) void wgrad_pair_kernel(const WgArgs a, const W
 // activation tiles in LDS, so every frame's tile is loaded once (the generic kernel loaded three per frame) while the next
 // frame's two tiles are prefetched into registers; wave w multiplies with the ring slot of frame t + w - 1.
 // bz / nz: this workgroup's gradient plane and the number of gradient planes of its net (blockIdx.z / gridDim.z of a one-net launch)
-__device__ __forceinline__ void wgrad_temporal_body(const WgArgs& a, const int bz, const int nz) {
+__device__ __forceinline__ void wgrad_temporal_body(const WgArgs& a, const int bz, const int nz, const int gx, const int gy) {
   constexpr int NT = 192, PI = (1024 + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) unsigned char lp[256 * 64];
   __shared__ __attribute__((aligned(16))) unsigned char lq[3 * 256 * 64];
@@ -376,7 +394,7 @@ __device__ __forceinline__ void wgrad_temporal_body(const WgArgs& a, const int b
   };
 
   const int nunits = (a.N / T) * a.tiles_x * a.tiles_y;
-  for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+  for (int unit = blockIdx.x; unit < nunits; unit += gx) {
     const int tx = unit % a.tiles_x, ty = (unit / a.tiles_x) % a.tiles_y, clip = unit / (a.tiles_x * a.tiles_y);
     const int tx0 = tx * 16, ty0 = ty * 16, nbase = clip * T;
     // ring slots: frame f lives in slot (f + 1) % 3; slot of frame -1 is zero, frame 0 is loaded up front
@@ -408,8 +426,8 @@ __device__ __forceinline__ void wgrad_temporal_body(const WgArgs& a, const int b
       }
     }
   }
-  const int npairs = (int)gridDim.y * nz;
-  const int pair = bz * (int)gridDim.y + (int)blockIdx.y;
+  const int npairs = gy * nz;
+  const int pair = bz * gy + (int)blockIdx.y;
   float* __restrict__ base = a.part + ((((size_t)blockIdx.x * npairs + pair) * 3 + wave) << 10);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -424,14 +442,29 @@ __device__ __forceinline__ void wgrad_temporal_body(const WgArgs& a, const int b
 }
 
 __global__ __launch_bounds__(192) void wgrad_temporal_kernel(const WgArgs a) {
-  wgrad_temporal_body(a, (int)blockIdx.z, (int)gridDim.z);
+  wgrad_temporal_body(a, (int)blockIdx.z, (int)gridDim.z, (int)gridDim.x, (int)gridDim.y);
 }
 
 // two nets of one geometry: blockIdx.z in [0, 2 Pn)
 __global__ __launch_bounds__(192) void wgrad_temporal_pair_kernel(const WgArgs a, const WgArgs b) {
   const int nz = (int)gridDim.z >> 1;
-  if ((int)blockIdx.z >= nz) wgrad_temporal_body(b, (int)blockIdx.z - nz, nz);
-  else wgrad_temporal_body(a, (int)blockIdx.z, nz);
+  if ((int)blockIdx.z >= nz) wgrad_temporal_body(b, (int)blockIdx.z - nz, nz, (int)gridDim.x, (int)gridDim.y);
+  else wgrad_temporal_body(a, (int)blockIdx.z, nz, (int)gridDim.x, (int)gridDim.y);
+}
+
+// Up to WG_TABLE temporal (conv5) jobs in one launch: blockIdx.z runs over all jobs' gradient planes (zstart: job j owns
+// [zstart[j], zstart[j + 1])), each job with its own extent gx x gy
+struct WgTTable {
+  int n;
+  int gx[WG_TABLE], gy[WG_TABLE], zstart[WG_TABLE + 1];
+  WgArgs job[WG_TABLE];
+};
+static_assert(sizeof(WgTTable) <= 4096, "kernel argument limit");
+__global__ __launch_bounds__(192) void wgrad_temporal_table_kernel(const WgTTable t) {
+  int j = 0;
+  while (j + 1 < t.n && (int)blockIdx.z >= t.zstart[j + 1]) ++j;                  // workgroup-uniform
+  if ((int)blockIdx.x >= t.gx[j] || (int)blockIdx.y >= t.gy[j]) return;
+  wgrad_temporal_body(t.job[j], (int)blockIdx.z - t.zstart[j], t.zstart[j + 1] - t.zstart[j], t.gx[j], t.gy[j]);
 }
 
 struct FinArgs {
@@ -763,7 +796,16 @@ int launch_wgrad_any(const WgArgs& a, int nsplit, int gy, int gz, hipStream_t s)
 }
 }  // namespace
 
-static int bwd_wgrad_impl(const WgradJob& j, const float* amax, void* scratch, int N, int T, int H, int W, hipStream_t s, FinArgs* defer) {
+// a deferred weight-gradient launch (host side): the kernel arguments + its own grid extent
+struct WgJob {
+  WgArgs a;
+  int kind;              // 0: conv1..4 (wgrad_body<9>, multi), 1: temporal conv5
+  int gx, gy, nz;        // pixel splits, pairs (kind 0) / input planes (kind 1), gradient planes (kind 1)
+};
+
+static void wg_job_set(WgJob* dst, const WgArgs& a, int kind, int gx, int gy, int nz);
+static int bwd_wgrad_impl(const WgradJob& j, const float* amax, void* scratch, int N, int T, int H, int W, hipStream_t s, FinArgs* defer,
+                          WgJob* defer_wg = nullptr) {
   const size_t npix = (size_t)N * H * W, plane = npix * 32;
   const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
   const int qtot = j.Qn[0] + j.Qn[1];
@@ -780,9 +822,12 @@ static int bwd_wgrad_impl(const WgradJob& j, const float* amax, void* scratch, i
   a.P = (const f16*)j.P; a.Q0 = (const f16*)j.Q[0]; a.nq0 = j.Qn[0]; a.Q1 = (const f16*)j.Q[1];
   a.part = part; a.bpart = j.bout ? bpart : nullptr; a.plane = plane;
   a.N = N; a.T = T; a.H = H; a.W = W; a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.ntiles = N * tiles_x * tiles_y;
-  int rc = ttot == 9 ? launch_wgrad_any<9>(a, nsplit, qtot, j.Pn, s)
-         : ttot == 1 ? launch_wgrad_any<1>(a, nsplit, qtot, j.Pn, s) : SELFC_OK;
-  if (ttot == 3) {
+  int rc = SELFC_OK;
+  const bool dwg = defer_wg && defer && ttot == 3;           // only the temporal job can be deferred (the table kernels cover multi + temporal)
+  if (dwg) wg_job_set(defer_wg, a, 1, nsplit, qtot, j.Pn);
+  else rc = ttot == 9 ? launch_wgrad_any<9>(a, nsplit, qtot, j.Pn, s)
+          : ttot == 1 ? launch_wgrad_any<1>(a, nsplit, qtot, j.Pn, s) : SELFC_OK;
+  if (ttot == 3 && !dwg) {
     hipLaunchKernelGGL(wgrad_temporal_kernel, dim3((unsigned)nsplit, (unsigned)qtot, (unsigned)j.Pn), dim3(192), 0, s, a);
     rc = hip_rc(hipGetLastError());
   }
@@ -823,15 +868,49 @@ static void wgrad14_args(const void* dpre, const void* Q0, int nq0, const void* 
 
 int bwd_wgrad14(const void* dpre, const void* Q0, int nq0, const void* Q1, int nqc1, int cin, int nx,
                 float* const* wout, float* const* bout, float beta, const float* amax, void* scratch,
-                int N, int T, int H, int W, hipStream_t s, FinArgs* defer) {
+                int N, int T, int H, int W, hipStream_t s, FinArgs* defer, WgJob* defer_wg = nullptr) {
   WgArgs a; FinArgs f; int nsplit, npairs;
   wgrad14_args(dpre, Q0, nq0, Q1, nqc1, cin, nx, wout, bout, beta, amax, scratch, N, T, H, W, a, f, nsplit, npairs);
+  if (defer_wg && defer) { *defer_wg = WgJob{a, 0, nsplit, npairs, 1}; *defer = f; return SELFC_OK; }
   int rc = launch_wgrad_any<9>(a, nsplit, npairs, 1, s);
   if (rc) return rc;
   if (defer) { *defer = f; return SELFC_OK; }
   hipLaunchKernelGGL(wgrad_finish_kernel, dim3(fin_blocks(f)), dim3(256), 0, s, f);
   return hip_rc(hipGetLastError());
 }
+
+// run deferred weight-gradient jobs: all conv1..4 jobs as one launch per WG_TABLE, all temporal jobs as another
+static int launch_wg_jobs(const WgJob* jobs, int njobs, hipStream_t s) {
+  for (int kind = 0; kind < 2; ++kind) {
+    int j = 0;
+    while (j < njobs) {
+      WgTable t{};
+      WgTTable tt{};
+      int mx = 0, my = 0, nz = 0, n = 0;
+      for (; j < njobs && n < WG_TABLE; ++j) {
+        if (jobs[j].kind != kind) continue;
+        if (kind == 0) { t.job[n] = jobs[j].a; t.gx[n] = jobs[j].gx; t.gy[n] = jobs[j].gy; }
+        else { tt.job[n] = jobs[j].a; tt.gx[n] = jobs[j].gx; tt.gy[n] = jobs[j].gy; tt.zstart[n] = nz; nz += jobs[j].nz; }
+        mx = jobs[j].gx > mx ? jobs[j].gx : mx;
+        my = jobs[j].gy > my ? jobs[j].gy : my;
+        ++n;
+      }
+      if (!n) break;
+      if (kind == 0) {
+        t.n = n;
+        hipLaunchKernelGGL(wgrad_table_kernel, dim3((unsigned)mx, (unsigned)my, (unsigned)n), dim3(192), 0, s, t);
+      } else {
+        tt.n = n; tt.zstart[n] = nz;
+        hipLaunchKernelGGL(wgrad_temporal_table_kernel, dim3((unsigned)mx, (unsigned)my, (unsigned)nz), dim3(192), 0, s, tt);
+      }
+      const int rc = hip_rc(hipGetLastError());
+      if (rc) return rc;
+    }
+  }
+  return SELFC_OK;
+}
+
+static void wg_job_set(WgJob* dst, const WgArgs& a, int kind, int gx, int gy, int nz) { *dst = WgJob{a, kind, gx, gy, nz}; }
 
 // launch up to FIN_TABLE deferred finish jobs per kernel
 static int launch_fin_jobs(const FinArgs* jobs, int njobs, hipStream_t s) {
@@ -877,10 +956,16 @@ int selfc_subnet_bwd_phase_x(int phases, const selfc_subnet_bw* bw, int kind, co
                              void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout,
                              const float* dout_amax, float* dx_amax_out, void* stream) {
   return selfc_subnet_bwd_phase_d(phases, bw, kind, dense, xin, dout, sign, dx, accumulate_dx, wgrad, bgrad, beta, scratch, scratch_bytes,
-                                  N, T, H, W, cin, cout, dout_amax, dx_amax_out, nullptr, stream);
+                                  N, T, H, W, cin, cout, dout_amax, dx_amax_out, nullptr, nullptr, stream);
 }
 
 size_t selfc_fin_job_bytes(void) { return sizeof(FinArgs); }
+size_t selfc_wg_job_bytes(void) { return sizeof(WgJob); }
+
+int selfc_wgrad_run_jobs(const void* jobs, int njobs, void* stream) {
+  if (!jobs || njobs < 0) return SELFC_EINVAL;
+  return launch_wg_jobs((const WgJob*)jobs, njobs, (hipStream_t)stream);
+}
 
 int selfc_wgrad_finish_jobs(const void* jobs, int njobs, void* stream) {
   if (!jobs || njobs < 0) return SELFC_EINVAL;
@@ -890,8 +975,9 @@ int selfc_wgrad_finish_jobs(const void* jobs, int njobs, void* stream) {
 int selfc_subnet_bwd_phase_d(int phases, const selfc_subnet_bw* bw, int kind, const void* dense, const float* xin, const float* dout,
                              float sign, float* dx, int accumulate_dx, float* const* wgrad, float* const* bgrad, float beta,
                              void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout,
-                             const float* dout_amax, float* dx_amax_out, void* fin_jobs, void* stream) {
+                             const float* dout_amax, float* dx_amax_out, void* fin_jobs, void* wg_jobs, void* stream) {
   if (!(phases & (SELFC_BWD_DATA | SELFC_BWD_WEIGHTS))) return SELFC_EINVAL;
+  if (wg_jobs && (!fin_jobs || kind != SELFC_SUBNET_D2DT)) return SELFC_EINVAL;      // deferred launches need deferred finishes; temporal conv5 only
   if (!bw || !dense || !dout || !scratch || !bw->wt5 || !bw->wtx || !bw->wtd[0] || !bw->wtd[1] || !bw->wtd[2]) return SELFC_EINVAL;
   if (N <= 0 || T <= 0 || N % T || H <= 0 || W <= 0 || cin < 1 || cin > 96 || cout < 1 || cout > 96) return SELFC_EINVAL;
   if (kind != SELFC_SUBNET_D2DT && kind != SELFC_SUBNET_DB2D) return SELFC_EINVAL;
@@ -976,7 +1062,8 @@ weights:
     const void* q0 = L.hasx ? (const void*)xpl : (const void*)dn;
     const int nq0 = L.hasx ? 1 : L.nx + 4;
     FinArgs fa{}, fb{};
-    if ((rc = bwd_wgrad14(gb, q0, nq0, feat, L.nx, cin, L.nx, wgrad, bgrad, beta, amax, wgs, N, T, H, W, s, &fa))) return rc;
+    WgJob* wj = (WgJob*)wg_jobs;
+    if ((rc = bwd_wgrad14(gb, q0, nq0, feat, L.nx, cin, L.nx, wgrad, bgrad, beta, amax, wgs, N, T, H, W, s, &fa, wj))) return rc;
     WgradJob j{};
     j.P = gpl; j.Pn = L.ng;
     j.Q[0] = q0; j.Qn[0] = nq0;
@@ -987,7 +1074,8 @@ weights:
     j.bout = bgrad ? bgrad[4] : nullptr;
     j.O = cout; j.Ctot = cin + 128; j.cin = cin; j.nx = L.nx; j.beta = beta;
     const bool has5 = j.wout || j.bout;
-    if ((rc = bwd_wgrad_impl(j, amax, sb + L.off_wg5, N, T, H, W, s, &fb))) return rc;
+    if (wj) wj[1] = WgJob{WgArgs{}, 1, 0, 0, 0};           // (stays empty when conv5 wants no gradient: extent 0)
+    if ((rc = bwd_wgrad_impl(j, amax, sb + L.off_wg5, N, T, H, W, s, &fb, wj ? wj + 1 : nullptr))) return rc;
     if (fin_jobs) {          // deferred: the caller finishes many subnets' jobs in one launch (selfc_wgrad_finish_jobs); a job without
       FinArgs* out = (FinArgs*)fin_jobs;       // outputs has zero blocks there
       out[0] = fa;
@@ -1049,8 +1137,9 @@ int selfc_gh_bwd_pair(int phases, const selfc_subnet_bw* bw_g, const selfc_subne
                       const float* xin, const float* dout_g, const float* dout_h, float sign_g, float sign_h,
                       float* dx, int accumulate_dx, float* const* wgrad_g, float* const* bgrad_g, float* const* wgrad_h, float* const* bgrad_h,
                       float beta, void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout,
-                      const float* amax_g, const float* amax_h, float* dx_amax_out, void* fin_jobs, void* stream) {
+                      const float* amax_g, const float* amax_h, float* dx_amax_out, void* fin_jobs, void* wg_jobs, void* stream) {
   if (!(phases & (SELFC_BWD_DATA | SELFC_BWD_WEIGHTS))) return SELFC_EINVAL;
+  if (wg_jobs && !fin_jobs) return SELFC_EINVAL;
   if (!bw_g || !bw_h || !dense_g || !dense_h || !xin || !dout_g || !dout_h || !scratch) return SELFC_EINVAL;
   for (const selfc_subnet_bw* bw : {bw_g, bw_h})
     if (!bw->wt5 || !bw->wtx || !bw->wtd[0] || !bw->wtd[1] || !bw->wtd[2]) return SELFC_EINVAL;
@@ -1146,17 +1235,83 @@ int selfc_gh_bwd_pair(int phases, const selfc_subnet_bw* bw_g, const selfc_subne
         f.O = cout; f.Ctot = cin + 128; f.cin = cin; f.nx = L.nx; f.npairs = L.ng * qtot; f.amax = amax; f.beta = beta;
       }
     }
+    const FinArgs jobs[4] = {f14[0], f5[0], f14[1], f5[1]};
+    if (wg_jobs) {           // the launches themselves are deferred too: the caller runs a whole stack's jobs as two launches
+      WgJob* wj = (WgJob*)wg_jobs;
+      for (int q = 0; q < 2; ++q) {
+        wj[2 * q] = WgJob{a14[q], 0, nsplit14, npairs14, 1};
+        wj[2 * q + 1] = WgJob{a5[q], 1, nsplit5, qtot, L.ng};
+      }
+      for (int j = 0; j < 4; ++j) ((FinArgs*)fin_jobs)[j] = jobs[j];
+      return SELFC_OK;
+    }
     hipLaunchKernelGGL(wgrad_pair_kernel, dim3((unsigned)nsplit14, (unsigned)npairs14, 2), dim3(192), 0, s, a14[0], a14[1]);
     if ((rc = hip_rc(hipGetLastError()))) return rc;
     hipLaunchKernelGGL(wgrad_temporal_pair_kernel, dim3((unsigned)nsplit5, (unsigned)qtot, (unsigned)(2 * L.ng)), dim3(192), 0, s, a5[0], a5[1]);
     if ((rc = hip_rc(hipGetLastError()))) return rc;
-    const FinArgs jobs[4] = {f14[0], f5[0], f14[1], f5[1]};
     if (fin_jobs) {
       for (int j = 0; j < 4; ++j) ((FinArgs*)fin_jobs)[j] = jobs[j];
       return SELFC_OK;
     }
     return launch_fin_jobs(jobs, 4, s);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ReconstructionLoss (models/modules/loss.py:5-21) as two launches: v = (x - t)^2 ('l2') or sqrt((x - t)^2 + eps) ('l1'), the
+// reference's mean over the four axes (equal group sizes: sum / count), AND dv/dx in the same pass (the gradient of the loss w.r.t.
+// x does not depend on the loss value) - the torch expression is ~10 element-wise / reduction launches forward and ~12 backward, each
+// a 4.5-us node of a replayed training step.  Deterministic: a fixed block -> chunk map, a tree per block, partials summed in order
+// by one block (no atomics, no memset: capturable).  x / t: n_outer rows of `inner` contiguous floats at row strides sx / st (a
+// channel slice of an NCHW tensor is such a view).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int LOSS_BLOCKS = 512;
+__global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict__ x, size_t sx, const float* __restrict__ t, size_t st, size_t n_outer,
+                                                         size_t inner, int l1, float eps, float gscale, float* __restrict__ grad, double* __restrict__ partial) {
+  const size_t total = n_outer * inner;
+  const size_t chunk = (total + gridDim.x - 1) / gridDim.x;
+  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < total ? lo + chunk : total;
+  double acc = 0.0;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const size_t r = i / inner, c = i - r * inner;
+    const float d = x[r * sx + c] - t[r * st + c];
+    float v, g;
+    if (l1) { v = sqrtf(d * d + eps); g = d / v; }
+    else { v = d * d; g = 2.f * d; }
+    acc += (double)v;
+    if (grad) grad[i] = g * gscale;
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(64) void recon_loss_final_kernel(const double* __restrict__ partial, int n, double scale, float* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    double s_ = 0.0;
+    for (int i = 0; i < n; ++i) s_ += partial[i];
+    *out = (float)(s_ * scale);
+  }
+}
+}  // namespace
+
+int selfc_recon_loss_blocks(void) { return LOSS_BLOCKS; }
+
+int selfc_recon_loss(const float* x, size_t stride_x, const float* t, size_t stride_t, size_t n_outer, size_t inner, int l1, float eps,
+                     float weight, float* grad, double* partial, float* out, void* stream) {
+  if (!x || !t || !partial || !out || n_outer == 0 || inner == 0 || stride_x < inner || stride_t < inner) return SELFC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const double inv = (double)weight / ((double)n_outer * (double)inner);
+  hipLaunchKernelGGL(recon_loss_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, s, x, stride_x, t, stride_t, n_outer, inner, l1, eps, (float)inv, grad, partial);
+  int rc = hip_rc(hipGetLastError());
+  if (rc) return rc;
+  hipLaunchKernelGGL(recon_loss_final_kernel, dim3(1), dim3(64), 0, s, partial, LOSS_BLOCKS, inv, out);
+  return hip_rc(hipGetLastError());
 }
 
 int selfc_coupling_fwd(int rev, const float* x2, const float* g, const float* h, float* y2, float* s, float clamp, size_t n, void* stream) {

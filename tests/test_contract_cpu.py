@@ -175,3 +175,39 @@ def test_bench_host_weights_checks_its_copies(tmp_path, monkeypatch):
     assert info["wrong_bytes_equal_the_same_region_of"] == ["other"] and not info["wrong_bytes_all_zero"]
     assert info["second_copy_matches_the_device"] and os.path.exists(os.path.join(str(tmp_path), info["dump"]))
     assert "host" in bench.box_identity()
+
+
+def test_bench_compact_line_is_what_the_driver_keeps():
+    """bench.py prints ONE line of the driver's standard keys + config / roofline / cpu_baseline with scalar values only and
+    strings under 120 characters (the driver's record drops nested objects and every other top-level key: BENCH_r05 lost all
+    secondary legs that way); the secondary legs travel as flat scalars inside `roofline`."""
+    import json
+    import bench
+    out = {"metric": "m", "value": 1500.0, "unit": "septuplets/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 2.6, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic", "rccl_ranks": 1,
+           "config": {"workload": "w" * 300, "septuplets_per_gpu": 4, "launch": "hipGraph replay (one graph)", "streams": 2, "sharding": "s" * 200, "prewarm": "p" * 200,
+                      "graph_form_probe": {"a": 1}},
+           "box_calibration": {"shader_clock_GHz_under_the_workload": 2.4, "mfma_f16_loop_TFLOPs": 2500.0, "device_copy_GBps": 5000.0},
+           "box_identity": {"host": "h"},
+           "roofline": {"bound": "mfma", "kernel": "k" * 200, "achieved": 660.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.264, "traffic": 1.0e8,
+                        "avg_launch_us": 71.0, "rocprof_avg_us": 77.0, "pmc_reference_file": "profiles/r6/pmc_traffic.json"},
+           "roofline_other": {"conv5_GH": {"achieved": 4500.0, "frac": 0.56}, "conv3x3": {"frac": 0.3}},
+           "stack_roofline": {"mfma_frac": 0.26, "hbm_frac_layer_granular": 0.55},
+           "train_step": {"ms_per_step": 11.0, "captured_ms_per_step_by_local_batch": {"1": 6.0, "2": 7.0, "4": 8.0, "8": 11.0}, "mfma_frac": 0.08,
+                          "graph_nodes": 600, "graph_nodes_b1": 590, "eager_ms_per_step": 17.0, "pmc_reference_file": {"file": "x", "same_sources": None}},
+           "uvg_1080p": {"frames_per_s": 430.0, "mfma_frac_whole_path": 0.24}, "full_test_path": {"septuplets_per_s": 1090.0, "mfma_frac_whole_path": 0.237},
+           "headline_through_module_api": {"septuplets_per_s": 1440.0},
+           "parity": {"fwd_latent_rel_err": 3.2e-4, "inv_rel_err": 5.9e-4, "fwd_latent_rel_l2": 2.8e-4, "inv_rel_l2": 2.9e-4},
+           "cpu_baseline": {"value": 1.3, "unit": "septuplets/s", "cores": 16, "kind": "port", "cpu_model": "EPYC", "host_copy_errors": [], "sample": "x" * 300}}
+    line = bench.compact_line(out)
+    allowed = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+               "config", "roofline", "cpu_baseline"}
+    assert set(line) == allowed
+    for key in ("config", "roofline", "cpu_baseline"):
+        for k, v in line[key].items():
+            assert not isinstance(v, (dict, list)), (key, k)
+            assert not isinstance(v, str) or len(v) < 120, (key, k, len(v))
+    r = line["roofline"]
+    assert r["train_step_ms_b8"] == 11.0 and r["train_step_ms_b1"] == 6.0 and r["train_step_graph_nodes"] == 600 and r["uvg_1080p_frames_per_s"] == 430.0
+    assert r["full_test_path_septuplets_per_s"] == 1090.0 and r["parity_inv_rel_err"] == 5.9e-4 and r["rocprof_avg_us"] == 77.0
+    assert len(json.dumps(line)) < 3600

@@ -36,7 +36,7 @@ def test_bench_two_gpus_self_launched():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"],
                        env=_clean_env(), capture_output=True, text=True, timeout=900)
     d = _json_line(p)
-    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["value"] > 0
 
 
 def _train2(*extra):
@@ -58,7 +58,7 @@ def test_bench_two_ranks_share_one_gpu():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3"],
                        env=env, capture_output=True, text=True, timeout=900)
     d = _json_line(p)
-    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "REHEARSAL" in d["config"]["sharding"]
     assert "full_test_path" not in d and "train_step" not in d and "cpu_baseline" not in d      # the one-rank legs stay off
     assert d["value"] < 2500, d["value"]        # two ranks share one chip: the whole-job rate cannot be twice the one-GPU rate

@@ -561,11 +561,12 @@ def test_folded_gradient_maxima_change_nothing(dev):
         assert not bad, f"streams={two}: {len(bad)} gradients differ, e.g. {bad[:4]}"
 
 
-@pytest.mark.parametrize("defer", [True, False])
+@pytest.mark.parametrize("defer", ["launches+finishes", "finishes", "nothing"])
 def test_paired_gh_backward_equals_the_two_subnet_calls(dev, defer):
     """Round 6: G and H of a coupling block run their backward as ONE call (selfc_gh_bwd_pair: every launch covers both nets, one
     power-of-two gradient scale from the larger of the two maxima, the input gradient one conv over both nets' planes) and the
-    weight-gradient partials of the whole stack are reduced by one launch per 24 jobs (FinJobs).  Against round 5's two subnet calls on
+    weight-gradient work of the whole stack is deferred to the end of its data-gradient chain (FinJobs: the finishes as one launch per 24
+    jobs; with "launches+finishes" the weight-gradient kernels themselves as one launch per kind).  Against round 5's two subnet calls on
     two streams (SELFC_BWD_PAIR=0, finishes per subnet): the same f16 operands up to the exact power-of-two scale, the same fp32 sums
     up to the order of two additions in y1's gradient - which the next subnet rounds to f16 again, so a last-bit difference there is
     a 1e-3 difference of single elements further down the 16 block calls.  Measured: 1.6e-4 worst per-tensor relative L2 (floor: 1e-7
@@ -577,8 +578,8 @@ def test_paired_gh_backward_equals_the_two_subnet_calls(dev, defer):
     real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
 
     def grads(pair, defer_):
-        old = ag._PAIR, ag._DEFER_FIN
-        ag._PAIR, ag._DEFER_FIN = pair, defer_
+        old = ag._PAIR, ag._DEFER_FIN, ag._DEFER_WG
+        ag._PAIR, ag._DEFER_FIN, ag._DEFER_WG = pair, defer_ != "nothing", defer_ == "launches+finishes"
         try:
             net = _net(dev)
             tr = train.RescaleTrainer(net, dict(train.TRAIN_OPT_LARGE), flat_params=False)
@@ -587,13 +588,13 @@ def test_paired_gh_backward_equals_the_two_subnet_calls(dev, defer):
             torch.cuda.synchronize()
             return {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}, [float(v) for v in losses[:2]]
         finally:
-            ag._PAIR, ag._DEFER_FIN = old
+            ag._PAIR, ag._DEFER_FIN, ag._DEFER_WG = old
 
-    (a, la), (b, lb) = grads(False, False), grads(True, defer)
+    (a, la), (b, lb) = grads(False, "nothing"), grads(True, defer)
     assert set(a) == set(b) and la == lb
     g_all = float(torch.sqrt(sum((v.double() ** 2).sum() for v in a.values())))
     worst = max(float((a[n] - b[n]).norm() / (a[n].norm() + 1e-7 * g_all)) for n in a)
-    record(f"paired G/H backward (deferred finishes: {defer}) vs two subnet calls: worst per-tensor relative L2", worst)
+    record(f"paired G/H backward (deferred: {defer}) vs two subnet calls: worst per-tensor relative L2", worst)
     assert worst < 6e-4, worst
 
 

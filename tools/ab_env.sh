@@ -5,7 +5,7 @@
 set -u
 ROUNDS=$1; shift
 mkdir -p gpurun_out
-ARGS="bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline --no-full-path --no-uvg --no-train-step ${EXTRA:-}"
+ARGS="bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline --no-full-path --no-uvg --no-train-step --full-line ${EXTRA:-}"
 for r in $(seq 1 $ROUNDS); do
   for v in "$@"; do
     env $v timeout -k 10 180 python3 $ARGS 2>/dev/null | python3 -c "

@@ -5,7 +5,7 @@
 set -u
 ROUNDS=$1; shift
 mkdir -p gpurun_out
-ARGS="bench.py --steps ${STEPS:-40} --warmup 10 --no-cpu-baseline --no-full-path --no-uvg --no-train-step"
+ARGS="bench.py --steps ${STEPS:-40} --warmup 10 --no-cpu-baseline --no-full-path --no-uvg --no-train-step --full-line"
 for r in $(seq 1 $ROUNDS); do
   for lib in "$@"; do
     SELFC_LIB=$PWD/$lib timeout -k 10 120 python3 $ARGS 2>/dev/null | python3 -c "

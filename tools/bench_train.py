@@ -32,8 +32,18 @@ def run(batch=8, size=144, steps=10, warmup=3, fh_loss="gmm", profile=False, gra
     real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
     for _ in range(a.warmup):
         tr.optimize_parameters(real_h, ref_l)
+    graph_nodes = None
     if a.graph:
-        tr.capture(real_h, ref_l)
+        from selfc_amd import runtime as rt
+        keep, n_log = rt.KEEP_GRAPHS, len(rt.GRAPH_LOG)
+        rt.KEEP_GRAPHS = True                    # node census of the captured step (selfc_graph_stats)
+        try:
+            tr.capture(real_h, ref_l)
+        finally:
+            rt.KEEP_GRAPHS = keep
+        if len(rt.GRAPH_LOG) > n_log:
+            graph_nodes = rt.GRAPH_LOG[-1]
+            del rt.GRAPH_LOG[n_log:]
         if os.environ.get("SELFC_BT_TRACE"):
             print("static loss tensors", [(t_.data_ptr(), tuple(t_.shape), t_.dtype) for t_ in tr._static_losses], file=sys.stderr, flush=True)
         tr.optimize_parameters(real_h, ref_l)
@@ -51,7 +61,7 @@ def run(batch=8, size=144, steps=10, warmup=3, fh_loss="gmm", profile=False, gra
     dt = (time.perf_counter() - t0) / a.steps
     out = {"metric": "training septuplets/s (optimize_parameters, 7x3x%dx%d crops)" % (a.size, a.size), "value": a.batch / dt,
            "ms_per_step": dt * 1e3, "batch": a.batch, "fh_loss": a.fh_loss, "loss": log["loss"], "dtype": _lib.OPERAND,
-           "launch": "hipGraph replay of the whole step" if a.graph else "eager"}
+           "launch": "hipGraph replay of the whole step" if a.graph else "eager", "graph_nodes": graph_nodes}
     if a.profile:
         L.selfc_profile_enable(0)
         names = {0: "conv3x3", 1: "conv5_F", 2: "conv5_GH", 3: "transforms", 4: "conv5_plain", 5: "stp", 6: "fused_gh", 7: "backward"}

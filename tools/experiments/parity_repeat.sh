@@ -7,7 +7,7 @@
 N=${1:-6}
 mkdir -p gpurun_out
 for i in $(seq 1 $N); do
-  python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/_pr_line.json 2> gpurun_out/_pr_err.txt; rc=$?
+  python3 bench.py --gpus 1 --steps 20 --warmup 5 --full-line > gpurun_out/_pr_line.json 2> gpurun_out/_pr_err.txt; rc=$?
   if [ $rc -ne 0 ] || [ ! -s gpurun_out/_pr_line.json ]; then
     cp gpurun_out/_pr_err.txt gpurun_out/parity_repeat_fail_$i.err
     echo "run $i FAILED rc=$rc (line on stdout: $(wc -c < gpurun_out/_pr_line.json) bytes): $(grep -v amdgpu.ids gpurun_out/_pr_err.txt | grep -v '^Extension modules' | tail -12 | tr '\n' '|' | cut -c1-900)"

@@ -1,0 +1,26 @@
+export TMPDIR=/tmp
+O=gpurun_out/r6knobs2
+mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_gpu_train.py -x -q -k "paired or trajectory or memset or captured_step or bit_identical or side_stream or folded" > $O/pytest.log 2>&1 || { tail -40 $O/pytest.log; exit 1; }
+tail -3 $O/pytest.log
+run() { tag=$1; shift; env "$@" timeout -k 10 200 python3 tools/bench_train.py --steps 30 --warmup 3 --batch $B --graph > $O/$tag.log 2>&1; python3 - <<PY
+import json
+try:
+    d=json.loads(open("$O/$tag.log").read().strip().splitlines()[-1]); print("$tag", "B=$B", round(d["ms_per_step"],3), (d.get("graph_nodes") or {}).get("nodes"))
+except Exception as e: print("$tag FAILED", e)
+PY
+}
+for B in 1 2 4 8; do
+  run base_b$B X=1
+  run base2_b$B X=1
+  run nodeferwg_b$B SELFC_BWD_DEFER_WG=0
+  run onestream_b$B SELFC_BWD_STREAMS=1
+  run old_b$B SELFC_BWD_PAIR=0 SELFC_BWD_DEFER_FIN=0
+  run old2_b$B SELFC_BWD_PAIR=0 SELFC_BWD_DEFER_FIN=0
+done
+for B in 1 8; do
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/tr$B -- python3 tools/bench_train.py --steps 8 --warmup 3 --batch $B --graph > $O/tr$B.log 2>&1
+python3 tools/trace_steps.py $O/tr$B 4 > $O/steps_b$B.txt 2>&1
+head -24 $O/steps_b$B.txt
+done
+find $O -name "*.csv" -size +30M -delete
