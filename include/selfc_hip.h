@@ -265,6 +265,16 @@ int selfc_gh_bwd_pair(int phases, const selfc_subnet_bw* bw_g, const selfc_subne
 int selfc_recon_loss_blocks(void);
 int selfc_recon_loss(const float* x, size_t stride_x, const float* t, size_t stride_t, size_t n_outer, size_t inner, int l1, float eps,
                      float weight, float* grad, double* partial, float* out, void* stream);
+/* (abi 13) nn.utils.clip_grad_norm_(max_norm) + torch.optim.Adam.step() (models/SelfC_model.py:172-176) on ONE flat fp32 buffer of n
+ * elements as two launches: the gradient's L2 norm (deterministic two-stage sum, *norm_out, the value clip_grad_norm_ returns), the
+ * gradient scaled IN PLACE by min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: no clipping) and Adam's update of param / exp_avg /
+ * exp_avg_sq in torch's operation order (amsgrad and maximize off).  step: `step_dev` (device float, incremented here - a capturable
+ * optimizer's state) or, when NULL, `step_host` = the already incremented count; lr likewise (`lr_dev` or `lr_host`).  partial:
+ * scratch of selfc_clip_adam_blocks() doubles.  No atomics, no memset: capturable. */
+int selfc_clip_adam_blocks(void);
+int selfc_clip_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double* partial, float max_norm,
+                    const float* lr_dev, float lr_host, double beta1, double beta2, float eps, float weight_decay,
+                    float* step_dev, float step_host, float* norm_out, void* stream);
 /* Adjoint of selfc_freq_fwd (latent grads d1 [N][h][w][4], d2 [N][h][w][48] -> dx NCHW (N,3,H,W)) and of selfc_freq_inv
  * (dout NCHW -> d1, d2). */
 int selfc_freq_fwd_bwd(const float* d1, const float* d2, float* dx, int N, int H, int W, void* stream);

@@ -43,7 +43,7 @@ SYMBOLS = [
     "selfc_globalagg_bwd_scratch_bytes", "selfc_globalagg_bwd", "selfc_rowsum_accum",
     "selfc_coupling_bwd_x", "selfc_add_absmax", "selfc_subnet_bwd_phase_x", "selfc_stream_create", "selfc_stream_destroy", "selfc_set_pointers", "selfc_freq_fwd_ind", "selfc_freq_inv_ind", "selfc_nchw_to_latent_ind", "selfc_latent_to_nchw_ind",
     "selfc_nchw_to_nhwc4_ind", "selfc_nhwc4_to_nchw_ind", "selfc_graph_stats",
-    "selfc_fin_job_bytes", "selfc_wgrad_finish_jobs", "selfc_subnet_bwd_phase_d", "selfc_gh_bwd_pair_scratch_bytes", "selfc_gh_bwd_pair", "selfc_recon_loss_blocks", "selfc_recon_loss", "selfc_wg_job_bytes", "selfc_wgrad_run_jobs",
+    "selfc_fin_job_bytes", "selfc_wgrad_finish_jobs", "selfc_subnet_bwd_phase_d", "selfc_gh_bwd_pair_scratch_bytes", "selfc_gh_bwd_pair", "selfc_recon_loss_blocks", "selfc_recon_loss", "selfc_wg_job_bytes", "selfc_wgrad_run_jobs", "selfc_clip_adam_blocks", "selfc_clip_adam",
 ]
 
 
@@ -138,6 +138,8 @@ def lib():
             "selfc_wgrad_run_jobs": [vp, i, vp],
             "selfc_recon_loss": [vp, sz, vp, sz, sz, sz, i, f, f, vp, vp, vp, vp],
             "selfc_recon_loss_blocks": [],
+            "selfc_clip_adam_blocks": [],
+            "selfc_clip_adam": [vp, vp, vp, vp, sz, vp, f, vp, f, C.c_double, C.c_double, f, f, vp, f, vp, vp],
             "selfc_coupling_bwd_x": [i, vp, vp, vp, vp, vp, f, sz, vp, vp, vp],
             "selfc_add_absmax": [vp, vp, sz, vp, vp],
             "selfc_coupling_fwd": [i, vp, vp, vp, vp, vp, f, sz, vp],

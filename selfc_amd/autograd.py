@@ -86,9 +86,12 @@ class FinJobs:
             self.n = 0
 
 
-#: weight gradients run on a second HIP stream, overlapping the (latency-bound) data-gradient chain of the next subnet;
-#: SELFC_BWD_STREAMS=1 keeps everything on the caller's stream
-_TWO_STREAMS = os.environ.get("SELFC_BWD_STREAMS", "2") != "1"
+#: SELFC_BWD_STREAMS=2: weight gradients (of the subnets outside a paired block stack: the STP chain) run on a second HIP stream and H's
+#: backward of an unpaired block on a third, as in rounds 1-5.  Default since round 6: ONE stream.  Inside a replayed graph the executor
+#: of this runtime maps branches onto hardware queues its own way (the "side" work lands in front of the main chain on the same queue,
+#: every cross-queue dependency costs ~10 us): measured 6.0 against 6.3 ms per step at one septuplet per rank, 7.2 / 7.4 at two,
+#: 9.4 / 9.5 at four, equal at eight (profiles/r6/ab_experiments.txt)
+_TWO_STREAMS = os.environ.get("SELFC_BWD_STREAMS", "1") == "2"
 _SIDE: Dict[Tuple, "torch.cuda.Stream"] = {}
 
 

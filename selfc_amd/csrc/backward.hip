@@ -1028,8 +1028,9 @@ int selfc_subnet_bwd_phase_d(int phases, const selfc_subnet_bw* bw, int kind, co
   // SELFC_BWD_CHAIN=0 / 1: never / always (tests).
   {
     static const int chain_env = getenv("SELFC_BWD_CHAIN") ? atoi(getenv("SELFC_BWD_CHAIN")) : -1;
+    static const long chain_max = getenv("SELFC_BWD_CHAIN_MAX1") ? atol(getenv("SELFC_BWD_CHAIN_MAX1")) : 256;
     const long chain_wgs = (long)N * ((H + 11) / 12) * ((W + 15) / 16);
-    if (chain_env == 1 || (chain_env < 0 && chain_wgs <= 256)) {
+    if (chain_env == 1 || (chain_env < 0 && chain_wgs <= chain_max)) {
       const void* wtd[3] = {bw->wtd[0], bw->wtd[1], bw->wtd[2]};
       if ((rc = bwd_dgrad_chain(gb, t5, feat, wtd, bw->wtx, dx, L.nx, cinp, accumulate_dx, amax, dx_amax_out, N, H, W, s))) return rc;
       goto weights;
@@ -1175,8 +1176,9 @@ int selfc_gh_bwd_pair(int phases, const selfc_subnet_bw* bw_g, const selfc_subne
                                L.nx + 3, gb[0], gb[1], N, T, H, W, s))) return rc;
     // 3. dpre3, dpre2, dpre1 of both nets: the chain kernel while its workgroups fit the chip in one round, else layer by layer
     static const int chain_env = getenv("SELFC_BWD_CHAIN") ? atoi(getenv("SELFC_BWD_CHAIN")) : -1;
+    static const long chain_max = getenv("SELFC_BWD_CHAIN_MAX2") ? atol(getenv("SELFC_BWD_CHAIN_MAX2")) : 256;
     const long chain_wgs = 2L * N * ((H + 11) / 12) * ((W + 15) / 16);
-    if (chain_env == 1 || (chain_env < 0 && chain_wgs <= 256)) {
+    if (chain_env == 1 || (chain_env < 0 && chain_wgs <= chain_max)) {
       const void* wtd0[3] = {bw_g->wtd[0], bw_g->wtd[1], bw_g->wtd[2]};
       const void* wtd1[3] = {bw_h->wtd[0], bw_h->wtd[1], bw_h->wtd[2]};
       if ((rc = bwd_dgrad_chain_pair(gb[0], gb[1], t5[0], t5[1], feat[0], feat[1], wtd0, wtd1, L.nx, amax, N, H, W, s))) return rc;
@@ -1311,6 +1313,86 @@ int selfc_recon_loss(const float* x, size_t stride_x, const float* t, size_t str
   int rc = hip_rc(hipGetLastError());
   if (rc) return rc;
   hipLaunchKernelGGL(recon_loss_final_kernel, dim3(1), dim3(64), 0, s, partial, LOSS_BLOCKS, inv, out);
+  return hip_rc(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// clip_grad_norm_ + Adam on ONE flat buffer as two launches (models/SelfC_model.py:172-176: nn.utils.clip_grad_norm_ then
+// optimizer.step(); torch.optim.Adam's capturable multi-tensor step is 16 launches + ~10 for the staged norm and the clip - 0.23 ms of
+// 4.5-us nodes at the end of every replayed step).  Launch 1: per-block sums of squares of the gradient (fixed block -> chunk map,
+// double, no atomics) and step += 1.  Launch 2: every block sums the partials in the same order (the norm, bit-identical in every
+// block), scales its gradient slice by min(1, max_norm / (norm + 1e-6)) IN PLACE (the caller's .grad views hold the clipped
+// gradient, as after clip_grad_norm_) and applies torch's Adam update in torch's operation order:
+//   g += wd * p;  m = lerp(m, g, 1 - b1);  v = b2 * v + (1 - b2) g^2;
+//   p += m / ((sqrt(v) / sqrt(1 - b2^t) + eps) / (lr / (b1^t - 1)))
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int ADAM_BLOCKS = 512;
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, size_t n, double* __restrict__ partial, float* __restrict__ step) {
+  const size_t chunk = ((n + gridDim.x - 1) / gridDim.x + 3) & ~(size_t)3;
+  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  double acc = 0.0;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) { const float v = g[i]; acc += (double)v * (double)v; }
+  __shared__ double red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = red[0];
+    if (blockIdx.x == 0 && step) *step += 1.f;
+  }
+}
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                        const double* __restrict__ partial, int nb, float max_norm, const float* __restrict__ lr_dev, float lr_host,
+                                                        float beta1, float beta2, float omb1, float omb2, float eps, float wd, const float* __restrict__ step_dev,
+                                                        float step_host, float* __restrict__ norm_out) {
+  __shared__ float s_coef;
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < nb; ++i) t += partial[i];
+    const float norm = (float)sqrt(t);
+    if (blockIdx.x == 0 && norm_out) *norm_out = norm;
+    s_coef = max_norm > 0.f ? fminf(max_norm / (norm + 1e-6f), 1.f) : 1.f;
+  }
+  __syncthreads();
+  const float coef = s_coef;
+  const float lr = lr_dev ? *lr_dev : lr_host;
+  const float t = step_dev ? *step_dev : step_host;              // already incremented
+  const float ss = 1.f / ((powf(beta1, t) - 1.f) / lr);           // torch: bias_correction1 = beta1^t - 1; /= lr; reciprocal  (negative step size)
+  const float bc2s = sqrtf(-(powf(beta2, t) - 1.f));              // sqrt(1 - beta2^t)
+  const size_t chunk = ((n + gridDim.x - 1) / gridDim.x + 3) & ~(size_t)3;
+  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+    float gi = g[i] * coef;
+    g[i] = gi;
+    const float pi = p[i];
+    if (wd != 0.f) gi = gi + wd * pi;
+    float mi = m[i], vi = v[i];
+    mi = mi + omb1 * (gi - mi);                                   // lerp (weight 1 - beta1 rounded from double, as torch passes it)
+    vi = vi * beta2 + omb2 * gi * gi;                             // mul_, addcmul_ (value 1 - beta2 likewise)
+    m[i] = mi; v[i] = vi;
+    const float den = (sqrtf(vi) / bc2s + eps) / ss;
+    p[i] = pi + mi / den;
+  }
+}
+}  // namespace
+
+int selfc_clip_adam_blocks(void) { return ADAM_BLOCKS; }
+
+int selfc_clip_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double* partial, float max_norm,
+                    const float* lr_dev, float lr_host, double beta1_d, double beta2_d, float eps, float weight_decay,
+                    float* step_dev, float step_host, float* norm_out, void* stream) {
+  const float beta1 = (float)beta1_d, beta2 = (float)beta2_d;
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !partial || n == 0) return SELFC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(ADAM_BLOCKS), dim3(256), 0, s, grad, n, partial, step_dev);
+  int rc = hip_rc(hipGetLastError());
+  if (rc) return rc;
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(ADAM_BLOCKS), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, partial, ADAM_BLOCKS, max_norm,
+                     lr_dev, lr_host, beta1, beta2, (float)(1.0 - (double)beta1_d), (float)(1.0 - (double)beta2_d), eps, weight_decay, step_dev, step_host, norm_out);
   return hip_rc(hipGetLastError());
 }
 

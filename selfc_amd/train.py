@@ -31,9 +31,55 @@ import torch
 import torch.nn as nn
 from torch.optim.lr_scheduler import _LRScheduler
 
-from . import autograd as ag, harness, runtime as rt
+from . import _lib, autograd as ag, harness, runtime as rt
 from .global_var import GlobalVar
 from .modules.Quantization import Quantization
+
+
+#: SELFC_FUSED_LOSS=0: the loss is the reference's torch expression again (~10 element-wise / reduction launches forward and ~12
+#: backward per loss, 4.5 us each inside a replayed step) instead of selfc_recon_loss (two launches, the gradient in the same pass)
+_FUSED_LOSS = os.environ.get("SELFC_FUSED_LOSS", "1") != "0"
+#: SELFC_FUSED_ADAM=0: gradient clipping + Adam are torch's launches again (the staged norm, the clip, 16 multi-tensor launches)
+#: instead of selfc_clip_adam (two launches on the flat buffer, torch's operation order, torch.optim.Adam's own state tensors)
+_FUSED_ADAM = os.environ.get("SELFC_FUSED_ADAM", "1") != "0"
+
+
+def _rows(t_: torch.Tensor):
+    """(tensor, n_outer, inner, row stride) of a 4-D tensor whose rows [n] are contiguous blocks of C*H*W floats (a channel slice
+    out[:, :3] of an NCHW tensor is such a view), or None"""
+    if t_.dim() != 4 or t_.dtype != torch.float32 or not t_.is_cuda:
+        return None
+    n, c, h, w = t_.shape
+    if n == 0 or c * h * w == 0:
+        return None
+    sn, sc, sh, sw = t_.stride()
+    if sw != 1 or sh != w or sc != h * w or (n > 1 and sn < c * h * w):
+        return None
+    return t_, n, c * h * w, (sn if n > 1 else c * h * w)
+
+
+class ReconLossFn(torch.autograd.Function):
+    """weight * ReconstructionLoss(x, target) (loss.py:5-21) on selfc_recon_loss: the value (deterministic two-stage sum) and
+    d loss / d x in one pass over x and target; backward scales that gradient by the incoming scalar (d / d target = its negative)."""
+
+    @staticmethod
+    def forward(ctx, x, target, l1, eps, weight):
+        rx, rt_ = _rows(x), _rows(target)
+        dev = x.device
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        grad = torch.empty(x.shape, dtype=torch.float32, device=dev) if need else None
+        nb = int(_lib.lib().selfc_recon_loss_blocks())
+        partial = torch.empty(nb, dtype=torch.float64, device=dev)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        rt.call("selfc_recon_loss", rx[0].data_ptr(), rx[3], rt_[0].data_ptr(), rt_[3], rx[1], rx[2], 1 if l1 else 0, float(eps), float(weight),
+                None if grad is None else grad.data_ptr(), partial.data_ptr(), out.data_ptr(), _lib.stream_ptr())
+        ctx.grad = grad
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gx = ctx.grad * g if ctx.grad is not None else None
+        return (gx if ctx.needs_input_grad[0] else None, (-gx) if ctx.needs_input_grad[1] else None, None, None, None)
 
 
 class ReconstructionLoss(nn.Module):
@@ -45,6 +91,9 @@ class ReconstructionLoss(nn.Module):
         self.eps = eps
 
     def forward(self, x, target):
+        if _FUSED_LOSS and self.losstype in ("l2", "l1") and x.shape == target.shape and _rows(x) is not None and _rows(target) is not None:
+            # the mean over the four axes one after the other = sum / count (equal group sizes)
+            return ReconLossFn.apply(x, target, self.losstype == "l1", self.eps, 1.0)
         if self.losstype == "l2":
             v = (x - target) ** 2
         elif self.losstype == "l1":
@@ -370,11 +419,52 @@ class RescaleTrainer:
         if self.data_parallel:
             self.sink.all_reduce(self.process_group, average=True)
 
+    def _fused_clip_adam(self, max_norm) -> bool:
+        """clip_grad_norm_ + Adam.step() of the ONE flat tensor as two launches (selfc_clip_adam) on torch.optim.Adam's own state
+        tensors (step / exp_avg / exp_avg_sq, created here as torch would create them), so state_dict / load_state_dict / the LR
+        scheduler see a stock optimizer.  False: not applicable (the caller takes the torch path)."""
+        opt = self.optimizer_G
+        grp = opt.param_groups[0]
+        if len(opt.param_groups) != 1 or len(grp["params"]) != 1 or grp.get("amsgrad") or grp.get("maximize") or grp.get("differentiable"):
+            return False
+        p_ = grp["params"][0]
+        if p_.grad is None or not p_.is_cuda or p_.dtype != torch.float32 or not p_.is_contiguous() or not p_.grad.is_contiguous():
+            return False
+        st = opt.state[p_]
+        if len(st) == 0:
+            st["step"] = torch.zeros((), dtype=torch.float32, device=p_.device) if grp.get("capturable") else torch.tensor(0.0, dtype=torch.float32)
+            st["exp_avg"] = torch.zeros_like(p_, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p_, memory_format=torch.preserve_format)
+        step, lr = st["step"], grp["lr"]
+        if torch.is_tensor(step) and step.is_cuda:
+            step_dev, step_host = step.data_ptr(), 0.0
+        else:
+            if torch.is_tensor(step):
+                step += 1
+            else:
+                step = st["step"] = step + 1
+            step_dev, step_host = None, float(step)
+        lr_dev, lr_host = (lr.data_ptr(), 0.0) if (torch.is_tensor(lr) and lr.is_cuda) else (None, float(lr))
+        tmp = self.__dict__.get("_adam_tmp")
+        if tmp is None or tmp[0].device != p_.device:
+            tmp = self._adam_tmp = (torch.empty(int(_lib.lib().selfc_clip_adam_blocks()), dtype=torch.float64, device=p_.device),
+                                    torch.zeros((), dtype=torch.float32, device=p_.device))
+        b1, b2 = grp["betas"]
+        rt.call("selfc_clip_adam", p_.data_ptr(), p_.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p_.numel(),
+                tmp[0].data_ptr(), float(max_norm or 0.0), lr_dev, lr_host, float(b1), float(b2), float(grp["eps"]), float(grp["weight_decay"]),
+                step_dev, step_host, tmp[1].data_ptr(), _lib.stream_ptr())
+        self.grad_norm = tmp[1]
+        opt._opt_called = True             # what the LR scheduler's wrapper of optimizer.step() records
+        return True
+
     def _clip_and_step(self):
         """gradient clipping + optimizer step (SelfC_model.py:172-176)."""
         if self.before_clip is not None:
             self.before_clip(self)
         max_norm = self.train_opt.get("gradient_clipping")
+        if _FUSED_ADAM and self.flat_optimizer and self.sink is not None and self._fused_clip_adam(max_norm):
+            rt.invalidate_weights()
+            return
         if max_norm and self.sink is not None:
             # clip_grad_norm_ on the flat buffer (pads are zero): three launches instead of a foreach over 350 views
             self.grad_norm = self.sink.norm()              # staged: no multi-block reduction inside a captured step (GradSink.norm)
@@ -430,7 +520,10 @@ class RescaleTrainer:
         with torch.cuda.stream(s):
             for _ in range(warmup):
                 self._zero_grad()
-                warm.append(self._step(self._static_h, self._static_l) + (getattr(self, "grad_norm", None),))
+                gn_ = getattr(self, "grad_norm", None)
+                warm.append(self._step(self._static_h, self._static_l) + (None,))
+                gn_ = getattr(self, "grad_norm", None)
+                warm[-1] = warm[-1][:-1] + ((gn_.clone() if torch.is_tensor(gn_) else gn_),)     # (the fused step reuses one norm tensor)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         #: the warm-up steps are real optimisation steps: their log entries (read after the synchronize, not between the steps)

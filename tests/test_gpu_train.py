@@ -598,6 +598,83 @@ def test_paired_gh_backward_equals_the_two_subnet_calls(dev, defer):
     assert worst < 6e-4, worst
 
 
+@pytest.mark.parametrize("losstype", ["l2", "l1"])
+def test_fused_reconstruction_loss_equals_the_torch_expression(dev, losstype):
+    """ReconstructionLoss on selfc_recon_loss (two launches: value + gradient) against the reference's torch expression
+    (loss.py:5-21: element-wise value, mean over the four axes one after the other) - the value, and the gradients w.r.t. BOTH
+    arguments through a channel-slice view (out[:, :3] of a 51-channel tensor: SelfC_model.py:156) and a scaled sum of two losses."""
+    from selfc_amd import train
+    g = torch.Generator().manual_seed(5)
+    full = torch.rand(14, 51, 9, 12, generator=g).to(dev).requires_grad_(True)
+    tgt = torch.rand(14, 3, 9, 12, generator=g).to(dev).requires_grad_(True)
+    res = {}
+    for fused in (False, True):
+        old = train._FUSED_LOSS
+        train._FUSED_LOSS = fused
+        try:
+            full.grad = tgt.grad = None
+            crit = train.ReconstructionLoss(losstype)
+            loss = (crit(full[:, :3], tgt) * 0.7 + crit(tgt, full[:, 3:6])) * 144 * 144 * 3
+            loss.backward()
+            res[fused] = (loss.detach().clone(), full.grad.clone(), tgt.grad.clone())
+        finally:
+            train._FUSED_LOSS = old
+    (l0, a0, b0), (l1, a1, b1) = res[False], res[True]
+    assert abs(float(l1) - float(l0)) < 2e-6 * abs(float(l0)), (float(l0), float(l1))
+    assert float((a1 - a0).abs().max()) < 2e-6 * float(a0.abs().max()) and float((b1 - b0).abs().max()) < 2e-6 * float(b0.abs().max())
+    assert float(a1[:, 6:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("capturable", [False, True])
+def test_fused_clip_and_adam_equals_torch(dev, capturable):
+    """selfc_clip_adam (two launches: norm partials, then clip + Adam on the flat buffer in torch's operation order) against
+    GradSink.norm + the clip + torch.optim.Adam.step() on the same flat tensor (SelfC_model.py:172-176): three steps from the same
+    weights with the same gradients - the norm clip_grad_norm_ returns, the clipped gradient, the moments and the parameters."""
+    from selfc_amd import train
+    x = load_golden("g8_large_stack")["x"]
+    gt = x.reshape(1, T, 3, 32, 48).transpose(1, 2).to(dev)
+    real_h, ref_l, _ = train.feed_data(gt, "sr_bd", 4)
+    trs = {}
+    for fused in (False, True):
+        old = train._FUSED_ADAM
+        train._FUSED_ADAM = fused
+        try:
+            tr = trs[fused] = train.RescaleTrainer(_net(dev), dict(train.TRAIN_OPT_LARGE), capturable=capturable)
+            assert tr.flat_optimizer
+        finally:
+            train._FUSED_ADAM = old
+    for step in range(3):
+        # one backward, its gradient handed to BOTH trainers (their own backward would differ by LeakyReLU kinks once weights differ by 1e-9)
+        trs[False]._zero_grad()
+        trs[False]._forward_backward(real_h, ref_l)
+        g = trs[False].sink.flat.clone()
+        out = {}
+        for fused in (False, True):
+            old = train._FUSED_ADAM
+            train._FUSED_ADAM = fused
+            try:
+                tr = trs[fused]
+                tr.sink.flat.copy_(g)
+                tr._clip_and_step()
+                st = tr.optimizer_G.state[tr.sink.flat_param]
+                out[fused] = (float(tr.grad_norm), tr.sink.flat.clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), tr.sink.flat_param.detach().clone(), float(st["step"]))
+            finally:
+                train._FUSED_ADAM = old
+        a, b = out[False], out[True]
+        assert a[5] == b[5] == step + 1
+        assert abs(a[0] - b[0]) < 2e-6 * a[0], (a[0], b[0])
+        for i, what in ((1, "clipped gradient"), (2, "exp_avg"), (3, "exp_avg_sq")):
+            assert float((a[i] - b[i]).abs().max()) <= 4e-6 * float(a[i].abs().max()), (step, what)
+        # parameters: the same update up to ONE rounding of p + delta (an ulp of the largest parameter; |update| <= lr = 1e-4)
+        assert float((a[4] - b[4]).abs().max()) <= 1.2e-7 * float(a[4].abs().max()), (step, float((a[4] - b[4]).abs().max()))
+        with torch.no_grad():                                      # same weights into the next step
+            trs[True].sink.flat_param.copy_(trs[False].sink.flat_param)
+            for k in ("exp_avg", "exp_avg_sq"):
+                trs[True].optimizer_G.state[trs[True].sink.flat_param][k].copy_(trs[False].optimizer_G.state[trs[False].sink.flat_param][k])
+        from selfc_amd import runtime as rt
+        rt.invalidate_weights()
+
+
 def test_backward_is_linear_in_the_output_gradient_at_chain_level(dev):
     """A bar the LeakyReLU kinks cannot loosen: with the forward fixed (same input, same weights -> the same f16 features and
     the same masks), the backward of the WHOLE stack (FrequencyAnalyzer + 8 InvBlockExp, selfc_amd.autograd.InvStackFn) is a
