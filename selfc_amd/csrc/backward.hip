@@ -739,6 +739,17 @@ BwdLayout bwd_layout(int N, int H, int W, int cin, int cout) {
 
 // pixel splits of a weight-gradient job: enough workgroups to fill the chip (~2 per CU), bounded by the tile count and
 // by 12 MiB of partials (written once, read once by the finish pass)
+// SELFC_WG_TILES: when the launches of many subnets are deferred into ONE (wgrad_table_kernel) there is no chip to fill per job:
+// every workgroup then takes at least this many tiles (fewer partials to write and to reduce)
+static long wg_min_tiles() {
+  static const long v = getenv("SELFC_WG_TILES") ? atol(getenv("SELFC_WG_TILES")) : 32;
+  return v < 1 ? 1 : v;
+}
+int wgrad_nsplit_table(int nsplit, long units) {
+  const long cap = (units + wg_min_tiles() - 1) / wg_min_tiles();
+  return (int)(nsplit > cap ? (cap < 1 ? 1 : cap) : nsplit);
+}
+
 int wgrad_nsplit(int N, int H, int W, int npairs, int ttot) {
   const long ntiles = (long)N * ((H + 15) / 16) * ((W + 15) / 16);
   long ns = (768 + (long)npairs - 1) / (long)npairs;           // 512 / 1024 / 1536 / 2048 measured: all slower (profiles/r4/ab_experiments.txt)
@@ -814,6 +825,7 @@ static int bwd_wgrad_impl(const WgradJob& j, const float* amax, void* scratch, i
   if (ttot == 3) {                                   // the temporal kernel's units are (clip, tile): never more splits than units
     const int nunits = (N / T) * tiles_x * tiles_y;
     if (nsplit > nunits) nsplit = nunits;
+    if (defer_wg && defer) nsplit = wgrad_nsplit_table(nsplit, (long)nunits * T);
   }
   float* bpart = (float*)scratch;
   float* part = (float*)((unsigned char*)scratch + up256((size_t)nsplit * (j.Pn < 4 ? 4 : j.Pn) * 32 * sizeof(float)));
@@ -849,10 +861,11 @@ int bwd_wgrad(const WgradJob& j, const float* amax, void* scratch, int N, int T,
 // arguments of the conv1..4 job (one launch) and of its finish
 static void wgrad14_args(const void* dpre, const void* Q0, int nq0, const void* Q1, int nqc1, int cin, int nx,
                          float* const* wout, float* const* bout, float beta, const float* amax, void* scratch,
-                         int N, int T, int H, int W, WgArgs& a, FinArgs& f, int& nsplit, int& npairs) {
+                         int N, int T, int H, int W, WgArgs& a, FinArgs& f, int& nsplit, int& npairs, bool table = false) {
   const size_t npix = (size_t)N * H * W, plane = npix * 32;
   npairs = 4 * nqc1 + 6;
   nsplit = wgrad_nsplit(N, H, W, npairs, 9);
+  if (table) nsplit = wgrad_nsplit_table(nsplit, (long)N * ((H + 15) / 16) * ((W + 15) / 16));
   float* bpart = (float*)scratch;
   float* part = (float*)((unsigned char*)scratch + up256((size_t)nsplit * 4 * 32 * sizeof(float)));
   a = WgArgs{};
@@ -870,7 +883,7 @@ int bwd_wgrad14(const void* dpre, const void* Q0, int nq0, const void* Q1, int n
                 float* const* wout, float* const* bout, float beta, const float* amax, void* scratch,
                 int N, int T, int H, int W, hipStream_t s, FinArgs* defer, WgJob* defer_wg = nullptr) {
   WgArgs a; FinArgs f; int nsplit, npairs;
-  wgrad14_args(dpre, Q0, nq0, Q1, nqc1, cin, nx, wout, bout, beta, amax, scratch, N, T, H, W, a, f, nsplit, npairs);
+  wgrad14_args(dpre, Q0, nq0, Q1, nqc1, cin, nx, wout, bout, beta, amax, scratch, N, T, H, W, a, f, nsplit, npairs, defer_wg && defer);
   if (defer_wg && defer) { *defer_wg = WgJob{a, 0, nsplit, npairs, 1}; *defer = f; return SELFC_OK; }
   int rc = launch_wgrad_any<9>(a, nsplit, npairs, 1, s);
   if (rc) return rc;
@@ -1216,11 +1229,13 @@ int selfc_gh_bwd_pair(int phases, const selfc_subnet_bw* bw_g, const selfc_subne
     int nsplit14 = 0, npairs14 = 0, nsplit5 = 0;
     const int qtot = 1 + 4;                                  // x plane (the scratch copy) + f1..f4
     for (int q = 0; q < 2; ++q) {
-      wgrad14_args(gb[q], xpl, 1, feat[q], L.nx, cin, L.nx, wg[q], bg[q], beta, amax, sb + L.off_wg[q], N, T, H, W, a14[q], f14[q], nsplit14, npairs14);
+      wgrad14_args(gb[q], xpl, 1, feat[q], L.nx, cin, L.nx, wg[q], bg[q], beta, amax, sb + L.off_wg[q], N, T, H, W, a14[q], f14[q], nsplit14, npairs14,
+                   wg_jobs != nullptr);
       // conv5 (temporal taps): P = the dOut planes, Q = [x | f1..f4]
       nsplit5 = wgrad_nsplit(N, H, W, L.ng * qtot, 3);
       const int nunits = (N / T) * ((W + 15) / 16) * ((H + 15) / 16);
       if (nsplit5 > nunits) nsplit5 = nunits;
+      if (wg_jobs) nsplit5 = wgrad_nsplit_table(nsplit5, (long)nunits * T);
       float* bpart = (float*)(sb + L.off_wg5[q]);
       float* part = (float*)(sb + L.off_wg5[q] + up256((size_t)nsplit5 * (L.ng < 4 ? 4 : L.ng) * 32 * sizeof(float)));
       float* wout = wg[q] ? wg[q][4] : nullptr;
@@ -1268,6 +1283,15 @@ int selfc_gh_bwd_pair(int phases, const selfc_subnet_bw* bw_g, const selfc_subne
 // channel slice of an NCHW tensor is such a view).
 // ---------------------------------------------------------------------------------------------------------
 namespace {
+// sum of n doubles by ONE wave, the same order in every caller: lane l adds elements l, l + 64, ... in sequence, then a fixed
+// xor tree (deterministic; a single thread walking 512 partials in global memory took 23 us)
+__device__ __forceinline__ double wave_sum(const double* __restrict__ p, const int n, const int lane) {
+  double t = 0.0;
+  for (int i = lane; i < n; i += 64) t += p[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+  return t;
+}
 constexpr int LOSS_BLOCKS = 512;
 __global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict__ x, size_t sx, const float* __restrict__ t, size_t st, size_t n_outer,
                                                          size_t inner, int l1, float eps, float gscale, float* __restrict__ grad, double* __restrict__ partial) {
@@ -1294,11 +1318,8 @@ __global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 __global__ __launch_bounds__(64) void recon_loss_final_kernel(const double* __restrict__ partial, int n, double scale, float* __restrict__ out) {
-  if (threadIdx.x == 0) {
-    double s_ = 0.0;
-    for (int i = 0; i < n; ++i) s_ += partial[i];
-    *out = (float)(s_ * scale);
-  }
+  const double s_ = wave_sum(partial, n, threadIdx.x);
+  if (threadIdx.x == 0) *out = (float)(s_ * scale);
 }
 }  // namespace
 
@@ -1350,12 +1371,13 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, f
                                                         float beta1, float beta2, float omb1, float omb2, float eps, float wd, const float* __restrict__ step_dev,
                                                         float step_host, float* __restrict__ norm_out) {
   __shared__ float s_coef;
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int i = 0; i < nb; ++i) t += partial[i];
-    const float norm = (float)sqrt(t);
-    if (blockIdx.x == 0 && norm_out) *norm_out = norm;
-    s_coef = max_norm > 0.f ? fminf(max_norm / (norm + 1e-6f), 1.f) : 1.f;
+  if (threadIdx.x < 64) {
+    const double t = wave_sum(partial, nb, threadIdx.x);
+    if (threadIdx.x == 0) {
+      const float norm = (float)sqrt(t);
+      if (blockIdx.x == 0 && norm_out) *norm_out = norm;
+      s_coef = max_norm > 0.f ? fminf(max_norm / (norm + 1e-6f), 1.f) : 1.f;
+    }
   }
   __syncthreads();
   const float coef = s_coef;

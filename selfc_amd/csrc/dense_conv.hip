@@ -626,10 +626,14 @@ struct T5Args {
 // leaving the rest to the MFMA-bound kernels of other streams): 0.29 -> 0.33 ms per step, headline -0.5 %.
 template <int EPI> constexpr int t5_waves() { return 8; }
 
-template <int NETS, int OT, int KD, int HASX, int EPI>
+// FP ("frame-parallel", small problems only): a workgroup owns 16 pixels of one clip and wave w computes output frame t = w from the
+// three input frames t-1, t, t+1 (loaded by that wave) instead of eight pixel groups each walking the clip's frames in sequence - 3x the
+// loads, no serial walk: on one 36x36 training septuplet the walk is 11 workgroups x 7 dependent steps (27 us), this is 81 x 1.  Every
+// output accumulates its taps in the walk's order (tap 0 on frame t-1, tap 1 on t, tap 2 on t+1; k-steps ascending): bit-identical.
+template <int NETS, int OT, int KD, int HASX, int EPI, bool FP = false>
 __global__ __launch_bounds__(t5_waves<EPI>() * 64) void tconv5_kernel(const T5Args a) {
   constexpr int KS = KD + HASX;
-  constexpr int NTH = t5_waves<EPI>() * 64, PXWG = t5_waves<EPI>() * 16;
+  constexpr int NTH = t5_waves<EPI>() * 64, PXWG = FP ? 16 : t5_waves<EPI>() * 16;
   constexpr int NFRAG = 3 * NETS * KS * OT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -655,13 +659,14 @@ __global__ __launch_bounds__(t5_waves<EPI>() * 64) void tconv5_kernel(const T5Ar
   const int tiles = (a.HW + PXWG - 1) / PXWG;
   const int wg = xcd_swizzle(blockIdx.x, gridDim.x);
   const int b = wg / tiles;
-  const int p0 = (wg % tiles) * PXWG + wave * 16;
+  const int p0 = (wg % tiles) * PXWG + (FP ? 0 : wave * 16);
   const int pl = p0 + (lane & 15);
   const bool pvalid = pl < a.HW;
   const int pc = pvalid ? pl : a.HW - 1;   // clamp loads of masked lanes to a valid pixel
   const int kq = lane >> 4;                // this lane's 8-channel group of a 32-wide k-step
   if (p0 >= a.HW) return;                  // whole wave outside (no barriers below)
   const bool net2 = EPI == EPI_T5B && a.pair_planes && (int)blockIdx.y >= a.pair_planes;     // workgroup-uniform
+  if (FP && wave >= a.T) return;           // frame-parallel: one wave per frame of the clip (T <= 8; no barriers below)
 
   f32x4 accp[NETS][OT], accc[NETS][OT], accn[NETS][OT];
 #pragma unroll
@@ -787,6 +792,47 @@ __global__ __launch_bounds__(t5_waves<EPI>() * 64) void tconv5_kernel(const T5Ar
     }
   };
 
+  if constexpr (FP) {
+    const int t = wave;
+    u32x4 bprv[NETS][KD];
+    float4 xprv = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool vp = t >= 1, vn = t + 1 < a.T;                       // wave-uniform: frames outside the clip contribute nothing
+    prefetch_x2(t);
+    load_frame(bprv, xprv, vp ? t - 1 : t);
+    load_frame(bcur, xcur, t);
+    load_frame(bnxt, xnxt, vn ? t + 1 : t);
+    auto tap_step = [&](const int tap, u32x4 (&bb)[NETS][KD], const float4& xx) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < NETS; ++q) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          f16x8 bf;
+          if (HASX && ks == 0) {
+            u32x4 u = {0u, 0u, 0u, 0u};
+            if (kq == 0) {
+              u.x = pack2(xx.x, xx.y);
+              u.y = pack2(xx.z, 0.f);
+            }
+            bf = __builtin_bit_cast(f16x8, u);
+          } else {
+            bf = __builtin_bit_cast(f16x8, bb[q][ks - HASX]);
+          }
+#pragma unroll
+          for (int o = 0; o < OT; ++o) {
+            constexpr size_t TAPSTRIDE = (size_t)NETS * KS * OT * 1024;
+            const unsigned char* wb = smem + ((size_t)((q * KS + ks) * OT + o) * 64 + lane) * 16 + (size_t)tap * TAPSTRIDE;
+            accc[q][o] = mfma_16x16x32(*reinterpret_cast<const f16x8*>(wb), bf, accc[q][o]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    if (vp) tap_step(0, bprv, xprv);
+    tap_step(1, bcur, xcur);
+    if (vn) tap_step(2, bnxt, xnxt);
+    epilogue(t, accc);
+    return;
+  }
   load_frame(bcur, xcur, 0);
   for (int t = 0; t < a.T; ++t) {
     // (Measured and dropped: a THREE-frame register ring - biases in LDS, A fragments three at a time, SGPR-base
@@ -940,6 +986,20 @@ inline int dense_channels(int cin) { return cin <= 3 ? 128 : ((cin + 31) & ~31) 
 template <int NETS, int OT, int KD, int HASX, int EPI>
 int launch_t5(const T5Args& a, hipStream_t s) {
   constexpr int lds = 3 * NETS * (KD + HASX) * OT * 1024;
+  if constexpr (EPI == EPI_GH || EPI == EPI_T5B) {
+    // frame-parallel instance for small problems (SELFC_T5_FP_MAX pixel-frames, default two 36x36 training septuplets; 0: never)
+    static const long fp_max = getenv("SELFC_T5_FP_MAX") ? atol(getenv("SELFC_T5_FP_MAX")) : 20000;
+    if (a.T <= t5_waves<EPI>() && (long)a.B * a.T * a.HW <= fp_max) {
+      static std::atomic<unsigned long long> optin_fp{0};
+      if (lds > 64 * 1024)
+        if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&tconv5_kernel<NETS, OT, KD, HASX, EPI, true>), lds, optin_fp); e != hipSuccess) return hip_rc(e);
+      const int tiles_fp = (a.HW + 15) / 16;
+      ProfScope prof(EPI == EPI_GH ? PROF_CONV5_GH : -1, s);
+      hipLaunchKernelGGL((tconv5_kernel<NETS, OT, KD, HASX, EPI, true>), dim3((unsigned)(tiles_fp * a.B), EPI == EPI_T5B ? (unsigned)(a.pair_planes ? 2 * a.pair_planes : a.coutp) : 1u),
+                         dim3(t5_waves<EPI>() * 64), lds, s, a);
+      return hip_rc(hipGetLastError());
+    }
+  }
   static std::atomic<unsigned long long> optin{0};
   if (lds > 64 * 1024)
     if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&tconv5_kernel<NETS, OT, KD, HASX, EPI>), lds, optin); e != hipSuccess) return hip_rc(e);

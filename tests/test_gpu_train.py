@@ -332,8 +332,15 @@ def test_weight_gradients_do_not_depend_on_side_stream_timing(dev):
         assert not ag._SLOT_BUSY, "slot events must not outlive the backward that recorded them"
         return {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
 
-    ref = grads(0)
-    late = grads(30000)
+    # the multi-stream mode (SELFC_BWD_STREAMS=2; one stream is the default since round 6) with the weight-gradient launches on the
+    # side stream per subnet (SELFC_BWD_DEFER_WG=0) - the configuration that HAS a side stream to stall
+    old = ag._TWO_STREAMS, ag._DEFER_WG
+    ag._TWO_STREAMS, ag._DEFER_WG = True, False
+    try:
+        ref = grads(0)
+        late = grads(30000)
+    finally:
+        ag._TWO_STREAMS, ag._DEFER_WG = old
     assert ref.keys() == late.keys() and len(ref) > 300
     bad = [n for n in ref if not torch.equal(ref[n], late[n])]
     assert not bad, f"{len(bad)} gradients changed with the side stream delayed, e.g. {bad[:4]}"
@@ -752,6 +759,26 @@ def test_fused_data_gradient_chain_is_bit_identical_to_the_layer_wise_launches(d
     out = str(tmp_path / "grads.npz")
     subprocess.run([sys.executable, "-c", _CHILD_GRADS, root, out], check=True, env=dict(os.environ, SELFC_BWD_CHAIN="0"), timeout=600)
     mine = _chain_case_grads(dev)                                    # this process: the default (one launch at this size)
+    with np.load(out) as ref:
+        assert set(ref.files) == set(mine) and len(mine) > 300
+        bad = [n for n in mine if not np.array_equal(mine[n].cpu().numpy(), ref[n])]
+    assert not bad, f"{len(bad)} gradients differ, e.g. {bad[:4]}"
+
+
+def test_frame_parallel_temporal_conv_is_bit_identical_to_the_frame_walk(dev, tmp_path):
+    """Round 6: on small problems the temporal conv5 kernels (forward G/H conv5 + coupling, and conv5^T of the backward) run
+    FRAME-PARALLEL - one wave per output frame, its three input frames loaded by that wave - instead of walking a clip's frames in
+    sequence (27 us of dependent steps on one 36x36 training septuplet).  Taps and k-steps accumulate in the walk's order, so the
+    forward latent, the losses and every gradient of a training step must equal the walk's (SELFC_T5_FP_MAX=0, child process)
+    bit for bit (Subnet_constructor.py:106,130-131 and its backward)."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "grads_walk.npz")
+    subprocess.run([sys.executable, "-c", _CHILD_GRADS, root, out], check=True, env=dict(os.environ, SELFC_T5_FP_MAX="0"), timeout=600)
+    mine = _chain_case_grads(dev)                                    # this process: frame-parallel at this size
     with np.load(out) as ref:
         assert set(ref.files) == set(mine) and len(mine) > 300
         bad = [n for n in mine if not np.array_equal(mine[n].cpu().numpy(), ref[n])]
