@@ -174,7 +174,13 @@ class MultiStreamRoundTrip:
             p.out = self.out[i * self.per:(i + 1) * self.per]
         self.graph, self.graphs = None, None
 
+    def _alive(self):
+        if rt.SHUT_DOWN:
+            raise RuntimeError("selfc_amd has shut down (interpreter exit: its own HIP streams are destroyed, runtime._shutdown) - "
+                               "a multi-stream pipeline cannot run from an atexit handler registered before the package was imported")
+
     def run(self, x: torch.Tensor) -> torch.Tensor:
+        self._alive()
         cur = torch.cuda.current_stream()
         for i, (p, st) in enumerate(zip(self.parts, self.streams)):
             st.wait_stream(cur)
@@ -209,6 +215,7 @@ class MultiStreamRoundTrip:
             p._graph_stamp = p._stamp
 
     def replay(self):
+        self._alive()
         self.parts[0]._fresh(replaying=True)
         if self.graphs is not None:
             cur = torch.cuda.current_stream()
@@ -395,7 +402,7 @@ def module_graph(net, mode: str, n: int, h: int, w: int, device):
     somebody else in progress on this stream (pipeline.*, RescaleTrainer.capture), injected STP noise (`stp_net.eps`, a
     host-side test hook), a clip length that does not divide the batch, or the FIRST call of a shape - a shape is captured
     on its second call, so one-off calls do not pay for a capture."""
-    if not MODULE_GRAPH or torch.cuda.is_current_stream_capturing():
+    if not MODULE_GRAPH or rt.SHUT_DOWN or torch.cuda.is_current_stream_capturing():
         return None
     t = GlobalVar.get_Temporal_LEN()
     if not t or n % t:

@@ -168,13 +168,13 @@ def packed_subnet(mod, virt: Tuple[int, int] = None) -> PackedSubnet:
 
 
 def plist(mod):
-    """list(mod.parameters()), cached on the module (its parameter set does not change after construction; `_apply`
-    - .to() / .cuda() - replaces tensors in place of the same Parameter objects, or re-registers them: the cache is keyed
-    on the first parameter's identity to notice the latter)."""
+    """list(mod.parameters()) as ONE list object per parameter set: the cached list is kept while every Parameter object is the
+    same (identity of all of them - `blk.G.conv3.weight = nn.Parameter(...)`, parametrize, load_state_dict(assign=True) replace
+    objects anywhere in the module), so callers can key their own caches on the list's identity."""
     cached = mod.__dict__.get("_plist")
-    first = next(torch.nn.Module.parameters(mod), None)     # unbound: STPNet shadows `parameters` with a tensor (as the reference does)
-    if cached is None or (cached and cached[0] is not first):
-        cached = mod.__dict__["_plist"] = list(torch.nn.Module.parameters(mod))
+    cur = list(torch.nn.Module.parameters(mod))             # unbound: STPNet shadows `parameters` with a tensor (as the reference does)
+    if cached is None or len(cached) != len(cur) or any(a_ is not b_ for a_, b_ in zip(cached, cur)):
+        cached = mod.__dict__["_plist"] = cur               # a re-registered parameter ANYWHERE in the module (not only the first one)
     return cached
 
 
@@ -195,8 +195,10 @@ def invalidate_weights() -> int:
 
 def weights_stamp(params) -> Tuple:
     """O(n) but cheap (no data_ptr calls) change detector over a fixed parameter list: weight epoch + sum of the version
-    counters (+ the first tensor's address, which moves on .to() / .cuda()).  pipeline.* compare it before every run."""
-    return (_WEIGHT_EPOCH, sum(p._version for p in params), params[0].data_ptr() if params else 0)
+    counters (+ the first tensor's address, which moves on .to() / .cuda(), + the identity of every Parameter object: a replaced
+    parameter anywhere in the list - `blk.G.conv3.weight = nn.Parameter(...)` - is a different stamp).  pipeline.* compare it
+    before every run."""
+    return (_WEIGHT_EPOCH, sum(p._version for p in params), params[0].data_ptr() if params else 0, hash(tuple(map(id, params))))
 
 
 def params_key(*mods) -> Tuple:
@@ -239,6 +241,9 @@ def graph_stats(g) -> Dict[str, int]:
     return dict(zip(("nodes", "kernel", "memset", "memcpy", "other"), (int(v) for v in counts)))
 
 
+#: set by _shutdown(): the package's own streams are gone (interpreter exit)
+SHUT_DOWN = False
+
 #: every live OwnStream (weak): closed by _shutdown() at interpreter exit, while the HIP runtime is still there
 _LIVE_STREAMS: "weakref.WeakSet" = weakref.WeakSet()
 
@@ -255,6 +260,12 @@ def _shutdown():
         gc.collect()
         if torch.cuda.is_available() and torch.cuda.is_initialized():
             torch.cuda.synchronize()
+        # the streams that are still alive belong to objects somebody still holds (a cached ModuleGraph, a trainer, a pre-bound
+        # pipeline).  atexit is LIFO: a handler registered BEFORE this package was imported runs AFTER this one - it may still call
+        # the net.  From here on the module API takes its eager path on the caller's stream (pipeline.module_graph_call checks
+        # SHUT_DOWN) and the multi-stream pipelines refuse loudly instead of launching on destroyed streams.
+        global SHUT_DOWN
+        SHUT_DOWN = True
         for s_ in list(_LIVE_STREAMS):
             s_.close()
         gc.collect()

@@ -386,7 +386,15 @@ class RescaleTrainer:
                 if k_ == "lr" and torch.is_tensor(own.get("lr")):
                     own["lr"].fill_(float(val))                       # the tensor a captured step reads: same object, new value
                 else:
+                    if self.graph is not None and k_ not in ("lr", "initial_lr") and k_ in own:
+                        # betas / eps / weight_decay / amsgrad are constants of the CAPTURED step (kernel arguments of the replayed
+                        # launches): adopting other values here would make param_groups say one thing and the replay do another
+                        same = (tuple(own[k_]) == tuple(val)) if isinstance(val, (tuple, list)) else (own[k_] == val)
+                        if not same:
+                            raise RuntimeError(f"optimizer state changes {k_} ({own[k_]!r} -> {val!r}), a constant of the captured step: capture again")
                     own[k_] = float(val) if torch.is_tensor(val) and val.numel() == 1 and k_ in ("lr", "initial_lr") else val
+                    if k_ in ("betas", "eps", "weight_decay", "amsgrad"):
+                        self._adam_kw[k_] = tuple(val) if isinstance(val, list) else val     # what a rebuilt optimizer (_per_tensor_optimizer) starts from
             for pid, p_ in zip(saved["params"], own["params"]):
                 new, cur = state.get(pid), opt.state.get(p_)
                 if new is None:

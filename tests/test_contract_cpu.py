@@ -8,7 +8,7 @@ import os
 import pytest
 import torch
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 from selfc_amd import GlobalVar
 from selfc_amd.modules import Inv_arch, SelfC_GMM_arch_inv, SelfC_arch_inv, Subnet_constructor as SC
 
@@ -211,3 +211,22 @@ def test_bench_compact_line_is_what_the_driver_keeps():
     assert r["train_step_ms_b8"] == 11.0 and r["train_step_ms_b1"] == 6.0 and r["train_step_graph_nodes"] == 600 and r["uvg_1080p_frames_per_s"] == 430.0
     assert r["full_test_path_septuplets_per_s"] == 1090.0 and r["parity_inv_rel_err"] == 5.9e-4 and r["rocprof_avg_us"] == 77.0
     assert len(json.dumps(line)) < 3600
+
+
+def test_shutdown_marks_the_package_instead_of_leaving_dead_streams_behind():
+    """runtime._shutdown (atexit) destroys the package's own HIP streams; an atexit handler registered before the import
+    runs after it.  From then on the module API must take its eager path (pipeline.module_graph_call checks rt.SHUT_DOWN) and a
+    multi-stream pipeline must refuse loudly."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from selfc_amd import runtime as rt, pipeline\n"
+            "assert rt.SHUT_DOWN is False\n"
+            "rt._shutdown()\n"
+            "assert rt.SHUT_DOWN is True\n"
+            "import inspect\n"
+            "assert 'rt.SHUT_DOWN' in inspect.getsource(pipeline)\n"
+            "m = pipeline.MultiStreamRoundTrip.__new__(pipeline.MultiStreamRoundTrip)\n"
+            "try:\n    m.replay()\nexcept RuntimeError as e:\n    assert 'shut down' in str(e); print('refused')\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "refused" in p.stdout, p.stderr[-1500:]

@@ -946,3 +946,20 @@ def test_module_graph_follows_re_registered_parameters(dev):
         assert not torch.equal(y_new, y_old)
         z_or = O.large_fwd({k: v.cpu() for k, v in new_sd.items()}, x.cpu(), T)
         assert rel_err(z3.cpu(), z_or) < TOL
+        # ONE parameter in the middle of a block replaced (not the block's first one): every cache keyed on the parameter
+        # list must notice - the module graph re-captures, the pre-bound pipeline refuses its stale replay
+        rtp.capture(x)
+        z4, _ = net(x=x, rev=False)                                          # cached graph on the current weights
+        blk = net.operations[5]
+        blk.G.conv3.weight = torch.nn.Parameter(blk.G.conv3.weight.detach() * 0.9)
+        z5, _ = net(x=x, rev=False)
+        pipeline.MODULE_GRAPH = False
+        try:
+            z5_eager, _ = net(x=x, rev=False)
+        finally:
+            pipeline.MODULE_GRAPH = True
+        assert torch.equal(z5, z5_eager) and not torch.equal(z5, z4)
+        with pytest.raises(RuntimeError, match="capture\\(\\) again"):
+            rtp.replay()
+        sd5 = {k: v.cpu() for k, v in net.state_dict().items()}
+        assert rel_err(z5.cpu(), O.large_fwd(sd5, x.cpu(), T)) < TOL

@@ -480,6 +480,13 @@ def test_reference_optimizer_state_loads_into_a_capturable_trainer(dev):
     bad = {"state": {}, "param_groups": sd2["param_groups"]}
     with pytest.raises(RuntimeError, match="capture again"):
         tr_b.load_optimizer_state_dict(bad)
+    # (d) ADVICE r5: a state file with OTHER betas / eps / weight decay after capture() - constants of the captured step - is refused
+    import copy
+    other = copy.deepcopy(sd2)
+    other["param_groups"][0]["betas"] = (0.8, 0.99)
+    with pytest.raises(RuntimeError, match="constant of the captured step"):
+        tr_b.load_optimizer_state_dict(other)
+    assert tuple(tr_b.optimizer_G.param_groups[0]["betas"]) == (0.9, 0.999)
 
 
 #: bar of the two update errors above (an eager, non-capturable Adam against replayed capturable steps of the same kernels): measured
