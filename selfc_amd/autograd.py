@@ -1267,11 +1267,15 @@ class STPSampleFn(torch.autograd.Function):
         side = side_stream(dev)
         turn = 0                                           # two scratch slots; subnet_bwd reuses a slot only behind its last weight phase
         fc_maps: list = []
+        # the chain's dense blocks leave their weight-gradient launches and finishes to ONE launch per kind behind the chain (FinJobs,
+        # as the block stacks do): every subnet then needs its own scratch slot until the flush
+        n_sub = sum(isinstance(m_, D2DTInput) for m_, _, _ in ctx.stages)
+        fin = FinJobs(2 * n_sub, defer_wg=True) if (_DEFER_FIN and _DEFER_WG and n_sub) else None
         for m, xin, dense in reversed(ctx.stages):
             if isinstance(m, D2DTInput):
                 dxl = torch.empty((n, h, w, roundup(m.channel_in, 4)), dtype=torch.float32, device=dev)
-                g = subnet_bwd(m, dense, xin, d, 1.0, dxl, False, n, t, h, w, True, None, side, f"stp{turn}")
-                turn ^= 1
+                g = subnet_bwd(m, dense, xin, d, 1.0, dxl, False, n, t, h, w, True, None, side, f"stp{turn}", fin=fin)
+                turn = turn + 1 if fin is not None else turn ^ 1
                 for prm, gg in zip(subnet_params(m), g):
                     grads[id(prm)] = gg
                 d = dxl
@@ -1281,6 +1285,10 @@ class STPSampleFn(torch.autograd.Function):
                 for name, prm in m.named_parameters():
                     grads[id(prm)] = g[name]
                 d = dxl
+        if fin is not None:
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+            fin.flush()
         if fc_maps:                   # d fc.weight of every GlobalAgg: ONE batched fold (packing.pool_weight_map_grad_batch)
             folded = pool_weight_map_grad_batch(torch.stack([dm for _, dm in fc_maps]), h, w)
             for i, (m, _) in enumerate(fc_maps):

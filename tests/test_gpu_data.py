@@ -119,18 +119,19 @@ def test_vid4_geometry_and_clip_lengths_against_the_oracle(dev, seq):
     z_or = O.large_fwd(g, x, 7)
     e_z = rel_err(z.cpu(), z_or)
     lr_or = O.quantize(z_or[:, :3])
-    # quantisation ties: a latent value within 1e-3 relative of a rounding boundary may land on the other 1/255 step; compare the
-    # HIP path's reverse on the HIP path's OWN quantised LR (what the caller feeds it) against the oracle on the same LR
+    # quantisation: the LR latent is within ~1e-4 absolute of the oracle's, i.e. +-0.03 of a 1/255 step - a value that close to a
+    # rounding boundary lands on the neighbouring step (expected share = 2 x 255 x mean|error|: measured 1.8 %), never further.  The
+    # HIP path's reverse is therefore compared on the HIP path's OWN quantised LR (what the caller feeds it) against the oracle on it
     flips = float((lrq.cpu() != lr_or).float().mean())
-    record(f"Vid4 geometry {seq}: fraction of LR pixels on the other quantisation step", flips)
-    assert flips < 2e-3 and float((lrq.cpu() - lr_or).abs().max()) <= 1.0 / 255 + 1e-6
+    record(f"Vid4 geometry {seq}: fraction of LR pixels on the neighbouring quantisation step", flips)
+    assert flips < 5e-2 and float((lrq.cpu() - lr_or).abs().max()) <= 1.0 / 255 + 1e-6
     hf_or = O.stp_v2_parameters(subdict(s, "stp_net"), lrq.cpu(), 7)
     e_hf = rel_err(hf.cpu(), hf_or)
     x_or = O.large_inv_from_latent(g, torch.cat((lrq.cpu(), hf_or), 1), 7)
     e_x = rel_err(xr.cpu(), x_or)
     assert max(e_z, e_hf, e_x) < 1e-3, (e_z, e_hf, e_x)
     p_hip = harness.psnr_y(xr[:, :3], x.to(dev))
-    p_or = O.psnr_per_frame(x_or[:, :3], x)
+    p_or = O.psnr_per_frame(O.rgb_to_y(x_or[:, :3]), O.rgb_to_y(x))         # Y channel, as test_rescaling.py:93-96 / harness.psnr_y
     d_psnr = record(f"Vid4 geometry {seq}: max per-frame |Y-PSNR(HIP) - Y-PSNR(oracle)| dB", max(abs(a - b) for a, b in zip(p_hip, p_or)))
     assert d_psnr < 0.02, (p_hip, p_or)
     # --- first GOP: the four corners of the frame against the oracle on crops (forward latent and inverse)

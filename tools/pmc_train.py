@@ -3,6 +3,18 @@ kernel time - launches and time per step (kernel trace, eager step), MFMA-busy s
 bank-conflict share, HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE, KiB) and GB/s per launch.
     python3 tools/pmc_train.py gpurun_out/pmc_train profiles/r5 [steps traced = 8]"""
 import json, os, re, sys
+
+def _csrc_sha16():
+    """the hash bench.py compares per counter file: every kernel source and header of csrc/, names included"""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "selfc_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(n_ for n_ in os.listdir(csrc) if n_.endswith((".hip", ".hpp"))):
+        h.update(f.encode())
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
 d, out = sys.argv[1], sys.argv[2]
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 def read(path):
@@ -21,7 +33,7 @@ for line in open(os.path.join(d, "kernel_trace_summary.txt")):
     if m:
         trace.append((m.group(1).strip(), int(m.group(2)), float(m.group(3)), float(m.group(4))))
 p = [read(os.path.join(d, f"pmc{i}_summary.txt")) for i in (1, 2, 3, 4)]
-res = {"_meta": {"config": "tools/pmc_train.sh: tools/bench_train.py --batch 8 (8 x 7x3x144x144, fh_loss gmm), EAGER step; durations from a kernel-trace "
+res = {"_meta": {"csrc_sha16": _csrc_sha16(), "config": "tools/pmc_train.sh: tools/bench_train.py --batch 8 (8 x 7x3x144x144, fh_loss gmm), EAGER step; durations from a kernel-trace "
                            f"pass over {steps} steps, counters = means per dispatch of one step under rocprofv3 --pmc", "steps_traced": steps}}
 hot = [t for t in trace if t[0].startswith(("conv3x3_kernel", "wgrad", "tconv5_kernel", "selfc::fused", "selfc::dgrad", "coupling_bwd", "_ZN12_GLOBAL__N_121grad_to_planes"))][:9]
 for name, calls, total_ms, avg in hot:

@@ -2,6 +2,18 @@
 trace duration, HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE, KiB: MI355X_MICROARCH.md HBM section), achieved GB/s, MFMA-busy share and,
 where the algorithmic bytes / FLOPs per LR pixel-frame are known, the ratio to them.   python3 tools/pmc_uvg.py profiles/r5"""
 import json, os, re, sys
+
+def _csrc_sha16():
+    """the hash bench.py compares per counter file: every kernel source and header of csrc/, names included"""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "selfc_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(n_ for n_ in os.listdir(csrc) if n_.endswith((".hip", ".hpp"))):
+        h.update(f.encode())
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
 d = sys.argv[1]
 NPX = 7 * 270 * 480
 def read(path, counter=None):
@@ -23,7 +35,7 @@ fetch, write, sq = (read(os.path.join(d, f"uvg1080p_pmc_{k}.txt")) for k in ("fe
 NAMES = {"fused_gh": ("selfc::fused_gh_kernel", None, 2 * 9 * 32 * (3 + 35 + 67 + 99)), "fused_f16<0>": ("selfc::fused_f16_kernel<0>", None, 9 * 32 * 128),
          "fused_f16<1>": ("selfc::fused_f16_kernel<1>", None, 9 * 32 * 256), "tconv5_GH": ("tconv5_kernel<2, 3, 4, 1, 3>", 1004, None),
          "f_couple": ("selfc::f_couple_kernel", 128, None), "conv3x3 (STP, layer-wise)": ("conv3x3_kernel<16, 16, 4, 2, 0, false>", None, None)}
-out = {"_meta": {"config": "tools/profile_uvg.sh: ONE 7x3x1080x1920 GOP through pipeline.FullTestPath, eager, one stream; counters = means per dispatch under rocprofv3 --pmc",
+out = {"_meta": {"csrc_sha16": _csrc_sha16(), "config": "tools/profile_uvg.sh: ONE 7x3x1080x1920 GOP through pipeline.FullTestPath, eager, one stream; counters = means per dispatch under rocprofv3 --pmc",
                  "px_frames_per_launch": NPX}}
 for key, (pat, abytes, mac) in NAMES.items():
     k = next((n for n in trace if n.startswith(pat)), None)
