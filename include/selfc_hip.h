@@ -202,6 +202,9 @@ int selfc_subnet_bwd(const selfc_subnet_bw* bw, int kind, const void* dense, con
  * the data phase) produces wgrad / bgrad. */
 #define SELFC_BWD_DATA 1
 #define SELFC_BWD_WEIGHTS 2
+/* (abi 13, with wg_jobs of selfc_subnet_bwd_phase_d / selfc_gh_bwd_pair) the deferred weight-gradient jobs are built THIN: one workgroup
+ * per (conv, input plane) pair walking every tile - a launch meant to run in the background of another stream's kernels */
+#define SELFC_BWD_WG_THIN 8
 int selfc_subnet_bwd_phase(int phases, const selfc_subnet_bw* bw, int kind, const void* dense, const float* xin, const float* dout,
                            float sign, float* dx, int accumulate_dx, float* const* wgrad, float* const* bgrad, float beta,
                            void* scratch, size_t scratch_bytes, int N, int T, int H, int W, int cin, int cout, void* stream);

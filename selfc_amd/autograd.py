@@ -49,11 +49,52 @@ _DEFER_FIN = os.environ.get("SELFC_BWD_DEFER_FIN", "1") != "0"
 _DEFER_WG = os.environ.get("SELFC_BWD_DEFER_WG", "1") != "0"
 
 
+#: SELFC_BWD_BG_WG=1 (measured, NOT the default: 5.50 vs 5.31 ms at one septuplet per rank, 13.4 vs 13.5 at eight - one more data point
+#: that a forked branch of a replayed graph buys no overlap on this runtime; profiles/r6/ab_experiments.txt r6i): the weight gradients of
+#: the FIRST block stack of a backward pass (the reverse direction's) are built thin (one long-lived workgroup per (conv, input plane)
+#: pair: ~290 workgroups for a stack) and run on a background stream UNDER the rest of the backward - the STP chain and the second
+#: stack's data chain, whose thin launches leave most of every CU idle; one fork and one join instead of the 48 fine-grained ones that
+#: bought nothing (this runtime's graph executor, _TWO_STREAMS above).  The second stack's flush joins the background stream first
+#: (both finishes accumulate into the same gradient slices: beta = 1), then runs fat on the main stream.
+_BG_WG = os.environ.get("SELFC_BWD_BG_WG", "0") == "1"
+_BG_ON = False                       # set by the trainer around loss.backward() (background_wgrad)
+_BG_PENDING: Dict[str, "torch.cuda.Stream"] = {}
+
+
+def bg_stream(device):
+    key = (str(device), 2)
+    if key not in _SIDE:
+        _SIDE[key] = rt.distinct_streams(1, device, avoid=[v for k, v in _SIDE.items() if k[0] == str(device)])[0]
+    return _SIDE[key]
+
+
+def join_background(device=None):
+    """main stream waits for the background weight gradients (the trainer calls it behind loss.backward(), before the clip)"""
+    for key in [k for k in _BG_PENDING if device is None or k == str(device)]:
+        torch.cuda.current_stream().wait_stream(_BG_PENDING.pop(key))
+
+
+class background_wgrad:
+    """with background_wgrad(): loss.backward() - lets the first block stack's weight gradients run in the background; the caller
+    must call join_background() (the exit does) before it reads any parameter gradient"""
+
+    def __enter__(self):
+        global _BG_ON
+        self.old, _BG_ON = _BG_ON, _BG_WG
+        return self
+
+    def __exit__(self, *exc):
+        global _BG_ON
+        _BG_ON = self.old
+        join_background()
+
+
 class FinJobs:
     """Deferred weight-gradient finishes of a block stack's backward (selfc_subnet_bwd_phase_d / selfc_gh_bwd_pair leave job
     descriptors here, host memory; flush() reduces all of them with one launch per 24 jobs, in the order they were left)."""
 
-    def __init__(self, capacity: int, defer_wg: bool = False):
+    def __init__(self, capacity: int, defer_wg: bool = False, thin: bool = False):
+        self.thin = thin and defer_wg          # jobs built for a background launch (SELFC_BWD_WG_THIN)
         self.size = int(_lib.lib().selfc_fin_job_bytes())
         self.buf = (C.c_ubyte * (self.size * capacity))()
         self.cap, self.n = capacity, 0
@@ -362,7 +403,7 @@ def subnet_bwd(mod, dense: torch.Tensor, xin: Optional[torch.Tensor], dout: torc
     wjobs = fin.take_wg(2) if (jobs is not None and mod.kind == rt.SUBNET_D2DT) else None
     if wjobs is not None:
         # the weight-gradient launches are deferred as well: nothing of this call runs beside the data chain
-        rt.call("selfc_subnet_bwd_phase_d", 3, *args, jobs, wjobs, _lib.stream_ptr())
+        rt.call("selfc_subnet_bwd_phase_d", 3 | (8 if fin.thin else 0), *args, jobs, wjobs, _lib.stream_ptr())
         if on_data_done is not None:
             on_data_done()
         return grads
@@ -435,7 +476,7 @@ def gh_pair_bwd(blk, pb, gd: torch.Tensor, hd: torch.Tensor, xin: torch.Tensor, 
     jobs = fin.take(4) if (fin is not None and want_params) else None
     wjobs = fin.take_wg(4) if jobs is not None else None
     if side is None or not want_params or wjobs is not None:
-        rt.call("selfc_gh_bwd_pair", 3 if want_params else 1, *args, jobs, wjobs, _lib.stream_ptr())
+        rt.call("selfc_gh_bwd_pair", (3 if want_params else 1) | (8 if (fin is not None and fin.thin) else 0), *args, jobs, wjobs, _lib.stream_ptr())
         return gG, gH
     rt.call("selfc_gh_bwd_pair", 1, *args, None, None, _lib.stream_ptr())
     side.wait_event(torch.cuda.current_stream().record_event())
@@ -878,16 +919,26 @@ class InvStackFn(torch.autograd.Function):
         amax = None
         # the weight-gradient partials of every subnet are reduced by ONE launch per 24 jobs behind the last block (FinJobs); each block
         # has its own scratch set (tag), so nothing is overwritten before that
-        fin = FinJobs(6 * len(ctx.saves), defer_wg=_DEFER_WG and _PAIR) if (want and _DEFER_FIN) else None
+        # reverse-direction stack = the first to run in a training backward: its weight gradients may go to the background
+        bg = bool(_BG_ON and rev and want and _DEFER_FIN and _DEFER_WG and _PAIR)
+        fin = FinJobs(6 * len(ctx.saves), defer_wg=_DEFER_WG and _PAIR, thin=bg) if (want and _DEFER_FIN) else None
         for i, (blk, sv, keep, fd_intact) in enumerate(reversed(ctx.saves)):
             d1, d2, gF, gG, gH, amax = _block_backward(blk, sv, keep, rev, t, d1, d2, want, restore_fd=not fd_intact, tag=str(i), amax_in=amax,
                                                        amax_slots=None if slots is None else slots[3 * i:3 * i + 3], fin=fin)
             grads[id(blk)] = (*gF, *gG, *gH)
         if fin is not None and fin.n:
             side = side_stream(dev)
-            if side is None or fin.defer_wg:
+            if fin.thin:
+                # background: one fork here; the join is the next stack's flush (below) or the trainer's join_background()
+                bgs = bg_stream(dev)
+                bgs.wait_event(torch.cuda.current_stream().record_event())
+                with torch.cuda.stream(bgs):
+                    fin.flush()
+                _BG_PENDING[str(dev)] = bgs
+            elif side is None or fin.defer_wg:
                 if side is not None:         # (a subnet kind whose launches cannot be deferred ran its weight phase there)
                     torch.cuda.current_stream().wait_stream(side)
+                join_background(dev)         # an earlier stack's background finishes accumulate into the same gradient slices
                 fin.flush()                  # the stack's weight gradients: two fat launches + the finishes, behind the data chain
             else:
                 # behind every weight-gradient phase (the side stream is in order; H's non-paired phases, stream 1, are joined first)

@@ -745,10 +745,19 @@ static long wg_min_tiles() {
   static const long v = getenv("SELFC_WG_TILES") ? atol(getenv("SELFC_WG_TILES")) : 32;
   return v < 1 ? 1 : v;
 }
+// SELFC_BWD_WG_THIN (phase flag of the calling entry point): ONE workgroup per pair walks every tile - a launch of a few hundred
+// long-lived workgroups (a stack: ~290) that leaves most of every CU to the kernels of another stream (the next stack's data chain)
+static thread_local bool g_wg_thin = false;
 int wgrad_nsplit_table(int nsplit, long units) {
+  if (g_wg_thin) return 1;
   const long cap = (units + wg_min_tiles() - 1) / wg_min_tiles();
   return (int)(nsplit > cap ? (cap < 1 ? 1 : cap) : nsplit);
 }
+struct ThinScope {
+  bool old;
+  explicit ThinScope(bool on) : old(g_wg_thin) { g_wg_thin = on; }
+  ~ThinScope() { g_wg_thin = old; }
+};
 
 int wgrad_nsplit(int N, int H, int W, int npairs, int ttot) {
   const long ntiles = (long)N * ((H + 15) / 16) * ((W + 15) / 16);
@@ -991,6 +1000,7 @@ int selfc_subnet_bwd_phase_d(int phases, const selfc_subnet_bw* bw, int kind, co
                              const float* dout_amax, float* dx_amax_out, void* fin_jobs, void* wg_jobs, void* stream) {
   if (!(phases & (SELFC_BWD_DATA | SELFC_BWD_WEIGHTS))) return SELFC_EINVAL;
   if (wg_jobs && (!fin_jobs || kind != SELFC_SUBNET_D2DT)) return SELFC_EINVAL;      // deferred launches need deferred finishes; temporal conv5 only
+  ThinScope thin((phases & SELFC_BWD_WG_THIN) != 0 && wg_jobs != nullptr);
   if (!bw || !dense || !dout || !scratch || !bw->wt5 || !bw->wtx || !bw->wtd[0] || !bw->wtd[1] || !bw->wtd[2]) return SELFC_EINVAL;
   if (N <= 0 || T <= 0 || N % T || H <= 0 || W <= 0 || cin < 1 || cin > 96 || cout < 1 || cout > 96) return SELFC_EINVAL;
   if (kind != SELFC_SUBNET_D2DT && kind != SELFC_SUBNET_DB2D) return SELFC_EINVAL;
@@ -1154,6 +1164,7 @@ int selfc_gh_bwd_pair(int phases, const selfc_subnet_bw* bw_g, const selfc_subne
                       const float* amax_g, const float* amax_h, float* dx_amax_out, void* fin_jobs, void* wg_jobs, void* stream) {
   if (!(phases & (SELFC_BWD_DATA | SELFC_BWD_WEIGHTS))) return SELFC_EINVAL;
   if (wg_jobs && !fin_jobs) return SELFC_EINVAL;
+  ThinScope thin((phases & SELFC_BWD_WG_THIN) != 0 && wg_jobs != nullptr);
   if (!bw_g || !bw_h || !dense_g || !dense_h || !xin || !dout_g || !dout_h || !scratch) return SELFC_EINVAL;
   for (const selfc_subnet_bw* bw : {bw_g, bw_h})
     if (!bw->wt5 || !bw->wtx || !bw->wtd[0] || !bw->wtd[1] || !bw->wtd[2]) return SELFC_EINVAL;

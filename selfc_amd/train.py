@@ -267,7 +267,7 @@ class RescaleTrainer:
         LR = self.Quantization(lr_before_quant)
         l_back_rec = self.loss_backward(real_H, LR)
         loss = (l_forw_fit + l_back_rec + loss_c) * 144 * 144 * 3
-        with ag.grad_sink(self.sink):
+        with ag.grad_sink(self.sink), ag.background_wgrad():      # (joins the background weight gradients on its way out)
             loss.backward()
         if self.sink is not None:
             if self.data_parallel and not self.__dict__.get("_touched_checked"):

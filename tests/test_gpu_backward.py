@@ -601,6 +601,20 @@ def _bar_table(tag, mod, errs, errs16, g_ref):
     return rows
 
 
+def _floored(errs, g_ref, mod, floor=1e-5):
+    """the same per-tensor errors with the denominator floored at `floor` x the WHOLE gradient's norm: a tensor that carries 1e-7 of the
+    gradient (a GlobalAgg's fc / proj vectors: sums of cancelling terms) is judged against what it could move, not against its own noise"""
+    named = dict(mod.named_parameters())
+    tot = sum(float(v.double().pow(2).sum()) for v in g_ref.values()) ** 0.5
+    out = {}
+    for n_, e in errs.items():
+        nb = float(g_ref[n_].double().norm())
+        if n_.endswith("fc.weight"):
+            nb = (nb ** 2 + float(g_ref[n_[:-len("weight")] + "bias"].double().norm()) ** 2) ** 0.5
+        out[n_] = e * nb / (nb + floor * tot)
+    return out
+
+
 def _fc_merged_errs(mod, g_ref, skip=("proj3.bias",)):
     """per-tensor relative L2 with fc.weight / fc.bias of a GlobalAgg judged as one vector (fc.bias is a single scalar obtained
     by heavy cancellation) and proj3.bias skipped (exactly zero: the softmax is invariant to a key shift)"""
@@ -714,7 +728,9 @@ def test_codec_stp_trains(dev, hw):
     # bias, the 1024-tap pooled map fc.weight whose gradient is a sum of cancelling terms) are the f16-forward kink lottery;
     # the bar that binds is the one over all tensors
     assert tot < (2.5e-2 if hw == (8, 12) else 1.2e-2), tot
-    assert worst[0][1] < 1.5e-1, worst
+    # per tensor: measured worst 2.2e-2 (8x12) / 2.6e-2 (24x32), a third to a fifth of it left against the f16-forward oracle, i.e. mostly
+    # kinks (profiles/r6/gradient_bars.txt); bar = 3 x measured
+    assert worst[0][1] < 8e-2, worst
     assert len(list(stp.parameters())) == len(sd)         # `parameters` (the head output) is still callable
 
 
@@ -748,7 +764,14 @@ def test_stp_v2_gmm_thin_backward(dev):
     # which shows in the ill-conditioned small vectors of the LAST GlobalAgg (fc.weight: a sum of cancelling terms); all tensors
     # together and dx are what bind
     assert rel_l2(xd.grad.cpu(), dx_ref) < 5e-2 and tot < 2e-2, (tot, worst)
-    assert worst[0][1] < 2e-1, worst
+    # per tensor (profiles/r6/gradient_bars.txt): the five worst (6.8e-2 ... 1.3e-1) each carry < 3e-7 of the gradient's norm and are no
+    # better against the f16-forward oracle - cancellation noise of vectors that are sums of cancelling terms, not kinks; judged against
+    # a floor of 1e-5 of the whole gradient they vanish, and every tensor with a share above 1e-5 is within 2.4e-2.  Bars = 3 x measured
+    fl = _floored(errs, g_ref, stp)
+    from conftest import record
+    record("STP v2 gmm_thin backward: worst per-tensor relative L2 with the denominator floored at 1e-5 of the whole gradient", max(fl.values()))
+    assert max(fl.values()) < 7.5e-2, sorted(fl.items(), key=lambda kv: -kv[1])[:4]
+    assert worst[0][1] < 4e-1, worst
 
 
 def test_stp_v1_gmm_head_trains(dev):
