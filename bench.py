@@ -216,7 +216,7 @@ def rocprof_reference(kernel_key: str, csrc_sha16: str):
     try:
         with open(os.path.join(ROOT, "profiles", "r6", "rocprof_kernel_avgs.json")) as fh:
             ref = json.load(fh)
-        k = ref.get(kernel_key)
+        k = ref.get(kernel_key) or next((v for n_, v in ref.items() if n_ != "_meta" and kernel_key and n_.startswith(kernel_key)), None)
         meta = ref.get("_meta", {})
         if not k:
             return None
@@ -488,7 +488,7 @@ def main():
     dominant = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
     roofline = kern[dominant] if kern else None
     if roofline is not None:
-        ref_ = rocprof_reference({"fused_gh": "fused_gh_kernel", "conv3x3": "fused_f16_kernel<1>", "conv5_GH": "tconv5_kernel<2, 3, 4, 1, 3>"}.get(dominant, ""),
+        ref_ = rocprof_reference({"fused_gh": "fused_gh_kernel", "conv3x3": "fused_f16_kernel<1>", "conv5_GH": "tconv5_kernel<2, 3, 4, 1, 3"}.get(dominant, ""),
                                  hsh.hexdigest()[:16])
         # the same kernel's average in the tracked rocprofv3 trace of this command (another card, under the profiler): README explains gaps > 5 %
         roofline["rocprof_avg_us"] = ref_["avg_us"] if ref_ else None

@@ -33,7 +33,7 @@ for line in open(os.path.join(d, "uvg1080p_1stream_kernel_trace.txt")):
         trace[m.group(1).strip()] = float(m.group(4))
 fetch, write, sq = (read(os.path.join(d, f"uvg1080p_pmc_{k}.txt")) for k in ("fetch", "write", "sq"))
 NAMES = {"fused_gh": ("selfc::fused_gh_kernel", None, 2 * 9 * 32 * (3 + 35 + 67 + 99)), "fused_f16<0>": ("selfc::fused_f16_kernel<0>", None, 9 * 32 * 128),
-         "fused_f16<1>": ("selfc::fused_f16_kernel<1>", None, 9 * 32 * 256), "tconv5_GH": ("tconv5_kernel<2, 3, 4, 1, 3>", 1004, None),
+         "fused_f16<1>": ("selfc::fused_f16_kernel<1>", None, 9 * 32 * 256), "tconv5_GH": ("tconv5_kernel<2, 3, 4, 1, 3", 1004, None),
          "f_couple": ("selfc::f_couple_kernel", 128, None), "conv3x3 (STP, layer-wise)": ("conv3x3_kernel<16, 16, 4, 2, 0, false>", None, None)}
 out = {"_meta": {"csrc_sha16": _csrc_sha16(), "config": "tools/profile_uvg.sh: ONE 7x3x1080x1920 GOP through pipeline.FullTestPath, eager, one stream; counters = means per dispatch under rocprofv3 --pmc",
                  "px_frames_per_launch": NPX}}
