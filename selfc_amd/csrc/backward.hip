@@ -136,6 +136,7 @@ struct WgArgs {
   int nq0;
   int multi;             // conv1..4 of one dense block in a single launch: blockIdx.y enumerates (conv k, input plane q)
   int nqc1;              // multi: input planes of conv1 (conv k has nqc1 + k - 1)
+  int ts;                // tile side in pixels: 16, or 12 where that wastes less of the frame (wg_tile_side; 9-tap and temporal kernels)
 };
 
 // (conv k, plane q) of pair index y in multi mode
@@ -162,19 +163,23 @@ __device__ __forceinline__ f16x8 tr_frag(const unsigned char* lds, const int off
 // fetched into registers while the current one is multiplied (the launches are short: exposed load latency per tile
 // was most of their time).
 // gx / gy: the launch's extent in x (pixel splits) and y (pairs) for THIS job (gridDim.x / gridDim.y of a one-job launch)
-template <int TAPS>
-__device__ __forceinline__ void wgrad_body(const WgArgs& a, const int gx, const int gy) {
+// TS: tile side (16, or 12: a 36x36 training latent is 3 x 3 tiles of 12 with NO empty 4x4 patches - 9 patches per tile instead of
+// 16 of which 7 are skipped or half empty on average; the kernel is instruction-bound, so fewer patches per tile is the saving);
+// lp / lq: the workgroup's LDS tiles (declared by the kernel: two instantiations in one kernel share them)
+template <int TAPS, int TS = 16>
+__device__ __forceinline__ void wgrad_body(const WgArgs& a, const int gx, const int gy, const int bx, const int by,
+                                           unsigned char* const lp, unsigned char* const lq) {
+  static_assert(TS == 16 || (TS == 12 && TAPS == 9), "tile side");
   constexpr int NW = TAPS == 1 ? 4 : 3, NT = NW * 64;
   constexpr int TPW = TAPS == 9 ? 3 : 1;                    // taps per wave
   constexpr int HALO = TAPS == 9 ? 1 : 0;
-  constexpr int QW = 16 + 2 * HALO, QPIX = QW * QW, QF = TAPS == 3 ? 3 : 1;
-  constexpr int PI = (1024 + NT - 1) / NT, QI = (QF * QPIX * 4 + NT - 1) / NT;
-  __shared__ __attribute__((aligned(16))) unsigned char lp[256 * 64];
-  __shared__ __attribute__((aligned(16))) unsigned char lq[QF * QPIX * 64];
+  constexpr int QW = TS + 2 * HALO, QPIX = QW * QW, QF = TAPS == 3 ? 3 : 1;
+  constexpr int PPIX4 = TS * TS * 4, NP = TS / 4;
+  constexpr int PI = (PPIX4 + NT - 1) / NT, QI = (QF * QPIX * 4 + NT - 1) / NT;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int kconv = 0, qi = blockIdx.y;
-  if (a.multi) wg_pair(blockIdx.y, a.nqc1, kconv, qi);
+  int kconv = 0, qi = by;
+  if (a.multi) wg_pair(by, a.nqc1, kconv, qi);
   const f16* __restrict__ P = a.P + (size_t)(a.multi ? 4 - kconv : (int)blockIdx.z) * a.plane;
   const f16* __restrict__ Q = qi < a.nq0 ? a.Q0 + (size_t)qi * a.plane : a.Q1 + (size_t)(qi - a.nq0) * a.plane;
   const int H = a.H, W = a.W;
@@ -201,14 +206,14 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const int gx, const 
   unsigned okp = 0, okq = 0;
   auto fetch = [&](const int tile) __attribute__((always_inline)) {
     const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, n = tile / (a.tiles_x * a.tiles_y);
-    const int tx0 = tx * 16, ty0 = ty * 16;
+    const int tx0 = tx * TS, ty0 = ty * TS;
     const int tclip = n % a.T;
     okp = 0; okq = 0;
 #pragma unroll
     for (int it = 0; it < PI; ++it) {
-      const int i = min(tid + it * NT, 1023);
+      const int i = min(tid + it * NT, PPIX4 - 1);
       const int px = i >> 2, ch = i & 3;
-      const int y = ty0 + (px >> 4), x = tx0 + (px & 15);
+      const int y = ty0 + px / TS, x = tx0 + px % TS;
       okp |= (((y < H) & (x < W)) ? 1u : 0u) << it;
       const int yc = min(y, H - 1), xc = min(x, W - 1);
       preg[it] = *reinterpret_cast<const u32x4*>(P + ((size_t)(n * H + yc) * W + xc) * 32 + ch * 8);
@@ -229,16 +234,16 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const int gx, const 
     }
   };
 
-  int tile = blockIdx.x;
+  int tile = bx;
   if (tile < a.ntiles) fetch(tile);
   for (; tile < a.ntiles; tile += gx) {
     const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y;
-    const int tx0 = tx * 16, ty0 = ty * 16;
+    const int tx0 = tx * TS, ty0 = ty * TS;
     __syncthreads();                       // the previous tile's fragments have been read
 #pragma unroll
     for (int it = 0; it < PI; ++it) {
       const int i = tid + it * NT;
-      if (i < 1024) *reinterpret_cast<u32x4*>(lp + (i >> 2) * 64 + (i & 3) * 16) = ((okp >> it) & 1u) ? preg[it] : u32x4{0u, 0u, 0u, 0u};
+      if (i < PPIX4) *reinterpret_cast<u32x4*>(lp + (i >> 2) * 64 + (i & 3) * 16) = ((okp >> it) & 1u) ? preg[it] : u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
     for (int it = 0; it < QI; ++it) {
@@ -249,11 +254,11 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const int gx, const 
     if (tile + gx < a.ntiles) fetch(tile + gx);
     // 16 patches of 4x4 pixels; patches wholly outside the image are skipped (wave-uniform: the transposing
     // read needs EXEC all ones).  TAPS == 1: each wave takes 4 of them; otherwise each wave takes all 16 for its taps.
-    for (int pi = (TAPS == 1 ? wave : 0); pi < 16; pi += (TAPS == 1 ? 4 : 1)) {
-      const int pr = pi >> 2, pc = pi & 3;
+    for (int pi = (TAPS == 1 ? wave : 0); pi < NP * NP; pi += (TAPS == 1 ? 4 : 1)) {
+      const int pr = pi / NP, pc = pi % NP;
       if (ty0 + 4 * pr >= H || tx0 + 4 * pc >= W) continue;
-      const int arow = ((4 * pr + 2 * h) * 16 + 4 * pc + q) * 64 + choff;
-      const f16x8 af = tr_frag(lp, arow, arow + 16 * 64);
+      const int arow = ((4 * pr + 2 * h) * TS + 4 * pc + q) * 64 + choff;
+      const f16x8 af = tr_frag(lp, arow, arow + TS * 64);
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
         const int tap = TAPS == 9 ? wave * 3 + t : 0;
@@ -268,8 +273,8 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const int gx, const 
   }
   // D[o][c]: lane owns column c = lane & 31, rows o = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int npairs = a.multi ? gy : (int)(gy * gridDim.z);
-  const int pair = a.multi ? (int)blockIdx.y : (int)(blockIdx.z * gy + blockIdx.y);
-  const size_t blk = (size_t)blockIdx.x * npairs + pair;
+  const int pair = a.multi ? by : (int)(blockIdx.z * gy + by);
+  const size_t blk = (size_t)bx * npairs + pair;
   if (TAPS == 1) {
     // reduce the 4 waves' accumulators (and bias sums) through LDS, wave 0 writes
     __syncthreads();
@@ -306,22 +311,35 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const int gx, const 
     }
     if (want_bias && wave == 0 && (lane & 31) == 0) {
       const int nb = a.multi ? 4 : (int)gridDim.z, pb = a.multi ? kconv - 1 : (int)blockIdx.z;
-      float* __restrict__ bb = a.bpart + ((size_t)blockIdx.x * nb + pb) * 32;
+      float* __restrict__ bb = a.bpart + ((size_t)bx * nb + pb) * 32;
 #pragma unroll
       for (int r = 0; r < 16; ++r) bb[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = accb[r];
     }
   }
 }
 
+// LDS of a weight-gradient workgroup: the gradient tile [16 x 16 px][32 ch] and the activation tile(s) (18 x 18 with the 3x3 taps' halo)
+#define SELFC_WG_LDS(TAPS_) \
+  __shared__ __attribute__((aligned(16))) unsigned char lp[256 * 64]; \
+  __shared__ __attribute__((aligned(16))) unsigned char lq[((TAPS_) == 9 ? 18 * 18 : 256) * 64]
+// 9-tap body on the job's tile side
+__device__ __forceinline__ void wgrad9(const WgArgs& a, const int gx, const int gy, const int bx, const int by, unsigned char* lp, unsigned char* lq) {
+  if (a.ts == 12) wgrad_body<9, 12>(a, gx, gy, bx, by, lp, lq);
+  else wgrad_body<9, 16>(a, gx, gy, bx, by, lp, lq);
+}
+
 template <int TAPS>
 __global__ __launch_bounds__((TAPS == 1 ? 4 : 3) * 64) void wgrad_kernel(const WgArgs a) {
-  wgrad_body<TAPS>(a, (int)gridDim.x, (int)gridDim.y);
+  SELFC_WG_LDS(TAPS);
+  if constexpr (TAPS == 9) wgrad9(a, (int)gridDim.x, (int)gridDim.y, (int)blockIdx.x, (int)blockIdx.y, lp, lq);
+  else wgrad_body<TAPS>(a, (int)gridDim.x, (int)gridDim.y, (int)blockIdx.x, (int)blockIdx.y, lp, lq);
 }
 
 // multi mode only (conv1..4 of a dense block, grid.z unused by the body): the jobs of two nets of one geometry in one launch
 __global__ __launch_bounds__(192) void wgrad_pair_kernel(const WgArgs a, const WgArgs b) {
-  if (blockIdx.z) wgrad_body<9>(b, (int)gridDim.x, (int)gridDim.y);
-  else wgrad_body<9>(a, (int)gridDim.x, (int)gridDim.y);
+  SELFC_WG_LDS(9);
+  if (blockIdx.z) wgrad9(b, (int)gridDim.x, (int)gridDim.y, (int)blockIdx.x, (int)blockIdx.y, lp, lq);
+  else wgrad9(a, (int)gridDim.x, (int)gridDim.y, (int)blockIdx.x, (int)blockIdx.y, lp, lq);
 }
 
 // Up to WG_TABLE conv1..4 jobs (multi mode) in ONE launch: blockIdx.z = job, whose own extent is gx[z] x gy[z] (the rest of the grid
@@ -330,15 +348,33 @@ __global__ __launch_bounds__(192) void wgrad_pair_kernel(const WgArgs a, const W
 // behind them - are therefore ONE fat launch at the end of the stack's data-gradient chain instead of 24 thin ones beside it.
 constexpr int WG_TABLE = 32;
 struct WgTable {
-  int n;
+  int n, xcd;
   int gx[WG_TABLE], gy[WG_TABLE];
   WgArgs job[WG_TABLE];
 };
 static_assert(sizeof(WgTable) <= 4096, "kernel argument limit");
+// Workgroup -> (pixel split, pair): the grid is 1-D per job (x; a multiple of 8 workgroups, blockIdx.z = job) and workgroups reach the
+// eight XCDs round robin, so L & 7 is the XCD.  All pairs of ONE split - which read the same tiles of the same planes: a dpre plane is an
+// operand of 2..5 pairs, an activation plane of 1..4 - sit next to each other on ONE XCD and walk their tiles in step: the re-reads hit
+// that XCD's L2 instead of going out to the Infinity Cache / HBM once per pair (the launch moved 5.0 GB per stack at 5.5 TB/s: it was
+// bound by exactly that).  t.xcd == 0: plain x = split fastest (A/B).
+__device__ __forceinline__ bool wg_map(const int L, const int gx, const int gy, const int xcd_mode, int& bx, int& by) {
+  if (xcd_mode && gx >= 8) {               // (fewer than 8 splits: the XCD form would leave XCDs without work)
+    const int j = L >> 3;
+    by = j % gy;
+    bx = (j / gy) * 8 + (L & 7);
+  } else {
+    bx = L % gx;
+    by = L / gx;
+  }
+  return bx < gx && by < gy;
+}
 __global__ __launch_bounds__(192) void wgrad_table_kernel(const WgTable t) {
   const int z = blockIdx.z;
-  if ((int)blockIdx.x >= t.gx[z] || (int)blockIdx.y >= t.gy[z]) return;          // workgroup-uniform
-  wgrad_body<9>(t.job[z], t.gx[z], t.gy[z]);
+  int bx, by;
+  if (!wg_map((int)blockIdx.x, t.gx[z], t.gy[z], t.xcd, bx, by)) return;          // workgroup-uniform
+  SELFC_WG_LDS(9);
+  wgrad9(t.job[z], t.gx[z], t.gy[z], bx, by, lp, lq);
 }
 
 // Temporal weight gradient (conv5 of D2DTInput: dW[o][c][tap] = sum_px g[n][px][o] * in[n + tap - 1][px][c] inside each clip).
@@ -346,12 +382,12 @@ __global__ __launch_bounds__(192) void wgrad_table_kernel(const WgTable t) {
 // activation tiles in LDS, so every frame's tile is loaded once (the generic kernel loaded three per frame) while the next
 // frame's two tiles are prefetched into registers; wave w multiplies with the ring slot of frame t + w - 1.
 // bz / nz: this workgroup's gradient plane and the number of gradient planes of its net (blockIdx.z / gridDim.z of a one-net launch)
-__device__ __forceinline__ void wgrad_temporal_body(const WgArgs& a, const int bz, const int nz, const int gx, const int gy) {
-  constexpr int NT = 192, PI = (1024 + NT - 1) / NT;
-  __shared__ __attribute__((aligned(16))) unsigned char lp[256 * 64];
-  __shared__ __attribute__((aligned(16))) unsigned char lq[3 * 256 * 64];
+template <int TS>
+__device__ __forceinline__ void wgrad_temporal_body_ts(const WgArgs& a, const int bz, const int nz, const int gx, const int gy, const int bx, const int by,
+                                                       unsigned char* const lp, unsigned char* const lq) {
+  constexpr int NT = 192, PPIX4 = TS * TS * 4, PI = (PPIX4 + NT - 1) / NT, NP = TS / 4, SLOT = TS * TS * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qi = blockIdx.y;
+  const int qi = by;
   const f16* __restrict__ P = a.P + (size_t)bz * a.plane;
   const f16* __restrict__ Q = qi < a.nq0 ? a.Q0 + (size_t)qi * a.plane : a.Q1 + (size_t)(qi - a.nq0) * a.plane;
   const int H = a.H, W = a.W, T = a.T;
@@ -374,9 +410,9 @@ __device__ __forceinline__ void wgrad_temporal_body(const WgArgs& a, const int b
     const int np = nbase + max(0, min(t, T - 1)), nq = nbase + min(t + 1, T - 1);
 #pragma unroll
     for (int it = 0; it < PI; ++it) {
-      const int i = min(tid + it * NT, 1023);
+      const int i = min(tid + it * NT, PPIX4 - 1);
       const int px = i >> 2, ch = i & 3;
-      const int y = ty0 + (px >> 4), x = tx0 + (px & 15);
+      const int y = ty0 + px / TS, x = tx0 + px % TS;
       const bool in = (y < H) & (x < W);
       okm |= ((in & pv) ? 1u : 0u) << it;
       okm |= ((in & qv) ? 1u : 0u) << (16 + it);
@@ -389,82 +425,91 @@ __device__ __forceinline__ void wgrad_temporal_body(const WgArgs& a, const int b
 #pragma unroll
     for (int it = 0; it < PI; ++it) {
       const int i = tid + it * NT;
-      if (i < 1024) *reinterpret_cast<u32x4*>(lq + (size_t)slot * 16384 + (i >> 2) * 64 + (i & 3) * 16) = ((mask >> it) & 1u) ? qreg[it] : u32x4{0u, 0u, 0u, 0u};
+      if (i < PPIX4) *reinterpret_cast<u32x4*>(lq + (size_t)slot * SLOT + (i >> 2) * 64 + (i & 3) * 16) = ((mask >> it) & 1u) ? qreg[it] : u32x4{0u, 0u, 0u, 0u};
     }
   };
 
   const int nunits = (a.N / T) * a.tiles_x * a.tiles_y;
-  for (int unit = blockIdx.x; unit < nunits; unit += gx) {
+  for (int unit = bx; unit < nunits; unit += gx) {
     const int tx = unit % a.tiles_x, ty = (unit / a.tiles_x) % a.tiles_y, clip = unit / (a.tiles_x * a.tiles_y);
-    const int tx0 = tx * 16, ty0 = ty * 16, nbase = clip * T;
+    const int tx0 = tx * TS, ty0 = ty * TS, nbase = clip * T;
     // ring slots: frame f lives in slot (f + 1) % 3; slot of frame -1 is zero, frame 0 is loaded up front
     __syncthreads();
     fetch(nbase, -1 + 0, tx0, ty0);                    // t = -1: P invalid (unused), Q = frame 0
     // (fetch's P part for t = -1 reads frame 0's P rows harmlessly; only the Q half is stored)
     store_q(1, okm >> 16);
-    for (int i = tid; i < 1024; i += NT) *reinterpret_cast<u32x4*>(lq + (i >> 2) * 64 + (i & 3) * 16) = u32x4{0u, 0u, 0u, 0u};   // slot 0 = frame -1
+    for (int i = tid; i < PPIX4; i += NT) *reinterpret_cast<u32x4*>(lq + (i >> 2) * 64 + (i & 3) * 16) = u32x4{0u, 0u, 0u, 0u};   // slot 0 = frame -1
     fetch(nbase, 0, tx0, ty0);                          // P[0], Q[1]
     for (int t = 0; t < T; ++t) {
       __syncthreads();                                  // frame t-1's fragments have been read
 #pragma unroll
       for (int it = 0; it < PI; ++it) {
         const int i = tid + it * NT;
-        if (i < 1024) *reinterpret_cast<u32x4*>(lp + (i >> 2) * 64 + (i & 3) * 16) = ((okm >> it) & 1u) ? preg[it] : u32x4{0u, 0u, 0u, 0u};
+        if (i < PPIX4) *reinterpret_cast<u32x4*>(lp + (i >> 2) * 64 + (i & 3) * 16) = ((okm >> it) & 1u) ? preg[it] : u32x4{0u, 0u, 0u, 0u};
       }
       store_q((t + 2) % 3, okm >> 16);                  // frame t+1 (zeros past the clip end)
       __syncthreads();
       if (t + 1 < T) fetch(nbase, t + 1, tx0, ty0);     // P[t+1], Q[t+2] while frame t is multiplied
       const int slot = (t + wave) % 3;                  // frame t + wave - 1
-      for (int pi = 0; pi < 16; ++pi) {
-        const int pr = pi >> 2, pc = pi & 3;
+      for (int pi = 0; pi < NP * NP; ++pi) {
+        const int pr = pi / NP, pc = pi % NP;
         if (ty0 + 4 * pr >= H || tx0 + 4 * pc >= W) continue;
-        const int row = ((4 * pr + 2 * h) * 16 + 4 * pc + q) * 64 + choff;
-        const f16x8 af = tr_frag(lp, row, row + 16 * 64);
-        const f16x8 bf = tr_frag(lq + (size_t)slot * 16384, row, row + 16 * 64);
+        const int row = ((4 * pr + 2 * h) * TS + 4 * pc + q) * 64 + choff;
+        const f16x8 af = tr_frag(lp, row, row + TS * 64);
+        const f16x8 bf = tr_frag(lq + (size_t)slot * SLOT, row, row + TS * 64);
         acc = mfma_32x32x16(af, bf, acc);
         if (want_bias && wave == 0) accb = mfma_32x32x16(af, ones, accb);
       }
     }
   }
   const int npairs = gy * nz;
-  const int pair = bz * gy + (int)blockIdx.y;
-  float* __restrict__ base = a.part + ((((size_t)blockIdx.x * npairs + pair) * 3 + wave) << 10);
+  const int pair = bz * gy + by;
+  float* __restrict__ base = a.part + ((((size_t)bx * npairs + pair) * 3 + wave) << 10);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int o = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     base[o * 32 + (lane & 31)] = acc[r];
   }
   if (want_bias && wave == 0 && (lane & 31) == 0) {
-    float* __restrict__ bb = a.bpart + ((size_t)blockIdx.x * nz + bz) * 32;
+    float* __restrict__ bb = a.bpart + ((size_t)bx * nz + bz) * 32;
 #pragma unroll
     for (int r = 0; r < 16; ++r) bb[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = accb[r];
   }
 }
 
+__device__ __forceinline__ void wgrad_temporal_body(const WgArgs& a, const int bz, const int nz, const int gx, const int gy, const int bx, const int by) {
+  __shared__ __attribute__((aligned(16))) unsigned char lp[256 * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char lq[3 * 256 * 64];
+  if (a.ts == 12) wgrad_temporal_body_ts<12>(a, bz, nz, gx, gy, bx, by, lp, lq);
+  else wgrad_temporal_body_ts<16>(a, bz, nz, gx, gy, bx, by, lp, lq);
+}
+
 __global__ __launch_bounds__(192) void wgrad_temporal_kernel(const WgArgs a) {
-  wgrad_temporal_body(a, (int)blockIdx.z, (int)gridDim.z, (int)gridDim.x, (int)gridDim.y);
+  wgrad_temporal_body(a, (int)blockIdx.z, (int)gridDim.z, (int)gridDim.x, (int)gridDim.y, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // two nets of one geometry: blockIdx.z in [0, 2 Pn)
 __global__ __launch_bounds__(192) void wgrad_temporal_pair_kernel(const WgArgs a, const WgArgs b) {
   const int nz = (int)gridDim.z >> 1;
-  if ((int)blockIdx.z >= nz) wgrad_temporal_body(b, (int)blockIdx.z - nz, nz, (int)gridDim.x, (int)gridDim.y);
-  else wgrad_temporal_body(a, (int)blockIdx.z, nz, (int)gridDim.x, (int)gridDim.y);
+  if ((int)blockIdx.z >= nz) wgrad_temporal_body(b, (int)blockIdx.z - nz, nz, (int)gridDim.x, (int)gridDim.y, (int)blockIdx.x, (int)blockIdx.y);
+  else wgrad_temporal_body(a, (int)blockIdx.z, nz, (int)gridDim.x, (int)gridDim.y, (int)blockIdx.x, (int)blockIdx.y);
 }
 
-// Up to WG_TABLE temporal (conv5) jobs in one launch: blockIdx.z runs over all jobs' gradient planes (zstart: job j owns
-// [zstart[j], zstart[j + 1])), each job with its own extent gx x gy
+// Up to WG_TABLE temporal (conv5) jobs in one launch (blockIdx.z = job), each with its own extent: gx unit splits x (nz gradient
+// planes x gy input planes) pairs
 struct WgTTable {
-  int n;
-  int gx[WG_TABLE], gy[WG_TABLE], zstart[WG_TABLE + 1];
+  int n, xcd;
+  int gx[WG_TABLE], gy[WG_TABLE], nz[WG_TABLE];
   WgArgs job[WG_TABLE];
 };
 static_assert(sizeof(WgTTable) <= 4096, "kernel argument limit");
+// blockIdx.z = job; x enumerates (unit split, (gradient plane, input plane) pair) through wg_map: the pairs of one split - every
+// gradient plane against every input plane of the same tiles - next to each other on one XCD
 __global__ __launch_bounds__(192) void wgrad_temporal_table_kernel(const WgTTable t) {
-  int j = 0;
-  while (j + 1 < t.n && (int)blockIdx.z >= t.zstart[j + 1]) ++j;                  // workgroup-uniform
-  if ((int)blockIdx.x >= t.gx[j] || (int)blockIdx.y >= t.gy[j]) return;
-  wgrad_temporal_body(t.job[j], (int)blockIdx.z - t.zstart[j], t.zstart[j + 1] - t.zstart[j], t.gx[j], t.gy[j]);
+  const int j = blockIdx.z;
+  int bx, pr;
+  if (!wg_map((int)blockIdx.x, t.gx[j], t.gy[j] * t.nz[j], t.xcd, bx, pr)) return;   // workgroup-uniform
+  wgrad_temporal_body(t.job[j], pr / t.gy[j], t.nz[j], t.gx[j], t.gy[j], bx, pr % t.gy[j]);
 }
 
 struct FinArgs {
@@ -759,8 +804,19 @@ struct ThinScope {
   ~ThinScope() { g_wg_thin = old; }
 };
 
+// tile side of the 9-tap and temporal weight-gradient kernels: 12 where 12x12 tiles cover the frame with less waste than 16x16 ones
+// (36x36 training latents: 3 x 3 tiles of 12, no empty patch; 16: 3 x 3 tiles 56 % full).  SELFC_WG_TS=16: always 16 (A/B)
+int wg_tile_side(int H, int W) {
+  static const int force = getenv("SELFC_WG_TS") ? atoi(getenv("SELFC_WG_TS")) : 0;
+  if (force == 16 || force == 12) return force;
+  const long a16 = (long)((H + 15) / 16) * ((W + 15) / 16) * 256, a12 = (long)((H + 11) / 12) * ((W + 11) / 12) * 144;
+  return a12 < a16 ? 12 : 16;
+}
+inline int wg_tiles(int v, int ts) { return (v + ts - 1) / ts; }
+
 int wgrad_nsplit(int N, int H, int W, int npairs, int ttot) {
-  const long ntiles = (long)N * ((H + 15) / 16) * ((W + 15) / 16);
+  const int ts9 = ttot == 1 ? 16 : wg_tile_side(H, W);
+  const long ntiles = (long)N * wg_tiles(H, ts9) * wg_tiles(W, ts9);
   long ns = (768 + (long)npairs - 1) / (long)npairs;           // 512 / 1024 / 1536 / 2048 measured: all slower (profiles/r4/ab_experiments.txt)
   const long cap = 3072 / ((long)npairs * ttot);
   if (ns > cap) ns = cap;
@@ -827,9 +883,10 @@ static void wg_job_set(WgJob* dst, const WgArgs& a, int kind, int gx, int gy, in
 static int bwd_wgrad_impl(const WgradJob& j, const float* amax, void* scratch, int N, int T, int H, int W, hipStream_t s, FinArgs* defer,
                           WgJob* defer_wg = nullptr) {
   const size_t npix = (size_t)N * H * W, plane = npix * 32;
-  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
   const int qtot = j.Qn[0] + j.Qn[1];
   const int ttot = j.taps == 9 ? 9 : (j.temporal ? 3 : 1);
+  const int ts = ttot == 1 ? 16 : wg_tile_side(H, W);
+  const int tiles_x = wg_tiles(W, ts), tiles_y = wg_tiles(H, ts);
   int nsplit = wgrad_nsplit(N, H, W, j.Pn * qtot, ttot);
   if (ttot == 3) {                                   // the temporal kernel's units are (clip, tile): never more splits than units
     const int nunits = (N / T) * tiles_x * tiles_y;
@@ -842,7 +899,7 @@ static int bwd_wgrad_impl(const WgradJob& j, const float* amax, void* scratch, i
   WgArgs a{};
   a.P = (const f16*)j.P; a.Q0 = (const f16*)j.Q[0]; a.nq0 = j.Qn[0]; a.Q1 = (const f16*)j.Q[1];
   a.part = part; a.bpart = j.bout ? bpart : nullptr; a.plane = plane;
-  a.N = N; a.T = T; a.H = H; a.W = W; a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.ntiles = N * tiles_x * tiles_y;
+  a.N = N; a.T = T; a.H = H; a.W = W; a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.ntiles = N * tiles_x * tiles_y; a.ts = ts;
   int rc = SELFC_OK;
   const bool dwg = defer_wg && defer && ttot == 3;           // only the temporal job can be deferred (the table kernels cover multi + temporal)
   if (dwg) wg_job_set(defer_wg, a, 1, nsplit, qtot, j.Pn);
@@ -874,13 +931,14 @@ static void wgrad14_args(const void* dpre, const void* Q0, int nq0, const void* 
   const size_t npix = (size_t)N * H * W, plane = npix * 32;
   npairs = 4 * nqc1 + 6;
   nsplit = wgrad_nsplit(N, H, W, npairs, 9);
-  if (table) nsplit = wgrad_nsplit_table(nsplit, (long)N * ((H + 15) / 16) * ((W + 15) / 16));
+  const int ts = wg_tile_side(H, W);
+  if (table) nsplit = wgrad_nsplit_table(nsplit, (long)N * wg_tiles(H, ts) * wg_tiles(W, ts));
   float* bpart = (float*)scratch;
   float* part = (float*)((unsigned char*)scratch + up256((size_t)nsplit * 4 * 32 * sizeof(float)));
   a = WgArgs{};
   a.P = (const f16*)dpre; a.Q0 = (const f16*)Q0; a.nq0 = nq0; a.Q1 = (const f16*)Q1;
   a.part = part; a.bpart = bout ? bpart : nullptr; a.plane = plane;
-  a.N = N; a.T = T; a.H = H; a.W = W; a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16; a.ntiles = N * a.tiles_x * a.tiles_y;
+  a.N = N; a.T = T; a.H = H; a.W = W; a.tiles_x = wg_tiles(W, ts); a.tiles_y = wg_tiles(H, ts); a.ntiles = N * a.tiles_x * a.tiles_y; a.ts = ts;
   a.multi = 1; a.nqc1 = nqc1;
   f = FinArgs{};
   f.part = part; f.bpart = bpart; f.nW = nsplit; f.Pn = 4; f.ttot = 9; f.O = 32; f.cin = cin; f.nx = nx;
@@ -906,24 +964,27 @@ static int launch_wg_jobs(const WgJob* jobs, int njobs, hipStream_t s) {
   for (int kind = 0; kind < 2; ++kind) {
     int j = 0;
     while (j < njobs) {
+      static const int xcd_mode = getenv("SELFC_WG_XCD") ? atoi(getenv("SELFC_WG_XCD")) : 1;
       WgTable t{};
       WgTTable tt{};
-      int mx = 0, my = 0, nz = 0, n = 0;
+      int mx = 0, n = 0;                       // mx: workgroups per job slice (x), a multiple of 8 in XCD mode
       for (; j < njobs && n < WG_TABLE; ++j) {
         if (jobs[j].kind != kind) continue;
+        const int pairs = kind == 0 ? jobs[j].gy : jobs[j].gy * jobs[j].nz;
         if (kind == 0) { t.job[n] = jobs[j].a; t.gx[n] = jobs[j].gx; t.gy[n] = jobs[j].gy; }
-        else { tt.job[n] = jobs[j].a; tt.gx[n] = jobs[j].gx; tt.gy[n] = jobs[j].gy; tt.zstart[n] = nz; nz += jobs[j].nz; }
-        mx = jobs[j].gx > mx ? jobs[j].gx : mx;
-        my = jobs[j].gy > my ? jobs[j].gy : my;
+        else { tt.job[n] = jobs[j].a; tt.gx[n] = jobs[j].gx; tt.gy[n] = jobs[j].gy; tt.nz[n] = jobs[j].nz; }
+        const int need = (xcd_mode && jobs[j].gx >= 8) ? ((jobs[j].gx + 7) / 8) * 8 * pairs : jobs[j].gx * pairs;
+        mx = need > mx ? need : mx;
         ++n;
       }
       if (!n) break;
+      mx = (mx + 7) & ~7;                      // every job's slice starts on XCD 0
       if (kind == 0) {
-        t.n = n;
-        hipLaunchKernelGGL(wgrad_table_kernel, dim3((unsigned)mx, (unsigned)my, (unsigned)n), dim3(192), 0, s, t);
+        t.n = n; t.xcd = xcd_mode;
+        hipLaunchKernelGGL(wgrad_table_kernel, dim3((unsigned)mx, 1, (unsigned)n), dim3(192), 0, s, t);
       } else {
-        tt.n = n; tt.zstart[n] = nz;
-        hipLaunchKernelGGL(wgrad_temporal_table_kernel, dim3((unsigned)mx, (unsigned)my, (unsigned)nz), dim3(192), 0, s, tt);
+        tt.n = n; tt.xcd = xcd_mode;
+        hipLaunchKernelGGL(wgrad_temporal_table_kernel, dim3((unsigned)mx, 1, (unsigned)n), dim3(192), 0, s, tt);
       }
       const int rc = hip_rc(hipGetLastError());
       if (rc) return rc;
@@ -1244,7 +1305,8 @@ int selfc_gh_bwd_pair(int phases, const selfc_subnet_bw* bw_g, const selfc_subne
                    wg_jobs != nullptr);
       // conv5 (temporal taps): P = the dOut planes, Q = [x | f1..f4]
       nsplit5 = wgrad_nsplit(N, H, W, L.ng * qtot, 3);
-      const int nunits = (N / T) * ((W + 15) / 16) * ((H + 15) / 16);
+      const int ts5 = wg_tile_side(H, W);
+      const int nunits = (N / T) * wg_tiles(W, ts5) * wg_tiles(H, ts5);
       if (nsplit5 > nunits) nsplit5 = nunits;
       if (wg_jobs) nsplit5 = wgrad_nsplit_table(nsplit5, (long)nunits * T);
       float* bpart = (float*)(sb + L.off_wg5[q]);
@@ -1255,7 +1317,7 @@ int selfc_gh_bwd_pair(int phases, const selfc_subnet_bw* bw_g, const selfc_subne
       a = WgArgs{};
       a.P = gpl[q]; a.Q0 = xpl; a.nq0 = 1; a.Q1 = feat[q];
       a.part = part; a.bpart = bout ? bpart : nullptr; a.plane = plane;
-      a.N = N; a.T = T; a.H = H; a.W = W; a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16; a.ntiles = N * a.tiles_x * a.tiles_y;
+      a.N = N; a.T = T; a.H = H; a.W = W; a.tiles_x = wg_tiles(W, ts5); a.tiles_y = wg_tiles(H, ts5); a.ntiles = N * a.tiles_x * a.tiles_y; a.ts = ts5;
       FinArgs& f = f5[q];
       f = FinArgs{};
       if (wout || bout) {
