@@ -20,6 +20,7 @@
 // read): a k-step is a 4x4 pixel patch, each 16-lane group fetches 4 consecutive pixels x 16 channels = 256
 // contiguous bytes per 32-lane half, i.e. conflict-free.  Each wave keeps one 32x32 accumulator per tap and
 // writes a partial; wgrad_finish_kernel sums the partials into the PyTorch weight layout.
+#include <type_traits>
 #include "common.hpp"
 #include "prof.hpp"
 #include "bwd_internal.hpp"
@@ -234,6 +235,11 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const int gx, const 
     }
   };
 
+  // The tile loop in four straight-line forms (EX: the frame is whole tiles, no patch can lie outside - no skip test; BI: this workgroup
+  // also sums the bias gradient): with the tests inside the unrolled patch loop every patch was its own basic block, and the compiler
+  // moved the accumulators between VGPRs and AGPRs at every join (352 v_accvgpr_* for 100 MFMAs) in a kernel that is instruction-bound
+  auto run = [&](auto ex_c, auto bi_c) __attribute__((always_inline)) {
+  constexpr bool EX = decltype(ex_c)::value, BI = decltype(bi_c)::value;
   int tile = bx;
   if (tile < a.ntiles) fetch(tile);
   for (; tile < a.ntiles; tile += gx) {
@@ -254,9 +260,10 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const int gx, const 
     if (tile + gx < a.ntiles) fetch(tile + gx);
     // 16 patches of 4x4 pixels; patches wholly outside the image are skipped (wave-uniform: the transposing
     // read needs EXEC all ones).  TAPS == 1: each wave takes 4 of them; otherwise each wave takes all 16 for its taps.
+#pragma unroll
     for (int pi = (TAPS == 1 ? wave : 0); pi < NP * NP; pi += (TAPS == 1 ? 4 : 1)) {
       const int pr = pi / NP, pc = pi % NP;
-      if (ty0 + 4 * pr >= H || tx0 + 4 * pc >= W) continue;
+      if (!EX && (ty0 + 4 * pr >= H || tx0 + 4 * pc >= W)) continue;
       const int arow = ((4 * pr + 2 * h) * TS + 4 * pc + q) * 64 + choff;
       const f16x8 af = tr_frag(lp, arow, arow + TS * 64);
 #pragma unroll
@@ -268,8 +275,16 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const int gx, const 
         const f16x8 bf = tr_frag(lq, brow, brow + QW * 64);
         acc[t] = mfma_32x32x16(af, bf, acc[t]);
       }
-      if (want_bias && (TAPS == 1 || wave == 0)) accb = mfma_32x32x16(af, ones, accb);
+      if (BI) accb = mfma_32x32x16(af, ones, accb);       // (every wave: a wave test here is a branch per patch; wave 0's copy is stored)
     }
+  }
+  };
+  {
+    const bool exact = (H % TS == 0) && (W % TS == 0);      // workgroup-uniform
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (exact) { if (want_bias) run(T_{}, T_{}); else run(T_{}, F_{}); }
+    else { if (want_bias) run(F_{}, T_{}); else run(F_{}, F_{}); }
   }
   // D[o][c]: lane owns column c = lane & 31, rows o = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int npairs = a.multi ? gy : (int)(gy * gridDim.z);
@@ -430,6 +445,9 @@ __device__ __forceinline__ void wgrad_temporal_body_ts(const WgArgs& a, const in
   };
 
   const int nunits = (a.N / T) * a.tiles_x * a.tiles_y;
+  // four straight-line forms of the unit loop (EX: whole tiles only, no patch test; BI: bias sums), as in wgrad_body
+  auto run = [&](auto ex_c, auto bi_c) __attribute__((always_inline)) {
+  constexpr bool EX = decltype(ex_c)::value, BI = decltype(bi_c)::value;
   for (int unit = bx; unit < nunits; unit += gx) {
     const int tx = unit % a.tiles_x, ty = (unit / a.tiles_x) % a.tiles_y, clip = unit / (a.tiles_x * a.tiles_y);
     const int tx0 = tx * TS, ty0 = ty * TS, nbase = clip * T;
@@ -451,16 +469,25 @@ __device__ __forceinline__ void wgrad_temporal_body_ts(const WgArgs& a, const in
       __syncthreads();
       if (t + 1 < T) fetch(nbase, t + 1, tx0, ty0);     // P[t+1], Q[t+2] while frame t is multiplied
       const int slot = (t + wave) % 3;                  // frame t + wave - 1
+#pragma unroll
       for (int pi = 0; pi < NP * NP; ++pi) {
         const int pr = pi / NP, pc = pi % NP;
-        if (ty0 + 4 * pr >= H || tx0 + 4 * pc >= W) continue;
+        if (!EX && (ty0 + 4 * pr >= H || tx0 + 4 * pc >= W)) continue;
         const int row = ((4 * pr + 2 * h) * TS + 4 * pc + q) * 64 + choff;
         const f16x8 af = tr_frag(lp, row, row + TS * 64);
         const f16x8 bf = tr_frag(lq + (size_t)slot * SLOT, row, row + TS * 64);
         acc = mfma_32x32x16(af, bf, acc);
-        if (want_bias && wave == 0) accb = mfma_32x32x16(af, ones, accb);
+        if (BI) accb = mfma_32x32x16(af, ones, accb);      // (every wave; wave 0's copy is stored)
       }
     }
+  }
+  };
+  {
+    const bool exact = (H % TS == 0) && (W % TS == 0);      // workgroup-uniform
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (exact) { if (want_bias) run(T_{}, T_{}); else run(T_{}, F_{}); }
+    else { if (want_bias) run(F_{}, T_{}); else run(F_{}, F_{}); }
   }
   const int npairs = gy * nz;
   const int pair = bz * gy + by;
