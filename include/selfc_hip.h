@@ -421,6 +421,14 @@ int selfc_globalagg_bwd(const float* x, const float* dy, float* dx, const float*
                         float* dw1, float* db1_clip, float* dw2_clip, float* db2_clip, float* dw3_clip, float* db3_clip,
                         float* dfcb_clip, float* dwmap_clip, void* scratch, size_t scratch_bytes,
                         int N, int T, int H, int W, void* stream);
+/* (abi 13) the same with the gradient maxima folded in (as selfc_subnet_bwd_phase_x does inside the block stacks): `dy_amax` = the finished
+ * max|dy| of whoever produced dy (NULL: taken here), `dx_amax_out` = a zeroed float that receives max|dx| (NULL: not wanted) - the STP
+ * chain alternates dense blocks and GlobalAgg blocks, each consuming the other's input gradient */
+int selfc_globalagg_bwd_x(const float* x, const float* dy, float* dx, const float* wmap, const float* fc_bias, const void* w1t,
+                        const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                        float* dw1, float* db1_clip, float* dw2_clip, float* db2_clip, float* dw3_clip, float* db3_clip,
+                        float* dfcb_clip, float* dwmap_clip, void* scratch, size_t scratch_bytes,
+                        int N, int T, int H, int W, const float* dy_amax, float* dx_amax_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -43,7 +43,7 @@ SYMBOLS = [
     "selfc_globalagg_bwd_scratch_bytes", "selfc_globalagg_bwd", "selfc_rowsum_accum",
     "selfc_coupling_bwd_x", "selfc_add_absmax", "selfc_subnet_bwd_phase_x", "selfc_stream_create", "selfc_stream_destroy", "selfc_set_pointers", "selfc_freq_fwd_ind", "selfc_freq_inv_ind", "selfc_nchw_to_latent_ind", "selfc_latent_to_nchw_ind",
     "selfc_nchw_to_nhwc4_ind", "selfc_nhwc4_to_nchw_ind", "selfc_graph_stats",
-    "selfc_fin_job_bytes", "selfc_wgrad_finish_jobs", "selfc_subnet_bwd_phase_d", "selfc_gh_bwd_pair_scratch_bytes", "selfc_gh_bwd_pair", "selfc_recon_loss_blocks", "selfc_recon_loss", "selfc_wg_job_bytes", "selfc_wgrad_run_jobs", "selfc_clip_adam_blocks", "selfc_clip_adam",
+    "selfc_fin_job_bytes", "selfc_wgrad_finish_jobs", "selfc_subnet_bwd_phase_d", "selfc_gh_bwd_pair_scratch_bytes", "selfc_gh_bwd_pair", "selfc_recon_loss_blocks", "selfc_recon_loss", "selfc_wg_job_bytes", "selfc_wgrad_run_jobs", "selfc_clip_adam_blocks", "selfc_clip_adam", "selfc_globalagg_bwd_x",
 ]
 
 
@@ -166,6 +166,7 @@ def lib():
             "selfc_nchw_to_nhwc4_ind": [vp, sz, vp, i, i, i, i, vp],
             "selfc_nhwc4_to_nchw_ind": [vp, vp, sz, i, i, i, i, vp],
             "selfc_globalagg_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, i, vp],
+            "selfc_globalagg_bwd_x": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, i, vp, vp, vp],
         }
         for name, args in sigs.items():
             fn = getattr(L, name)

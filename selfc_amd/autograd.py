@@ -1091,8 +1091,10 @@ def _sink_add(param, grad: torch.Tensor) -> Optional[torch.Tensor]:
     return grad
 
 
-def globalagg_bwd(m, x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, n: int, t: int, h: int, w: int, defer_fc: Optional[list] = None) -> Dict[str, torch.Tensor]:
-    """Backward of GlobalAgg.run_nhwc: x, dy, dx fp32 [n][h*w][64]; returns {parameter name: gradient}."""
+def globalagg_bwd(m, x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, n: int, t: int, h: int, w: int, defer_fc: Optional[list] = None,
+                  dy_amax: Optional[torch.Tensor] = None, dx_amax_out: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """Backward of GlobalAgg.run_nhwc: x, dy, dx fp32 [n][h*w][64]; returns {parameter name: gradient}.  dy_amax: one-float tensor with
+    max|dy| taken by dy's producer (the call then skips its own pass); dx_amax_out: zeroed one-float tensor that receives max|dx|."""
     pk = m._packed(h, w)
     key = rt.params_key(m)
     if getattr(m, "_w1t_key", None) != key:
@@ -1107,10 +1109,11 @@ def globalagg_bwd(m, x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, n: int
     dwmapc = torch.empty((b, h * w), **f32)
     need = _lib.lib().selfc_globalagg_bwd_scratch_bytes(n, t, h, w)
     sc = _buf(_STP_CACHE, "gagg", need, dev)
-    rt.call("selfc_globalagg_bwd", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), pk["wmap"].data_ptr(), pk["fcb"].data_ptr(),
+    rt.call("selfc_globalagg_bwd_x", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), pk["wmap"].data_ptr(), pk["fcb"].data_ptr(),
             m._w1t.data_ptr(), pk["b1"].data_ptr(), pk["w2"].data_ptr(), pk["b2"].data_ptr(), pk["w3"].data_ptr(), pk["b3"].data_ptr(),
             dw1.data_ptr(), db1c.data_ptr(), dw2c.data_ptr(), db2c.data_ptr(), dw3c.data_ptr(), db3c.data_ptr(),
-            dfcbc.data_ptr(), dwmapc.data_ptr(), sc.data_ptr(), sc.numel(), n, t, h, w, _lib.stream_ptr())
+            dfcbc.data_ptr(), dwmapc.data_ptr(), sc.data_ptr(), sc.numel(), n, t, h, w,
+            None if dy_amax is None else dy_amax.data_ptr(), None if dx_amax_out is None else dx_amax_out.data_ptr(), _lib.stream_ptr())
     # the sums over the clips: ONE launch for the seven per-clip tensors (they were 7 torch sums + as many autograd accumulations);
     # with the trainer's flat gradient buffer the results are ADDED straight into the parameters' views and autograd sees None
     names = ["proj1.weight", "proj1.bias", "proj2.weight", "proj2.bias", "proj3.weight", "proj3.bias", "fc.bias"]
@@ -1322,28 +1325,45 @@ class STPSampleFn(torch.autograd.Function):
         # as the block stacks do): every subnet then needs its own scratch slot until the flush
         n_sub = sum(isinstance(m_, D2DTInput) for m_, _, _ in ctx.stages)
         fin = FinJobs(2 * n_sub, defer_wg=True) if (_DEFER_FIN and _DEFER_WG and n_sub) else None
-        for m, xin, dense in reversed(ctx.stages):
+        # max|gradient| travels with the gradient (as inside the block stacks): every stage leaves the maximum of the input gradient it
+        # writes for the next stage's scale - one fill for all slots instead of a zero + a pass per stage (the head's output has none)
+        slots = torch.zeros(len(ctx.stages), dtype=torch.float32, device=dev) if _FOLD_AMAX else None
+        amax_prev = None
+        for si, (m, xin, dense) in enumerate(reversed(ctx.stages)):
+            amax_out = None if slots is None else slots[si:si + 1]
             if isinstance(m, D2DTInput):
                 dxl = torch.empty((n, h, w, roundup(m.channel_in, 4)), dtype=torch.float32, device=dev)
-                g = subnet_bwd(m, dense, xin, d, 1.0, dxl, False, n, t, h, w, True, None, side, f"stp{turn}", fin=fin)
+                g = subnet_bwd(m, dense, xin, d, 1.0, dxl, False, n, t, h, w, True, None, side, f"stp{turn}", fin=fin,
+                               dout_amax=amax_prev, dx_amax_out=amax_out)
                 turn = turn + 1 if fin is not None else turn ^ 1
                 for prm, gg in zip(subnet_params(m), g):
                     grads[id(prm)] = gg
                 d = dxl
             else:
                 dxl = torch.empty_like(d)
-                g = globalagg_bwd(m, xin, d.reshape(n, h * w, 64), dxl, n, t, h, w, defer_fc=fc_maps)
+                g = globalagg_bwd(m, xin, d.reshape(n, h * w, 64), dxl, n, t, h, w, defer_fc=fc_maps, dy_amax=amax_prev, dx_amax_out=amax_out)
                 for name, prm in m.named_parameters():
                     grads[id(prm)] = g[name]
                 d = dxl
+            amax_prev = amax_out
         if fin is not None:
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
             fin.flush()
         if fc_maps:                   # d fc.weight of every GlobalAgg: ONE batched fold (packing.pool_weight_map_grad_batch)
-            folded = pool_weight_map_grad_batch(torch.stack([dm for _, dm in fc_maps]), h, w)
-            for i, (m, _) in enumerate(fc_maps):
-                grads[id(m.fc.weight)] = _sink_add(m.fc.weight, folded[i].reshape(1, 32 * 32))
+            folded = pool_weight_map_grad_batch(torch.stack([dm for _, dm in fc_maps]), h, w).float().contiguous()
+            views = [(_SINK.view_of(m.fc.weight) if _SINK is not None else None) for m, _ in fc_maps]
+            if all(v is not None for v in views) and len(fc_maps) <= 8:
+                # added into the flat gradient buffer by ONE launch (selfc_rowsum_accum: up to eight (source, destination) pairs)
+                job = _lib.RowSum()
+                for i, v in enumerate(views):
+                    job.src[i], job.dst[i], job.len[i], job.rows[i], job.beta[i] = folded[i].data_ptr(), v.data_ptr(), 32 * 32, 1, 1.0
+                    grads[id(fc_maps[i][0].fc.weight)] = None
+                job.n = len(views)
+                rt.call("selfc_rowsum_accum", C.byref(job), sp)
+            else:
+                for i, (m, _) in enumerate(fc_maps):
+                    grads[id(m.fc.weight)] = _sink_add(m.fc.weight, folded[i].reshape(1, 32 * 32))
         dlr = None
         if ctx.needs_input_grad[0]:
             dlr = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)

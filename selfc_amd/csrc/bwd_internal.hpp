@@ -47,7 +47,8 @@ int bwd_dgrad_chain(void* gb, const void* add, const void* feat, const void* con
                     int accumulate_dx, const float* amax, float* amax_out, int N, int H, int W, hipStream_t s);
 
 int bwd_dgrad_chain_pair(void* gb0, void* gb1, const void* add0, const void* add1, const void* feat0, const void* feat1,
-                         const void* const* wtd0, const void* const* wtd1, int nx, const float* amax, int N, int H, int W, hipStream_t s);
+                         const void* const* wtd0, const void* const* wtd1, int nx, const float* amax, int N, int H, int W, hipStream_t s,
+                         const void* wtx0 = nullptr, const void* wtx1 = nullptr, float* dx0 = nullptr, float* dx1 = nullptr, int cinp = 0, int acc0 = 0);
 
 // csrc/backward.hip building blocks (also used by the STP gradients in csrc/stp.hip)
 int bwd_absmax(const float* g, size_t n, float* amax, hipStream_t s);    // *amax = max|g| (zeroed first)

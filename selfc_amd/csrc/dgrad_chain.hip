@@ -291,8 +291,12 @@ inline int hip_rc(hipError_t e) { return e == hipSuccess ? SELFC_OK : -(int)e - 
 // dpre3, dpre2, dpre1 of TWO nets of one geometry in one launch (no input gradient: the pair's dx is one conv over both nets' planes,
 // bwd_conv_planes with a second source)
 int bwd_dgrad_chain_pair(void* gb0, void* gb1, const void* add0, const void* add1, const void* feat0, const void* feat1,
-                         const void* const* wtd0, const void* const* wtd1, int nx, const float* amax, int N, int H, int W, hipStream_t s) {
+                         const void* const* wtd0, const void* const* wtd1, int nx, const float* amax, int N, int H, int W, hipStream_t s,
+                         const void* wtx0, const void* wtx1, float* dx0, float* dx1, int cinp, int acc0) {
   DgArgs a{}, b{};
+  // optional input gradients: net 0 into dx0 (accumulated when acc0), net 1 into dx1 (the caller adds the two: each net's dx layer
+  // runs on its own LDS-resident chain - on a small problem that is cheaper than a separate eight-stage conv over both nets' planes)
+  a.wtx = (const f16*)wtx0; b.wtx = (const f16*)wtx1; a.dx = dx0; b.dx = dx1; a.cinp = b.cinp = cinp; a.acc_dx = acc0; b.acc_dx = 0;
   a.g4 = (const f16*)gb0; a.gb = (f16*)gb0; a.add = (const f16*)add0; a.feat = (const f16*)feat0;
   b.g4 = (const f16*)gb1; b.gb = (f16*)gb1; b.add = (const f16*)add1; b.feat = (const f16*)feat1;
   for (int i = 0; i < 3; ++i) { a.wtd[i] = (const f16*)wtd0[i]; b.wtd[i] = (const f16*)wtd1[i]; }

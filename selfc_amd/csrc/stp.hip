@@ -986,8 +986,11 @@ __global__ __launch_bounds__(64) void gagg_attn_bwd_kernel(const float* __restri
 template <int TT>
 __global__ __launch_bounds__(256) void gagg_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dz, const float* __restrict__ dy,
                                                           const float* __restrict__ A, const float* __restrict__ dg, const float* __restrict__ wmap,
-                                                          float* __restrict__ dx, float* __restrict__ dwmapc, f16* __restrict__ zp, int Trt, int HW, size_t npix_all) {
+                                                          float* __restrict__ dx, float* __restrict__ dwmapc, f16* __restrict__ zp, int Trt, int HW, size_t npix_all,
+                                                          unsigned* __restrict__ amax_out) {
   const int T = TT ? TT : Trt;
+  float bmax = 0.f;                      // max |dx| of this thread (amax_out: the scale of the subnet backward that consumes dx)
+  bool bnan = false;
   const int b = blockIdx.y;
   const int cq = threadIdx.x & 15;
   const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -1026,6 +1029,8 @@ __global__ __launch_bounds__(256) void gagg_bwd_dx_kernel(const float* __restric
       dw += gg.x * xv[t1].x + gg.y * xv[t1].y + gg.z * xv[t1].z + gg.w * xv[t1].w;
       if (ok) {
         *reinterpret_cast<float4*>(dx + o) = r;
+        bmax = fmaxf(fmaxf(bmax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+        bnan |= (r.x != r.x) | (r.y != r.y) | (r.z != r.z) | (r.w != r.w);
         uint2 u;
         u.x = pack2(zz.x, zz.y);
         u.y = pack2(zz.z, zz.w);
@@ -1037,6 +1042,12 @@ __global__ __launch_bounds__(256) void gagg_bwd_dx_kernel(const float* __restric
 #pragma unroll
   for (int d = 1; d < 16; d <<= 1) dw += __shfl_xor(dw, d, 16);
   if (ok && cq == 0) dwmapc[(size_t)b * HW + p] = dw;
+  if (amax_out) {                        // one atomic per wave, absmax_kernel's convention (NaN -> 0x7fc00000)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, o));
+    if (__any(bnan)) { if ((threadIdx.x & 63) == 0) atomicMax(amax_out, 0x7fc00000u); }
+    else if ((threadIdx.x & 63) == 0 && bmax > 0.f) atomicMax(amax_out, __float_as_uint(bmax));
+  }
 }
 
 // dst_i[j] = beta * dst_i[j] + sum_r src_i[r][j] for up to 8 small row-major matrices in ONE launch: the per-clip partial
@@ -1265,6 +1276,15 @@ int selfc_globalagg_bwd(const float* x, const float* dy, float* dx, const float*
                         float* dw1, float* db1_clip, float* dw2_clip, float* db2_clip, float* dw3_clip, float* db3_clip,
                         float* dfcb_clip, float* dwmap_clip, void* scratch, size_t scratch_bytes,
                         int N, int T, int H, int W, void* stream) {
+  return selfc_globalagg_bwd_x(x, dy, dx, wmap, fc_bias, w1t, b1, w2, b2, w3, b3, dw1, db1_clip, dw2_clip, db2_clip, dw3_clip, db3_clip,
+                               dfcb_clip, dwmap_clip, scratch, scratch_bytes, N, T, H, W, nullptr, nullptr, stream);
+}
+
+int selfc_globalagg_bwd_x(const float* x, const float* dy, float* dx, const float* wmap, const float* fc_bias, const void* w1t,
+                          const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                          float* dw1, float* db1_clip, float* dw2_clip, float* db2_clip, float* dw3_clip, float* db3_clip,
+                          float* dfcb_clip, float* dwmap_clip, void* scratch, size_t scratch_bytes,
+                          int N, int T, int H, int W, const float* dy_amax, float* dx_amax_out, void* stream) {
   if (!x || !dy || !dx || !wmap || !fc_bias || !w1t || !b1 || !w2 || !b2 || !w3 || !b3 || !scratch) return SELFC_EINVAL;
   if (!dw1 || !db1_clip || !dw2_clip || !db2_clip || !dw3_clip || !db3_clip || !dfcb_clip || !dwmap_clip) return SELFC_EINVAL;
   if (N <= 0 || T <= 0 || T > TMAX || N % T || H <= 0 || W <= 0 || x == dx) return SELFC_EINVAL;
@@ -1286,8 +1306,9 @@ int selfc_globalagg_bwd(const float* x, const float* dy, float* dx, const float*
   float* dg = (float*)(sb + L.off_dg);
   int rc;
   // dz = W1^T dy on the MFMA (scaled f16 planes in, fp32 rows out)
-  if ((rc = bwd_absmax(dy, npix * 64, amax, s))) return rc;
-  if ((rc = bwd_to_planes(dy, dyp, npix, 64, 64, 2, 0, 1.f, amax, s))) return rc;
+  // dy_amax: the producer of dy already took max|dy| (a subnet backward's dx epilogue); the to-planes kernel hands it on to this call's slot
+  if (!dy_amax && (rc = bwd_absmax(dy, npix * 64, amax, s))) return rc;
+  if ((rc = bwd_to_planes(dy, dyp, npix, 64, 64, 2, 0, 1.f, dy_amax ? dy_amax : amax, s, dy_amax ? amax : nullptr))) return rc;
   {
     BwdConv c{};
     c.in = dyp; c.nplanes_in = 2; c.kt = 1; c.sp1 = 1; c.w = w1t; c.ngroups = 2; c.mask_z = -1;
@@ -1306,13 +1327,13 @@ int selfc_globalagg_bwd(const float* x, const float* dy, float* dx, const float*
 #undef SELFC_GATTN
   if (T == 7) {
     hipLaunchKernelGGL(gagg_bwd_dx_kernel<7>, dim3((unsigned)((HW + 15) / 16), (unsigned)B), dim3(256), 0, s, x, dz, dy, A, dg, wmap, dx,
-                     dwmap_clip, zp, T, HW, npix);
+                     dwmap_clip, zp, T, HW, npix, (unsigned*)dx_amax_out);
   } else if (T == 3) {
     hipLaunchKernelGGL(gagg_bwd_dx_kernel<3>, dim3((unsigned)((HW + 15) / 16), (unsigned)B), dim3(256), 0, s, x, dz, dy, A, dg, wmap, dx,
-                     dwmap_clip, zp, T, HW, npix);
+                     dwmap_clip, zp, T, HW, npix, (unsigned*)dx_amax_out);
   } else {
     hipLaunchKernelGGL(gagg_bwd_dx_kernel<0>, dim3((unsigned)((HW + 15) / 16), (unsigned)B), dim3(256), 0, s, x, dz, dy, A, dg, wmap, dx,
-                     dwmap_clip, zp, T, HW, npix);
+                     dwmap_clip, zp, T, HW, npix, (unsigned*)dx_amax_out);
   }
   if ((rc = hip_rc(hipGetLastError()))) return rc;
   WgradJob j{};

@@ -67,10 +67,15 @@ class ReconLossFn(torch.autograd.Function):
         rx, rt_ = _rows(x), _rows(target)
         dev = x.device
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        # only the target needs a gradient (the reverse loss: Reconstruction_back(real_H, x_samples)): store -d/dx at once
+        flip = ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
+        ctx.flip = flip
         grad = torch.empty(x.shape, dtype=torch.float32, device=dev) if need else None
         nb = int(_lib.lib().selfc_recon_loss_blocks())
         partial = torch.empty(nb, dtype=torch.float64, device=dev)
         out = torch.empty((), dtype=torch.float32, device=dev)
+        if flip:      # loss(x, t) is symmetric in its arguments' difference up to the sign of the gradient: swap them
+            rx, rt_ = rt_, rx
         rt.call("selfc_recon_loss", rx[0].data_ptr(), rx[3], rt_[0].data_ptr(), rt_[3], rx[1], rx[2], 1 if l1 else 0, float(eps), float(weight),
                 None if grad is None else grad.data_ptr(), partial.data_ptr(), out.data_ptr(), _lib.stream_ptr())
         ctx.grad = grad
@@ -79,6 +84,8 @@ class ReconLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         gx = ctx.grad * g if ctx.grad is not None else None
+        if ctx.flip:                  # ctx.grad is d loss / d target already
+            return (None, gx, None, None, None)
         return (gx if ctx.needs_input_grad[0] else None, (-gx) if ctx.needs_input_grad[1] else None, None, None, None)
 
 
@@ -90,10 +97,13 @@ class ReconstructionLoss(nn.Module):
         self.losstype = losstype
         self.eps = eps
 
-    def forward(self, x, target):
+    def forward(self, x, target, weight: float = 1.0):
+        """weight: a factor folded into the fused kernel (the trainer's lambda_fit_forw / lambda_rec_back: one launch less each)"""
         if _FUSED_LOSS and self.losstype in ("l2", "l1") and x.shape == target.shape and _rows(x) is not None and _rows(target) is not None:
             # the mean over the four axes one after the other = sum / count (equal group sizes)
-            return ReconLossFn.apply(x, target, self.losstype == "l1", self.eps, 1.0)
+            return ReconLossFn.apply(x, target, self.losstype == "l1", self.eps, float(weight))
+        if weight != 1.0:
+            return weight * self.forward(x, target)
         if self.losstype == "l2":
             v = (x - target) ** 2
         elif self.losstype == "l1":
@@ -248,11 +258,11 @@ class RescaleTrainer:
         self.before_clip = None          # optional callable(trainer): runs after backward, before clipping (tests, logging)
 
     def loss_forward(self, out, y):
-        return self.train_opt["lambda_fit_forw"] * self.Reconstruction_forw(out, y)
+        return self.Reconstruction_forw(out, y, weight=self.train_opt["lambda_fit_forw"])
 
     def loss_backward(self, x, y):
         x_samples, _ = self.netG(x=y, rev=True)
-        return self.train_opt["lambda_rec_back"] * self.Reconstruction_back(x, x_samples[:, :3, :, :])
+        return self.Reconstruction_back(x, x_samples[:, :3, :, :], weight=self.train_opt["lambda_rec_back"])
 
     def _forward_backward(self, real_H: torch.Tensor, ref_L: torch.Tensor):
         """optimize_parameters (SelfC_model.py:153-170) up to and including loss.backward(); returns the loss tensors."""
@@ -261,12 +271,15 @@ class RescaleTrainer:
                                "RescaleTrainer was built): construct the trainer after moving the net, or pass flat_params=False")
         self._repack()
         output, loss_c = self.netG(x=real_H, rev=False)
-        loss_c = loss_c.mean() * self.train_opt.get("lambda_cond_prob", 0)
+        lam_c = self.train_opt.get("lambda_cond_prob", 0)
+        # (lambda_cond_prob: 0 in every shipped yml - SelfC_model.py:157 multiplies the term away; no launches for it then)
+        loss_c = loss_c.mean() * lam_c if lam_c else None
         lr_before_quant = output[:, :3, :, :]
         l_forw_fit = self.loss_forward(lr_before_quant, ref_L.detach())
         LR = self.Quantization(lr_before_quant)
         l_back_rec = self.loss_backward(real_H, LR)
-        loss = (l_forw_fit + l_back_rec + loss_c) * 144 * 144 * 3
+        total = l_forw_fit + l_back_rec
+        loss = (total if loss_c is None else total + loss_c) * float(144 * 144 * 3)
         with ag.grad_sink(self.sink), ag.background_wgrad():      # (joins the background weight gradients on its way out)
             loss.backward()
         if self.sink is not None:
@@ -277,7 +290,7 @@ class RescaleTrainer:
                 self.sink.assert_touched_equal(self.process_group)
             if self.sink.detach_untouched() and self.flat_optimizer:
                 self._per_tensor_optimizer()   # tensors without a gradient must be skipped: one flat tensor cannot do that
-        return l_forw_fit.detach(), l_back_rec.detach(), loss_c.detach(), loss.detach()
+        return l_forw_fit.detach(), l_back_rec.detach(), (0.0 if loss_c is None else loss_c.detach()), loss.detach()
 
     def _repack(self):
         """The weights changed with the last optimizer step: repack every module's kernel-layout tensors in ONE gather

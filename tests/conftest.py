@@ -13,6 +13,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle is torch on the CPU: on the GPU box's 256-thread host its convs collapse with the default thread count (bench.py
+    # calibrates for the same reason: 355 s per septuplet at 256 threads against 0.8 s at 16)
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
 
 
 def load_golden(name):

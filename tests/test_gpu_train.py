@@ -763,13 +763,23 @@ def test_fused_data_gradient_chain_is_bit_identical_to_the_layer_wise_launches(d
     import sys
     import numpy as np
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = str(tmp_path / "grads.npz")
-    subprocess.run([sys.executable, "-c", _CHILD_GRADS, root, out], check=True, env=dict(os.environ, SELFC_BWD_CHAIN="0"), timeout=600)
-    mine = _chain_case_grads(dev)                                    # this process: the default (one launch at this size)
-    with np.load(out) as ref:
-        assert set(ref.files) == set(mine) and len(mine) > 300
-        bad = [n for n in mine if not np.array_equal(mine[n].cpu().numpy(), ref[n])]
-    assert not bad, f"{len(bad)} gradients differ, e.g. {bad[:4]}"
+    out, out2 = str(tmp_path / "grads.npz"), str(tmp_path / "grads_chain.npz")
+    # (round 6: by default a G/H pair's chains also run their own dx layers and the two input gradients are added - a different fp32
+    # summation of y1's gradient than the layer-wise path's ONE conv over both nets' planes; SELFC_BWD_CHAIN_DX=0 keeps that conv
+    # behind the chain, which is the configuration that must be bit-identical to the layer-wise launches)
+    subprocess.run([sys.executable, "-c", _CHILD_GRADS, root, out], check=True, env=dict(os.environ, SELFC_BWD_CHAIN="0", SELFC_BWD_CHAIN_DX="0"), timeout=600)
+    subprocess.run([sys.executable, "-c", _CHILD_GRADS, root, out2], check=True, env=dict(os.environ, SELFC_BWD_CHAIN_DX="0"), timeout=600)
+    with np.load(out) as ref, np.load(out2) as chain:
+        assert set(ref.files) == set(chain.files) and len(ref.files) > 300
+        bad = [n for n in ref.files if not np.array_equal(chain[n], ref[n])]
+        assert not bad, f"{len(bad)} gradients differ, e.g. {bad[:4]}"
+        # the default (chains with their own dx layers + one add): the same gradients up to that summation order
+        mine = _chain_case_grads(dev)
+        g_all = float(np.sqrt(sum((ref[n].astype(np.float64) ** 2).sum() for n in ref.files)))
+        worst = max(float(np.linalg.norm(mine[n].cpu().numpy().astype(np.float64) - ref[n]) / (np.linalg.norm(ref[n].astype(np.float64)) + 1e-7 * g_all)) for n in ref.files)
+    from conftest import record
+    record("chain pair with its own dx layers vs one conv over both nets' planes: worst per-tensor relative L2", worst)
+    assert worst < 6e-4, worst
 
 
 def test_frame_parallel_temporal_conv_is_bit_identical_to_the_frame_walk(dev, tmp_path):
