@@ -83,10 +83,17 @@ __global__ __launch_bounds__(256) void grad_to_planes_kernel(const float* __rest
   const size_t pix = i / ((size_t)nplanes * 4);
   const int ch0 = chunk * 8;
   f16x8 o;
+  float in[8];
+  if (ch0 + 8 <= c && (cs & 3) == 0) {           // whole chunk inside the row, rows 16-byte aligned: two 16-byte loads instead of eight scalar ones
+    const float4 a = *reinterpret_cast<const float4*>(g + pix * cs + ch0), b = *reinterpret_cast<const float4*>(g + pix * cs + ch0 + 4);
+    in[0] = a.x; in[1] = a.y; in[2] = a.z; in[3] = a.w; in[4] = b.x; in[5] = b.y; in[6] = b.z; in[7] = b.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) in[e] = (ch0 + e < c) ? g[pix * cs + ch0 + e] : 0.f;
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const int ch = ch0 + e;
-    float v = (ch < c) ? g[pix * cs + ch] : 0.f;
+    float v = in[e];
     if (lrelu) v = lrelu02(v);
     o[e] = (f16)(v * sc);
   }
@@ -114,12 +121,16 @@ __global__ __launch_bounds__(256) void grad_to_planes2_kernel(const float* __res
   const size_t pix = i / ((size_t)nplanes * 4);
   const int ch0 = chunk * 8;
   f16x8 o;
+  float in[8];
+  if (ch0 + 8 <= c && (cs & 3) == 0) {
+    const float4 a = *reinterpret_cast<const float4*>(g + pix * cs + ch0), b = *reinterpret_cast<const float4*>(g + pix * cs + ch0 + 4);
+    in[0] = a.x; in[1] = a.y; in[2] = a.z; in[3] = a.w; in[4] = b.x; in[5] = b.y; in[6] = b.z; in[7] = b.w;
+  } else {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int ch = ch0 + e;
-    const float v = (ch < c) ? g[pix * cs + ch] : 0.f;
-    o[e] = (f16)(v * sc);
+    for (int e = 0; e < 8; ++e) in[e] = (ch0 + e < c) ? g[pix * cs + ch0 + e] : 0.f;
   }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (f16)(in[e] * sc);
   *reinterpret_cast<f16x8*>(planes + (size_t)(ch0 >> 5) * npix * 32 + pix * 32 + (ch0 & 31)) = o;
 }
 
