@@ -1042,11 +1042,17 @@ __global__ __launch_bounds__(256) void gagg_bwd_dx_kernel(const float* __restric
 #pragma unroll
   for (int d = 1; d < 16; d <<= 1) dw += __shfl_xor(dw, d, 16);
   if (ok && cq == 0) dwmapc[(size_t)b * HW + p] = dw;
-  if (amax_out) {                        // one atomic per wave, absmax_kernel's convention (NaN -> 0x7fc00000)
-#pragma unroll
+  if (amax_out) {                        // ONE atomic per workgroup (same-address atomics serialise at ~90 per microsecond: one per wave
+#pragma unroll                           // of 648 workgroups cost this kernel 27 us), absmax_kernel's convention (NaN -> 0x7fc00000)
     for (int o = 32; o > 0; o >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, o));
-    if (__any(bnan)) { if ((threadIdx.x & 63) == 0) atomicMax(amax_out, 0x7fc00000u); }
-    else if ((threadIdx.x & 63) == 0 && bmax > 0.f) atomicMax(amax_out, __float_as_uint(bmax));
+    __shared__ unsigned smax[4];
+    const unsigned bits = __any(bnan) ? 0x7fc00000u : __float_as_uint(bmax);
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned m = max(max(smax[0], smax[1]), max(smax[2], smax[3]));      // non-negative floats and the NaN pattern order as unsigned
+      if (m) atomicMax(amax_out, m);
+    }
   }
 }
 
