@@ -119,6 +119,9 @@ struct C3Args {
   int c2p, coutp, rev;
   float clamp;
   int ablate;            // -DSELFC_DEV only (see ABL above)
+#ifdef SELFC_DEV
+  unsigned long long* stamps;   // 8 x u64 per workgroup of this launch (100-MHz clock): entry, stage 0 staged, stages done, rows ready, stores issued, stores done
+#endif
 };
 
 // ---------------------------------------------------------------------------------
@@ -139,9 +142,15 @@ __device__ __forceinline__ C3Stage stage_of(const C3Args& a, const int s) {
   return C3Stage{a.fbase + 32 * (s - a.n_in), 32, 0, 0};
 }
 
+#ifdef SELFC_DEV
+#define C3STAMP(i) do { if (a.stamps && threadIdx.x == 0 && blockIdx.x < 512 && blockIdx.z == 0) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define C3STAMP(i) do { } while (0)
+#endif
+
 // GEN: generic plane-list mode (temporal taps, output groups) as a template parameter so that the hot
 // non-generic instantiations keep their register budget (as a runtime flag it cost 21 VGPRs = one wave/SIMD).
-template <int TH, int TW, int NW, int MT, int EPI, bool GEN>
+template <int TH, int TW, int NW, int MT, int EPI, bool GEN, bool ROWEPI = true>
 __device__ __forceinline__ void conv3x3_body(const C3Args& a) {
   static_assert(TH * TW == NW * MT * 32, "tile must be covered by the waves' M-tiles");
   static_assert(TW % 16 == 0 && TH % 2 == 0, "M-tiles are 2 rows x 16 cols");
@@ -159,6 +168,7 @@ __device__ __forceinline__ void conv3x3_body(const C3Args& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const lact = smem;
   unsigned char* const lw = smem + ACT_BYTES;
+  C3STAMP(0);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wg = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -212,6 +222,41 @@ __device__ __forceinline__ void conv3x3_body(const C3Args& a) {
     okmask |= (ok ? 1u : 0u) << it;
   }
 
+  // EPI_BWD with f16 plane output: the epilogue works on ROWS of an M-tile - lane l owns channels 8*(l&3).. of pixel l>>2 of a
+  // 16-pixel row, so every global access of a wave is one contiguous KiB (the accumulator layout gives 8-byte pieces of 32
+  // different pixels per instruction: the epilogue was 1.6 of the 3.0 ms the data-gradient convs cost a step at 8 per rank,
+  // profiles/r6/ab_experiments.txt r6r).  The addends and the mask do not depend on the conv: they are fetched under the last
+  // stage's MFMAs.  The accumulators change lanes through LDS (wave-private, after the last stage's barrier).
+  // They land in the stage-prefetch registers, which the last stage no longer needs (registers of their own took the G/H pair launch
+  // from 4 to 2 workgroups per CU, i.e. to two rounds).
+  constexpr int EROWS = (EPI == EPI_BWD) ? 2 * MT : 1;
+  constexpr int NEX = 3 * EROWS > AITER + WITER ? 3 * EROWS - AITER - WITER : 1;
+  u32x4 areg[AITER];
+  u32x4 wreg[WITER];
+  u32x4 epx[NEX];
+  auto ep_slot = [&](const int i) __attribute__((always_inline)) -> u32x4& {
+    return i < AITER ? areg[i] : (i < AITER + WITER ? wreg[i - AITER] : epx[i - AITER - WITER]);
+  };
+  auto epi_row = [&](const int e, bool& ok) __attribute__((always_inline)) -> size_t {
+    const int mt = wave * MT + (e >> 1);
+    const int y = ty0 + 2 * (mt / (TW / 16)) + (e & 1), x = tx0 + 16 * (mt % (TW / 16)) + (lane >> 2);
+    ok = (y < H) & (x < W);
+    return ((size_t)(n * H + min(y, H - 1)) * W + min(x, W - 1)) * 32 + 8 * (lane & 3);
+  };
+  auto epi_bwd_prefetch = [&]() __attribute__((always_inline)) {
+    const int z = zg;
+    const bool masked = a.bw_mask && (a.bw_mask_z <= -2 || z == a.bw_mask_z);
+#pragma unroll
+    for (int e = 0; e < EROWS; ++e) {
+      bool ok;
+      const size_t o = epi_row(e, ok);
+      if (ABL(a, 128)) continue;
+      if (a.bw_add) ep_slot(e) = *reinterpret_cast<const u32x4*>(a.bw_add + (size_t)z * a.plane + o);
+      if (a.bw_add2) ep_slot(EROWS + e) = *reinterpret_cast<const u32x4*>(a.bw_add2 + (size_t)z * a.plane + o);
+      if (masked) ep_slot(2 * EROWS + e) = *reinterpret_cast<const u32x4*>(a.bw_mask + (a.bw_mask_z <= -2 ? (size_t)z * a.plane : 0) + o);
+    }
+  };
+
 #pragma unroll
   for (int net_i = 0; net_i < NNETS; ++net_i) {
     constexpr bool gen = GEN;
@@ -222,8 +267,6 @@ __device__ __forceinline__ void conv3x3_body(const C3Args& a) {
     const int tclip = gen ? n % a.T : 0;                 // frame index inside its clip (temporal taps)
     const long frame_stride = (long)H * W * 32;           // halfs per frame inside a plane
 
-    u32x4 areg[AITER];
-    u32x4 wreg[WITER];
     int fragbase = 0;      // fragments consumed by earlier stages
 
     // -- staging helpers -------------------------------------------------------
@@ -348,12 +391,14 @@ __device__ __forceinline__ void conv3x3_body(const C3Args& a) {
     }
     __syncthreads();
 
+    C3STAMP(1);
     for (int s = 0; s < a.nstages; ++s) {
       const C3Stage st = stage_of<GEN>(a, s);
       const C3Stage stn = stage_of<GEN>(a, s + 1);
       const int nfr = (st.kind == 1 || (GEN && a.gen_sp1)) ? 2 : 9 * (st.width >> 4);
       const bool more = s + 1 < a.nstages;
       if (more) load_stage(stn, fragbase + nfr);
+      else if (ROWEPI && EPI == EPI_BWD && !a.plain) epi_bwd_prefetch();
 
       if (ABL(a, 1)) {
       } else if (st.kind == 1 || (GEN && a.gen_sp1)) {
@@ -400,6 +445,7 @@ __device__ __forceinline__ void conv3x3_body(const C3Args& a) {
     }
   }
 
+  C3STAMP(2);
   // -- epilogue -------------------------------------------------------------------
   // acc[..][m][r]: pixel = lane&31 of M-tile m, outch = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int half = lane >> 5;
@@ -408,6 +454,51 @@ __device__ __forceinline__ void conv3x3_body(const C3Args& a) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) keep += acc[0][m][0] + acc[NNETS - 1][m][5];
     if (keep == 123.456f) a.out[0][0] = (f16)keep;
+    return;
+  }
+  if (ROWEPI && EPI == EPI_BWD && !a.plain) {
+    constexpr int EP = 144;      // bytes per pixel of the fp32 exchange image (32 channels + 16: conflict-free 16-byte writes)
+    __syncthreads();             // every wave is done with the halo image and the weights
+    unsigned char* const ex = smem + wave * (MT * 32 * EP);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(ex + (m * 32 + (lane & 31)) * EP + (8 * g + 4 * half) * 4) =
+            make_float4(acc[0][m][4 * g], acc[0][m][4 * g + 1], acc[0][m][4 * g + 2], acc[0][m][4 * g + 3]);
+    const bool masked = a.bw_mask && (a.bw_mask_z <= -2 || zg == a.bw_mask_z);
+    const float mslope = a.bw_mask_z == -3 ? 0.f : 0.2f;
+    f16* const obase = (a.bw_alt && zg == a.bw_mask_z) ? a.bw_alt : a.out[0] + (size_t)((a.out_coff >> 5) + zg) * a.plane;
+    C3STAMP(3);
+#pragma unroll
+    for (int e = 0; e < EROWS; ++e) {
+      bool ok;
+      const size_t o = epi_row(e, ok);
+      const unsigned char* src = ex + ((e >> 1) * 32 + (e & 1) * 16 + (lane >> 2)) * EP + (lane & 3) * 32;
+      const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 16);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      if (a.bw_add) {
+        const f16x8 t = __builtin_bit_cast(f16x8, ep_slot(e));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)t[j];
+      }
+      if (a.bw_add2) {
+        const f16x8 t = __builtin_bit_cast(f16x8, ep_slot(EROWS + e));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)t[j];
+      }
+      if (masked) {
+        const f16x8 t = __builtin_bit_cast(f16x8, ep_slot(2 * EROWS + e));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= ((float)t[j] > 0.f) ? 1.f : mslope;
+      }
+      if (ABL(a, 256) && v[0] + v[5] != 123.456f) continue;
+      if (ok) *reinterpret_cast<u32x4*>(obase + o) = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+    }
+#ifdef SELFC_DEV
+    C3STAMP(4);
+    if (a.stamps) { __builtin_amdgcn_s_waitcnt(0); C3STAMP(5); if (threadIdx.x == 0 && blockIdx.x < 512 && blockIdx.z == 0) a.stamps[blockIdx.x * 8 + 6] = a.nstages; }
+#endif
     return;
   }
   float bwmax = 0.f;           // EPI_BWD plain output with bw_amax_out: max |stored value| of this lane
@@ -494,7 +585,7 @@ __device__ __forceinline__ void conv3x3_body(const C3Args& a) {
             bwnan |= (o.x != o.x) | (o.y != o.y) | (o.z != o.z) | (o.w != o.w);
           }
         }
-      } else {
+      } else if (!ROWEPI) {     // f16 plane output in the accumulator layout (ROWEPI: the row epilogue above)
         f16* dst = ((a.bw_alt && zg == a.bw_mask_z) ? a.bw_alt : a.out[0] + (size_t)((a.out_coff >> 5) + zg) * a.plane) + pix * 32 + 4 * half;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -579,8 +670,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
 // run side by side on two streams - with a cross-queue dependency (~10 us each on this runtime) at the fork and at the join.
 template <int TH, int TW, int NW, int MT, int EPI, bool GEN>
 __global__ __launch_bounds__(NW * 64) void conv3x3_pair_kernel(const C3Args a, const C3Args b) {
-  if (blockIdx.y) conv3x3_body<TH, TW, NW, MT, EPI, GEN>(b);
-  else conv3x3_body<TH, TW, NW, MT, EPI, GEN>(a);
+  if (blockIdx.y) conv3x3_body<TH, TW, NW, MT, EPI, GEN, false>(b);
+  else conv3x3_body<TH, TW, NW, MT, EPI, GEN, false>(a);
 }
 
 // ---------------------------------------------------------------------------------
@@ -946,9 +1037,28 @@ int launch_conv3x3_pair_cfg(C3Args& a, C3Args& b, int nets_z, hipStream_t s) {
   return hip_rc(hipGetLastError());
 }
 
+#ifdef SELFC_DEV
+// timing aid (SELFC_ABLATE & 512): per-workgroup phase stamps of the last 256 EPI_BWD launches; tools/experiments/c3_stamps.py
+unsigned long long* g_c3_stamps = nullptr;
+int g_c3_launch = 0;
+unsigned long long* c3_stamp_slot() {
+  if (!g_c3_stamps) {
+    if (hipMalloc(&g_c3_stamps, 256 * 512 * 8 * 8) != hipSuccess) return nullptr;
+    (void)hipMemset(g_c3_stamps, 0, 256 * 512 * 8 * 8);
+  }
+  return g_c3_stamps + (size_t)(g_c3_launch++ % 256) * 512 * 8;
+}
+#endif
+
 // two convs of one geometry (same N, H, W, stage count) in one launch
 template <int EPI, bool GEN>
 int launch_conv3x3_pair(C3Args& a, C3Args& b, int nets_z, hipStream_t s) {
+#ifdef SELFC_DEV
+  static const int ablate = getenv("SELFC_ABLATE") ? atoi(getenv("SELFC_ABLATE")) : 0;
+  a.ablate = b.ablate = ablate;
+  a.stamps = b.stamps = nullptr;
+  if (EPI == EPI_BWD && (ablate & 512)) { a.stamps = c3_stamp_slot(); b.stamps = c3_stamp_slot(); }
+#endif
   const int rows16 = (a.H + 15) / 16 * 16, rows12 = (a.H + 11) / 12 * 12;
   if (rows12 < rows16) return launch_conv3x3_pair_cfg<12, 16, 3, 2, EPI, GEN>(a, b, nets_z, s);
   return launch_conv3x3_pair_cfg<16, 16, 4, 2, EPI, GEN>(a, b, nets_z, s);
@@ -959,6 +1069,7 @@ int launch_conv3x3(C3Args& a, int nets_z, hipStream_t s) {
 #ifdef SELFC_DEV
   static const int ablate = getenv("SELFC_ABLATE") ? atoi(getenv("SELFC_ABLATE")) : 0;
   a.ablate = ablate;
+  a.stamps = (EPI == EPI_BWD && (ablate & 512)) ? c3_stamp_slot() : nullptr;
 #endif
   const int rows16 = (a.H + 15) / 16 * 16, rows12 = (a.H + 11) / 12 * 12;
   if (rows12 < rows16) return launch_conv3x3_cfg<12, 16, 3, 2, EPI, GEN>(a, nets_z, s);
@@ -1327,3 +1438,18 @@ int selfc_conv_planes_run(void* dense, int nplanes_in, int kt, const void* w, co
 }
 
 }  // extern "C"
+
+#ifdef SELFC_DEV
+extern "C" int selfc_dev_c3_stamps(const char* path) {
+  if (!g_c3_stamps) return -1;
+  const size_t n = 256 * 512 * 8;
+  unsigned long long* h = (unsigned long long*)malloc(n * 8);
+  if (hipMemcpy(h, g_c3_stamps, n * 8, hipMemcpyDeviceToHost) != hipSuccess) { free(h); return -2; }
+  FILE* f = fopen(path, "wb");
+  if (!f) { free(h); return -3; }
+  fwrite(h, 8, n, f);
+  fclose(f);
+  free(h);
+  return g_c3_launch;
+}
+#endif
