@@ -431,7 +431,7 @@ def main():
     # kernel sources still hash to what was profiled; otherwise it stays null.
     import hashlib
     traffic_all, pmc_meta = {}, {}
-    for rnd in ("r5", "r4", "r3", "r2"):
+    for rnd in ("r6", "r5", "r4", "r3", "r2"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as fh:
                 traffic_all = json.load(fh)
