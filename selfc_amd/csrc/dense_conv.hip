@@ -150,9 +150,10 @@ __device__ __forceinline__ C3Stage stage_of(const C3Args& a, const int s) {
 
 // GEN: generic plane-list mode (temporal taps, output groups) as a template parameter so that the hot
 // non-generic instantiations keep their register budget (as a runtime flag it cost 21 VGPRs = one wave/SIMD).
-template <int TH, int TW, int NW, int MT, int EPI, bool GEN>
+// ROWEPI (EPI_BWD only): the row epilogue of conv3x3_body.hpp - 165 + 62 registers = 2 waves per SIMD, chosen by the launcher while
+// the launch's workgroups fit the chip two per CU (the training crops); larger problems keep the 132-register form (3 per SIMD).
+template <int TH, int TW, int NW, int MT, int EPI, bool GEN, bool ROWEPI = false>
 __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(const C3Args a) {
-  constexpr bool ROWEPI = true;
 #include "conv3x3_body.hpp"
 }
 
@@ -522,7 +523,10 @@ int launch_conv3x3_cfg(C3Args& a, int nets_z, hipStream_t s) {
   a.tiles_y = (a.H + TH - 1) / TH;
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), 1, (unsigned)nets_z);
   ProfScope prof(EPI == EPI_LRELU ? PROF_CONV3X3 : EPI == EPI_F ? PROF_CONV5_F : EPI == EPI_GH ? PROF_CONV5_GH : EPI == EPI_BWD ? -1 : PROF_CONV5_PLAIN, s);
-  hipLaunchKernelGGL((conv3x3_kernel<TH, TW, NW, MT, EPI, GEN>), grid, dim3(NW * 64), (c3_lds<TH, TW>()), s, a);
+  if (EPI == EPI_BWD && (size_t)grid.x * grid.z <= 2 * 256)
+    hipLaunchKernelGGL((conv3x3_kernel<TH, TW, NW, MT, EPI, GEN, EPI == EPI_BWD>), grid, dim3(NW * 64), (c3_lds<TH, TW>()), s, a);
+  else
+    hipLaunchKernelGGL((conv3x3_kernel<TH, TW, NW, MT, EPI, GEN>), grid, dim3(NW * 64), (c3_lds<TH, TW>()), s, a);
   return hip_rc(hipGetLastError());
 }
 

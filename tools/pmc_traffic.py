@@ -41,7 +41,7 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 NAMES = {"fused_gh": r"fused_gh_kernel", "fused_f<0>": r"fused_f(16)?_kernel<0", "fused_f<1>": r"fused_f(16)?_kernel<1",
-         "conv3x3": r"^conv3x3_kernel<16, 16, 4, 2, 0, false>", "conv5_GH": r"tconv5_kernel<2, 3, 4, 1, 3[,>]", "conv5_F": r"tconv5_kernel<1, 1, 6, 0, 2[,>]",
+         "conv3x3": r"^conv3x3_kernel<16, 16, 4, 2, 0, false[,>]", "conv5_GH": r"tconv5_kernel<2, 3, 4, 1, 3[,>]", "conv5_F": r"tconv5_kernel<1, 1, 6, 0, 2[,>]",
          "f_couple": r"f_couple_kernel"}
 
 

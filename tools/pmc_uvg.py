@@ -34,7 +34,7 @@ for line in open(os.path.join(d, "uvg1080p_1stream_kernel_trace.txt")):
 fetch, write, sq = (read(os.path.join(d, f"uvg1080p_pmc_{k}.txt")) for k in ("fetch", "write", "sq"))
 NAMES = {"fused_gh": ("selfc::fused_gh_kernel", None, 2 * 9 * 32 * (3 + 35 + 67 + 99)), "fused_f16<0>": ("selfc::fused_f16_kernel<0>", None, 9 * 32 * 128),
          "fused_f16<1>": ("selfc::fused_f16_kernel<1>", None, 9 * 32 * 256), "tconv5_GH": ("tconv5_kernel<2, 3, 4, 1, 3", 1004, None),
-         "f_couple": ("selfc::f_couple_kernel", 128, None), "conv3x3 (STP, layer-wise)": ("conv3x3_kernel<16, 16, 4, 2, 0, false>", None, None),
+         "f_couple": ("selfc::f_couple_kernel", 128, None), "conv3x3 (STP, layer-wise)": ("conv3x3_kernel<16, 16, 4, 2, 0, false", None, None),
          # the largest non-stack launches.  GMM head + sampler: 64->128->256->720 pointwise + sample = 225,280 MAC per
          # pixel; bytes: 64 fp32 features in, 240 fp32 noise values in, 48 fp32 out = 1,408 B.  GlobalAgg mix (consumer = a D2DT block):
          # 64 fp32 channels in, 64 f16 channels out (proj1 64x64 on the MFMA) = 384 B, 4,096 MAC
