@@ -71,4 +71,8 @@ size_t bwd_wgrad_scratch_bytes(int N, int H, int W, int Pn, int qtot, int ttot);
 int bwd_wgrad(const WgradJob& j, const float* amax, void* scratch, int N, int T, int H, int W, hipStream_t s);
 size_t bwd_wgrad14_scratch_bytes(int N, int H, int W, int nqc1);
 
+#ifdef SELFC_DEV
+unsigned long long* dev_stamp_slot();    // timing aid (SELFC_ABLATE & 512): 512 x 8 u64 of the next launch, tools/experiments/c3_stamps.py
+#endif
+
 }  // namespace selfc

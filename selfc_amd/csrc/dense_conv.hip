@@ -754,6 +754,9 @@ int run_GH(const selfc_invblock_w* blk, const selfc_latent* l, int rev, const fl
 }  // namespace
 
 namespace selfc {
+#ifdef SELFC_DEV
+unsigned long long* dev_stamp_slot() { return c3_stamp_slot(); }     // csrc/dgrad_chain.hip stamps its launches into the same ring
+#endif
 
 // conv5^T of a temporal dense block: out plane z (z < nplanes_out) = sum over the three temporal taps of W_z[tap] g[t + tap - 1];
 // g = ng scaled f16 gradient planes; plane mask_z is multiplied by LeakyReLU'(mask) and stored to `alt`.

@@ -43,9 +43,19 @@ struct DgArgs {
   size_t plane;           // halfs per plane
   int N, H, W, tiles_x, tiles_y;
   int nx, cinp, acc_dx;
+#ifdef SELFC_DEV
+  int ablate;                   // dev build, timing only: 1024 = no epilogue operand loads
+  unsigned long long* stamps;   // dev build: 8 x u64 per workgroup (100-MHz clock): entry, dpre4 staged, after dpre3 / dpre2 / dpre1, end, stage count
+#endif
 };
 
 namespace {
+
+#ifdef SELFC_DEV
+#define DGSTAMP(i) do { if (a.stamps && threadIdx.x == 0 && blockIdx.x < 512) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DGSTAMP(i) do { } while (0)
+#endif
 
 constexpr int TW = 16;
 constexpr int NWAVE = 8, NT = NWAVE * 64;
@@ -77,6 +87,7 @@ template <int TH>
 __device__ __forceinline__ void dgrad_chain_body(const DgArgs& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const lw = smem + off_w<TH>();
+  DGSTAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int wg = xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
   const int tx = wg % a.tiles_x, ty = (wg / a.tiles_x) % a.tiles_y, n = wg / (a.tiles_x * a.tiles_y);
@@ -136,6 +147,7 @@ __device__ __forceinline__ void dgrad_chain_body(const DgArgs& a) {
   }
   store_w();
   __syncthreads();
+  DGSTAMP(1);
 
   int gstage = 0;        // the stage whose fragments are in LDS
   float bwmax = 0.f;
@@ -168,6 +180,13 @@ __device__ __forceinline__ void dgrad_chain_body(const DgArgs& a) {
       const int y = ty0 + rr[mi] - J, x = tx0 + cc[mi] - J;
       inimg[mi] = (cc[mi] < RW) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
       pixv[mi] = inimg[mi] ? (size_t)(n * H + y) * W + x : 0;
+#ifdef SELFC_DEV
+      if (a.ablate & 1024) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { tadd[mi][g] = f16x4{}; if constexpr (J > 0) tmask[mi][g] = f16x4{}; else told[mi][g] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        continue;
+      }
+#endif
       const f16* __restrict__ ad = a.add + (size_t)(J > 0 ? a.nx + J - 1 : zg) * a.plane + pixv[mi] * 32 + 4 * half;
 #pragma unroll
       for (int g = 0; g < 4; ++g) tadd[mi][g] = *reinterpret_cast<const f16x4*>(ad + 8 * g);
@@ -258,8 +277,11 @@ __device__ __forceinline__ void dgrad_chain_body(const DgArgs& a) {
   };
 
   layer(std::integral_constant<int, 3>{}, 0);
+  DGSTAMP(2);
   layer(std::integral_constant<int, 2>{}, 0);
+  DGSTAMP(3);
   layer(std::integral_constant<int, 1>{}, 0);
+  DGSTAMP(4);
   if (a.dx) {
     for (int z = 0; z < a.nx; ++z) layer(std::integral_constant<int, 0>{}, z);
     if (a.amax_out) {        // one atomic per wave, the convention of dense_conv.hip's EPI_BWD (NaN -> 0x7fc00000)
@@ -270,6 +292,9 @@ __device__ __forceinline__ void dgrad_chain_body(const DgArgs& a) {
       else if (lane == 0 && bwmax > 0.f) atomicMax(bits, __float_as_uint(bwmax));
     }
   }
+#ifdef SELFC_DEV
+  if (a.stamps) { __builtin_amdgcn_s_waitcnt(0); DGSTAMP(5); if (threadIdx.x == 0 && blockIdx.x < 512) { a.stamps[blockIdx.x * 8 + 6] = 100 + nstage_all; } }
+#endif
 }
 
 template <int TH>
@@ -307,6 +332,11 @@ int bwd_dgrad_chain_pair(void* gb0, void* gb1, const void* add0, const void* add
   a.nx = b.nx = nx;
   static const int th_env = getenv("SELFC_BWD_CHAIN_TH") ? atoi(getenv("SELFC_BWD_CHAIN_TH")) : 0;
   const bool th6 = th_env ? th_env == 6 : 2L * N * a.tiles_x * ((H + 5) / 6) <= 256;
+#ifdef SELFC_DEV
+  static const int dev_abl = getenv("SELFC_ABLATE") ? atoi(getenv("SELFC_ABLATE")) : 0;
+  if (dev_abl & 512) { a.stamps = dev_stamp_slot(); b.stamps = dev_stamp_slot(); }
+  a.ablate = b.ablate = dev_abl;
+#endif
   static std::atomic<unsigned long long> optin12{0}, optin6{0};
   ProfScope prof(-1, s);
   if (th6) {
@@ -334,6 +364,11 @@ int bwd_dgrad_chain(void* gb, const void* add, const void* feat, const void* con
   a.nx = nx; a.cinp = cinp; a.acc_dx = accumulate_dx;
   static const int th_env = getenv("SELFC_BWD_CHAIN_TH") ? atoi(getenv("SELFC_BWD_CHAIN_TH")) : 0;
   const bool th6 = th_env ? th_env == 6 : (long)N * a.tiles_x * ((H + 5) / 6) <= 256;
+#ifdef SELFC_DEV
+  static const int dev_abl = getenv("SELFC_ABLATE") ? atoi(getenv("SELFC_ABLATE")) : 0;
+  if (dev_abl & 512) a.stamps = dev_stamp_slot();
+  a.ablate = dev_abl;
+#endif
   static std::atomic<unsigned long long> optin12{0}, optin6{0};
   if (th6) {
     if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&dgrad_chain_kernel<6>), dg_lds<6>(), optin6); e != hipSuccess) return hip_rc(e);
