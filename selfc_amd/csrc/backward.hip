@@ -271,10 +271,41 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const int gx, const 
     if (tile + gx < a.ntiles) fetch(tile + gx);
     // 16 patches of 4x4 pixels; patches wholly outside the image are skipped (wave-uniform: the transposing
     // read needs EXEC all ones).  TAPS == 1: each wave takes 4 of them; otherwise each wave takes all 16 for its taps.
+    if constexpr (EX) {
+      // whole tiles: the patch loop is straight-line, and the fragments of patch k + 1 are requested before the MFMAs of patch k
+      // (as hipcc scheduled the plain loop every MFMA sat behind an s_waitcnt lgkmcnt(0) for the four transposing reads just in
+      // front of it: profiles/r6/ab_experiments.txt r6z)
+      constexpr int NIT = TAPS == 1 ? NP * NP / 4 : NP * NP;
+      f16x8 afr[2], bfr[2][TPW];
+      auto read_patch = [&](const int k, f16x8& af, f16x8 (&bf)[TPW]) __attribute__((always_inline)) {
+        const int pi = TAPS == 1 ? wave + 4 * k : k;
+        const int pr = pi / NP, pc = pi % NP;
+        const int arow = ((4 * pr + 2 * h) * TS + 4 * pc + q) * 64 + choff;
+        af = tr_frag(lp, arow, arow + TS * 64);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          const int tap = TAPS == 9 ? wave * 3 + t : 0;
+          const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap - 3 * (tap / 3) : 0;
+          const int fr = TAPS == 3 ? wave : 0;
+          const int brow = (fr * QPIX + (4 * pr + 2 * h + dy) * QW + 4 * pc + q + dx) * 64 + choff;
+          bf[t] = tr_frag(lq, brow, brow + QW * 64);
+        }
+      };
+      read_patch(0, afr[0], bfr[0]);
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        if (k + 1 < NIT) read_patch(k + 1, afr[(k + 1) & 1], bfr[(k + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = mfma_32x32x16(afr[k & 1], bfr[k & 1][t], acc[t]);
+        if (BI) accb = mfma_32x32x16(afr[k & 1], ones, accb);       // (every wave: a wave test here is a branch per patch; wave 0's copy is stored)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int pi = (TAPS == 1 ? wave : 0); pi < NP * NP; pi += (TAPS == 1 ? 4 : 1)) {
       const int pr = pi / NP, pc = pi % NP;
-      if (!EX && (ty0 + 4 * pr >= H || tx0 + 4 * pc >= W)) continue;
+      if (ty0 + 4 * pr >= H || tx0 + 4 * pc >= W) continue;
       const int arow = ((4 * pr + 2 * h) * TS + 4 * pc + q) * 64 + choff;
       const f16x8 af = tr_frag(lp, arow, arow + TS * 64);
 #pragma unroll
@@ -287,6 +318,7 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const int gx, const 
         acc[t] = mfma_32x32x16(af, bf, acc[t]);
       }
       if (BI) accb = mfma_32x32x16(af, ones, accb);       // (every wave: a wave test here is a branch per patch; wave 0's copy is stored)
+    }
     }
   }
   };
@@ -362,7 +394,7 @@ __global__ __launch_bounds__((TAPS == 1 ? 4 : 3) * 64) void wgrad_kernel(const W
 }
 
 // multi mode only (conv1..4 of a dense block, grid.z unused by the body): the jobs of two nets of one geometry in one launch
-__global__ __launch_bounds__(192) void wgrad_pair_kernel(const WgArgs a, const WgArgs b) {
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_pair_kernel(const WgArgs a, const WgArgs b) {
   SELFC_WG_LDS(9);
   if (blockIdx.z) wgrad9(b, (int)gridDim.x, (int)gridDim.y, (int)blockIdx.x, (int)blockIdx.y, lp, lq);
   else wgrad9(a, (int)gridDim.x, (int)gridDim.y, (int)blockIdx.x, (int)blockIdx.y, lp, lq);
@@ -395,7 +427,7 @@ __device__ __forceinline__ bool wg_map(const int L, const int gx, const int gy, 
   }
   return bx < gx && by < gy;
 }
-__global__ __launch_bounds__(192) void wgrad_table_kernel(const WgTable t) {
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_table_kernel(const WgTable t) {
   const int z = blockIdx.z;
   int bx, by;
   if (!wg_map((int)blockIdx.x, t.gx[z], t.gy[z], t.xcd, bx, by)) return;          // workgroup-uniform

@@ -207,19 +207,31 @@ __device__ __forceinline__ void dgrad_chain_body(const DgArgs& a) {
       constexpr int ROWB = Img<TH, K>::rowb;
       if (gstage + 1 < nstage_all) load_w(gstage + 1);
       const unsigned char* const img = smem + img_off<TH, K>();
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
+      // The operands of tap t + 1 are requested BEFORE the MFMAs of tap t, into a second register set (written as it falls out of the
+      // loop nest - read, wait, MFMA, with the M-tile test around each pair - hipcc put an s_waitcnt lgkmcnt(0) in front of EVERY
+      // MFMA: ~3 us per stage for 0.7 us of matrix time, r6v).  The reads of a wave's unused M-tile slot go to a valid tile and
+      // are dropped.
+      f16x8 afr[2][2], bfr[2][2][MT];
+      auto read_tap = [&](const int tap, f16x8 (&af)[2], f16x8 (&bf)[2][MT]) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const f16x8 af = *reinterpret_cast<const f16x8*>(lw + (tap * 2 + ks) * 1024 + lane * 16);
+          af[ks] = *reinterpret_cast<const f16x8*>(lw + (tap * 2 + ks) * 1024 + lane * 16);
 #pragma unroll
-          for (int mi = 0; mi < MT; ++mi) {
-            if (wave + NWAVE * mi < NMT) {       // wave-uniform
-              const f16x8 bf = *reinterpret_cast<const f16x8*>(img + (rr[mi] + SH + tap / 3) * ROWB + (cc[mi] + SH + tap % 3) * PS + half * 16 + ks * 32);
-              acc[mi] = mfma_32x32x16(af, bf, acc[mi]);
-            }
-          }
+          for (int mi = 0; mi < MT; ++mi)
+            bf[ks][mi] = *reinterpret_cast<const f16x8*>(img + (rr[mi] + SH + tap / 3) * ROWB + (cc[mi] + SH + tap % 3) * PS + half * 16 + ks * 32);
         }
+      };
+      read_tap(0, afr[0], bfr[0]);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) read_tap(tap + 1, afr[(tap + 1) & 1], bfr[(tap + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi)
+            if (wave + NWAVE * mi < NMT) acc[mi] = mfma_32x32x16(afr[tap & 1][ks], bfr[tap & 1][ks][mi], acc[mi]);       // wave-uniform
+        __builtin_amdgcn_sched_barrier(0);
       }
       ++gstage;
       __syncthreads();                           // every wave is done with this stage's fragments
