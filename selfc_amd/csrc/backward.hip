@@ -856,16 +856,18 @@ BwdLayout bwd_layout(int N, int H, int W, int cin, int cout) {
 // by 12 MiB of partials (written once, read once by the finish pass)
 // SELFC_WG_TILES: when the launches of many subnets are deferred into ONE (wgrad_table_kernel) there is no chip to fill per job:
 // every workgroup then takes at least this many tiles (fewer partials to write and to reduce)
-static long wg_min_tiles() {
-  static const long v = getenv("SELFC_WG_TILES") ? atol(getenv("SELFC_WG_TILES")) : 32;
-  return v < 1 ? 1 : v;
+// Default: 16 while the job has at most 256 tiles (training crops at 1..4 septuplets per rank: more, shorter workgroups), 32 beyond
+// (8 per rank: fewer partials) - same-box sweep on the final kernels, profiles/r6/ab_experiments.txt r6aa.
+static long wg_min_tiles(long units) {
+  static const long v = getenv("SELFC_WG_TILES") ? atol(getenv("SELFC_WG_TILES")) : 0;
+  return v >= 1 ? v : (units <= 256 ? 16 : 32);
 }
 // SELFC_BWD_WG_THIN (phase flag of the calling entry point): ONE workgroup per pair walks every tile - a launch of a few hundred
 // long-lived workgroups (a stack: ~290) that leaves most of every CU to the kernels of another stream (the next stack's data chain)
 static thread_local bool g_wg_thin = false;
 int wgrad_nsplit_table(int nsplit, long units) {
   if (g_wg_thin) return 1;
-  const long cap = (units + wg_min_tiles() - 1) / wg_min_tiles();
+  const long cap = (units + wg_min_tiles(units) - 1) / wg_min_tiles(units);
   return (int)(nsplit > cap ? (cap < 1 ? 1 : cap) : nsplit);
 }
 struct ThinScope {
@@ -1176,13 +1178,13 @@ int selfc_subnet_bwd_phase_d(int phases, const selfc_subnet_bw* bw, int kind, co
     if ((rc = bwd_conv_planes(c, N, T, H, W, s))) return rc;
   }
   // 3 + 4 as ONE launch (csrc/dgrad_chain.hip: the chain in LDS, bit-identical values) while its workgroups - one per 12x16
-  // tile and frame, one per CU - fit the chip in a single round: training crops at 1..4 septuplets per rank (63..252 tiles;
-  // captured step 8.4 -> 7.8, 9.0 -> 8.3, 10.3 -> 9.85 ms).  Beyond that the layer-wise launches win (3-wave workgroups, four
-  // per CU, G's and H's chains side by side: 13.8 against 14.6 ms at 8 septuplets; the chain for F alone: 13.95).
+  // tile and frame, one per CU - need at most two rounds (F: 512 workgroups; a G/H pair: four rounds, 1,024): since the chain's
+  // MFMAs are fed one tap ahead (r6y) it beats the layer-wise launches up to there (same-box sweep r6aa: 7.98 -> 7.75 ms at four
+  // septuplets per rank, 11.98 -> 11.88 at eight; in round 5, with hipcc's read - wait - multiply loop, one round was the limit).
   // SELFC_BWD_CHAIN=0 / 1: never / always (tests).
   {
     static const int chain_env = getenv("SELFC_BWD_CHAIN") ? atoi(getenv("SELFC_BWD_CHAIN")) : -1;
-    static const long chain_max = getenv("SELFC_BWD_CHAIN_MAX1") ? atol(getenv("SELFC_BWD_CHAIN_MAX1")) : 256;
+    static const long chain_max = getenv("SELFC_BWD_CHAIN_MAX1") ? atol(getenv("SELFC_BWD_CHAIN_MAX1")) : 512;
     const long chain_wgs = (long)N * ((H + 11) / 12) * ((W + 15) / 16);
     if (chain_env == 1 || (chain_env < 0 && chain_wgs <= chain_max)) {
       const void* wtd[3] = {bw->wtd[0], bw->wtd[1], bw->wtd[2]};
@@ -1332,7 +1334,7 @@ int selfc_gh_bwd_pair(int phases, const selfc_subnet_bw* bw_g, const selfc_subne
                                L.nx + 3, gb[0], gb[1], N, T, H, W, s))) return rc;
     // 3. dpre3, dpre2, dpre1 of both nets: the chain kernel while its workgroups fit the chip in one round, else layer by layer
     static const int chain_env = getenv("SELFC_BWD_CHAIN") ? atoi(getenv("SELFC_BWD_CHAIN")) : -1;
-    static const long chain_max = getenv("SELFC_BWD_CHAIN_MAX2") ? atol(getenv("SELFC_BWD_CHAIN_MAX2")) : 256;
+    static const long chain_max = getenv("SELFC_BWD_CHAIN_MAX2") ? atol(getenv("SELFC_BWD_CHAIN_MAX2")) : 1024;
     const long chain_wgs = 2L * N * ((H + 11) / 12) * ((W + 15) / 16);
     if (chain_env == 1 || (chain_env < 0 && chain_wgs <= chain_max)) {
       const void* wtd0[3] = {bw_g->wtd[0], bw_g->wtd[1], bw_g->wtd[2]};
