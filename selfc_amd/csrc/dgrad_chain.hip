@@ -71,7 +71,7 @@ template <int TH, int K> constexpr int img_off() {
   return K == 4 ? 0 : K == 3 ? Img<TH, 4>::bytes : K == 2 ? Img<TH, 4>::bytes + Img<TH, 3>::bytes : Img<TH, 4>::bytes + Img<TH, 3>::bytes + Img<TH, 2>::bytes;
 }
 template <int TH> constexpr int off_w() { return img_off<TH, 1>() + Img<TH, 1>::bytes; }
-template <int TH> constexpr int dg_lds() { return off_w<TH>() + 18 * 1024; }
+template <int TH> constexpr int dg_lds() { return off_w<TH>() + 2 * 18 * 1024; }      // TWO fragment buffers: stage g lives in buffer g & 1
 static_assert(dg_lds<12>() <= 160 * 1024, "LDS budget");
 constexpr int WITER = (18 * 64 + NT - 1) / NT;      // 3
 
@@ -86,7 +86,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int TH>
 __device__ __forceinline__ void dgrad_chain_body(const DgArgs& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const lw = smem + off_w<TH>();
+  unsigned char* const lw0 = smem + off_w<TH>();
   DGSTAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int wg = xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
@@ -110,7 +110,11 @@ __device__ __forceinline__ void dgrad_chain_body(const DgArgs& a) {
 #pragma unroll
     for (int it = 0; it < WITER; ++it) wreg[it] = src[min(tid + it * NT, 18 * 64 - 1)];
   };
-  auto store_w = [&]() __attribute__((always_inline)) {
+  // Two LDS fragment buffers: the fragments of stage g + 1 (requested when stage g - 1 started) go to LDS when stage g STARTS, into
+  // the buffer stage g - 1 read - behind that stage's closing barrier - so a stage is [fragments g + 1 to LDS, request g + 2, MFMAs
+  // of g, ONE barrier] where it used to be [request g + 1, MFMAs, barrier, fragments to LDS, barrier] (r6ab).
+  auto store_w = [&](const int g) __attribute__((always_inline)) {
+    unsigned char* const lw = lw0 + (g & 1) * (18 * 1024);
 #pragma unroll
     for (int it = 0; it < WITER; ++it) {
       const int i = tid + it * NT;
@@ -145,7 +149,8 @@ __device__ __forceinline__ void dgrad_chain_body(const DgArgs& a) {
       }
     }
   }
-  store_w();
+  store_w(0);
+  load_w(1);
   __syncthreads();
   DGSTAMP(1);
 
@@ -205,7 +210,9 @@ __device__ __forceinline__ void dgrad_chain_body(const DgArgs& a) {
     static_for<0, NST>([&](auto stag) __attribute__((always_inline)) {
       constexpr int S = decltype(stag)::value, K = 4 - S, SH = K - J - 1;
       constexpr int ROWB = Img<TH, K>::rowb;
-      if (gstage + 1 < nstage_all) load_w(gstage + 1);
+      if (gstage + 1 < nstage_all) store_w(gstage + 1);
+      if (gstage + 2 < nstage_all) load_w(gstage + 2);
+      const unsigned char* const lw = lw0 + (gstage & 1) * (18 * 1024);
       const unsigned char* const img = smem + img_off<TH, K>();
       // The operands of tap t + 1 are requested BEFORE the MFMAs of tap t, into a second register set (written as it falls out of the
       // loop nest - read, wait, MFMA, with the M-tile test around each pair - hipcc put an s_waitcnt lgkmcnt(0) in front of EVERY
@@ -234,11 +241,10 @@ __device__ __forceinline__ void dgrad_chain_body(const DgArgs& a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       ++gstage;
-      __syncthreads();                           // every wave is done with this stage's fragments
-      if (gstage < nstage_all) store_w();
-      if constexpr (S + 1 < NST) __syncthreads();
+      if constexpr (S + 1 < NST) __syncthreads();      // every wave is done with this stage's fragment buffer, and the next stage's is written
     });
-    // ---- epilogue (the next stage's fragments are already in LDS; the barrier after it also publishes G_J)
+    // ---- epilogue (no barrier in front of it: it reads accumulators and writes G_J, which nobody reads before the barrier behind it -
+    // the same barrier closes the layer's last stage)
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
       if (wave + NWAVE * mi >= NMT) continue;
